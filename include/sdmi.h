@@ -1,0 +1,189 @@
+/*
+ * sdmi.h -- C ABI of libsdmi.so: the MI355X (gfx950) Stable Diffusion v1.4
+ * sampling hot path (UNet DDIM+CFG loop and VAE decoder) that sits behind the
+ * `StableDiffusion::sample_image` surface of Gadersd/stable-diffusion-burn.
+ *
+ * Every entry point below names the reference interface it replaces
+ * (file:line relative to the reference repo).  The reference has no FFI of its
+ * own -- its "plugin" seam is the Burn `Backend` type parameter
+ * (src/bin/sample/main.rs:59-83) plus the commented-out operator-override
+ * trait in src/backend.rs:4-84 -- so this header is what a Rust shim
+ * (ffi/sdmi.rs) binds with `extern "C"`.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++/torch types
+ *  - host-pointer functions take row-major fp32 in the REFERENCE's logical
+ *    layouts (NCHW images/latents, [n, tokens, channels] sequences); the
+ *    library copies in/out and blocks until results are in host memory.
+ *    NHWC and packed weights are internal.
+ *  - *_dev functions take DEVICE pointers (same logical layouts) and enqueue
+ *    on the context's HIP stream; sdmi_synchronize() waits for it.
+ *  - every function returns 0 (SDMI_OK) or a negative sdmi_status; the
+ *    message is available from sdmi_last_error() (thread-local).  The
+ *    reference's hot path is infallible by type and panics on shape errors
+ *    (stablediffusion/mod.rs:86, unet/mod.rs:134); the Rust shim panics on a
+ *    non-zero status to keep that contract.
+ *  - a context is not re-entrant: one call at a time per context.
+ *  - the caller owns every in/out buffer; the context owns device weights,
+ *    activation pool and stream.  Nothing returned needs freeing but the ctx.
+ */
+#ifndef SDMI_H
+#define SDMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdmi_ctx sdmi_ctx;
+
+typedef enum sdmi_status {
+    SDMI_OK = 0,
+    SDMI_ERR_INVALID = -1,     /* bad argument / shape (reference: panic)      */
+    SDMI_ERR_HIP = -2,         /* a hip* call failed                           */
+    SDMI_ERR_WEIGHTS = -3,     /* missing / mis-shaped weight tensor           */
+    SDMI_ERR_IO = -4,          /* weight file / directory unreadable           */
+    SDMI_ERR_UNSUPPORTED = -5, /* valid in the reference, not built here yet   */
+    SDMI_ERR_STATE = -6        /* call order (e.g. forward before finalize)    */
+} sdmi_status;
+
+/* Model / device configuration.  Defaults (sdmi_default_config) are the
+ * reference's hard-coded hyper-parameters: UNetConfig::init unet/mod.rs:36-92,
+ * AutoencoderConfig::init autoencoder/mod.rs:30-36, latent 4x64x64
+ * stablediffusion/mod.rs:116.  Tests shrink them; nothing else should. */
+typedef struct sdmi_config {
+    int32_t device;          /* HIP device ordinal                              */
+    int32_t model_channels;  /* 320                                             */
+    int32_t n_head;          /* 8                                               */
+    int32_t ctx_dim;         /* 768  (CLIP text width)                          */
+    int32_t latent_h;        /* 64   (image = 8x)                               */
+    int32_t latent_w;        /* 64                                              */
+    int32_t vae_ch;          /* 128  (decoder channels 4c,4c,2c,c)              */
+    int32_t max_batch;       /* images per call the pool is sized for           */
+    int32_t precision;       /* 0 = fp32 (only value this round)                */
+    int32_t reserved[7];
+} sdmi_config;
+
+int sdmi_default_config(sdmi_config* cfg);
+
+/* ---- lifecycle ------------------------------------------------------------ */
+int sdmi_create(sdmi_ctx** out, const sdmi_config* cfg);
+void sdmi_destroy(sdmi_ctx* ctx);
+const char* sdmi_last_error(void);
+int sdmi_synchronize(sdmi_ctx* ctx);
+/* library / build identification, e.g. "sdmi 0.1 gfx950 fp32" */
+const char* sdmi_version(void);
+
+/* ---- weights -------------------------------------------------------------
+ * Names are the reference's npy-dump tree paths (src/model/unet/load.rs:217-305,
+ * src/model/autoencoder/load.rs:135-157, src/model/stablediffusion/load.rs:20-24),
+ * e.g. "unet/input_blocks/rt1/res/conv_in/weight", "autoencoder/post_quant_conv/bias",
+ * "alphas_cumprod".  Shapes are the reference's: Conv2d weight [Cout,Cin,kh,kw],
+ * Linear weight [in,out] (python/save.py:19), norms [C].  Replaces
+ * load_stable_diffusion (stablediffusion/load.rs:16-33) for the hot-path
+ * subset (UNet, VAE decoder + post_quant_conv, alphas_cumprod). */
+int sdmi_set_weight(sdmi_ctx* ctx, const char* name, const float* data, int32_t ndim, const int64_t* dims);
+/* number of tensors the configured model needs / name + shape of the i-th */
+int sdmi_weight_count(sdmi_ctx* ctx);
+int sdmi_weight_info(sdmi_ctx* ctx, int32_t index, const char** name, int32_t* ndim, int64_t dims[4]);
+/* reads the npy-dump directory written by the reference's python/ exporters
+ * (format: src/model/load.rs:17-28 -- 1-D float32 .npy whose first D values
+ * are the shape). */
+int sdmi_load_weights_dir(sdmi_ctx* ctx, const char* dump_dir);
+/* packs everything into the device layouts; fails listing the first missing tensor */
+int sdmi_finalize_weights(sdmi_ctx* ctx);
+
+/* ---- hot path, host pointers ------------------------------------------------ */
+
+/* UNet::forward (src/model/unet/mod.rs:109-143).
+ * x [n,4,h,w] NCHW, t scalar timestep (the reference passes a 1-element Int
+ * tensor shared by the batch), context [n,T,ctx_dim] -> out [n,4,h,w]. */
+int sdmi_unet_forward(sdmi_ctx* ctx, const float* x, int32_t t, const float* context,
+                      int32_t n, int32_t T, float* out);
+
+/* StableDiffusion::sample_latent (src/model/stablediffusion/mod.rs:102-160),
+ * DDIM eta=0 with classifier-free guidance (forward_diffuser :162-192).
+ * context [n,T,ctx_dim]; uncond [Tu,ctx_dim] (broadcast over the batch);
+ * init_latent [n,4,h,w] = x_T (the reference draws it from an unseeded backend
+ * RNG, :115-121; here it is an explicit input) or NULL to draw N(0,1) from
+ * `seed` (image i uses stream seed+i); latent_out [n,4,h,w]. */
+int sdmi_sample_latent(sdmi_ctx* ctx, const float* context, int32_t n, int32_t T,
+                       const float* uncond, int32_t Tu, double scale, size_t n_steps,
+                       const float* init_latent, uint64_t seed, float* latent_out);
+
+/* Autoencoder::decode_latent (src/model/autoencoder/mod.rs:68-71):
+ * latent [n,4,h,w] (already divided by 0.18215 by the caller, as in
+ * latent_to_image) -> img_out [n,3,8h,8w] fp32 NCHW. */
+int sdmi_decode_latent(sdmi_ctx* ctx, const float* latent, int32_t n, float* img_out);
+
+/* StableDiffusion::latent_to_image (stablediffusion/mod.rs:69-100):
+ * latent [n,4,h,w] -> rgb_out n x [8h,8w,3] uint8 (HWC, truncating cast). */
+int sdmi_latent_to_image(sdmi_ctx* ctx, const float* latent, int32_t n, uint8_t* rgb_out);
+
+/* StableDiffusion::sample_image (stablediffusion/mod.rs:51-67). */
+int sdmi_sample_image(sdmi_ctx* ctx, const float* context, int32_t n, int32_t T,
+                      const float* uncond, int32_t Tu, double scale, size_t n_steps,
+                      const float* init_latent, uint64_t seed, uint8_t* rgb_out);
+
+/* qkv_attention (src/model/attention.rs:5-45 == src/backend.rs:88-128; the
+ * operator seam of the commented-out `trait Backend`, backend.rs:4-84).
+ * q [n,nq,n_state], k,v [n,nk,n_state], mask [>=nq, mask_ld>=nk] additive or
+ * NULL -> out [n,nq,n_state]. */
+int sdmi_qkv_attention(sdmi_ctx* ctx, const float* q, const float* k, const float* v,
+                       const float* mask, int32_t mask_ld, int32_t n, int32_t nq, int32_t nk,
+                       int32_t n_state, int32_t n_head, float* out);
+
+/* ---- hot path, device pointers (zero-copy; same layouts) ---------------------- */
+int sdmi_sample_latent_dev(sdmi_ctx* ctx, const float* context, int32_t n, int32_t T,
+                           const float* uncond, int32_t Tu, double scale, size_t n_steps,
+                           const float* init_latent, float* latent_out);
+int sdmi_latent_to_image_dev(sdmi_ctx* ctx, const float* latent, int32_t n, uint8_t* rgb_out);
+int sdmi_sample_image_dev(sdmi_ctx* ctx, const float* context, int32_t n, int32_t T,
+                          const float* uncond, int32_t Tu, double scale, size_t n_steps,
+                          const float* init_latent, uint8_t* rgb_out);
+
+/* ---- operator-level entry points (parity tests, profiling) -------------------
+ * Same math as the Burn primitives / reference modules named; host pointers
+ * in reference layouts.  These let tests/ compare each HIP kernel with the
+ * oracle at the op boundary (SURVEY.md section 8c "per-op KATs"). */
+
+/* GroupNorm::forward (+ optional SILU::forward): groupnorm/mod.rs:53-82, silu.rs:14-16.
+ * x,out [n,c,h,w]; gamma,beta [c]. */
+int sdmi_op_group_norm(sdmi_ctx* ctx, const float* x, const float* gamma, const float* beta,
+                       int32_t n, int32_t c, int32_t h, int32_t w, int32_t n_group, float eps,
+                       int32_t fuse_silu, float* out);
+/* Burn nn::LayerNorm (unet/mod.rs:523-525): x,out [rows,c]. */
+int sdmi_op_layer_norm(sdmi_ctx* ctx, const float* x, const float* gamma, const float* beta,
+                       int32_t rows, int32_t c, float eps, float* out);
+/* Burn nn::conv::Conv2d::forward: x [n,cin,h,w], weight [cout,cin,k,k], bias [cout] or NULL,
+ * symmetric zero padding `pad`, `stride`; upsample2x != 0 applies the reference's
+ * nearest-2x (unet/mod.rs:392-396) to x first.  out [n,cout,ho,wo]. */
+int sdmi_op_conv2d(sdmi_ctx* ctx, const float* x, const float* weight, const float* bias,
+                   int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t k,
+                   int32_t stride, int32_t pad, int32_t upsample2x, float* out);
+/* Burn nn::Linear::forward: x [rows,cin] @ weight [cin,cout] + bias. */
+int sdmi_op_linear(sdmi_ctx* ctx, const float* x, const float* weight, const float* bias,
+                   int32_t rows, int32_t cin, int32_t cout, float* out);
+/* GEGLU gate (unet/mod.rs:579-591): proj [rows,2*hidden] -> out [rows,hidden] = a*gelu_erf(gate). */
+int sdmi_op_geglu(sdmi_ctx* ctx, const float* proj, int32_t rows, int32_t hidden, float* out);
+/* timestep_embedding (unet/mod.rs:19-30): out [dim] for timestep t. */
+int sdmi_op_timestep_embedding(sdmi_ctx* ctx, int32_t t, int32_t dim, float* out);
+
+/* ---- tuning / introspection ---------------------------------------------------- */
+/* "key=value" knobs, e.g. "gemm_tile=auto", "splitk=0", "graph=1". */
+int sdmi_set_option(sdmi_ctx* ctx, const char* key, const char* value);
+/* time (ms, HIP events on the context stream) and kernel count of the last
+ * hot-path call; flops = algorithmic FLOPs it executed (2*MAC of conv/GEMM/attention). */
+int sdmi_last_call_stats(sdmi_ctx* ctx, double* gpu_ms, int64_t* n_kernels, double* flops);
+/* micro-benchmark one implicit-GEMM conv shape on device-resident synthetic
+ * data: returns average kernel ms over `iters` launches (HIP events). */
+int sdmi_bench_conv(sdmi_ctx* ctx, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
+                    int32_t k, int32_t stride, int32_t upsample2x, int32_t tile_cfg, int32_t splitk,
+                    int32_t iters, double* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDMI_H */

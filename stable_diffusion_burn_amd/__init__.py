@@ -1,0 +1,12 @@
+"""stable_diffusion_burn_amd -- MI355X (gfx950) native SD v1.4 sampling hot path.
+
+The package is a thin host layer over `libsdmi.so` (hand-written HIP kernels +
+C++ engine, C ABI in include/sdmi.h).  It exposes the reference's
+`StableDiffusion` surface (Gadersd/stable-diffusion-burn,
+src/model/stablediffusion/mod.rs) and nothing else; there is no CPU or PyTorch
+fallback -- importing the pipeline without a built library raises.
+"""
+from .pipeline import Autoencoder, ModelConfig, SdmiError, StableDiffusion, UNet, qkv_attention  # noqa: F401
+from . import synthetic  # noqa: F401
+
+__all__ = ["StableDiffusion", "UNet", "Autoencoder", "ModelConfig", "SdmiError", "qkv_attention", "synthetic"]

@@ -1,0 +1,974 @@
+// engine.cpp -- see engine.hpp.  Reference citations are relative to
+// Gadersd/stable-diffusion-burn (src/model/...).
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace sdmi {
+
+// =============================================================================
+// DevPool
+// =============================================================================
+static constexpr size_t kAlign = 256;
+static constexpr size_t kSlabMin = (size_t)1 << 30;  // 1 GiB
+
+DevPool::~DevPool() {
+    for (auto& s : slabs_) (void)hipFree(s.base);
+}
+
+void* DevPool::alloc(size_t bytes) {
+    if (bytes == 0) bytes = kAlign;
+    bytes = (bytes + kAlign - 1) / kAlign * kAlign;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (size_t si = 0; si < slabs_.size(); ++si) {
+            auto& fl = slabs_[si].free_list;
+            for (size_t i = 0; i < fl.size(); ++i) {
+                if (fl[i].size >= bytes) {
+                    void* p = slabs_[si].base + fl[i].off;
+                    if (fl[i].size == bytes) fl.erase(fl.begin() + i);
+                    else { fl[i].off += bytes; fl[i].size -= bytes; }
+                    live_[p] = {(int)si, bytes};
+                    in_use_ += bytes;
+                    high_ = std::max(high_, in_use_);
+                    return p;
+                }
+            }
+        }
+        // no fit: new slab
+        size_t sz = std::max(bytes, kSlabMin);
+        char* base = nullptr;
+        hipError_t e = hipMalloc((void**)&base, sz);
+        if (e != hipSuccess && sz > bytes) { sz = bytes; e = hipMalloc((void**)&base, sz); }
+        if (e != hipSuccess)
+            throw Error(SDMI_ERR_HIP, std::string("DevPool: hipMalloc(") + std::to_string(sz) + ") failed: " + hipGetErrorString(e));
+        Slab s; s.base = base; s.size = sz; s.free_list.push_back({0, sz});
+        slabs_.push_back(std::move(s));
+        reserved_ += sz;
+    }
+    throw Error(SDMI_ERR_HIP, "DevPool: allocation failed");
+}
+
+void DevPool::free(void* p) {
+    if (!p) return;
+    auto it = live_.find(p);
+    if (it == live_.end()) throw Error(SDMI_ERR_STATE, "DevPool: free of unknown pointer");
+    const int si = it->second.first;
+    const size_t size = it->second.second;
+    live_.erase(it);
+    in_use_ -= size;
+    auto& sl = slabs_[si];
+    const size_t off = (char*)p - sl.base;
+    auto& fl = sl.free_list;
+    size_t pos = 0;
+    while (pos < fl.size() && fl[pos].off < off) ++pos;
+    fl.insert(fl.begin() + pos, {off, size});
+    if (pos + 1 < fl.size() && fl[pos].off + fl[pos].size == fl[pos + 1].off) {
+        fl[pos].size += fl[pos + 1].size;
+        fl.erase(fl.begin() + pos + 1);
+    }
+    if (pos > 0 && fl[pos - 1].off + fl[pos - 1].size == fl[pos].off) {
+        fl[pos - 1].size += fl[pos].size;
+        fl.erase(fl.begin() + pos);
+    }
+}
+
+// =============================================================================
+// construction / model definition
+// =============================================================================
+Engine::Engine(const sdmi_config& cfg) : cfg_(cfg) {
+    if (cfg.precision != 0) throw Error(SDMI_ERR_UNSUPPORTED, "only precision=0 (fp32) is built in this round");
+    if (cfg.model_channels % 32 || cfg.model_channels <= 0) throw Error(SDMI_ERR_INVALID, "model_channels must be a positive multiple of 32");
+    if (cfg.vae_ch % 32 || cfg.vae_ch <= 0) throw Error(SDMI_ERR_INVALID, "vae_ch must be a positive multiple of 32");
+    if (cfg.n_head <= 0 || cfg.model_channels % cfg.n_head) throw Error(SDMI_ERR_INVALID, "n_head must divide model_channels");
+    if (cfg.ctx_dim % 32 || cfg.ctx_dim <= 0) throw Error(SDMI_ERR_INVALID, "ctx_dim must be a positive multiple of 32");
+    if (cfg.latent_h % 8 || cfg.latent_w % 8 || cfg.latent_h <= 0 || cfg.latent_w <= 0)
+        throw Error(SDMI_ERR_INVALID, "latent_h/latent_w must be positive multiples of 8");
+    int ndev = 0;
+    SDMI_HIP(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) throw Error(SDMI_ERR_HIP, "no HIP device visible: libsdmi has no CPU fallback");
+    if (cfg.device < 0 || cfg.device >= ndev) throw Error(SDMI_ERR_INVALID, "device ordinal out of range");
+    SDMI_HIP(hipSetDevice(cfg.device));
+    hipDeviceProp_t prop;
+    SDMI_HIP(hipGetDeviceProperties(&prop, cfg.device));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        throw Error(SDMI_ERR_UNSUPPORTED, std::string("libsdmi is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
+    SDMI_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    SDMI_HIP(hipEventCreate(&ev0_));
+    SDMI_HIP(hipEventCreate(&ev1_));
+    build_model();
+}
+
+Engine::~Engine() {
+    (void)hipSetDevice(cfg_.device);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    for (void* p : weight_allocs_) (void)hipFree(p);
+    if (ev0_) (void)hipEventDestroy(ev0_);
+    if (ev1_) (void)hipEventDestroy(ev1_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Engine::add_entry(const std::string& name, int kind, std::initializer_list<int64_t> dims, float** dst) {
+    WeightEntry e;
+    e.name = name; e.kind = kind; e.ndim = (int)dims.size(); e.dst = dst;
+    int i = 0;
+    for (int k = 0; k < 4; ++k) e.dims[k] = 1;
+    for (auto d : dims) e.dims[i++] = d;
+    entry_index_[name] = (int)entries_.size();
+    entries_.push_back(e);
+}
+
+// The structs build_model() fills live in members / vectors whose storage is fixed
+// before any entry is added (entries_ keeps float** into them).
+void Engine::build_model() {
+    const int mc = cfg_.model_channels, ed = 4 * mc, cd = cfg_.ctx_dim;
+    const int c1 = mc, c2 = 2 * mc, c4 = 4 * mc;
+    auto add = [](Engine* e, const std::string& n, int kind, std::initializer_list<int64_t> d, float** dst) { e->add_entry(n, kind, d, dst); };
+    auto conv = [&](ConvW& w, const std::string& path, int cin, int cout, int k) {
+        w.cin = cin; w.cout = cout; w.k = k;
+        add(this, path + "/weight", 0, {cout, cin, k, k}, &w.bt);
+        add(this, path + "/bias", 2, {cout}, &w.bias);
+    };
+    auto lin = [&](LinW& w, const std::string& path, int cin, int cout, bool bias) {
+        w.cin = cin; w.cout = cout;
+        add(this, path + "/weight", 1, {cin, cout}, &w.bt);
+        if (bias) add(this, path + "/bias", 2, {cout}, &w.bias);
+    };
+    auto norm = [&](NormW& w, const std::string& path, int c) {
+        w.c = c;
+        add(this, path + "/weight", 2, {c}, &w.gamma);
+        add(this, path + "/bias", 2, {c}, &w.beta);
+    };
+    auto res = [&](ResW& r, const std::string& path, int cin, int cout, bool unet) {
+        r.cin = cin; r.cout = cout; r.has_embed = unet; r.has_skip = cin != cout;
+        if (unet) {  // ResBlock, unet/mod.rs:679-734; names unet/load.rs:20-25
+            norm(r.norm_in, path + "/norm_in", cin);
+            conv(r.conv_in, path + "/conv_in", cin, cout, 3);
+            lin(r.lin_embed, path + "/lin_embed", ed, cout, true);
+            norm(r.norm_out, path + "/norm_out", cout);
+            conv(r.conv_out, path + "/conv_out", cout, cout, 3);
+            if (r.has_skip) conv(r.skip, path + "/skip_connection", cin, cout, 1);
+        } else {  // ResnetBlock, autoencoder/mod.rs:472-528; names autoencoder/load.rs:39-45
+            norm(r.norm_in, path + "/norm1", cin);
+            conv(r.conv_in, path + "/conv1", cin, cout, 3);
+            norm(r.norm_out, path + "/norm2", cout);
+            conv(r.conv_out, path + "/conv2", cout, cout, 3);
+            if (r.has_skip) conv(r.skip, path + "/nin_shortcut", cin, cout, 1);
+        }
+    };
+    auto mha = [&](MhaW& m, const std::string& path, int c, int cctx) {  // unet/mod.rs:603-653
+        lin(m.q, path + "/query", c, c, false);
+        lin(m.k, path + "/key", cctx, c, false);
+        lin(m.v, path + "/value", cctx, c, false);
+        lin(m.out, path + "/out", c, c, true);
+    };
+    auto spatial = [&](SpatialW& s, const std::string& path, int c) {  // unet/mod.rs:436-527
+        s.c = c;
+        norm(s.norm, path + "/norm", c);
+        conv(s.proj_in, path + "/proj_in", c, c, 1);
+        const std::string t = path + "/transformer";
+        norm(s.ln1, t + "/norm1", c);
+        mha(s.attn1, t + "/attn1", c, c);
+        norm(s.ln2, t + "/norm2", c);
+        mha(s.attn2, t + "/attn2", c, cd);
+        norm(s.ln3, t + "/norm3", c);
+        lin(s.geglu_proj, t + "/mlp/geglu/proj", c, 8 * c, true);
+        lin(s.mlp_lin, t + "/mlp/lin", 4 * c, c, true);
+        conv(s.proj_out, path + "/proj_out", c, c, 1);
+    };
+
+    add(this, "alphas_cumprod", 3, {1000}, nullptr);
+
+    // ---- UNet (unet/mod.rs:36-92) ------------------------------------------------
+    lin(lin1_time_, "unet/lin1_time_embed", mc, ed, true);
+    lin(lin2_time_, "unet/lin2_time_embed", ed, ed, true);
+    struct Spec { BlockKind kind; const char* name; int cin, cout; };
+    const Spec in_spec[12] = {
+        {BK_CONV, "conv", 4, c1},   {BK_RES_ST, "rt1", c1, c1}, {BK_RES_ST, "rt2", c1, c1}, {BK_DOWN, "d1", c1, c1},
+        {BK_RES_ST, "rt3", c1, c2}, {BK_RES_ST, "rt4", c2, c2}, {BK_DOWN, "d2", c2, c2},    {BK_RES_ST, "rt5", c2, c4},
+        {BK_RES_ST, "rt6", c4, c4}, {BK_DOWN, "d3", c4, c4},    {BK_RES, "r1", c4, c4},     {BK_RES, "r2", c4, c4}};
+    const Spec out_spec[12] = {
+        {BK_RES, "r1", 2 * c4, c4},        {BK_RES, "r2", 2 * c4, c4},        {BK_RES_UP, "ru", 2 * c4, c4},
+        {BK_RES_ST, "rt1", 2 * c4, c4},    {BK_RES_ST, "rt2", 2 * c4, c4},    {BK_RES_ST_UP, "rtu1", c4 + c2, c4},
+        {BK_RES_ST, "rt3", c4 + c2, c2},   {BK_RES_ST, "rt4", 2 * c2, c2},    {BK_RES_ST_UP, "rtu2", c2 + c1, c2},
+        {BK_RES_ST, "rt5", c2 + c1, c1},   {BK_RES_ST, "rt6", 2 * c1, c1},    {BK_RES_ST, "rt7", 2 * c1, c1}};
+    in_blocks_.resize(12);
+    out_blocks_.resize(12);
+    auto def_block = [&](UBlock& b, const Spec& s, const std::string& root) {
+        b.kind = s.kind; b.cin = s.cin; b.cout = s.cout;
+        const std::string path = root + "/" + s.name;
+        switch (s.kind) {
+            case BK_CONV: conv(b.conv, path, s.cin, s.cout, 3); break;
+            case BK_DOWN: conv(b.conv, path, s.cin, s.cout, 3); break;  // load_downsample: path itself (unet/load.rs:138-143)
+            case BK_RES: res(b.res, path, s.cin, s.cout, true); break;
+            default:
+                res(b.res, path + "/res", s.cin, s.cout, true);
+                if (s.kind == BK_RES_ST || s.kind == BK_RES_ST_UP) spatial(b.st, path + "/transformer", s.cout);
+                if (s.kind == BK_RES_UP || s.kind == BK_RES_ST_UP) conv(b.up, path + "/upsample/conv", s.cout, s.cout, 3);
+        }
+    };
+    for (int i = 0; i < 12; ++i) def_block(in_blocks_[i], in_spec[i], "unet/input_blocks");
+    res(mid_res1_, "unet/middle_block/res1", c4, c4, true);
+    spatial(mid_st_, "unet/middle_block/transformer", c4);
+    res(mid_res2_, "unet/middle_block/res2", c4, c4, true);
+    for (int i = 0; i < 12; ++i) def_block(out_blocks_[i], out_spec[i], "unet/output_blocks");
+    norm(unet_norm_out_, "unet/norm_out", c1);
+    conv(unet_conv_out_, "unet/conv_out", c1, 4, 3);
+
+    // index ResBlocks / SpatialTransformers for the hoisted per-call tables
+    auto idx_res = [&](ResW& r) { r.temb_index = (int)res_list_.size(); res_list_.push_back(&r); };
+    auto idx_st = [&](SpatialW& s) { s.ctx_index = (int)st_list_.size(); st_list_.push_back(&s); };
+    auto idx_block = [&](UBlock& b) {
+        if (b.kind == BK_CONV || b.kind == BK_DOWN) return;
+        idx_res(b.res);
+        if (b.kind == BK_RES_ST || b.kind == BK_RES_ST_UP) idx_st(b.st);
+    };
+    for (auto& b : in_blocks_) idx_block(b);
+    idx_res(mid_res1_); idx_st(mid_st_); idx_res(mid_res2_);
+    for (auto& b : out_blocks_) idx_block(b);
+
+    // ---- VAE decoder (autoencoder/mod.rs:30-36,154-191) ------------------------------
+    const int vc = cfg_.vae_ch;
+    const int dch[4][2] = {{4 * vc, 4 * vc}, {4 * vc, 4 * vc}, {4 * vc, 2 * vc}, {2 * vc, vc}};
+    conv(post_quant_, "autoencoder/post_quant_conv", 4, 4, 1);
+    conv(dec_conv_in_, "autoencoder/decoder/conv_in", 4, 4 * vc, 3);
+    res(dec_mid1_, "autoencoder/decoder/mid/block_1", 4 * vc, 4 * vc, false);
+    dec_attn_.c = 4 * vc;
+    norm(dec_attn_.norm, "autoencoder/decoder/mid/attn/norm", 4 * vc);
+    conv(dec_attn_.q, "autoencoder/decoder/mid/attn/q", 4 * vc, 4 * vc, 1);
+    conv(dec_attn_.k, "autoencoder/decoder/mid/attn/k", 4 * vc, 4 * vc, 1);
+    conv(dec_attn_.v, "autoencoder/decoder/mid/attn/v", 4 * vc, 4 * vc, 1);
+    conv(dec_attn_.proj_out, "autoencoder/decoder/mid/attn/proj_out", 4 * vc, 4 * vc, 1);
+    res(dec_mid2_, "autoencoder/decoder/mid/block_2", 4 * vc, 4 * vc, false);
+    for (int i = 0; i < 4; ++i) {
+        DecBlockW& b = dec_blocks_[i];
+        b.cin = dch[i][0]; b.cout = dch[i][1]; b.has_up = i != 3;
+        const std::string bp = "autoencoder/decoder/blocks/" + std::to_string(i);
+        res(b.res[0], bp + "/res1", b.cin, b.cout, false);
+        res(b.res[1], bp + "/res2", b.cout, b.cout, false);
+        res(b.res[2], bp + "/res3", b.cout, b.cout, false);
+        if (b.has_up) conv(b.upsampler, bp + "/upsampler", b.cout, b.cout, 3);
+    }
+    norm(dec_norm_out_, "autoencoder/decoder/norm_out", vc);
+    conv(dec_conv_out_, "autoencoder/decoder/conv_out", vc, 3, 3);
+}
+
+// =============================================================================
+// weights
+// =============================================================================
+void Engine::set_weight(const char* name, const float* data, int ndim, const int64_t* dims) {
+    if (!name || !data || !dims) throw Error(SDMI_ERR_INVALID, "set_weight: null argument");
+    auto it = entry_index_.find(name);
+    if (it == entry_index_.end()) throw Error(SDMI_ERR_WEIGHTS, std::string("set_weight: unknown tensor '") + name + "'");
+    WeightEntry& e = entries_[it->second];
+    bool ok = ndim == e.ndim;
+    size_t count = 1;
+    for (int i = 0; ok && i < ndim; ++i) { ok = dims[i] == e.dims[i]; count *= (size_t)dims[i]; }
+    if (!ok) {
+        std::ostringstream os;
+        os << "set_weight: '" << name << "' expects shape [";
+        for (int i = 0; i < e.ndim; ++i) os << (i ? "," : "") << e.dims[i];
+        os << "], got [";
+        for (int i = 0; i < ndim; ++i) os << (i ? "," : "") << dims[i];
+        os << "]";
+        throw Error(SDMI_ERR_WEIGHTS, os.str());
+    }
+    SDMI_HIP(hipSetDevice(cfg_.device));
+    if (e.kind == 3) {
+        alphas_.assign(data, data + count);
+        e.set = true;
+        return;
+    }
+    if (!*e.dst) {
+        void* p = nullptr;
+        SDMI_HIP(hipMalloc(&p, count * sizeof(float)));
+        weight_allocs_.push_back(p);
+        *e.dst = reinterpret_cast<float*>(p);
+    }
+    if (e.kind == 2) {
+        SDMI_HIP(hipMemcpy(*e.dst, data, count * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        void* stage = nullptr;
+        SDMI_HIP(hipMalloc(&stage, count * sizeof(float)));
+        hipError_t err = hipMemcpy(stage, data, count * sizeof(float), hipMemcpyHostToDevice);
+        if (err == hipSuccess) {
+            if (e.kind == 0) {
+                const int cout = (int)e.dims[0], cin = (int)e.dims[1], k = (int)e.dims[2];
+                if (!(cin % 32 == 0 || (cin < 32 && cin % 4 == 0))) {
+                    (void)hipFree(stage);
+                    throw Error(SDMI_ERR_UNSUPPORTED, "conv Cin must be a multiple of 32, or < 32 and a multiple of 4");
+                }
+                err = launch_pack_conv_weight((const float*)stage, *e.dst, cout, cin, k, k, stream_);
+            } else {
+                err = launch_pack_linear_weight((const float*)stage, *e.dst, (int)e.dims[0], (int)e.dims[1], stream_);
+            }
+        }
+        if (err == hipSuccess) err = hipStreamSynchronize(stream_);
+        (void)hipFree(stage);
+        SDMI_HIP(err);
+    }
+    e.set = true;
+    finalized_ = false;
+}
+
+void Engine::finalize_weights() {
+    for (auto& e : entries_)
+        if (!e.set) throw Error(SDMI_ERR_WEIGHTS, "finalize_weights: tensor '" + e.name + "' was never set");
+    finalized_ = true;
+}
+
+// npy-dump reader: src/model/load.rs:17-28 -- a 1-D float32 .npy whose first D
+// values are the shape and whose remaining values are the row-major data.
+static std::vector<float> read_npy_f32(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw Error(SDMI_ERR_IO, "cannot open " + path);
+    char magic[8];
+    f.read(magic, 8);
+    if (!f || std::memcmp(magic, "\x93NUMPY", 6) != 0) throw Error(SDMI_ERR_IO, "not an npy file: " + path);
+    uint32_t hlen = 0;
+    if (magic[6] == 1) { uint16_t h16; f.read((char*)&h16, 2); hlen = h16; }
+    else { f.read((char*)&hlen, 4); }
+    std::string header(hlen, ' ');
+    f.read(&header[0], hlen);
+    if (header.find("'<f4'") == std::string::npos && header.find("\"<f4\"") == std::string::npos)
+        throw Error(SDMI_ERR_IO, "npy dtype is not <f4: " + path);
+    if (header.find("'fortran_order': True") != std::string::npos) throw Error(SDMI_ERR_IO, "fortran-order npy: " + path);
+    const std::streampos start = f.tellg();
+    f.seekg(0, std::ios::end);
+    const size_t bytes = (size_t)(f.tellg() - start);
+    f.seekg(start);
+    std::vector<float> v(bytes / sizeof(float));
+    f.read((char*)v.data(), (std::streamsize)(v.size() * sizeof(float)));
+    return v;
+}
+
+void Engine::load_weights_dir(const char* dir) {
+    if (!dir) throw Error(SDMI_ERR_INVALID, "load_weights_dir: null path");
+    for (auto& e : entries_) {
+        const std::string path = std::string(dir) + "/" + e.name + ".npy";
+        std::vector<float> raw = read_npy_f32(path);
+        if ((int)raw.size() < e.ndim) throw Error(SDMI_ERR_WEIGHTS, "truncated tensor file " + path);
+        int64_t dims[4];
+        size_t count = 1;
+        for (int i = 0; i < e.ndim; ++i) { dims[i] = (int64_t)raw[i]; count *= (size_t)dims[i]; }
+        if (raw.size() != count + (size_t)e.ndim) throw Error(SDMI_ERR_WEIGHTS, "shape prefix does not match payload in " + path);
+        set_weight(e.name.c_str(), raw.data() + e.ndim, e.ndim, dims);
+    }
+}
+
+// =============================================================================
+// primitive ops
+// =============================================================================
+Act Engine::new_act(int n, int h, int w, int c) {
+    Act a; a.n = n; a.h = h; a.w = w; a.c = c;
+    a.p = reinterpret_cast<float*>(pool_.alloc(a.bytes()));
+    return a;
+}
+void Engine::release(Act& a) { if (a.p) pool_.free(a.p); a.p = nullptr; }
+
+void Engine::sync() { SDMI_HIP(hipStreamSynchronize(stream_)); }
+
+void Engine::begin_call() {
+    SDMI_HIP(hipSetDevice(cfg_.device));
+    n_kernels_ = 0; flops_ = 0;
+    SDMI_HIP(hipEventRecord(ev0_, stream_));
+}
+void Engine::end_call() {
+    SDMI_HIP(hipEventRecord(ev1_, stream_));
+    SDMI_HIP(hipEventSynchronize(ev1_));
+    float ms = 0;
+    SDMI_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
+    last_ms = ms; last_kernels = n_kernels_; last_flops = flops_;
+}
+
+void Engine::set_option(const std::string& key, const std::string& value) {
+    if (key == "gemm_tile") opt_force_tile_ = (value == "auto") ? -1 : std::stoi(value);
+    else if (key == "splitk") opt_force_splits_ = std::stoi(value);
+    else if (key == "tune") {
+        // "M,N,K=cfg,splits"
+        const size_t eq = value.find('=');
+        if (eq == std::string::npos) throw Error(SDMI_ERR_INVALID, "tune expects M,N,K=cfg,splits");
+        TileChoice tc{0, 1};
+        if (std::sscanf(value.c_str() + eq + 1, "%d,%d", &tc.cfg, &tc.splits) != 2 || tc.cfg < 0 || tc.cfg >= kNumGemmTiles || tc.splits < 1)
+            throw Error(SDMI_ERR_INVALID, "tune: bad value");
+        tuned_[value.substr(0, eq)] = tc;
+    } else if (key == "tune_clear") tuned_.clear();
+    else throw Error(SDMI_ERR_INVALID, "unknown option '" + key + "'");
+}
+
+// Heuristic tile / split-K choice: minimise (work per CU after round-robin
+// placement) / (tile efficiency) + split-K slab traffic.  Overridden per shape by
+// measured entries ("tune" option, see tools/autotune.py).  The K-reduction order
+// depends only on (M,N,K), so a sample's result is independent of where it sits
+// in the batch only for equal M; see DESIGN.md "Determinism".
+TileChoice Engine::choose_tile(int M, int N, int kt_total) const {
+    static const double eff[kNumGemmTiles] = {0.85, 0.75, 0.60, 0.90, 0.75, 0.85, 0.75, 0.85};
+    static const int split_opts[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
+    const int n_cu = 256;
+    double best = 1e300;
+    TileChoice bc{0, 1};
+    for (int c = 0; c < kNumGemmTiles; ++c) {
+        const int bm = gemm_tile_info(c).bm, bn = gemm_tile_info(c).bn;
+        const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+        for (int s : split_opts) {
+            if (s > 1 && kt_total / s < 4) break;
+            const int kt_per = (kt_total + s - 1) / s;
+            const long long wgs = tiles * ((kt_total + kt_per - 1) / kt_per);
+            const double per_cu = (double)((wgs + n_cu - 1) / n_cu);
+            // cycles: one k tile of a bm x bn block = bm*bn*32*2 flop at 256 flop/clk/CU
+            double t = per_cu * (double)bm * bn * kt_per * 64.0 / 256.0 / eff[c];
+            t += 3000.0 * per_cu;  // prologue / epilogue per workgroup
+            if (s > 1) t += 8000.0 + (double)M * N * 4.0 * (s + 1) / (5.0e12 / 2.4e9);  // reduce launch + slab traffic
+            if (t < best) { best = t; bc = {c, s}; }
+        }
+    }
+    return bc;
+}
+
+void Engine::launch_gemm(ConvGemm& p, int force_cfg, int force_splits) {
+    p.kt_total = (p.K + 31) / 32;
+    TileChoice tc;
+    char key[64];
+    std::snprintf(key, sizeof key, "%d,%d,%d", p.M, p.N, p.K);
+    auto it = tuned_.find(key);
+    if (it != tuned_.end()) tc = it->second;
+    else tc = choose_tile(p.M, p.N, p.kt_total);
+    if (opt_force_tile_ >= 0) tc.cfg = opt_force_tile_;
+    if (opt_force_splits_ > 0) tc.splits = opt_force_splits_;
+    if (force_cfg >= 0) tc.cfg = force_cfg;
+    if (force_splits > 0) tc.splits = force_splits;
+    int splits = std::max(1, std::min(tc.splits, p.kt_total));
+    p.kt_per_split = (p.kt_total + splits - 1) / splits;
+    splits = (p.kt_total + p.kt_per_split - 1) / p.kt_per_split;
+    p.splits = splits;
+    const double flops = 2.0 * p.M * (double)p.N * p.K;
+    if (splits == 1) {
+        p.slab_stride = 0;
+        SDMI_HIP(launch_conv_gemm(p, tc.cfg, stream_));
+        count_kernel(flops);
+    } else {
+        p.slab_stride = (long long)p.M * p.N;
+        Buf slab(this, (size_t)splits * p.slab_stride * sizeof(float));
+        float* real_c = p.C;
+        p.C = slab.f();
+        SDMI_HIP(launch_conv_gemm(p, tc.cfg, stream_));
+        count_kernel(flops);
+        SDMI_HIP(launch_splitk_reduce(p, slab.f(), real_c, stream_));
+        count_kernel();
+        p.C = real_c;
+    }
+}
+
+void Engine::conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, const float* rowvec, int rowvec_stride,
+                  const float* resid) {
+    if (x.c != w.cin) throw Error(SDMI_ERR_INVALID, "conv: input channels mismatch");
+    const int pad = w.k == 3 ? 1 : 0;
+    const int hin = x.h << ups, win = x.w << ups;
+    const int ho = (hin + 2 * pad - w.k) / stride + 1, wo = (win + 2 * pad - w.k) / stride + 1;
+    if (y.n != x.n || y.h != ho || y.w != wo || y.c != w.cout) throw Error(SDMI_ERR_INVALID, "conv: output shape mismatch");
+    ConvGemm p{};
+    p.A = x.p; p.Bt = w.bt; p.C = y.p; p.bias = w.bias; p.rowvec = rowvec; p.resid = resid;
+    p.M = x.n * ho * wo; p.N = w.cout; p.K = w.cin * w.k * w.k;
+    p.NB = x.n; p.Hs = x.h; p.Ws = x.w; p.Cin = w.cin; p.Ho = ho; p.Wo = wo;
+    p.KH = w.k; p.KW = w.k; p.stride = stride; p.pad = pad; p.ups = ups;
+    p.ldc = y.c; p.ldr = y.c; p.a_ld = x.c; p.b_ld = p.K; p.rowvec_stride = rowvec_stride;
+    p.CS = std::min(32, w.cin);
+    launch_gemm(p);
+}
+
+void Engine::gemm(const float* A, int a_rows, const float* bt, const float* bias, int cin, int cout, float* C, int ldc,
+                  const float* resid, int ldr) {
+    if (cin % 32) throw Error(SDMI_ERR_UNSUPPORTED, "linear: in_features must be a multiple of 32");
+    ConvGemm p{};
+    p.A = A; p.Bt = bt; p.C = C; p.bias = bias; p.resid = resid;
+    p.M = a_rows; p.N = cout; p.K = cin;
+    p.NB = 1; p.Hs = 1; p.Ws = a_rows; p.Cin = cin; p.Ho = 1; p.Wo = a_rows;
+    p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.ups = 0;
+    p.ldc = ldc; p.ldr = ldr; p.a_ld = cin; p.b_ld = cin; p.rowvec_stride = 0; p.CS = 32;
+    launch_gemm(p);
+}
+
+void Engine::group_norm(const NormW& w, const Act& x, Act& y, bool silu) {
+    const int hw = x.h * x.w;
+    Buf part(this, gn_partials_bytes(x.n, hw, x.c));
+    SDMI_HIP(launch_group_norm(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, 32, 1e-5f, silu, part.p, stream_));
+    count_kernel(); count_kernel();
+}
+
+void Engine::layer_norm(const NormW& w, const float* x, long long rows, float* y) {
+    SDMI_HIP(launch_layer_norm(x, y, w.gamma, w.beta, (int)rows, w.c, 1e-5f, stream_));
+    count_kernel();
+}
+
+// qkv_attention (attention.rs:5-45).  Head dims with a fused instance use the flash
+// kernel; others (the VAE's single 512-wide head) run QK^T -> row softmax -> PV on
+// the GEMM kernel, one (batch, head) at a time.
+void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, int ldk, long long k_bs,
+                       const float* v, int ldv, long long v_bs, float* o, int ldo, long long o_bs, int n, int nq,
+                       int nk, int n_head, int d_head, const int* kv_len_dev, const int* kv_len_host,
+                       const float* mask, int mask_ld) {
+    if (nq <= 0 || nk <= 0) throw Error(SDMI_ERR_INVALID, "attention: empty sequence");
+    const float scale = (float)std::pow((double)d_head, -0.25);
+    if (attn_supported_head_dim(d_head)) {
+        AttnParams p{};
+        p.q = q; p.k = k; p.v = v; p.o = o; p.kv_len = kv_len_dev; p.mask = mask; p.mask_ld = mask_ld;
+        p.n = n; p.n_head = n_head; p.nq = nq; p.nk = nk; p.d_head = d_head;
+        p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+        p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs; p.scale = scale;
+        SDMI_HIP(launch_attention(p, stream_));
+        count_kernel(4.0 * n * n_head * (double)nq * nk * d_head);
+        return;
+    }
+    if (mask) throw Error(SDMI_ERR_UNSUPPORTED, "attention: additive mask is only supported for head dims 40/80/160");
+    if (d_head % 32) throw Error(SDMI_ERR_UNSUPPORTED, "attention: head dim must be 40/80/160 or a multiple of 32");
+    for (int b = 0; b < n; ++b) {
+        const int nkb = kv_len_host ? kv_len_host[b] : nk;
+        if (nkb % 32) throw Error(SDMI_ERR_UNSUPPORTED, "attention (unfused path): key count must be a multiple of 32");
+        Buf s(this, (size_t)nq * nkb * sizeof(float));
+        Buf vt(this, (size_t)d_head * nkb * sizeof(float));
+        for (int h = 0; h < n_head; ++h) {
+            const float* qb = q + b * q_bs + h * d_head;
+            const float* kb = k + b * k_bs + h * d_head;
+            const float* vb = v + b * v_bs + h * d_head;
+            float* ob = o + b * o_bs + h * d_head;
+            ConvGemm g{};
+            g.A = qb; g.Bt = kb; g.C = s.f();
+            g.M = nq; g.N = nkb; g.K = d_head; g.NB = 1; g.Hs = 1; g.Ws = nq; g.Cin = d_head; g.Ho = 1; g.Wo = nq;
+            g.KH = g.KW = 1; g.stride = 1; g.ldc = nkb; g.ldr = nkb; g.a_ld = ldq; g.b_ld = ldk; g.CS = 32;
+            launch_gemm(g);
+            SDMI_HIP(launch_softmax_rows(s.f(), nq, nkb, scale * scale, stream_));
+            count_kernel();
+            SDMI_HIP(launch_transpose2d(vb, vt.f(), nkb, d_head, ldv, stream_));
+            count_kernel();
+            ConvGemm g2{};
+            g2.A = s.f(); g2.Bt = vt.f(); g2.C = ob;
+            g2.M = nq; g2.N = d_head; g2.K = nkb; g2.NB = 1; g2.Hs = 1; g2.Ws = nq; g2.Cin = nkb; g2.Ho = 1; g2.Wo = nq;
+            g2.KH = g2.KW = 1; g2.stride = 1; g2.ldc = ldo; g2.ldr = ldo; g2.a_ld = nkb; g2.b_ld = nkb; g2.CS = 32;
+            launch_gemm(g2);
+        }
+    }
+}
+
+// =============================================================================
+// composite blocks
+// =============================================================================
+// ResBlock::forward (unet/mod.rs:713-733) / ResnetBlock::forward (autoencoder/mod.rs:514-527)
+void Engine::res_block(const ResW& w, const Act& x, Act& y, int step) {
+    Act h1 = new_act(x.n, x.h, x.w, x.c);
+    group_norm(w.norm_in, x, h1, true);
+    Act h2 = new_act(x.n, x.h, x.w, w.cout);
+    const float* rowvec = nullptr;
+    if (w.has_embed) rowvec = us_.temb.at(w.temb_index) + (size_t)step * w.cout;  // shared by the batch (one timestep)
+    conv(w.conv_in, h1, h2, 1, 0, rowvec, 0, nullptr);
+    release(h1);
+    Act h3 = new_act(x.n, x.h, x.w, w.cout);
+    group_norm(w.norm_out, h2, h3, true);
+    release(h2);
+    if (w.has_skip) {
+        conv(w.skip, x, y, 1, 0, nullptr, 0, nullptr);
+        conv(w.conv_out, h3, y, 1, 0, nullptr, 0, y.p);
+    } else {
+        conv(w.conv_out, h3, y, 1, 0, nullptr, 0, x.p);
+    }
+    release(h3);
+}
+
+// SpatialTransformer::forward (unet/mod.rs:462-480) + TransformerBlock (:522-526) +
+// MultiHeadAttention (:642-652) + MLP/GEGLU (:552-591).  NHWC makes the reference's
+// two NCHW<->token transposes disappear.
+void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
+    const int C = w.c, nb = x.n, hw = x.h * x.w;
+    const long long M = x.rows();
+    const int heads = cfg_.n_head, d = C / heads;
+    Act g = new_act(x.n, x.h, x.w, C);
+    group_norm(w.norm, x, g, false);
+    Act h = new_act(x.n, x.h, x.w, C);
+    conv(w.proj_in, g, h, 1, 0, nullptr, 0, nullptr);
+    release(g);
+    {
+        Buf ln(this, (size_t)M * C * 4), q(this, (size_t)M * C * 4), a(this, (size_t)M * C * 4);
+        // self attention
+        layer_norm(w.ln1, h.p, M, ln.f());
+        {
+            Buf k(this, (size_t)M * C * 4), v(this, (size_t)M * C * 4);
+            gemm(ln.f(), (int)M, w.attn1.q.bt, nullptr, C, C, q.f(), C, nullptr, 0);
+            gemm(ln.f(), (int)M, w.attn1.k.bt, nullptr, C, C, k.f(), C, nullptr, 0);
+            gemm(ln.f(), (int)M, w.attn1.v.bt, nullptr, C, C, v.f(), C, nullptr, 0);
+            attention(q.f(), C, (long long)hw * C, k.f(), C, (long long)hw * C, v.f(), C, (long long)hw * C, a.f(), C,
+                      (long long)hw * C, nb, hw, hw, heads, d, nullptr, nullptr, nullptr, 0);
+        }
+        gemm(a.f(), (int)M, w.attn1.out.bt, w.attn1.out.bias, C, C, h.p, C, h.p, C);
+        // cross attention against the hoisted K/V of the text context
+        layer_norm(w.ln2, h.p, M, ln.f());
+        gemm(ln.f(), (int)M, w.attn2.q.bt, nullptr, C, C, q.f(), C, nullptr, 0);
+        const long long cbs = (long long)us_.t_max * C;
+        attention(q.f(), C, (long long)hw * C, us_.kc.at(w.ctx_index), C, cbs, us_.vc.at(w.ctx_index), C, cbs, a.f(),
+                  C, (long long)hw * C, nb, hw, us_.t_max, heads, d, us_.kv_len_dev, us_.kv_len_host.data(), nullptr, 0);
+        gemm(a.f(), (int)M, w.attn2.out.bt, w.attn2.out.bias, C, C, h.p, C, h.p, C);
+        // GEGLU MLP
+        layer_norm(w.ln3, h.p, M, ln.f());
+        {
+            Buf proj(this, (size_t)M * 8 * C * 4), u(this, (size_t)M * 4 * C * 4);
+            gemm(ln.f(), (int)M, w.geglu_proj.bt, w.geglu_proj.bias, C, 8 * C, proj.f(), 8 * C, nullptr, 0);
+            SDMI_HIP(launch_geglu(proj.f(), u.f(), M, 4 * C, stream_));
+            count_kernel();
+            gemm(u.f(), (int)M, w.mlp_lin.bt, w.mlp_lin.bias, 4 * C, C, h.p, C, h.p, C);
+        }
+    }
+    conv(w.proj_out, h, y, 1, 0, nullptr, 0, x.p);
+    release(h);
+}
+
+// ConvSelfAttentionBlock::forward (autoencoder/mod.rs:563-607)
+void Engine::vae_attn(const VaeAttnW& w, const Act& x, Act& y) {
+    const int C = w.c, hw = x.h * x.w;
+    Act g = new_act(x.n, x.h, x.w, C);
+    group_norm(w.norm, x, g, false);
+    Act q = new_act(x.n, x.h, x.w, C), k = new_act(x.n, x.h, x.w, C), v = new_act(x.n, x.h, x.w, C);
+    conv(w.q, g, q, 1, 0, nullptr, 0, nullptr);
+    conv(w.k, g, k, 1, 0, nullptr, 0, nullptr);
+    conv(w.v, g, v, 1, 0, nullptr, 0, nullptr);
+    release(g);
+    Act a = new_act(x.n, x.h, x.w, C);
+    const long long bs = (long long)hw * C;
+    attention(q.p, C, bs, k.p, C, bs, v.p, C, bs, a.p, C, bs, x.n, hw, hw, 1, C, nullptr, nullptr, nullptr, 0);
+    release(q); release(k); release(v);
+    conv(w.proj_out, a, y, 1, 0, nullptr, 0, x.p);
+    release(a);
+}
+
+// =============================================================================
+// UNet driver
+// =============================================================================
+void Engine::unet_release() {
+    for (void* p : us_.owned) pool_.free(p);
+    us_ = UNetState{};
+}
+
+// Hoists everything that does not depend on the latent out of the step loop:
+// the time-embedding MLP for every timestep (unet/mod.rs:115-118), each ResBlock's
+// Linear(SiLU(emb)) (unet/mod.rs:718-719) and each cross-attention's K/V projection
+// of the text context (unet/mod.rs:646-647), which the reference recomputes in all
+// 2*n_steps forwards.
+void Engine::unet_prepare(const float* ctx_packed, int nb, int t_max, const int* kv_len_host,
+                          const std::vector<int>& ts) {
+    unet_release();
+    const int S = (int)ts.size(), mc = cfg_.model_channels, ed = 4 * mc, cd = cfg_.ctx_dim;
+    us_.nb = nb; us_.t_max = t_max; us_.steps = S;
+    us_.kv_len_host.assign(kv_len_host, kv_len_host + nb);
+    auto own = [&](size_t bytes) { void* p = pool_.alloc(bytes); us_.owned.push_back(p); return p; };
+    us_.kv_len_dev = (int*)own(nb * sizeof(int));
+    int* t_dev = (int*)own(S * sizeof(int));
+    SDMI_HIP(hipMemcpyAsync(us_.kv_len_dev, us_.kv_len_host.data(), nb * sizeof(int), hipMemcpyHostToDevice, stream_));
+    SDMI_HIP(hipMemcpyAsync(t_dev, ts.data(), S * sizeof(int), hipMemcpyHostToDevice, stream_));
+    SDMI_HIP(hipStreamSynchronize(stream_));  // host vectors may go away; once per call, outside the step loop
+
+    Buf te(this, (size_t)S * mc * 4), e1(this, (size_t)S * ed * 4), e2(this, (size_t)S * ed * 4);
+    SDMI_HIP(launch_timestep_embedding(t_dev, S, mc, te.f(), stream_));
+    count_kernel();
+    gemm(te.f(), S, lin1_time_.bt, lin1_time_.bias, mc, ed, e1.f(), ed, nullptr, 0);
+    SDMI_HIP(launch_silu(e1.f(), e1.f(), (long long)S * ed, stream_));
+    count_kernel();
+    gemm(e1.f(), S, lin2_time_.bt, lin2_time_.bias, ed, ed, e2.f(), ed, nullptr, 0);
+    SDMI_HIP(launch_silu(e2.f(), e2.f(), (long long)S * ed, stream_));  // SiLU(emb), shared by all ResBlocks
+    count_kernel();
+    us_.temb.resize(res_list_.size());
+    for (size_t i = 0; i < res_list_.size(); ++i) {
+        const ResW& r = *res_list_[i];
+        us_.temb[i] = (float*)own((size_t)S * r.cout * 4);
+        gemm(e2.f(), S, r.lin_embed.bt, r.lin_embed.bias, ed, r.cout, us_.temb[i], r.cout, nullptr, 0);
+    }
+    us_.kc.resize(st_list_.size());
+    us_.vc.resize(st_list_.size());
+    for (size_t i = 0; i < st_list_.size(); ++i) {
+        const SpatialW& s = *st_list_[i];
+        us_.kc[i] = (float*)own((size_t)nb * t_max * s.c * 4);
+        us_.vc[i] = (float*)own((size_t)nb * t_max * s.c * 4);
+        gemm(ctx_packed, nb * t_max, s.attn2.k.bt, nullptr, cd, s.c, us_.kc[i], s.c, nullptr, 0);
+        gemm(ctx_packed, nb * t_max, s.attn2.v.bt, nullptr, cd, s.c, us_.vc[i], s.c, nullptr, 0);
+    }
+}
+
+// UNet::forward (unet/mod.rs:109-143) on NHWC activations
+void Engine::unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc) {
+    const int H = cfg_.latent_h, W = cfg_.latent_w;
+    Act x; x.p = const_cast<float*>(x_nhwc); x.n = nb; x.h = H; x.w = W; x.c = 4;
+    bool x_owned = false;
+    std::vector<Act> skips;
+
+    auto run_block = [&](const UBlock& b, const Act& in) -> Act {
+        switch (b.kind) {
+            case BK_CONV: { Act y = new_act(in.n, in.h, in.w, b.cout); conv(b.conv, in, y, 1, 0, nullptr, 0, nullptr); return y; }
+            case BK_DOWN: { Act y = new_act(in.n, in.h / 2, in.w / 2, b.cout); conv(b.conv, in, y, 2, 0, nullptr, 0, nullptr); return y; }
+            case BK_RES: { Act y = new_act(in.n, in.h, in.w, b.cout); res_block(b.res, in, y, step); return y; }
+            case BK_RES_ST: {
+                Act r = new_act(in.n, in.h, in.w, b.cout); res_block(b.res, in, r, step);
+                Act y = new_act(in.n, in.h, in.w, b.cout); spatial_transformer(b.st, r, y); release(r); return y;
+            }
+            case BK_RES_UP: {
+                Act r = new_act(in.n, in.h, in.w, b.cout); res_block(b.res, in, r, step);
+                Act y = new_act(in.n, in.h * 2, in.w * 2, b.cout); conv(b.up, r, y, 1, 1, nullptr, 0, nullptr); release(r); return y;
+            }
+            case BK_RES_ST_UP: {
+                Act r = new_act(in.n, in.h, in.w, b.cout); res_block(b.res, in, r, step);
+                Act s = new_act(in.n, in.h, in.w, b.cout); spatial_transformer(b.st, r, s); release(r);
+                Act y = new_act(in.n, in.h * 2, in.w * 2, b.cout); conv(b.up, s, y, 1, 1, nullptr, 0, nullptr); release(s); return y;
+            }
+        }
+        throw Error(SDMI_ERR_STATE, "bad block kind");
+    };
+
+    for (const UBlock& b : in_blocks_) {
+        Act y = run_block(b, x);
+        skips.push_back(y);  // saved_inputs.push (unet/mod.rs:126)
+        x = y;
+    }
+    // middle (x aliases skips.back(): not owned here)
+    {
+        Act a = new_act(x.n, x.h, x.w, mid_res1_.cout); res_block(mid_res1_, x, a, step);
+        Act b = new_act(x.n, x.h, x.w, mid_st_.c); spatial_transformer(mid_st_, a, b); release(a);
+        Act c = new_act(x.n, x.h, x.w, mid_res2_.cout); res_block(mid_res2_, b, c, step); release(b);
+        x = c; x_owned = true;
+    }
+    for (const UBlock& b : out_blocks_) {
+        Act s = skips.back(); skips.pop_back();
+        Act cat = new_act(x.n, x.h, x.w, x.c + s.c);  // Tensor::cat(vec![x, saved.pop()], 1) (unet/mod.rs:134)
+        SDMI_HIP(launch_concat_channels(x.p, s.p, cat.p, x.rows(), x.c, s.c, stream_));
+        count_kernel();
+        if (x_owned) release(x);
+        release(s);
+        Act y = run_block(b, cat);
+        release(cat);
+        x = y; x_owned = true;
+    }
+    Act gn = new_act(x.n, x.h, x.w, x.c);
+    group_norm(unet_norm_out_, x, gn, true);
+    release(x);
+    Act out; out.p = out_nhwc; out.n = nb; out.h = H; out.w = W; out.c = 4;
+    conv(unet_conv_out_, gn, out, 1, 0, nullptr, 0, nullptr);
+    release(gn);
+}
+
+void Engine::unet_forward_dev(const float* x_nchw, int t, const float* context, int n, int T, float* out_nchw) {
+    if (!finalized_) throw Error(SDMI_ERR_STATE, "weights not finalized");
+    if (n <= 0 || T <= 0) throw Error(SDMI_ERR_INVALID, "unet_forward: n and T must be positive");
+    const int H = cfg_.latent_h, W = cfg_.latent_w;
+    std::vector<int> kv(n, T), ts(1, t);
+    unet_prepare(context, n, T, kv.data(), ts);
+    Buf xin(this, (size_t)n * H * W * 4 * 4), xout(this, (size_t)n * H * W * 4 * 4);
+    SDMI_HIP(launch_nchw_to_nhwc(x_nchw, xin.f(), n, 4, H, W, 1.0f, stream_));
+    count_kernel();
+    unet_run(xin.f(), n, 0, xout.f());
+    SDMI_HIP(launch_nhwc_to_nchw(xout.f(), out_nchw, n, 4, H, W, stream_));
+    count_kernel();
+    unet_release();
+}
+
+// StableDiffusion::sample_latent + forward_diffuser (stablediffusion/mod.rs:102-192)
+void Engine::sample_latent_dev(const float* context, int n, int T, const float* uncond, int Tu, double scale,
+                               size_t n_steps, const float* init_latent, float* latent_out) {
+    if (!finalized_) throw Error(SDMI_ERR_STATE, "weights not finalized");
+    if (n <= 0 || T <= 0 || Tu <= 0) throw Error(SDMI_ERR_INVALID, "sample_latent: n, T, Tu must be positive");
+    const size_t total = alphas_.size();
+    if (n_steps == 0 || n_steps > total) throw Error(SDMI_ERR_INVALID, "sample_latent: n_steps out of range");
+    const int H = cfg_.latent_h, W = cfg_.latent_w, cd = cfg_.ctx_dim;
+    const int nb = 2 * n, t_max = std::max(T, Tu);
+    const size_t step_size = total / n_steps;                       // :111
+    std::vector<int> ts;
+    for (long long t = (long long)total - 1; t >= 0; t -= (long long)step_size) ts.push_back((int)t);  // :123
+
+    // packed context [2n][t_max][cd]: rows 0..n-1 = uncond (broadcast, :173-177), n..2n-1 = cond
+    Buf ctx(this, (size_t)nb * t_max * cd * 4);
+    SDMI_HIP(hipMemsetAsync(ctx.p, 0, (size_t)nb * t_max * cd * 4, stream_));
+    for (int b = 0; b < n; ++b)
+        SDMI_HIP(hipMemcpyAsync(ctx.f() + (size_t)b * t_max * cd, uncond, (size_t)Tu * cd * 4, hipMemcpyDeviceToDevice, stream_));
+    for (int b = 0; b < n; ++b)
+        SDMI_HIP(hipMemcpyAsync(ctx.f() + (size_t)(n + b) * t_max * cd, context + (size_t)b * T * cd, (size_t)T * cd * 4,
+                                hipMemcpyDeviceToDevice, stream_));
+    std::vector<int> kv(nb);
+    for (int b = 0; b < n; ++b) { kv[b] = Tu; kv[n + b] = T; }
+    unet_prepare(ctx.f(), nb, t_max, kv.data(), ts);
+
+    const long long per_half = (long long)n * H * W * 4;
+    Buf latent(this, per_half * 4), unet_in(this, 2 * per_half * 4), eps(this, 2 * per_half * 4);
+    SDMI_HIP(launch_nchw_to_nhwc(init_latent, latent.f(), n, 4, H, W, 1.0f, stream_));
+    SDMI_HIP(launch_dup_latent(latent.f(), unet_in.f(), per_half, stream_));
+    count_kernel(); count_kernel();
+    for (size_t s = 0; s < ts.size(); ++s) {
+        const size_t t = (size_t)ts[s];
+        const double cur = (double)alphas_[t];                                           // :124-129
+        const double prev = t >= step_size ? (double)alphas_[t - step_size] : 1.0;       // :131-140
+        DdimCoef c{};
+        c.scale = (float)scale;
+        c.sqrt_noise = (float)std::sqrt(1.0 - cur);                                      // :142
+        c.sqrt_cur = (float)std::sqrt(cur);
+        c.sqrt_prev = (float)std::sqrt(prev);
+        c.dir_coef = (float)std::sqrt(1.0 - prev - 0.0);                                 // :153 (sigma = 0)
+        unet_run(unet_in.f(), nb, (int)s, eps.f());
+        SDMI_HIP(launch_cfg_ddim(eps.f(), latent.f(), unet_in.f(), per_half, c, stream_));
+        count_kernel();
+    }
+    SDMI_HIP(launch_nhwc_to_nchw(latent.f(), latent_out, n, 4, H, W, stream_));
+    count_kernel();
+    unet_release();
+}
+
+// Autoencoder::decode_latent (autoencoder/mod.rs:68-71) -> Decoder::forward (:205-217)
+void Engine::decode_one(const float* z_nhwc, int n, Act& img) {
+    const int H = cfg_.latent_h, W = cfg_.latent_w, vc = cfg_.vae_ch;
+    Act z; z.p = const_cast<float*>(z_nhwc); z.n = n; z.h = H; z.w = W; z.c = 4;
+    Act pq = new_act(n, H, W, 4);
+    conv(post_quant_, z, pq, 1, 0, nullptr, 0, nullptr);
+    Act x = new_act(n, H, W, 4 * vc);
+    conv(dec_conv_in_, pq, x, 1, 0, nullptr, 0, nullptr);
+    release(pq);
+    {   // Mid (:457-462)
+        Act a = new_act(n, H, W, 4 * vc); res_block(dec_mid1_, x, a, 0); release(x);
+        Act b = new_act(n, H, W, 4 * vc); vae_attn(dec_attn_, a, b); release(a);
+        Act c = new_act(n, H, W, 4 * vc); res_block(dec_mid2_, b, c, 0); release(b);
+        x = c;
+    }
+    for (int i = 0; i < 4; ++i) {  // DecoderBlock::forward (:308-323)
+        const DecBlockW& b = dec_blocks_[i];
+        for (int r = 0; r < 3; ++r) {
+            Act y = new_act(x.n, x.h, x.w, b.cout);
+            res_block(b.res[r], x, y, 0);
+            release(x);
+            x = y;
+        }
+        if (b.has_up) {
+            Act y = new_act(x.n, x.h * 2, x.w * 2, b.cout);
+            conv(b.upsampler, x, y, 1, 1, nullptr, 0, nullptr);
+            release(x);
+            x = y;
+        }
+    }
+    Act gn = new_act(x.n, x.h, x.w, x.c);
+    group_norm(dec_norm_out_, x, gn, true);
+    release(x);
+    conv(dec_conv_out_, gn, img, 1, 0, nullptr, 0, nullptr);
+    release(gn);
+}
+
+// in_scale = 1/0.18215 for latent_to_image (stablediffusion/mod.rs:71), 1 for decode_latent.
+// Exactly one of img_nchw / rgb_u8 is written.
+void Engine::decode_latent_dev(const float* latent_nchw, int n, float in_scale, float* img_nchw, uint8_t* rgb_u8) {
+    if (!finalized_) throw Error(SDMI_ERR_STATE, "weights not finalized");
+    if (n <= 0) throw Error(SDMI_ERR_INVALID, "decode: n must be positive");
+    const int H = cfg_.latent_h, W = cfg_.latent_w;
+    const size_t lat_elems = (size_t)4 * H * W, img_elems = (size_t)3 * 64 * H * W;
+    for (int i = 0; i < n; ++i) {  // one image at a time: peak activations are ~1 GB per image at 512x512
+        Buf z(this, lat_elems * 4);
+        SDMI_HIP(launch_nchw_to_nhwc(latent_nchw + i * lat_elems, z.f(), 1, 4, H, W, in_scale, stream_));
+        count_kernel();
+        Act img = new_act(1, 8 * H, 8 * W, 3);
+        decode_one(z.f(), 1, img);
+        if (rgb_u8) SDMI_HIP(launch_image_to_u8(img.p, rgb_u8 + i * img_elems, (long long)img_elems, stream_));
+        else SDMI_HIP(launch_nhwc_to_nchw(img.p, img_nchw + i * img_elems, 1, 3, 8 * H, 8 * W, stream_));
+        count_kernel();
+        release(img);
+    }
+}
+
+void Engine::qkv_attention_dev(const float* q, const float* k, const float* v, const float* mask, int mask_ld, int n,
+                               int nq, int nk, int n_state, int n_head, float* out) {
+    if (n <= 0 || nq <= 0 || nk <= 0 || n_head <= 0 || n_state % n_head) throw Error(SDMI_ERR_INVALID, "qkv_attention: bad shape");
+    if (mask && mask_ld < nk) throw Error(SDMI_ERR_INVALID, "qkv_attention: mask_ld < nk");
+    attention(q, n_state, (long long)nq * n_state, k, n_state, (long long)nk * n_state, v, n_state,
+              (long long)nk * n_state, out, n_state, (long long)nq * n_state, n, nq, nk, n_head, n_state / n_head,
+              nullptr, nullptr, mask, mask_ld);
+}
+
+// =============================================================================
+// operator-level entry points (device pointers, reference layouts)
+// =============================================================================
+void Engine::op_group_norm(const float* x, const float* gamma, const float* beta, int n, int c, int h, int w,
+                           int groups, float eps, bool silu, float* out) {
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0 || groups <= 0 || c % groups || c % 4) throw Error(SDMI_ERR_INVALID, "group_norm: bad shape");
+    Act a = new_act(n, h, w, c), b = new_act(n, h, w, c);
+    SDMI_HIP(launch_nchw_to_nhwc(x, a.p, n, c, h, w, 1.0f, stream_));
+    Buf part(this, gn_partials_bytes(n, h * w, c));
+    SDMI_HIP(launch_group_norm(a.p, b.p, gamma, beta, n, h * w, c, groups, eps, silu, part.p, stream_));
+    SDMI_HIP(launch_nhwc_to_nchw(b.p, out, n, c, h, w, stream_));
+    release(a); release(b);
+}
+
+void Engine::op_layer_norm(const float* x, const float* gamma, const float* beta, int rows, int c, float eps, float* out) {
+    if (rows <= 0 || c <= 0) throw Error(SDMI_ERR_INVALID, "layer_norm: bad shape");
+    SDMI_HIP(launch_layer_norm(x, out, gamma, beta, rows, c, eps, stream_));
+}
+
+void Engine::op_conv2d(const float* x, const float* wt, const float* bias, int n, int cin, int h, int wd, int cout,
+                       int k, int stride, int pad, int ups, float* out) {
+    if (!(k == 1 || k == 3) || pad != (k == 3 ? 1 : 0) || !(stride == 1 || stride == 2))
+        throw Error(SDMI_ERR_UNSUPPORTED, "conv2d: only 3x3 pad 1 / 1x1 pad 0, stride 1|2 are on the hot path");
+    if (!(cin % 32 == 0 || (cin < 32 && cin % 4 == 0))) throw Error(SDMI_ERR_UNSUPPORTED, "conv2d: Cin must be a multiple of 32, or < 32 and a multiple of 4");
+    ConvW w; w.cin = cin; w.cout = cout; w.k = k;
+    Buf bt(this, (size_t)cout * cin * k * k * 4);
+    SDMI_HIP(launch_pack_conv_weight(wt, bt.f(), cout, cin, k, k, stream_));
+    w.bt = bt.f(); w.bias = const_cast<float*>(bias);
+    Act a = new_act(n, h, wd, cin);
+    SDMI_HIP(launch_nchw_to_nhwc(x, a.p, n, cin, h, wd, 1.0f, stream_));
+    const int hin = h << ups, win = wd << ups;
+    const int ho = (hin + 2 * pad - k) / stride + 1, wo = (win + 2 * pad - k) / stride + 1;
+    Act y = new_act(n, ho, wo, cout);
+    conv(w, a, y, stride, ups, nullptr, 0, nullptr);
+    SDMI_HIP(launch_nhwc_to_nchw(y.p, out, n, cout, ho, wo, stream_));
+    release(a); release(y);
+}
+
+void Engine::op_linear(const float* x, const float* wt, const float* bias, int rows, int cin, int cout, float* out) {
+    Buf bt(this, (size_t)cin * cout * 4);
+    SDMI_HIP(launch_pack_linear_weight(wt, bt.f(), cin, cout, stream_));
+    gemm(x, rows, bt.f(), bias, cin, cout, out, cout, nullptr, 0);
+}
+
+void Engine::op_geglu(const float* proj, int rows, int hidden, float* out) {
+    SDMI_HIP(launch_geglu(proj, out, rows, hidden, stream_));
+}
+
+void Engine::op_timestep_embedding(int t, int dim, float* out) {
+    Buf td(this, sizeof(int));
+    SDMI_HIP(hipMemcpyAsync(td.p, &t, sizeof(int), hipMemcpyHostToDevice, stream_));
+    SDMI_HIP(hipStreamSynchronize(stream_));
+    SDMI_HIP(launch_timestep_embedding((const int*)td.p, 1, dim, out, stream_));
+    SDMI_HIP(hipStreamSynchronize(stream_));
+}
+
+double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int stride, int ups, int tile_cfg, int splitk,
+                          int iters) {
+    SDMI_HIP(hipSetDevice(cfg_.device));
+    const int pad = k == 3 ? 1 : 0;
+    const int hin = h << ups, win = w << ups;
+    const int ho = (hin + 2 * pad - k) / stride + 1, wo = (win + 2 * pad - k) / stride + 1;
+    Act a = new_act(n, h, w, cin), y = new_act(n, ho, wo, cout);
+    Buf bt(this, (size_t)cout * cin * k * k * 4), bias(this, (size_t)cout * 4);
+    SDMI_HIP(launch_fill_normal(a.p, (long long)a.rows() * cin, 11, stream_));
+    SDMI_HIP(launch_fill_normal(bt.f(), (long long)cout * cin * k * k, 12, stream_));
+    SDMI_HIP(launch_fill_normal(bias.f(), cout, 13, stream_));
+    ConvW cw; cw.cin = cin; cw.cout = cout; cw.k = k; cw.bt = bt.f(); cw.bias = bias.f();
+    const int save_t = opt_force_tile_, save_s = opt_force_splits_;
+    opt_force_tile_ = tile_cfg; opt_force_splits_ = splitk;
+    float ms = 0;
+    try {
+        conv(cw, a, y, stride, ups, nullptr, 0, nullptr);  // warm-up
+        SDMI_HIP(hipEventRecord(ev0_, stream_));
+        for (int i = 0; i < iters; ++i) conv(cw, a, y, stride, ups, nullptr, 0, nullptr);
+        SDMI_HIP(hipEventRecord(ev1_, stream_));
+        SDMI_HIP(hipEventSynchronize(ev1_));
+        SDMI_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
+    } catch (...) {
+        opt_force_tile_ = save_t; opt_force_splits_ = save_s;
+        release(a); release(y);
+        throw;
+    }
+    opt_force_tile_ = save_t; opt_force_splits_ = save_s;
+    release(a); release(y);
+    return (double)ms / std::max(1, iters);
+}
+
+}  // namespace sdmi

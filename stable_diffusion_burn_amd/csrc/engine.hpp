@@ -1,0 +1,229 @@
+// engine.hpp -- host runtime of libsdmi: device pool, weight registry, the static
+// UNet / VAE-decoder launch graphs and the DDIM+CFG sampler.
+//
+// Mirrors the reference's L4/L3 structure:
+//   Engine::sample_latent   <- StableDiffusion::sample_latent  (stablediffusion/mod.rs:102-160)
+//   Engine::unet_run        <- UNet::forward                   (unet/mod.rs:109-143)
+//   Engine::decode          <- Autoencoder::decode_latent      (autoencoder/mod.rs:68-71,205-217)
+// but is not a translation: activations are NHWC, weights are pre-packed for the
+// implicit-GEMM kernel, cond+uncond run as ONE batch-2n forward, time-embedding
+// projections and cross-attention K/V are hoisted out of the step loop, and all
+// launches go to one HIP stream with no host synchronisation inside the loop.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/sdmi.h"
+#include "kernels.hpp"
+
+namespace sdmi {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int st, const std::string& m) : std::runtime_error(m), status(st) {}
+};
+
+#define SDMI_HIP(expr)                                                                                   \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess)                                                                            \
+            throw ::sdmi::Error(SDMI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + \
+                                                  __FILE__ + ":" + std::to_string(__LINE__) + ")");      \
+    } while (0)
+
+// ---- device memory pool: host-side first-fit allocator over big slabs -------------
+// All work is on one stream, so a block may be reused as soon as it is freed
+// (kernel order == program order).  Addresses are deterministic for a given call
+// sequence, which keeps launches graph-capturable.
+class DevPool {
+public:
+    ~DevPool();
+    void* alloc(size_t bytes);
+    void free(void* p);
+    size_t reserved() const { return reserved_; }
+    size_t high_water() const { return high_; }
+
+private:
+    struct Block { size_t off, size; };
+    struct Slab { char* base; size_t size; std::vector<Block> free_list; };
+    std::vector<Slab> slabs_;
+    std::map<void*, std::pair<int, size_t>> live_;  // ptr -> (slab, size)
+    size_t reserved_ = 0, in_use_ = 0, high_ = 0;
+};
+
+struct Act {
+    float* p = nullptr;
+    int n = 0, h = 0, w = 0, c = 0;
+    long long rows() const { return (long long)n * h * w; }
+    size_t bytes() const { return (size_t)rows() * c * sizeof(float); }
+};
+
+struct ConvW { float* bt = nullptr; float* bias = nullptr; int cin = 0, cout = 0, k = 1; };
+struct LinW { float* bt = nullptr; float* bias = nullptr; int cin = 0, cout = 0; };
+struct NormW { float* gamma = nullptr; float* beta = nullptr; int c = 0; };
+
+struct ResW {  // UNet ResBlock (unet/mod.rs:700-734) and VAE ResnetBlock (autoencoder/mod.rs:503-528)
+    NormW norm_in; ConvW conv_in; LinW lin_embed; NormW norm_out; ConvW conv_out; ConvW skip;
+    bool has_skip = false, has_embed = false;
+    int cin = 0, cout = 0, temb_index = -1;
+};
+struct MhaW { LinW q, k, v, out; };
+struct SpatialW {  // SpatialTransformer + TransformerBlock (unet/mod.rs:454-527)
+    NormW norm; ConvW proj_in, proj_out; NormW ln1, ln2, ln3; MhaW attn1, attn2; LinW geglu_proj, mlp_lin;
+    int c = 0, ctx_index = -1;
+};
+enum BlockKind { BK_CONV, BK_DOWN, BK_RES, BK_RES_ST, BK_RES_UP, BK_RES_ST_UP };
+struct UBlock { BlockKind kind; int cin, cout; ConvW conv; ResW res; SpatialW st; ConvW up; };
+struct VaeAttnW { NormW norm; ConvW q, k, v, proj_out; int c = 0; };
+struct DecBlockW { ResW res[3]; ConvW upsampler; bool has_up = false; int cin = 0, cout = 0; };
+
+struct WeightEntry {
+    std::string name;
+    int kind;  // 0 conv (OIHW), 1 linear ([in,out]), 2 vector, 3 alphas (host)
+    int ndim;
+    int64_t dims[4];
+    float** dst;  // where the device pointer lives (null for alphas)
+    bool set = false;
+};
+
+struct TileChoice { int cfg; int splits; };
+
+class Engine {
+public:
+    explicit Engine(const sdmi_config& cfg);
+    ~Engine();
+
+    // weights
+    void set_weight(const char* name, const float* data, int ndim, const int64_t* dims);
+    void load_weights_dir(const char* dir);
+    void finalize_weights();
+    const std::vector<WeightEntry>& entries() const { return entries_; }
+
+    // hot path (device pointers, reference layouts)
+    void unet_forward_dev(const float* x_nchw, int t, const float* context, int n, int T, float* out_nchw);
+    void sample_latent_dev(const float* context, int n, int T, const float* uncond, int Tu, double scale,
+                           size_t n_steps, const float* init_latent, float* latent_out);
+    void decode_latent_dev(const float* latent_nchw, int n, float in_scale, float* img_nchw, uint8_t* rgb_u8);
+    void qkv_attention_dev(const float* q, const float* k, const float* v, const float* mask, int mask_ld, int n,
+                           int nq, int nk, int n_state, int n_head, float* out);
+
+    // operator-level (device pointers, reference layouts)
+    void op_group_norm(const float* x, const float* gamma, const float* beta, int n, int c, int h, int w, int groups,
+                       float eps, bool silu, float* out);
+    void op_layer_norm(const float* x, const float* gamma, const float* beta, int rows, int c, float eps, float* out);
+    void op_conv2d(const float* x, const float* w, const float* bias, int n, int cin, int h, int wd, int cout, int k,
+                   int stride, int pad, int ups, float* out);
+    void op_linear(const float* x, const float* w, const float* bias, int rows, int cin, int cout, float* out);
+    void op_geglu(const float* proj, int rows, int hidden, float* out);
+    void op_timestep_embedding(int t, int dim, float* out);
+    double bench_conv(int n, int cin, int h, int w, int cout, int k, int stride, int ups, int tile_cfg, int splitk,
+                      int iters);
+
+    void set_option(const std::string& key, const std::string& value);
+    void sync();
+    void begin_call();
+    void end_call();
+    double last_ms = 0;
+    long long last_kernels = 0;
+    double last_flops = 0;
+
+    hipStream_t stream() const { return stream_; }
+    DevPool& pool() { return pool_; }
+    const sdmi_config& config() const { return cfg_; }
+    int latent_h() const { return cfg_.latent_h; }
+    int latent_w() const { return cfg_.latent_w; }
+
+    // RAII helper for pool scratch
+    struct Buf {
+        Engine* e; void* p;
+        Buf(Engine* e_, size_t bytes) : e(e_), p(e_->pool_.alloc(bytes)) {}
+        ~Buf() { if (p) e->pool_.free(p); }
+        Buf(const Buf&) = delete;
+        Buf& operator=(const Buf&) = delete;
+        float* f() const { return reinterpret_cast<float*>(p); }
+    };
+
+private:
+    // model definition
+    void add_entry(const std::string& name, int kind, std::initializer_list<int64_t> dims, float** dst);
+    void build_model();
+
+    // primitive ops on device activations (NHWC)
+    Act new_act(int n, int h, int w, int c);
+    void release(Act& a);
+    void conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, const float* rowvec, int rowvec_stride,
+              const float* resid);
+    void gemm(const float* A, int a_rows, const float* bt, const float* bias, int cin, int cout, float* C, int ldc,
+              const float* resid, int ldr);
+    void launch_gemm(ConvGemm& p, int force_cfg = -1, int force_splits = 0);
+    TileChoice choose_tile(int M, int N, int kt_total) const;
+    void group_norm(const NormW& w, const Act& x, Act& y, bool silu);
+    void layer_norm(const NormW& w, const float* x, long long rows, float* y);
+    void attention(const float* q, int ldq, long long q_bs, const float* k, int ldk, long long k_bs, const float* v,
+                   int ldv, long long v_bs, float* o, int ldo, long long o_bs, int n, int nq, int nk, int n_head,
+                   int d_head, const int* kv_len_dev, const int* kv_len_host, const float* mask, int mask_ld);
+
+    // composite blocks
+    void res_block(const ResW& w, const Act& x, Act& y, int step);
+    void spatial_transformer(const SpatialW& w, const Act& x, Act& y);
+    void vae_attn(const VaeAttnW& w, const Act& x, Act& y);
+
+    // UNet driver
+    void unet_prepare(const float* ctx_packed, int nb, int t_max, const int* kv_len_host, const std::vector<int>& ts);
+    void unet_release();
+    void unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc);
+    void decode_one(const float* z_nhwc, int n, Act& img);
+
+    void count_kernel(double flops = 0) { ++n_kernels_; flops_ += flops; }
+
+    sdmi_config cfg_;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    DevPool pool_;
+    std::vector<WeightEntry> entries_;
+    std::map<std::string, int> entry_index_;
+    std::vector<void*> weight_allocs_;
+    bool finalized_ = false;
+    std::vector<float> alphas_;
+    float* alphas_slot_ = nullptr;  // unused device slot (keeps entry handling uniform)
+
+    // UNet
+    LinW lin1_time_, lin2_time_;
+    std::vector<UBlock> in_blocks_, out_blocks_;
+    ResW mid_res1_, mid_res2_;
+    SpatialW mid_st_;
+    NormW unet_norm_out_;
+    ConvW unet_conv_out_;
+    std::vector<ResW*> res_list_;       // index = temb_index
+    std::vector<SpatialW*> st_list_;    // index = ctx_index
+    // VAE decoder
+    ConvW post_quant_, dec_conv_in_, dec_conv_out_;
+    ResW dec_mid1_, dec_mid2_;
+    VaeAttnW dec_attn_;
+    DecBlockW dec_blocks_[4];
+    NormW dec_norm_out_;
+
+    // per-call UNet state
+    struct UNetState {
+        int nb = 0, t_max = 0, steps = 0;
+        std::vector<float*> temb;   // per ResBlock [steps][cout]
+        std::vector<float*> kc, vc; // per SpatialTransformer [nb][t_max][c]
+        int* kv_len_dev = nullptr;
+        std::vector<int> kv_len_host;
+        std::vector<void*> owned;
+    } us_;
+
+    // options
+    int opt_force_tile_ = -1;
+    int opt_force_splits_ = 0;
+    std::map<std::string, TileChoice> tuned_;
+
+    long long n_kernels_ = 0;
+    double flops_ = 0;
+};
+
+}  // namespace sdmi

@@ -1,0 +1,100 @@
+// kernels.hpp -- launch interface of the gfx950 HIP kernels of libsdmi.
+//
+// Layout rules (DESIGN.md "Data layout in HBM"):
+//   activations  NHWC fp32: [NB][H][W][C]  == row-major [M = NB*H*W][C]
+//   conv/linear weights pre-packed "Bt": [N = Cout][K], K ordered
+//       k = (cs * T + tap) * CS + ci   with channel c = cs*CS + ci, tap = ky*KW+kx,
+//       T = KH*KW, CS = min(32, Cin)   (channel-slice outer, taps inner: the nine
+//       taps of one 32-channel slice reuse the same 128-byte pixel segments)
+// Every launcher enqueues on `stream` and returns the hipError of the launch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sdmi {
+
+// ---- implicit-GEMM convolution / linear on fp32 MFMA -------------------------
+// C[m][n] = sum_k A(m,k) * Bt[n][k]  (+ bias[n] + rowvec[sample(m)][n] + resid[m][n])
+// A(m,k) is gathered from the NHWC source: m -> (nb, oy, ox), k -> (tap, channel).
+struct ConvGemm {
+    const float* A;       // source activations [NB][Hs][Ws][Cin]
+    const float* Bt;      // packed weights [N][K]
+    float* C;             // output [M][ldc], or split-K slabs [splits][M][N]
+    const float* bias;    // [N] or null
+    const float* rowvec;  // per-sample per-channel add (time embedding) or null
+    const float* resid;   // residual [M][ldr] or null
+    int M, N, K;
+    int NB, Hs, Ws, Cin;  // source dims (before the optional nearest-2x upsample)
+    int Ho, Wo;           // output spatial dims
+    int KH, KW, stride, pad, ups;
+    int ldc, ldr;
+    int a_ld;             // floats between source pixels (normally Cin)
+    int b_ld;             // floats between Bt rows (normally K)
+    int rowvec_stride;    // floats between samples in rowvec (0: shared by the batch)
+    int CS;               // channel slice width: 32, or Cin when Cin < 32
+    int kt_total;         // number of 32-wide k tiles
+    int kt_per_split;     // k tiles per blockIdx.z slice
+    int splits;           // gridDim.z
+    long long slab_stride;  // M*N when splits > 1
+};
+
+// tile configurations (index = tile_cfg); BM x BN per 256-thread workgroup
+struct GemmTileInfo { int bm, bn; const char* name; };
+constexpr int kNumGemmTiles = 8;
+const GemmTileInfo& gemm_tile_info(int cfg);
+size_t gemm_tile_lds_bytes(int cfg);
+hipError_t launch_conv_gemm(const ConvGemm& p, int tile_cfg, hipStream_t stream);
+// sums split-K slabs in fixed order and applies the epilogue
+hipError_t launch_splitk_reduce(const ConvGemm& p, const float* slabs, float* C, hipStream_t stream);
+// weight packing (done once at load)
+hipError_t launch_pack_conv_weight(const float* w_oihw, float* bt, int cout, int cin, int kh, int kw, hipStream_t s);
+hipError_t launch_pack_linear_weight(const float* w_in_out, float* bt, int cin, int cout, hipStream_t s);
+
+// ---- flash-style attention on fp32 MFMA ---------------------------------------
+struct AttnParams {
+    const float* q; const float* k; const float* v; float* o;
+    const int* kv_len;      // [n] valid keys per batch entry, or null (= nk)
+    const float* mask;      // additive [>=nq][mask_ld] or null
+    int mask_ld;
+    int n, n_head, nq, nk, d_head;
+    int ldq, ldk, ldv, ldo;             // row strides in floats
+    long long q_bs, k_bs, v_bs, o_bs;   // batch strides in floats
+    float scale;                        // d_head^-0.25 applied to q and to k (attention.rs:15-26)
+};
+bool attn_supported_head_dim(int d);
+hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
+// row softmax (in place) for the unfused single-head VAE attention: x[rows][cols] *= scale first
+hipError_t launch_softmax_rows(float* x, int rows, int cols, float scale, hipStream_t stream);
+
+// ---- normalisation (HBM-bound class) --------------------------------------------
+// GroupNorm (+SiLU) over NHWC: stats pass (per-chunk partial sums) + apply pass.
+// `partials` needs gn_partials_bytes(n, hw, c) bytes of scratch.
+size_t gn_partials_bytes(int n, int hw, int c);
+hipError_t launch_group_norm(const float* x, float* y, const float* gamma, const float* beta,
+                             int n, int hw, int c, int n_group, float eps, bool silu,
+                             void* partials, hipStream_t stream);
+hipError_t launch_layer_norm(const float* x, float* y, const float* gamma, const float* beta,
+                             int rows, int c, float eps, hipStream_t stream);
+
+// ---- elementwise / data movement ---------------------------------------------------
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, float scale, hipStream_t s);
+hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, hipStream_t s);
+hipError_t launch_concat_channels(const float* a, const float* b, float* dst, long long rows, int ca, int cb, hipStream_t s);
+hipError_t launch_geglu(const float* proj, float* out, long long rows, int hidden, hipStream_t s);
+hipError_t launch_silu(const float* x, float* y, long long n, hipStream_t s);
+// dst[c][r] = src[r*src_ld + c]
+hipError_t launch_transpose2d(const float* src, float* dst, int rows, int cols, int src_ld, hipStream_t s);
+// out[s][0:half] = cos(t_s * f_i), out[s][half:dim] = sin(t_s * f_i)  (unet/mod.rs:19-30)
+hipError_t launch_timestep_embedding(const int* t_dev, int n_t, int dim, float* out, hipStream_t s);
+// CFG combine + DDIM update on NHWC latents (stablediffusion/mod.rs:152-156,190-191).
+// eps [2n][hw][4] (uncond rows first), latent [n][hw][4] updated in place, and
+// copied twice into unet_in [2n][hw][4] for the next step.
+struct DdimCoef { float scale, sqrt_noise, inv_div /*unused*/, sqrt_cur, sqrt_prev, dir_coef; };
+hipError_t launch_cfg_ddim(const float* eps, float* latent, float* unet_in, long long per_half,
+                           DdimCoef c, hipStream_t s);
+hipError_t launch_dup_latent(const float* latent, float* unet_in, long long per_half, hipStream_t s);
+// (img+1)/2*255 -> clamp -> truncating u8, NHWC in, HWC out (stablediffusion/mod.rs:79-99)
+hipError_t launch_image_to_u8(const float* img_nhwc, uint8_t* out, long long n_elem, hipStream_t s);
+hipError_t launch_fill_normal(float* dst, long long n, uint64_t seed, hipStream_t s);
+
+}  // namespace sdmi

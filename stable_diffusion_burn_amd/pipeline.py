@@ -1,0 +1,347 @@
+"""Host-side mirror of the reference's `StableDiffusion` surface over libsdmi.
+
+The reference's caller (src/bin/sample/main.rs:100-109) uses
+    sd.sample_image(context, unconditional_context, scale, n_steps) -> Vec<Vec<u8>>
+and the public-but-unused `sample_latent`, `latent_to_image`
+(src/model/stablediffusion/mod.rs:69,102), `UNet::forward` (unet/mod.rs:109),
+`Autoencoder::decode_latent` (autoencoder/mod.rs:68) and `qkv_attention`
+(attention.rs:5).  This module keeps those names, argument order and meaning;
+tensors are numpy float32 arrays in the reference's layouts (NCHW latents,
+[n, tokens, channels] sequences).  The Rust toolchain is absent here, so this
+Python layer plays the part of the Rust shim in ffi/sdmi.rs; both only marshal
+arguments into the C ABI -- all arithmetic happens in the HIP library.
+
+Errors: the reference panics on shape errors; here they raise SdmiError (from
+the C status) or ValueError (caught before the call).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _capi
+from ._capi import SdmiConfig, SdmiError, check, load_library
+
+__all__ = ["ModelConfig", "StableDiffusion", "UNet", "Autoencoder", "qkv_attention", "SdmiError"]
+
+
+@dataclass(frozen=True)
+class ModelConfig:
+    """Hyper-parameters hard-coded in the reference's *Config::init
+    (unet/mod.rs:36-92, autoencoder/mod.rs:30-36, stablediffusion/mod.rs:116)."""
+    model_channels: int = 320
+    n_head: int = 8
+    ctx_dim: int = 768
+    latent_h: int = 64
+    latent_w: int = 64
+    vae_ch: int = 128
+
+
+def _f32(a, shape=None, name="array") -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(a.shape)}")
+    return a
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class StableDiffusion:
+    """`StableDiffusion<B>` (src/model/stablediffusion/mod.rs:41-48) on one MI355X."""
+
+    def __init__(self, config: ModelConfig = ModelConfig(), device: int = 0):
+        self._lib = load_library()
+        self.config = config
+        cfg = SdmiConfig()
+        check(self._lib.sdmi_default_config(C.byref(cfg)))
+        cfg.device = device
+        cfg.model_channels = config.model_channels
+        cfg.n_head = config.n_head
+        cfg.ctx_dim = config.ctx_dim
+        cfg.latent_h = config.latent_h
+        cfg.latent_w = config.latent_w
+        cfg.vae_ch = config.vae_ch
+        self._ctx = C.c_void_p()
+        check(self._lib.sdmi_create(C.byref(self._ctx), C.byref(cfg)))
+        self.unet = UNet(self)
+        self.autoencoder = Autoencoder(self)
+
+    # ---- lifecycle -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.sdmi_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- weights ---------------------------------------------------------------
+    def weight_specs(self):
+        """[(name, shape)] of every tensor the hot path needs (reference dump names)."""
+        n = self._lib.sdmi_weight_count(self._ctx)
+        if n < 0:
+            check(n)
+        out = []
+        name = C.c_char_p()
+        ndim = C.c_int32()
+        dims = (C.c_int64 * 4)()
+        for i in range(n):
+            check(self._lib.sdmi_weight_info(self._ctx, i, C.byref(name), C.byref(ndim), dims))
+            out.append((name.value.decode(), tuple(int(dims[k]) for k in range(ndim.value))))
+        return out
+
+    def set_weight(self, name: str, array) -> None:
+        a = np.ascontiguousarray(array, dtype=np.float32)
+        dims = (C.c_int64 * max(1, a.ndim))(*a.shape)
+        check(self._lib.sdmi_set_weight(self._ctx, name.encode(), _fp(a), a.ndim, dims))
+
+    def load_weights(self, provider) -> None:
+        """Pull every tensor from `provider.get(name, shape, kind, fan_in)`
+        (synthetic.SyntheticWeights) -- the counterpart of load_stable_diffusion
+        (stablediffusion/load.rs:16-33) for seeded synthetic parameters."""
+        specs = self.weight_specs()
+        shapes = dict(specs)
+        for name, shape in specs:
+            if name == "alphas_cumprod":
+                from .synthetic import alphas_cumprod
+                self.set_weight(name, alphas_cumprod(shape[0]))
+                continue
+            parent, leaf = name.rsplit("/", 1)
+            wshape = shapes.get(parent + "/weight")
+            if leaf == "weight":
+                if len(shape) == 4:
+                    arr = provider.get(name, shape, "w", shape[1] * shape[2] * shape[3])
+                elif len(shape) == 2:
+                    arr = provider.get(name, shape, "w", shape[0])  # Linear weight is [in, out]
+                else:
+                    arr = provider.get(name, shape, "gamma")
+            else:  # bias
+                if wshape is not None and len(wshape) == 4:
+                    arr = provider.get(name, shape, "b", wshape[1] * wshape[2] * wshape[3])
+                elif wshape is not None and len(wshape) == 2:
+                    arr = provider.get(name, shape, "b", wshape[0])
+                else:
+                    arr = provider.get(name, shape, "beta")
+            self.set_weight(name, arr)
+        check(self._lib.sdmi_finalize_weights(self._ctx))
+
+    def load_weights_dir(self, dump_dir: str) -> None:
+        """npy-dump tree written by the reference's python/ exporters
+        (load_stable_diffusion, stablediffusion/load.rs:16-33)."""
+        check(self._lib.sdmi_load_weights_dir(self._ctx, str(dump_dir).encode()))
+        check(self._lib.sdmi_finalize_weights(self._ctx))
+
+    # ---- reference surface -------------------------------------------------------
+    def _check_ctx(self, context, unconditional_context):
+        cd = self.config.ctx_dim
+        context = _f32(context, name="context")
+        if context.ndim != 3 or context.shape[2] != cd:
+            raise ValueError(f"context must be [n, T, {cd}], got {context.shape}")
+        uncond = _f32(unconditional_context, name="unconditional_context")
+        if uncond.ndim != 2 or uncond.shape[1] != cd:
+            raise ValueError(f"unconditional_context must be [Tu, {cd}], got {uncond.shape}")
+        return context, uncond
+
+    def sample_latent(self, context, unconditional_context, unconditional_guidance_scale: float, n_steps: int,
+                      init_latent=None, seed: int = 0) -> np.ndarray:
+        """stablediffusion/mod.rs:102-160 -> latent [n,4,h,w].  `init_latent`
+        is x_T (the reference draws it from an unseeded RNG)."""
+        context, uncond = self._check_ctx(context, unconditional_context)
+        n, T, _ = context.shape
+        h, w = self.config.latent_h, self.config.latent_w
+        out = np.empty((n, 4, h, w), dtype=np.float32)
+        x0 = None if init_latent is None else _f32(init_latent, (n, 4, h, w), "init_latent")
+        check(self._lib.sdmi_sample_latent(self._ctx, _fp(context), n, T, _fp(uncond), uncond.shape[0],
+                                           float(unconditional_guidance_scale), int(n_steps),
+                                           None if x0 is None else _fp(x0), int(seed), _fp(out)))
+        return out
+
+    def latent_to_image(self, latent) -> np.ndarray:
+        """stablediffusion/mod.rs:69-100 -> uint8 [n, 8h, 8w, 3] (the reference's Vec<Vec<u8>>)."""
+        h, w = self.config.latent_h, self.config.latent_w
+        latent = _f32(latent, name="latent")
+        if latent.ndim != 4 or latent.shape[1:] != (4, h, w):
+            raise ValueError(f"latent must be [n,4,{h},{w}], got {latent.shape}")
+        n = latent.shape[0]
+        out = np.empty((n, 8 * h, 8 * w, 3), dtype=np.uint8)
+        check(self._lib.sdmi_latent_to_image(self._ctx, _fp(latent), n, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def sample_image(self, context, unconditional_context, unconditional_guidance_scale: float, n_steps: int,
+                     init_latent=None, seed: int = 0) -> np.ndarray:
+        """stablediffusion/mod.rs:51-67 -> uint8 [n, 8h, 8w, 3]."""
+        context, uncond = self._check_ctx(context, unconditional_context)
+        n, T, _ = context.shape
+        h, w = self.config.latent_h, self.config.latent_w
+        out = np.empty((n, 8 * h, 8 * w, 3), dtype=np.uint8)
+        x0 = None if init_latent is None else _f32(init_latent, (n, 4, h, w), "init_latent")
+        check(self._lib.sdmi_sample_image(self._ctx, _fp(context), n, T, _fp(uncond), uncond.shape[0],
+                                          float(unconditional_guidance_scale), int(n_steps),
+                                          None if x0 is None else _fp(x0), int(seed),
+                                          out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    # ---- device-pointer variants (zero copy; pointers are ints, e.g. torch .data_ptr()) ----
+    def sample_image_dev(self, context_ptr: int, n: int, T: int, uncond_ptr: int, Tu: int, scale: float,
+                         n_steps: int, init_latent_ptr: int, rgb_out_ptr: int) -> None:
+        check(self._lib.sdmi_sample_image_dev(self._ctx, context_ptr, n, T, uncond_ptr, Tu, float(scale),
+                                              int(n_steps), init_latent_ptr, rgb_out_ptr))
+
+    def sample_latent_dev(self, context_ptr: int, n: int, T: int, uncond_ptr: int, Tu: int, scale: float,
+                          n_steps: int, init_latent_ptr: int, latent_out_ptr: int) -> None:
+        check(self._lib.sdmi_sample_latent_dev(self._ctx, context_ptr, n, T, uncond_ptr, Tu, float(scale),
+                                               int(n_steps), init_latent_ptr, latent_out_ptr))
+
+    def latent_to_image_dev(self, latent_ptr: int, n: int, rgb_out_ptr: int) -> None:
+        check(self._lib.sdmi_latent_to_image_dev(self._ctx, latent_ptr, n, rgb_out_ptr))
+
+    # ---- introspection ------------------------------------------------------------------
+    def synchronize(self):
+        check(self._lib.sdmi_synchronize(self._ctx))
+
+    def set_option(self, key: str, value) -> None:
+        check(self._lib.sdmi_set_option(self._ctx, key.encode(), str(value).encode()))
+
+    def last_call_stats(self) -> dict:
+        ms, nk, fl = C.c_double(), C.c_int64(), C.c_double()
+        check(self._lib.sdmi_last_call_stats(self._ctx, C.byref(ms), C.byref(nk), C.byref(fl)))
+        return {"gpu_ms": ms.value, "kernels": nk.value, "flops": fl.value}
+
+    def bench_conv(self, n, cin, h, w, cout, k=3, stride=1, upsample2x=0, tile_cfg=-1, splitk=0, iters=10) -> float:
+        ms = C.c_double()
+        check(self._lib.sdmi_bench_conv(self._ctx, n, cin, h, w, cout, k, stride, upsample2x, tile_cfg, splitk, iters,
+                                        C.byref(ms)))
+        return ms.value
+
+    # ---- operator-level entry points (parity tests) ----------------------------------------
+    def op_group_norm(self, x, gamma, beta, n_group=32, eps=1e-5, silu=False):
+        x = _f32(x)
+        n, c, h, w = x.shape
+        out = np.empty_like(x)
+        check(self._lib.sdmi_op_group_norm(self._ctx, _fp(x), _fp(_f32(gamma, (c,))), _fp(_f32(beta, (c,))), n, c, h, w,
+                                           n_group, eps, int(silu), _fp(out)))
+        return out
+
+    def op_layer_norm(self, x, gamma, beta, eps=1e-5):
+        x = _f32(x)
+        c = x.shape[-1]
+        rows = x.size // c
+        out = np.empty_like(x)
+        check(self._lib.sdmi_op_layer_norm(self._ctx, _fp(x), _fp(_f32(gamma, (c,))), _fp(_f32(beta, (c,))), rows, c,
+                                           eps, _fp(out)))
+        return out
+
+    def op_conv2d(self, x, weight, bias=None, stride=1, pad=None, upsample2x=False):
+        x = _f32(x)
+        weight = _f32(weight)
+        n, cin, h, w = x.shape
+        cout, cin2, k, k2 = weight.shape
+        if cin2 != cin or k != k2:
+            raise ValueError("conv2d: weight shape does not match input")
+        if pad is None:
+            pad = 1 if k == 3 else 0
+        ups = 1 if upsample2x else 0
+        ho = ((h << ups) + 2 * pad - k) // stride + 1
+        wo = ((w << ups) + 2 * pad - k) // stride + 1
+        out = np.empty((n, cout, ho, wo), dtype=np.float32)
+        b = None if bias is None else _f32(bias, (cout,))
+        check(self._lib.sdmi_op_conv2d(self._ctx, _fp(x), _fp(weight), None if b is None else _fp(b), n, cin, h, w, cout,
+                                       k, stride, pad, ups, _fp(out)))
+        return out
+
+    def op_linear(self, x, weight, bias=None):
+        x = _f32(x)
+        weight = _f32(weight)
+        cin, cout = weight.shape
+        rows = x.size // cin
+        out = np.empty(x.shape[:-1] + (cout,), dtype=np.float32)
+        b = None if bias is None else _f32(bias, (cout,))
+        check(self._lib.sdmi_op_linear(self._ctx, _fp(x), _fp(weight), None if b is None else _fp(b), rows, cin, cout,
+                                       _fp(out)))
+        return out
+
+    def op_geglu(self, proj):
+        proj = _f32(proj)
+        hidden = proj.shape[-1] // 2
+        rows = proj.size // (2 * hidden)
+        out = np.empty(proj.shape[:-1] + (hidden,), dtype=np.float32)
+        check(self._lib.sdmi_op_geglu(self._ctx, _fp(proj), rows, hidden, _fp(out)))
+        return out
+
+    def op_timestep_embedding(self, t: int, dim: int):
+        out = np.empty((1, dim), dtype=np.float32)
+        check(self._lib.sdmi_op_timestep_embedding(self._ctx, int(t), dim, _fp(out)))
+        return out
+
+    def qkv_attention(self, q, k, v, mask, n_head: int):
+        """attention.rs:5-45: q [n,nq,c], k,v [n,nk,c], mask [>=nq, >=nk] or None."""
+        q, k, v = _f32(q), _f32(k), _f32(v)
+        n, nq, c = q.shape
+        nk = k.shape[1]
+        if k.shape != (n, nk, c) or v.shape != (n, nk, c):
+            raise ValueError("qkv_attention: q/k/v shapes disagree")
+        out = np.empty_like(q)
+        m = None if mask is None else _f32(mask)
+        check(self._lib.sdmi_qkv_attention(self._ctx, _fp(q), _fp(k), _fp(v), None if m is None else _fp(m),
+                                           0 if m is None else m.shape[1], n, nq, nk, c, n_head, _fp(out)))
+        return out
+
+
+class UNet:
+    """`UNet<B>` (src/model/unet/mod.rs:96-143): forward(x, timesteps, context)."""
+
+    def __init__(self, sd: StableDiffusion):
+        self._sd = sd
+
+    def forward(self, x, timesteps, context) -> np.ndarray:
+        sd = self._sd
+        h, w = sd.config.latent_h, sd.config.latent_w
+        x = _f32(x, name="x")
+        if x.ndim != 4 or x.shape[1:] != (4, h, w):
+            raise ValueError(f"x must be [n,4,{h},{w}], got {x.shape}")
+        ts = np.atleast_1d(np.asarray(timesteps)).astype(np.int64)
+        if ts.size != 1:
+            raise ValueError("the reference passes a single shared timestep (unet/mod.rs:112, Tensor<B,1,Int> of len 1)")
+        context = _f32(context, name="context")
+        n = x.shape[0]
+        if context.ndim != 3 or context.shape[0] != n or context.shape[2] != sd.config.ctx_dim:
+            raise ValueError(f"context must be [{n}, T, {sd.config.ctx_dim}], got {context.shape}")
+        out = np.empty_like(x)
+        check(sd._lib.sdmi_unet_forward(sd._ctx, _fp(x), int(ts[0]), _fp(context), n, context.shape[1], _fp(out)))
+        return out
+
+
+class Autoencoder:
+    """Decoder half of `Autoencoder<B>` (src/model/autoencoder/mod.rs:47-71)."""
+
+    def __init__(self, sd: StableDiffusion):
+        self._sd = sd
+
+    def decode_latent(self, latent) -> np.ndarray:
+        sd = self._sd
+        h, w = sd.config.latent_h, sd.config.latent_w
+        latent = _f32(latent, name="latent")
+        if latent.ndim != 4 or latent.shape[1:] != (4, h, w):
+            raise ValueError(f"latent must be [n,4,{h},{w}], got {latent.shape}")
+        n = latent.shape[0]
+        out = np.empty((n, 3, 8 * h, 8 * w), dtype=np.float32)
+        check(sd._lib.sdmi_decode_latent(sd._ctx, _fp(latent), n, _fp(out)))
+        return out
+
+
+def qkv_attention(sd: StableDiffusion, q, k, v, mask, n_head: int):
+    """Free-function form, as in the reference (attention.rs:5)."""
+    return sd.qkv_attention(q, k, v, mask, n_head)
