@@ -1,0 +1,152 @@
+"""Model-level parity of the HIP path (through the C ABI) against the CPU oracle.
+
+Runs the half-width model (same topology, same head dims 40/80/160, 16x16
+latent) so the oracle finishes in seconds; the full-size configuration is
+checked against committed golden fixtures in test_golden_gpu.py.
+
+Tolerances (BASELINE.json north_star: max per-pixel |delta| < 1e-3 vs the fp32
+reference): absolute 1e-3 on latents / float RGB, with the fp64
+oracle as tie-breaker -- |gpu - f64| <= max(1e-3, 2*|cpu_f32 - f64|) -- and
+<= 1 LSB on the u8 image (the reference truncates, so a +-1 flip is expected
+wherever |delta|*127.5 crosses an integer).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sd_oracle as O
+from stable_diffusion_burn_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(d, n, T, Tu):
+    lat = np.stack([syn.initial_latent(i, d.latent_h, d.latent_w) for i in range(n)])
+    ctx = np.stack([syn.cond_context(i, T, d.ctx_dim) for i in range(n)])
+    unc = syn.uncond_context(Tu, d.ctx_dim)
+    return lat, ctx, unc
+
+
+def _oracles(synth, d):
+    a = syn.alphas_cumprod()
+    return (O.StableDiffusionOracle(synth, a, d, torch.float32), O.StableDiffusionOracle(synth, a, d, torch.float64))
+
+
+def _assert_close(got, ref32, ref64, what, atol=1e-3):
+    got = np.asarray(got, np.float64)
+    r32 = np.asarray(ref32, np.float64)
+    r64 = np.asarray(ref64, np.float64)
+    assert np.isfinite(got).all(), f"{what}: non-finite"
+    e64 = np.abs(got - r64).max()
+    e32 = np.abs(r32 - r64).max()
+    bound = max(atol, 2 * e32)
+    assert e64 <= bound, f"{what}: max|gpu-f64|={e64:.3e} > {bound:.3e} (|f32-f64|={e32:.3e}, |gpu-f32|={np.abs(got - r32).max():.3e})"
+    return e64, e32
+
+
+@pytest.mark.parametrize("t", [999, 49])
+def test_unet_forward(sd_tiny, synth, tiny_dims, t):
+    """UNet::forward (unet/mod.rs:109-143), batch 2 with an unpadded context (T = 7)."""
+    d = tiny_dims
+    lat, ctx, _ = _inputs(d, 2, 7, 2)
+    o32, o64 = _oracles(synth, d)
+    got = sd_tiny.unet.forward(lat, [t], ctx)
+    r32 = o32.unet.forward(torch.from_numpy(lat), t, torch.from_numpy(ctx)).numpy()
+    r64 = o64.unet.forward(torch.from_numpy(lat), t, torch.from_numpy(ctx)).numpy()
+    e64, e32 = _assert_close(got, r32, r64, f"unet_forward t={t}", atol=1e-4)
+    print(f"unet t={t}: |gpu-f64|={e64:.2e} |f32-f64|={e32:.2e}")
+
+
+def test_unet_forward_batch_independent(sd_tiny, tiny_dims):
+    """Per-sample results do not depend on the batch (batch = n independent samples)."""
+    d = tiny_dims
+    lat, ctx, _ = _inputs(d, 2, 5, 2)
+    both = sd_tiny.unet.forward(lat, [500], ctx)
+    one = sd_tiny.unet.forward(lat[1:2], [500], ctx[1:2])
+    assert np.abs(both[1:2] - one).max() <= 1e-5
+
+
+@pytest.mark.parametrize("n_steps,scale,T,Tu", [(1, 1.0, 7, 7), (4, 7.5, 7, 2), (5, 7.5, 3, 6)])
+def test_sample_latent(sd_tiny, synth, tiny_dims, n_steps, scale, T, Tu):
+    """sample_latent (stablediffusion/mod.rs:102-160): DDIM + CFG, Tc != Tu, config-1 style 1 step."""
+    d = tiny_dims
+    lat, ctx, unc = _inputs(d, 1, T, Tu)
+    o32, o64 = _oracles(synth, d)
+    got = sd_tiny.sample_latent(ctx, unc, scale, n_steps, init_latent=lat)
+    args = (torch.from_numpy(ctx), torch.from_numpy(unc), scale, n_steps, torch.from_numpy(lat))
+    r32 = o32.sample_latent(*args).numpy()
+    r64 = o64.sample_latent(*args).numpy()
+    e64, e32 = _assert_close(got, r32, r64, f"sample_latent steps={n_steps}")
+    print(f"sample_latent steps={n_steps}: |gpu-f64|={e64:.2e} |f32-f64|={e32:.2e} absmax={np.abs(r64).max():.1f}")
+
+
+def test_sample_latent_batch2_matches_single(sd_tiny, tiny_dims):
+    d = tiny_dims
+    lat, ctx, unc = _inputs(d, 2, 7, 2)
+    both = sd_tiny.sample_latent(ctx, unc, 7.5, 3, init_latent=lat)
+    for i in range(2):
+        one = sd_tiny.sample_latent(ctx[i:i + 1], unc, 7.5, 3, init_latent=lat[i:i + 1])
+        scale = max(1.0, np.abs(one).max())
+        assert np.abs(both[i:i + 1] - one).max() <= 2e-5 * scale, f"sample {i}"
+
+
+def test_decode_latent(sd_tiny, synth, tiny_dims):
+    """Autoencoder::decode_latent (autoencoder/mod.rs:68-71, 205-217)."""
+    d = tiny_dims
+    z = (np.stack([syn.initial_latent(10 + i, d.latent_h, d.latent_w) for i in range(2)]) * 3.0).astype(np.float32)
+    o32, o64 = _oracles(synth, d)
+    got = sd_tiny.autoencoder.decode_latent(z)
+    r32 = o32.decoder.decode_latent(torch.from_numpy(z)).numpy()
+    r64 = o64.decoder.decode_latent(torch.from_numpy(z)).numpy()
+    e64, e32 = _assert_close(got, r32, r64, "decode_latent")
+    print(f"decode: |gpu-f64|={e64:.2e} |f32-f64|={e32:.2e} absmax={np.abs(r64).max():.1f}")
+
+
+def test_latent_to_image_and_sample_image(sd_tiny, synth, tiny_dims):
+    """latent_to_image (stablediffusion/mod.rs:69-100) and the whole sample_image (:51-67): u8 within 1 LSB."""
+    d = tiny_dims
+    lat, ctx, unc = _inputs(d, 1, 7, 2)
+    o32, _ = _oracles(synth, d)
+    z = (syn.initial_latent(3, d.latent_h, d.latent_w)[None] * 0.5).astype(np.float32)
+    img = sd_tiny.latent_to_image(z)
+    ref, _ = o32.latent_to_image(torch.from_numpy(z))
+    assert img.shape == ref.shape and img.dtype == np.uint8
+    assert np.abs(img.astype(np.int16) - ref.astype(np.int16)).max() <= 1
+    # not a constant image
+    assert img.std() > 1.0
+
+    full = sd_tiny.sample_image(ctx, unc, 7.5, 2, init_latent=lat)
+    ref_full = o32.sample_image(torch.from_numpy(ctx), torch.from_numpy(unc), 7.5, 2, torch.from_numpy(lat))
+    diff = np.abs(full.astype(np.int16) - ref_full.astype(np.int16))
+    assert diff.max() <= 1, f"u8 image differs by {diff.max()} LSB at {np.count_nonzero(diff > 1)} pixels"
+
+
+def test_sample_image_seed_path(sd_tiny, tiny_dims):
+    """init_latent = NULL draws x_T on the device from `seed` (deterministic, seed-dependent)."""
+    d = tiny_dims
+    _, ctx, unc = _inputs(d, 1, 7, 2)
+    a = sd_tiny.sample_latent(ctx, unc, 7.5, 1, init_latent=None, seed=5)
+    b = sd_tiny.sample_latent(ctx, unc, 7.5, 1, init_latent=None, seed=5)
+    c = sd_tiny.sample_latent(ctx, unc, 7.5, 1, init_latent=None, seed=6)
+    assert np.array_equal(a, b) and not np.array_equal(a, c) and np.isfinite(a).all()
+
+
+def test_run_to_run_bit_reproducible(sd_tiny, tiny_dims):
+    """No atomics in the results path: identical bits on repeated calls."""
+    d = tiny_dims
+    lat, ctx, unc = _inputs(d, 1, 7, 2)
+    a = sd_tiny.sample_image(ctx, unc, 7.5, 2, init_latent=lat)
+    b = sd_tiny.sample_image(ctx, unc, 7.5, 2, init_latent=lat)
+    assert np.array_equal(a, b)
+
+
+def test_shape_errors_raise(sd_tiny, tiny_dims):
+    d = tiny_dims
+    lat, ctx, unc = _inputs(d, 1, 7, 2)
+    with pytest.raises(ValueError):
+        sd_tiny.sample_latent(ctx[:, :, :-1], unc, 7.5, 1, init_latent=lat)
+    with pytest.raises(ValueError):
+        sd_tiny.latent_to_image(lat[:, :3])
+    from stable_diffusion_burn_amd import SdmiError
+    with pytest.raises(SdmiError):
+        sd_tiny.sample_latent(ctx, unc, 7.5, 0, init_latent=lat)  # n_steps = 0

@@ -1,0 +1,239 @@
+"""Operator-level parity: each HIP kernel, called through the C ABI, against the
+CPU oracle (fp64 restatement of the reference op) on seeded inputs.
+
+Tolerance (fp32 path, BASELINE.json: max |delta| < 1e-3 on the final image):
+per-op budget  max|gpu - f64| <= 2e-5 * max(1, max|ref|)  -- two orders below
+the end-to-end bar, a few times fp32 round-off of a K~3000 dot product.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sd_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-5
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+def _check(got, ref64, what, rtol=RTOL):
+    ref = np.asarray(ref64, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
+    assert np.isfinite(got).all(), f"{what}: non-finite output"
+    err = np.abs(got - ref)
+    bound = rtol * max(1.0, float(np.abs(ref).max()))
+    idx = np.unravel_index(int(err.argmax()), err.shape)
+    assert err.max() <= bound, (f"{what}: max|d|={err.max():.3e} > {bound:.3e} at {idx} "
+                                f"(got {got[idx]:.6f}, ref {ref[idx]:.6f}); mean|d|={err.mean():.3e}")
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a)).double()
+
+
+# ---- GroupNorm (+SiLU): groupnorm/mod.rs:53-82, silu.rs:14-16 -----------------------------
+@pytest.mark.parametrize("n,c,h,w", [(2, 320, 16, 16), (1, 1920, 8, 8), (1, 128, 32, 32), (2, 2560, 8, 8),
+                                     (1, 960, 16, 16), (1, 32, 4, 4), (2, 640, 1, 1), (1, 512, 64, 64)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_group_norm(sd_ops, n, c, h, w, silu):
+    g = _rng(c * 7 + h)
+    x = (g.standard_normal((n, c, h, w)) * 1.7 + 0.9).astype(np.float32)
+    gamma = (1 + 0.1 * g.standard_normal(c)).astype(np.float32)
+    beta = (0.1 * g.standard_normal(c)).astype(np.float32)
+    got = sd_ops.op_group_norm(x, gamma, beta, 32, 1e-5, silu)
+    ref = O.group_norm(_t(x), _t(gamma), _t(beta), 32, 1e-5)
+    if silu:
+        ref = O.silu(ref)
+    _check(got, ref.numpy(), f"group_norm{(n, c, h, w)} silu={silu}")
+
+
+def test_group_norm_large_mean(sd_ops):
+    """|mean| >> std stresses the E[x^2]-mean^2 form of the stats pass."""
+    g = _rng(5)
+    x = (g.standard_normal((1, 320, 32, 32)) * 0.05 + 30.0).astype(np.float32)
+    gamma = np.ones(320, np.float32)
+    beta = np.zeros(320, np.float32)
+    got = sd_ops.op_group_norm(x, gamma, beta, 32, 1e-5, False)
+    ref = O.group_norm(_t(x), _t(gamma), _t(beta), 32, 1e-5).numpy()
+    # x carries ~2e-6 relative quantisation of its own; allow 2e-2 absolute on O(1) outputs
+    assert np.abs(got - ref).max() < 2e-2
+
+
+# ---- LayerNorm: unet/mod.rs:523-525 --------------------------------------------------------
+@pytest.mark.parametrize("rows,c", [(64, 160), (257, 320), (100, 640), (33, 1280), (5, 2048)])
+def test_layer_norm(sd_ops, rows, c):
+    g = _rng(rows + c)
+    x = (g.standard_normal((rows, c)) * 2 - 0.5).astype(np.float32)
+    gamma = (1 + 0.1 * g.standard_normal(c)).astype(np.float32)
+    beta = (0.1 * g.standard_normal(c)).astype(np.float32)
+    got = sd_ops.op_layer_norm(x, gamma, beta, 1e-5)
+    ref = O.layer_norm(_t(x), _t(gamma), _t(beta), 1e-5)
+    _check(got, ref.numpy(), f"layer_norm({rows},{c})")
+
+
+# ---- Conv2d: all hot-path variants and every tile configuration -----------------------------
+CONV_CASES = [
+    # n, cin, h, w, cout, k, stride, ups
+    (2, 320, 16, 16, 320, 3, 1, 0),
+    (1, 4, 16, 16, 320, 3, 1, 0),     # conv_in: generic-K path (Cin = 4)
+    (1, 320, 16, 16, 4, 3, 1, 0),     # conv_out: N = 4
+    (1, 128, 16, 16, 3, 3, 1, 0),     # VAE conv_out: N = 3 (scalar epilogue)
+    (1, 4, 8, 8, 4, 1, 1, 0),         # post_quant_conv 1x1, K = 4
+    (2, 320, 16, 16, 320, 3, 2, 0),   # Downsample stride 2
+    (1, 640, 8, 8, 640, 3, 1, 1),     # Upsample: nearest-2x folded into the gather
+    (2, 640, 16, 16, 320, 1, 1, 0),   # 1x1 skip
+    (1, 960, 8, 8, 640, 3, 1, 0),
+    (1, 2560, 8, 8, 1280, 3, 1, 0),   # deepest level, K = 23040 (split-K)
+    (1, 256, 24, 40, 128, 3, 1, 0),   # non-square, M not a tile multiple
+    (3, 64, 5, 7, 96, 3, 1, 0),       # ragged everything
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(sd_ops, case):
+    n, cin, h, w, cout, k, stride, ups = case
+    g = _rng(hash(case) % (2 ** 31))
+    x = g.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (g.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k)).astype(np.float32)
+    b = g.standard_normal(cout).astype(np.float32)
+    sd_ops.set_option("gemm_tile", "auto")
+    sd_ops.set_option("splitk", 0)
+    got = sd_ops.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
+    xin = _t(x)
+    if ups:
+        xin = O.upsample2x(xin)
+    ref = O.conv2d(xin, (_t(wt), _t(b)), stride=stride, padding=1 if k == 3 else 0)
+    _check(got, ref.numpy(), f"conv2d{case}")
+
+
+@pytest.mark.parametrize("tile", range(8))
+@pytest.mark.parametrize("splitk", [1, 3])
+def test_conv2d_all_tiles(sd_ops, tile, splitk):
+    """Every tile configuration x split-K on one awkward shape (M, N not tile multiples)."""
+    n, cin, h, w, cout = 2, 96, 13, 11, 208
+    g = _rng(1000 + tile)
+    x = g.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+    b = g.standard_normal(cout).astype(np.float32)
+    try:
+        sd_ops.set_option("gemm_tile", tile)
+        sd_ops.set_option("splitk", splitk)
+        got = sd_ops.op_conv2d(x, wt, b)
+    finally:
+        sd_ops.set_option("gemm_tile", "auto")
+        sd_ops.set_option("splitk", 0)
+    ref = O.conv2d(_t(x), (_t(wt), _t(b)), padding=1)
+    _check(got, ref.numpy(), f"conv tile={tile} splitk={splitk}")
+
+
+def test_conv2d_asymmetric_weights_not_transposed(sd_ops):
+    """A = identity-like check with an asymmetric kernel: catches tap (ky,kx) swaps."""
+    x = np.zeros((1, 32, 6, 6), np.float32)
+    x[0, 0, 2, 3] = 1.0
+    wt = np.zeros((32, 32, 3, 3), np.float32)
+    wt[5, 0] = np.arange(9, dtype=np.float32).reshape(3, 3) + 1
+    got = sd_ops.op_conv2d(x, wt, None)
+    ref = O.conv2d(_t(x), (_t(wt), None), padding=1).numpy()
+    assert np.array_equal(got, ref.astype(np.float32))
+
+
+# ---- Linear ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,cin,cout", [(154, 768, 320), (20, 320, 1280), (512, 320, 2560), (1, 1280, 1280), (77, 64, 160)])
+def test_linear(sd_ops, rows, cin, cout):
+    g = _rng(rows * 3 + cout)
+    x = g.standard_normal((rows, cin)).astype(np.float32)
+    wt = (g.standard_normal((cin, cout)) / math.sqrt(cin)).astype(np.float32)
+    b = g.standard_normal(cout).astype(np.float32)
+    got = sd_ops.op_linear(x, wt, b)
+    _check(got, O.linear(_t(x), _t(wt), _t(b)).numpy(), f"linear({rows},{cin},{cout})")
+    got = sd_ops.op_linear(x, wt, None)
+    _check(got, O.linear(_t(x), _t(wt), None).numpy(), f"linear nobias({rows},{cin},{cout})")
+
+
+# ---- GEGLU, timestep embedding -------------------------------------------------------------------
+def test_geglu(sd_ops):
+    g = _rng(3)
+    proj = (g.standard_normal((37, 2 * 640)) * 2).astype(np.float32)
+    got = sd_ops.op_geglu(proj)
+    p = _t(proj)
+    ref = p[:, :640] * O.gelu_erf(p[:, 640:])
+    _check(got, ref.numpy(), "geglu", rtol=1e-5)
+
+
+@pytest.mark.parametrize("t", [999, 949, 49, 0, 1])
+def test_timestep_embedding(sd_ops, t):
+    got = sd_ops.op_timestep_embedding(t, 320)
+    ref32 = O.timestep_embedding(t, 320, 10000, torch.float32).numpy()
+    # cos/sin of arguments up to 999 rad in f32: the argument itself carries ~6e-5 abs error,
+    # so compare with the f32 oracle (same f32 argument), not the f64 one
+    assert np.abs(got - ref32).max() < 2e-6
+
+
+# ---- qkv_attention: attention.rs:5-45 ----------------------------------------------------------------
+ATTN_CASES = [
+    # n, nq, nk, n_state, n_head
+    (2, 256, 256, 320, 8),    # d = 40 self
+    (1, 1024, 1024, 320, 8),
+    (2, 64, 64, 640, 8),      # d = 80
+    (1, 256, 256, 1280, 8),   # d = 160
+    (2, 256, 77, 320, 8),     # cross, T = 77 (ragged last tile)
+    (2, 64, 2, 1280, 8),      # cross, Tu = 2 (unconditional context)
+    (1, 100, 37, 160, 4),     # ragged queries and keys
+    (1, 4, 4, 640, 4),        # 2x2 level of the tiny model
+    (1, 64, 64, 128, 1),      # unfused path (VAE-style single wide head)
+    (1, 256, 256, 512, 1),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_qkv_attention(sd_ops, case):
+    n, nq, nk, c, heads = case
+    g = _rng(hash(case) % (2 ** 31))
+    q = g.standard_normal((n, nq, c)).astype(np.float32)
+    k = g.standard_normal((n, nk, c)).astype(np.float32)
+    v = g.standard_normal((n, nk, c)).astype(np.float32)
+    got = sd_ops.qkv_attention(q, k, v, None, heads)
+    ref = O.qkv_attention(_t(q), _t(k), _t(v), None, heads)
+    _check(got, ref.numpy(), f"qkv_attention{case}")
+
+
+def test_qkv_attention_causal_mask(sd_ops):
+    """attn_decoder_mask (attention.rs:47-56) as the additive mask."""
+    n, s, c, heads = 1, 77, 320, 8
+    g = _rng(77)
+    q, k, v = (g.standard_normal((n, s, c)).astype(np.float32) for _ in range(3))
+    mask = np.triu(np.full((s, s), -np.inf, np.float32), 1)
+    got = sd_ops.qkv_attention(q, k, v, mask, heads)
+    ref = O.qkv_attention(_t(q), _t(k), _t(v), _t(mask), heads)
+    _check(got, ref.numpy(), "qkv_attention causal")
+
+
+def test_qkv_attention_spiked_scores(sd_ops):
+    """Online-softmax rescale: a key in a LATER tile dominates (forces the max to jump)."""
+    n, nq, nk, c, heads = 1, 64, 256, 320, 8
+    g = _rng(9)
+    q = g.standard_normal((n, nq, c)).astype(np.float32)
+    k = g.standard_normal((n, nk, c)).astype(np.float32)
+    v = g.standard_normal((n, nk, c)).astype(np.float32)
+    k[0, 200] = q[0, 7] * 6.0   # huge score for query 7 at key 200 (4th tile)
+    k[0, 3] = q[0, 9] * 6.0     # and in the first tile for query 9
+    got = sd_ops.qkv_attention(q, k, v, None, heads)
+    ref = O.qkv_attention(_t(q), _t(k), _t(v), None, heads)
+    _check(got, ref.numpy(), "qkv_attention spiked")
+
+
+def test_bad_arguments_fail_loudly(sd_ops):
+    from stable_diffusion_burn_amd import SdmiError
+    x = np.zeros((1, 48, 4, 4), np.float32)   # Cin = 48: neither < 32 nor a multiple of 32
+    w = np.zeros((32, 48, 3, 3), np.float32)
+    with pytest.raises(SdmiError):
+        sd_ops.op_conv2d(x, w, None)
+    with pytest.raises(SdmiError):
+        sd_ops.set_option("no_such_option", 1)

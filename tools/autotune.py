@@ -1,0 +1,112 @@
+"""Measure implicit-GEMM tile configurations / split-K factors per layer shape on the GPU.
+
+    python tools/autotune.py --quick            # a handful of representative shapes
+    python tools/autotune.py --out gpurun_out/tune_fp32.json
+
+Timing is done inside libsdmi with HIP events (sdmi_bench_conv).  The result is a
+JSON list of {shape, best cfg, best splits, ms, TF/s, all candidates}; `--emit`
+writes the "M,N,K=cfg,splits" lines the engine loads through set_option("tune", ...).
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+
+from stable_diffusion_burn_amd import ModelConfig, StableDiffusion  # noqa: E402
+
+TILES = ["128x128", "128x64", "64x64", "256x128", "128x80", "256x80", "64x128", "128x160"]
+
+# (n, cin, h, w, cout, k, stride, ups): UNet at batch 2 (cond+uncond of one image) + VAE at batch 1
+UNET_SHAPES = [
+    (2, 320, 64, 64, 320, 3, 1, 0), (2, 640, 64, 64, 320, 3, 1, 0), (2, 960, 64, 64, 320, 3, 1, 0),
+    (2, 320, 64, 64, 320, 3, 2, 0), (2, 320, 32, 32, 640, 3, 1, 0), (2, 640, 32, 32, 640, 3, 1, 0),
+    (2, 1280, 32, 32, 640, 3, 1, 0), (2, 1920, 32, 32, 640, 3, 1, 0), (2, 960, 32, 32, 640, 3, 1, 0),
+    (2, 640, 32, 32, 640, 3, 2, 0), (2, 640, 16, 16, 1280, 3, 1, 0), (2, 1280, 16, 16, 1280, 3, 1, 0),
+    (2, 2560, 16, 16, 1280, 3, 1, 0), (2, 1920, 16, 16, 1280, 3, 1, 0), (2, 1280, 16, 16, 1280, 3, 2, 0),
+    (2, 1280, 8, 8, 1280, 3, 1, 0), (2, 2560, 8, 8, 1280, 3, 1, 0),
+    (2, 1280, 8, 8, 1280, 3, 1, 1), (2, 1280, 16, 16, 1280, 3, 1, 1), (2, 640, 32, 32, 640, 3, 1, 1),
+    # 1x1 / linear shapes (as 1x1 convs over the token grid)
+    (2, 320, 64, 64, 320, 1, 1, 0), (2, 320, 64, 64, 2560, 1, 1, 0), (2, 1280, 64, 64, 320, 1, 1, 0),
+    (2, 640, 32, 32, 640, 1, 1, 0), (2, 640, 32, 32, 5120, 1, 1, 0), (2, 2560, 32, 32, 640, 1, 1, 0),
+    (2, 1280, 16, 16, 1280, 1, 1, 0), (2, 1280, 16, 16, 10240, 1, 1, 0), (2, 5120, 16, 16, 1280, 1, 1, 0),
+    (2, 1280, 8, 8, 10240, 1, 1, 0), (2, 5120, 8, 8, 1280, 1, 1, 0),
+    (2, 640, 64, 64, 320, 1, 1, 0), (2, 960, 64, 64, 320, 1, 1, 0), (2, 1920, 32, 32, 640, 1, 1, 0),
+]
+VAE_SHAPES = [
+    (1, 512, 64, 64, 512, 3, 1, 0), (1, 512, 64, 64, 512, 3, 1, 1), (1, 512, 128, 128, 512, 3, 1, 0),
+    (1, 512, 128, 128, 512, 3, 1, 1), (1, 512, 256, 256, 256, 3, 1, 0), (1, 256, 256, 256, 256, 3, 1, 0),
+    (1, 256, 256, 256, 256, 3, 1, 1), (1, 256, 512, 512, 128, 3, 1, 0), (1, 128, 512, 512, 128, 3, 1, 0),
+    (1, 128, 512, 512, 3, 3, 1, 0), (1, 512, 64, 64, 512, 1, 1, 0),
+]
+QUICK = [UNET_SHAPES[0], UNET_SHAPES[5], UNET_SHAPES[11], UNET_SHAPES[16], UNET_SHAPES[21], VAE_SHAPES[5], VAE_SHAPES[8]]
+
+
+def mnk(s):
+    n, cin, h, w, cout, k, stride, ups = s
+    hin, win = h << ups, w << ups
+    pad = 1 if k == 3 else 0
+    ho, wo = (hin + 2 * pad - k) // stride + 1, (win + 2 * pad - k) // stride + 1
+    return n * ho * wo, cout, cin * k * k
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--vae", action="store_true")
+    ap.add_argument("--out", default="gpurun_out/tune_fp32.json")
+    ap.add_argument("--emit", default="")
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--budget-s", type=float, default=240.0)
+    args = ap.parse_args()
+    shapes = QUICK if args.quick else (UNET_SHAPES + (VAE_SHAPES if args.vae else []))
+    sd = StableDiffusion(ModelConfig(32, 1, 32, 8, 8, 32))
+    results = []
+    t_start = time.time()
+    for s in shapes:
+        M, N, K = mnk(s)
+        flops = 2.0 * M * N * K
+        kt = (K + 31) // 32
+        cands = []
+        for cfg in range(len(TILES)):
+            bm, bn = map(int, TILES[cfg].split("x"))
+            tiles = -(-M // bm) * -(-N // bn)
+            split_opts = [1]
+            for sp in (2, 3, 4, 6, 8, 12, 16, 24, 32):
+                if tiles * sp <= 1024 and kt // sp >= 4 and tiles < 400:
+                    split_opts.append(sp)
+            for sp in split_opts:
+                if time.time() - t_start > args.budget_s:
+                    break
+                try:
+                    ms = sd.bench_conv(*s[:5], k=s[5], stride=s[6], upsample2x=s[7], tile_cfg=cfg, splitk=sp,
+                                       iters=args.iters if flops < 5e11 else 2)
+                except Exception as e:  # noqa: BLE001
+                    print(f"  {s} cfg={cfg} sp={sp}: {e}")
+                    continue
+                cands.append({"cfg": cfg, "tile": TILES[cfg], "splits": sp, "ms": ms, "tflops": flops / ms / 1e9})
+        if not cands:
+            continue
+        best = min(cands, key=lambda c: c["ms"])
+        auto_ms = sd.bench_conv(*s[:5], k=s[5], stride=s[6], upsample2x=s[7], tile_cfg=-1, splitk=0, iters=args.iters)
+        results.append({"shape": s, "M": M, "N": N, "K": K, "best": best, "heuristic_ms": auto_ms,
+                        "heuristic_tflops": flops / auto_ms / 1e9, "cands": cands})
+        print(f"{str(s):44s} M={M:6d} N={N:5d} K={K:5d}  best {best['tile']:8s} x{best['splits']:<2d} "
+              f"{best['ms']:8.3f} ms {best['tflops']:6.1f} TF | heuristic {auto_ms:8.3f} ms "
+              f"{flops / auto_ms / 1e9:6.1f} TF", flush=True)
+    Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+    Path(args.out).write_text(json.dumps(results, indent=1))
+    if args.emit:
+        with open(args.emit, "w") as f:
+            for r in results:
+                f.write(f"{r['M']},{r['N']},{r['K']}={r['best']['cfg']},{r['best']['splits']}\n")
+    tot = sum(2.0 * r["M"] * r["N"] * r["K"] for r in results)
+    tb = sum(r["best"]["ms"] for r in results)
+    th = sum(r["heuristic_ms"] for r in results)
+    print(f"sum over shapes: best {tot / tb / 1e9:.1f} TF/s, heuristic {tot / th / 1e9:.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()
