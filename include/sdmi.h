@@ -177,6 +177,11 @@ int sdmi_set_option(sdmi_ctx* ctx, const char* key, const char* value);
 /* time (ms, HIP events on the context stream) and kernel count of the last
  * hot-path call; flops = algorithmic FLOPs it executed (2*MAC of conv/GEMM/attention). */
 int sdmi_last_call_stats(sdmi_ctx* ctx, double* gpu_ms, int64_t* n_kernels, double* flops);
+/* Per-kernel-class timing collected while option "profile" = "1": HIP events around every
+ * launch on the context stream.  cls: 0 conv_gemm (implicit-GEMM conv/linear), 1 splitk_reduce,
+ * 2 attention, 3 group_norm(+silu), 4 layer_norm.  flops / bytes are the ALGORITHMIC work of
+ * those launches (2*M*N*K; one read + one write of the tensor).  "profile_reset" clears. */
+int sdmi_profile_stats(sdmi_ctx* ctx, int32_t cls, double* ms, int64_t* launches, double* flops, double* bytes);
 /* micro-benchmark one implicit-GEMM conv shape on device-resident synthetic
  * data: returns average kernel ms over `iters` launches (HIP events). */
 int sdmi_bench_conv(sdmi_ctx* ctx, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,

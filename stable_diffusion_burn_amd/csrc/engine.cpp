@@ -78,6 +78,49 @@ void DevPool::free(void* p) {
 }
 
 // =============================================================================
+// per-class kernel timing (HIP events on the engine stream)
+// =============================================================================
+hipEvent_t Engine::prof_event() {
+    if (!prof_free_.empty()) { hipEvent_t e = prof_free_.back(); prof_free_.pop_back(); return e; }
+    hipEvent_t e;
+    SDMI_HIP(hipEventCreate(&e));
+    return e;
+}
+
+Engine::ProfScope::ProfScope(Engine* e_, int cls_, double flops_, double bytes_) : e(e_), cls(cls_), flops(flops_), bytes(bytes_) {
+    if (!e->profiling_) return;
+    a = e->prof_event();
+    b = e->prof_event();
+    (void)hipEventRecord(a, e->stream_);
+}
+
+Engine::ProfScope::~ProfScope() {
+    if (!a) return;
+    (void)hipEventRecord(b, e->stream_);
+    e->prof_pending_.push_back({cls, a, b, flops, bytes});
+    if (e->prof_pending_.size() >= 2048) {
+        try { e->prof_flush(); } catch (...) {}
+    }
+}
+
+void Engine::prof_flush() {
+    if (prof_pending_.empty()) return;
+    SDMI_HIP(hipStreamSynchronize(stream_));
+    for (auto& p : prof_pending_) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            prof_[p.cls].ms += ms;
+            prof_[p.cls].launches += 1;
+            prof_[p.cls].flops += p.flops;
+            prof_[p.cls].bytes += p.bytes;
+        }
+        prof_free_.push_back(p.a);
+        prof_free_.push_back(p.b);
+    }
+    prof_pending_.clear();
+}
+
+// =============================================================================
 // construction / model definition
 // =============================================================================
 Engine::Engine(const sdmi_config& cfg) : cfg_(cfg) {
@@ -107,6 +150,8 @@ Engine::~Engine() {
     (void)hipSetDevice(cfg_.device);
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (void* p : weight_allocs_) (void)hipFree(p);
+    for (auto& p : prof_pending_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (hipEvent_t e : prof_free_) (void)hipEventDestroy(e);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -388,6 +433,8 @@ void Engine::end_call() {
 void Engine::set_option(const std::string& key, const std::string& value) {
     if (key == "gemm_tile") opt_force_tile_ = (value == "auto") ? -1 : std::stoi(value);
     else if (key == "splitk") opt_force_splits_ = std::stoi(value);
+    else if (key == "profile") { prof_flush(); profiling_ = std::stoi(value) != 0; }
+    else if (key == "profile_reset") prof_reset();
     else if (key == "tune") {
         // "M,N,K=cfg,splits"
         const size_t eq = value.find('=');
@@ -448,6 +495,7 @@ void Engine::launch_gemm(ConvGemm& p, int force_cfg, int force_splits) {
     const double flops = 2.0 * p.M * (double)p.N * p.K;
     if (splits == 1) {
         p.slab_stride = 0;
+        ProfScope ps(this, PC_CONV_GEMM, flops);
         SDMI_HIP(launch_conv_gemm(p, tc.cfg, stream_));
         count_kernel(flops);
     } else {
@@ -455,9 +503,15 @@ void Engine::launch_gemm(ConvGemm& p, int force_cfg, int force_splits) {
         Buf slab(this, (size_t)splits * p.slab_stride * sizeof(float));
         float* real_c = p.C;
         p.C = slab.f();
-        SDMI_HIP(launch_conv_gemm(p, tc.cfg, stream_));
+        {
+            ProfScope ps(this, PC_CONV_GEMM, flops);
+            SDMI_HIP(launch_conv_gemm(p, tc.cfg, stream_));
+        }
         count_kernel(flops);
-        SDMI_HIP(launch_splitk_reduce(p, slab.f(), real_c, stream_));
+        {
+            ProfScope ps(this, PC_SPLITK_REDUCE, 0, (double)(splits + 1) * p.slab_stride * 4.0);
+            SDMI_HIP(launch_splitk_reduce(p, slab.f(), real_c, stream_));
+        }
         count_kernel();
         p.C = real_c;
     }
@@ -495,11 +549,13 @@ void Engine::gemm(const float* A, int a_rows, const float* bt, const float* bias
 void Engine::group_norm(const NormW& w, const Act& x, Act& y, bool silu) {
     const int hw = x.h * x.w;
     Buf part(this, gn_partials_bytes(x.n, hw, x.c));
+    ProfScope ps(this, PC_GROUP_NORM, 0, 2.0 * (double)x.bytes());  // algorithmic: one read + one write
     SDMI_HIP(launch_group_norm(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, 32, 1e-5f, silu, part.p, stream_));
     count_kernel(); count_kernel();
 }
 
 void Engine::layer_norm(const NormW& w, const float* x, long long rows, float* y) {
+    ProfScope ps(this, PC_LAYER_NORM, 0, 2.0 * (double)rows * w.c * 4.0);
     SDMI_HIP(launch_layer_norm(x, y, w.gamma, w.beta, (int)rows, w.c, 1e-5f, stream_));
     count_kernel();
 }
@@ -519,8 +575,10 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
         p.n = n; p.n_head = n_head; p.nq = nq; p.nk = nk; p.d_head = d_head;
         p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
         p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs; p.scale = scale;
+        const double fl = 4.0 * n * n_head * (double)nq * nk * d_head;
+        ProfScope ps(this, PC_ATTENTION, fl);
         SDMI_HIP(launch_attention(p, stream_));
-        count_kernel(4.0 * n * n_head * (double)nq * nk * d_head);
+        count_kernel(fl);
         return;
     }
     if (mask) throw Error(SDMI_ERR_UNSUPPORTED, "attention: additive mask is only supported for head dims 40/80/160");

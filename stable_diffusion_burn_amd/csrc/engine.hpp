@@ -180,6 +180,27 @@ private:
 
     void count_kernel(double flops = 0) { ++n_kernels_; flops_ += flops; }
 
+public:
+    // per-kernel-class timing (option "profile=1"): HIP events around every launch on the
+    // engine's stream, accumulated per class.  Used by bench.py for the roofline line.
+    enum ProfClass { PC_CONV_GEMM, PC_SPLITK_REDUCE, PC_ATTENTION, PC_GROUP_NORM, PC_LAYER_NORM, PC_OTHER, PC_COUNT };
+    struct ProfStat { double ms = 0; long long launches = 0; double flops = 0; double bytes = 0; };
+    ProfStat prof_[PC_COUNT];
+    void prof_flush();
+    void prof_reset() { prof_flush(); for (auto& p : prof_) p = ProfStat{}; }
+
+private:
+    struct ProfScope {
+        Engine* e; int cls; double flops, bytes; hipEvent_t a = nullptr, b = nullptr;
+        ProfScope(Engine* e_, int cls_, double flops_ = 0, double bytes_ = 0);
+        ~ProfScope();
+    };
+    struct ProfPending { int cls; hipEvent_t a, b; double flops, bytes; };
+    hipEvent_t prof_event();
+    bool profiling_ = false;
+    std::vector<hipEvent_t> prof_free_;
+    std::vector<ProfPending> prof_pending_;
+
     sdmi_config cfg_;
     hipStream_t stream_ = nullptr;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;

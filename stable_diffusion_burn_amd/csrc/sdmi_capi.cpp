@@ -376,6 +376,18 @@ int sdmi_last_call_stats(sdmi_ctx* ctx, double* gpu_ms, int64_t* n_kernels, doub
     });
 }
 
+int sdmi_profile_stats(sdmi_ctx* ctx, int32_t cls, double* ms, int64_t* launches, double* flops, double* bytes) {
+    return guarded([&] {
+        Engine& e = eng(ctx);
+        if (cls < 0 || cls >= Engine::PC_COUNT) throw Error(SDMI_ERR_INVALID, "profile_stats: class out of range");
+        e.prof_flush();
+        if (ms) *ms = e.prof_[cls].ms;
+        if (launches) *launches = e.prof_[cls].launches;
+        if (flops) *flops = e.prof_[cls].flops;
+        if (bytes) *bytes = e.prof_[cls].bytes;
+    });
+}
+
 int sdmi_bench_conv(sdmi_ctx* ctx, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t k,
                     int32_t stride, int32_t upsample2x, int32_t tile_cfg, int32_t splitk, int32_t iters, double* ms_out) {
     return guarded([&] {

@@ -220,6 +220,17 @@ class StableDiffusion:
         check(self._lib.sdmi_last_call_stats(self._ctx, C.byref(ms), C.byref(nk), C.byref(fl)))
         return {"gpu_ms": ms.value, "kernels": nk.value, "flops": fl.value}
 
+    PROFILE_CLASSES = ("conv_gemm", "splitk_reduce", "attention", "group_norm", "layer_norm")
+
+    def profile_stats(self) -> dict:
+        """Per-kernel-class HIP-event timings gathered while set_option("profile", 1)."""
+        out = {}
+        for i, name in enumerate(self.PROFILE_CLASSES):
+            ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+            check(self._lib.sdmi_profile_stats(self._ctx, i, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+            out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+        return out
+
     def bench_conv(self, n, cin, h, w, cout, k=3, stride=1, upsample2x=0, tile_cfg=-1, splitk=0, iters=10) -> float:
         ms = C.c_double()
         check(self._lib.sdmi_bench_conv(self._ctx, n, cin, h, w, cout, k, stride, upsample2x, tile_cfg, splitk, iters,
