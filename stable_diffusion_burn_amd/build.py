@@ -22,7 +22,7 @@ LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libsdmi.so"
 OBJDIR = PKG / "build"
 
-SOURCES = ["k_gemm.hip", "k_attn.hip", "k_norm.hip", "k_elem.hip", "engine.cpp", "sdmi_capi.cpp"]
+SOURCES = ["k_gemm.hip", "k_gemm2.hip", "k_attn.hip", "k_norm.hip", "k_elem.hip", "engine.cpp", "sdmi_capi.cpp"]
 HEADERS = ["kernels.hpp", "engine.hpp", "../../include/sdmi.h"]
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]

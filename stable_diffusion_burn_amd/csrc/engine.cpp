@@ -433,6 +433,7 @@ void Engine::end_call() {
 void Engine::set_option(const std::string& key, const std::string& value) {
     if (key == "gemm_tile") opt_force_tile_ = (value == "auto") ? -1 : std::stoi(value);
     else if (key == "splitk") opt_force_splits_ = std::stoi(value);
+    else if (key == "gemm_variant") opt_gemm_variant_ = std::stoi(value);
     else if (key == "profile") { prof_flush(); profiling_ = std::stoi(value) != 0; }
     else if (key == "profile_reset") prof_reset();
     else if (key == "tune") {
@@ -493,10 +494,17 @@ void Engine::launch_gemm(ConvGemm& p, int force_cfg, int force_splits) {
     splits = (p.kt_total + p.kt_per_split - 1) / p.kt_per_split;
     p.splits = splits;
     const double flops = 2.0 * p.M * (double)p.N * p.K;
+    // v2 uses raw buffer loads whose range check needs 32-bit extents
+    const unsigned long long a_ext = ((unsigned long long)p.NB * p.Hs * p.Ws - 1) * (unsigned long long)p.a_ld * 4ull + (unsigned long long)p.Cin * 4ull;
+    const unsigned long long b_ext = ((unsigned long long)p.N - 1) * (unsigned long long)p.b_ld * 4ull + (unsigned long long)p.K * 4ull;
+    const bool v2 = opt_gemm_variant_ == 1 && a_ext < 0xFFFFFFE0ull && b_ext < 0xFFFFFFE0ull;
+    p.a_bytes = (unsigned)std::min<unsigned long long>(a_ext, 0xFFFFFFE0ull);
+    p.b_bytes = (unsigned)std::min<unsigned long long>(b_ext, 0xFFFFFFE0ull);
+    auto launch = [&](const ConvGemm& q) { return v2 ? launch_conv_gemm2(q, tc.cfg, stream_) : launch_conv_gemm(q, tc.cfg, stream_); };
     if (splits == 1) {
         p.slab_stride = 0;
         ProfScope ps(this, PC_CONV_GEMM, flops);
-        SDMI_HIP(launch_conv_gemm(p, tc.cfg, stream_));
+        SDMI_HIP(launch(p));
         count_kernel(flops);
     } else {
         p.slab_stride = (long long)p.M * p.N;
@@ -505,7 +513,7 @@ void Engine::launch_gemm(ConvGemm& p, int force_cfg, int force_splits) {
         p.C = slab.f();
         {
             ProfScope ps(this, PC_CONV_GEMM, flops);
-            SDMI_HIP(launch_conv_gemm(p, tc.cfg, stream_));
+            SDMI_HIP(launch(p));
         }
         count_kernel(flops);
         {

@@ -241,6 +241,7 @@ private:
     // options
     int opt_force_tile_ = -1;
     int opt_force_splits_ = 0;
+    int opt_gemm_variant_ = 1;  // 1: k_gemm2.hip (buffer loads, swizzled LDS, pipelined), 0: k_gemm.hip
     std::map<std::string, TileChoice> tuned_;
 
     long long n_kernels_ = 0;

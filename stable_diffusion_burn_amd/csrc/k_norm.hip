@@ -28,24 +28,37 @@ namespace sdmi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static inline int gn_rows_per_block(int cq) { return cq >= 256 ? 1 : 256 / cq; }
+// Geometry: a block is cq*R threads (cq = C/4 float4 columns, R pixel rows per pass, <= 1024
+// threads); a sample's hw rows are cut into `chunks` contiguous ranges of ~64 KiB, one block each,
+// the same cut for the stats and the apply pass.
+struct GnGeom { int cq, R, threads, chunks, rows_per_chunk; };
 
-static inline int gn_chunks(int hw, int cq) {
-    const int R = gn_rows_per_block(cq);
-    int chunks = hw / (R * 8);
+static inline GnGeom gn_geom(int hw, int c) {
+    GnGeom g;
+    g.cq = c / 4;
+    g.R = g.cq >= 1024 ? 1 : 1024 / g.cq;
+    if (g.R > 32) g.R = 32;
+    if (g.R > hw) g.R = hw;
+    g.threads = g.cq * g.R;
+    const long long bytes = (long long)hw * c * 4;
+    long long chunks = (bytes + 65535) / 65536;
+    if (chunks > 256) chunks = 256;
     if (chunks < 1) chunks = 1;
-    if (chunks > 1024) chunks = 1024;
-    return chunks;
+    int rpc = (int)((hw + chunks - 1) / chunks);
+    rpc = (rpc + g.R - 1) / g.R * g.R;
+    g.rows_per_chunk = rpc;
+    g.chunks = (hw + rpc - 1) / rpc;
+    return g;
 }
 
 size_t gn_partials_bytes(int n, int hw, int c) {
-    return (size_t)n * gn_chunks(hw, c / 4) * 64 * 2 * sizeof(double);
+    return (size_t)n * gn_geom(hw, c).chunks * 64 * 2 * sizeof(double);
 }
 
 // partial sums: part[((smp*chunks + chunk)*G + g)*2 + {0: sum, 1: sumsq}]
 __global__ void gn_stats_kernel(const float* __restrict__ x, int hw, int C, int G, int rows_per_chunk,
                                 double* __restrict__ part) {
-    extern __shared__ float sh[];  // [2][R][C]
+    extern __shared__ float sh[];  // [2][R][C] floats, then [2][C] doubles
     const int cq = C >> 2;
     const int R = blockDim.x / cq;
     const int tid = threadIdx.x;
@@ -55,27 +68,38 @@ __global__ void gn_stats_kernel(const float* __restrict__ x, int hw, int C, int 
     const int row_begin = chunk * rows_per_chunk;
     const int row_end = min(row_begin + rows_per_chunk, hw);
 
-    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, q0 = s0, s1 = s0, q1 = s0;
     const float* xb = x + (long long)smp * hw * C + c4 * 4;
-    for (int row = row_begin + r0; row < row_end; row += R) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long long)row * C);
-        s += v;
-        q += v * v;
+    int row = row_begin + r0;
+    for (; row + R < row_end; row += 2 * R) {  // two independent loads in flight per thread
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(xb + (long long)row * C);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(xb + (long long)(row + R) * C);
+        s0 += v0; q0 += v0 * v0;
+        s1 += v1; q1 += v1 * v1;
     }
+    if (row < row_end) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(xb + (long long)row * C);
+        s0 += v0; q0 += v0 * v0;
+    }
+    s0 += s1; q0 += q1;
     float* shs = sh;
     float* shq = sh + R * C;
-    *reinterpret_cast<f32x4*>(shs + r0 * C + c4 * 4) = s;
-    *reinterpret_cast<f32x4*>(shq + r0 * C + c4 * 4) = q;
+    double* chs = reinterpret_cast<double*>(sh + 2 * R * C);
+    double* chq = chs + C;
+    *reinterpret_cast<f32x4*>(shs + r0 * C + c4 * 4) = s0;
+    *reinterpret_cast<f32x4*>(shq + r0 * C + c4 * 4) = q0;
     __syncthreads();
-    if (tid < G) {
+    for (int ch = tid; ch < C; ch += blockDim.x) {  // per-channel sums over the R thread rows, fixed order
+        double ds = 0.0, dq = 0.0;
+        for (int r = 0; r < R; ++r) { ds += (double)shs[r * C + ch]; dq += (double)shq[r * C + ch]; }
+        chs[ch] = ds; chq[ch] = dq;
+    }
+    __syncthreads();
+    for (int gi = tid; gi < G; gi += blockDim.x) {
         const int cpg = C / G;
         double ds = 0.0, dq = 0.0;
-        for (int r = 0; r < R; ++r)
-            for (int ch = tid * cpg; ch < (tid + 1) * cpg; ++ch) {
-                ds += (double)shs[r * C + ch];
-                dq += (double)shq[r * C + ch];
-            }
-        double* o = part + ((long long)(smp * chunks + chunk) * G + tid) * 2;
+        for (int ch = gi * cpg; ch < (gi + 1) * cpg; ++ch) { ds += chs[ch]; dq += chq[ch]; }
+        double* o = part + ((long long)(smp * chunks + chunk) * G + gi) * 2;
         o[0] = ds;
         o[1] = dq;
     }
@@ -84,26 +108,36 @@ __global__ void gn_stats_kernel(const float* __restrict__ x, int hw, int C, int 
 template <bool SILU>
 __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, int hw, int C, int G, float eps, int stat_chunks,
-                                const double* __restrict__ part, int rows_per_block) {
+                                const double* __restrict__ part, int rows_per_chunk) {
     __shared__ float s_mean[64], s_rstd[64];
+    __shared__ double s_red[2][64][8];
     const int cq = C >> 2;
     const int R = blockDim.x / cq;
     const int tid = threadIdx.x;
     const int smp = blockIdx.y;
     const int cpg = C / G;
-    if (tid < G) {
+    // finalize the statistics: 8 threads per group stride over the chunk partials (fixed order)
+    for (int idx = tid; idx < G * 8; idx += blockDim.x) {
+        const int gi = idx >> 3, j = idx & 7;
         double ds = 0.0, dq = 0.0;
-        const double* pp = part + ((long long)smp * stat_chunks * G + tid) * 2;
-        for (int ch = 0; ch < stat_chunks; ++ch) {
+        const double* pp = part + ((long long)smp * stat_chunks * G + gi) * 2;
+        for (int ch = j; ch < stat_chunks; ch += 8) {
             ds += pp[(long long)ch * G * 2];
             dq += pp[(long long)ch * G * 2 + 1];
         }
+        s_red[0][gi][j] = ds;
+        s_red[1][gi][j] = dq;
+    }
+    __syncthreads();
+    for (int gi = tid; gi < G; gi += blockDim.x) {
+        double ds = 0.0, dq = 0.0;
+        for (int j = 0; j < 8; ++j) { ds += s_red[0][gi][j]; dq += s_red[1][gi][j]; }
         const double cnt = (double)hw * cpg;
         const double mean = ds / cnt;
         double var = dq / cnt - mean * mean;
         if (var < 0.0) var = 0.0;
-        s_mean[tid] = (float)mean;
-        s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+        s_mean[gi] = (float)mean;
+        s_rstd[gi] = (float)(1.0 / sqrt(var + (double)eps));
     }
     __syncthreads();
     const int c4 = tid % cq;
@@ -117,46 +151,49 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__
         mean[i] = s_mean[gi];
         rstd[i] = s_rstd[gi];
     }
-    const int row_begin = blockIdx.x * rows_per_block;
-    const int row_end = min(row_begin + rows_per_block, hw);
+    const int row_begin = blockIdx.x * rows_per_chunk;
+    const int row_end = min(row_begin + rows_per_chunk, hw);
     const long long base = (long long)smp * hw * C + c4 * 4;
-    for (int row = row_begin + r0; row < row_end; row += R) {
-        const long long off = base + (long long)row * C;
-        f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
+    auto norm = [&](f32x4 v) {
         v = (v - mean) * rstd;
         v = v * gm + bt;
         if (SILU) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.0f + __expf(-v[i]));
         }
-        *reinterpret_cast<f32x4*>(y + off) = v;
+        return v;
+    };
+    int row = row_begin + r0;
+    for (; row + R < row_end; row += 2 * R) {
+        const long long o0 = base + (long long)row * C, o1 = base + (long long)(row + R) * C;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + o0);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + o1);
+        *reinterpret_cast<f32x4*>(y + o0) = norm(v0);
+        *reinterpret_cast<f32x4*>(y + o1) = norm(v1);
+    }
+    if (row < row_end) {
+        const long long o0 = base + (long long)row * C;
+        *reinterpret_cast<f32x4*>(y + o0) = norm(*reinterpret_cast<const f32x4*>(x + o0));
     }
 }
 
 hipError_t launch_group_norm(const float* x, float* y, const float* gamma, const float* beta, int n, int hw, int c,
                              int n_group, float eps, bool silu, void* partials, hipStream_t stream) {
     if ((c & 3) || n_group > 64 || c % n_group) return hipErrorInvalidValue;
-    const int cq = c / 4;
-    if (cq > 1024) return hipErrorInvalidValue;
-    const int R = gn_rows_per_block(cq);
-    const int threads = cq * R;
-    const int chunks = gn_chunks(hw, cq);
-    const int rows_per_chunk = (hw + chunks - 1) / chunks;
+    if (c / 4 > 1024) return hipErrorInvalidValue;
+    const GnGeom g = gn_geom(hw, c);
     double* part = reinterpret_cast<double*>(partials);
-    const size_t lds = (size_t)2 * R * c * sizeof(float);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, n), dim3(threads), lds, stream, x, hw, c, n_group, rows_per_chunk,
-                       part);
+    const size_t lds = (size_t)2 * g.R * c * sizeof(float) + (size_t)2 * c * sizeof(double);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(g.chunks, n), dim3(g.threads), lds, stream, x, hw, c, n_group,
+                       g.rows_per_chunk, part);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // apply: ~16 rows per thread-row
-    int rows_per_block = R * 16;
-    int blocks = (hw + rows_per_block - 1) / rows_per_block;
     if (silu)
-        hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(blocks, n), dim3(threads), 0, stream, x, y, gamma, beta, hw, c,
-                           n_group, eps, chunks, part, rows_per_block);
+        hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(g.chunks, n), dim3(g.threads), 0, stream, x, y, gamma, beta, hw,
+                           c, n_group, eps, g.chunks, part, g.rows_per_chunk);
     else
-        hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(blocks, n), dim3(threads), 0, stream, x, y, gamma, beta, hw, c,
-                           n_group, eps, chunks, part, rows_per_block);
+        hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(g.chunks, n), dim3(g.threads), 0, stream, x, y, gamma, beta, hw,
+                           c, n_group, eps, g.chunks, part, g.rows_per_chunk);
     return hipGetLastError();
 }
 

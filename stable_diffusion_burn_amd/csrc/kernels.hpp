@@ -36,6 +36,7 @@ struct ConvGemm {
     int kt_per_split;     // k tiles per blockIdx.z slice
     int splits;           // gridDim.z
     long long slab_stride;  // M*N when splits > 1
+    unsigned a_bytes, b_bytes;  // extents of A / Bt for the buffer-load range check (v2 kernel)
 };
 
 // tile configurations (index = tile_cfg); BM x BN per 256-thread workgroup
@@ -43,7 +44,8 @@ struct GemmTileInfo { int bm, bn; const char* name; };
 constexpr int kNumGemmTiles = 8;
 const GemmTileInfo& gemm_tile_info(int cfg);
 size_t gemm_tile_lds_bytes(int cfg);
-hipError_t launch_conv_gemm(const ConvGemm& p, int tile_cfg, hipStream_t stream);
+hipError_t launch_conv_gemm(const ConvGemm& p, int tile_cfg, hipStream_t stream);   // v1 (k_gemm.hip)
+hipError_t launch_conv_gemm2(const ConvGemm& p, int tile_cfg, hipStream_t stream);  // v2 (k_gemm2.hip)
 // sums split-K slabs in fixed order and applies the epilogue
 hipError_t launch_splitk_reduce(const ConvGemm& p, const float* slabs, float* C, hipStream_t stream);
 // weight packing (done once at load)

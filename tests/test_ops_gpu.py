@@ -96,9 +96,11 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("variant", [1, 0])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d(sd_ops, case):
+def test_conv2d(sd_ops, case, variant):
     n, cin, h, w, cout, k, stride, ups = case
+    sd_ops.set_option("gemm_variant", variant)
     g = _rng(hash(case) % (2 ** 31))
     x = g.standard_normal((n, cin, h, w)).astype(np.float32)
     wt = (g.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k)).astype(np.float32)
@@ -109,13 +111,15 @@ def test_conv2d(sd_ops, case):
     xin = _t(x)
     if ups:
         xin = O.upsample2x(xin)
+    sd_ops.set_option("gemm_variant", 1)
     ref = O.conv2d(xin, (_t(wt), _t(b)), stride=stride, padding=1 if k == 3 else 0)
-    _check(got, ref.numpy(), f"conv2d{case}")
+    _check(got, ref.numpy(), f"conv2d{case} variant={variant}")
 
 
+@pytest.mark.parametrize("variant", [1, 0])
 @pytest.mark.parametrize("tile", range(8))
 @pytest.mark.parametrize("splitk", [1, 3])
-def test_conv2d_all_tiles(sd_ops, tile, splitk):
+def test_conv2d_all_tiles(sd_ops, tile, splitk, variant):
     """Every tile configuration x split-K on one awkward shape (M, N not tile multiples)."""
     n, cin, h, w, cout = 2, 96, 13, 11, 208
     g = _rng(1000 + tile)
@@ -123,14 +127,16 @@ def test_conv2d_all_tiles(sd_ops, tile, splitk):
     wt = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
     b = g.standard_normal(cout).astype(np.float32)
     try:
+        sd_ops.set_option("gemm_variant", variant)
         sd_ops.set_option("gemm_tile", tile)
         sd_ops.set_option("splitk", splitk)
         got = sd_ops.op_conv2d(x, wt, b)
     finally:
+        sd_ops.set_option("gemm_variant", 1)
         sd_ops.set_option("gemm_tile", "auto")
         sd_ops.set_option("splitk", 0)
     ref = O.conv2d(_t(x), (_t(wt), _t(b)), padding=1)
-    _check(got, ref.numpy(), f"conv tile={tile} splitk={splitk}")
+    _check(got, ref.numpy(), f"conv tile={tile} splitk={splitk} variant={variant}")
 
 
 def test_conv2d_asymmetric_weights_not_transposed(sd_ops):

@@ -60,9 +60,11 @@ def main():
     ap.add_argument("--emit", default="")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--budget-s", type=float, default=240.0)
+    ap.add_argument("--variant", type=int, default=1, help="gemm kernel generation: 1 = k_gemm2.hip, 0 = k_gemm.hip")
     args = ap.parse_args()
     shapes = QUICK if args.quick else (UNET_SHAPES + (VAE_SHAPES if args.vae else []))
     sd = StableDiffusion(ModelConfig(32, 1, 32, 8, 8, 32))
+    sd.set_option("gemm_variant", args.variant)
     results = []
     t_start = time.time()
     for s in shapes:
