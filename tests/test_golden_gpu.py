@@ -1,0 +1,103 @@
+"""FULL-SIZE parity (SD v1.4 dims, BASELINE.json configs[0] and configs[1]) of the HIP path
+against the committed golden fixtures produced by the CPU oracle
+(tests/golden/gen_golden.py; fp32 and fp64 runs of oracle/sd_oracle.py on the
+seeded synthetic weights / inputs of BASELINE.md section 3).
+
+Stated tolerances (BASELINE.json north_star):
+  * latents and decoded float RGB:  max |gpu - oracle_f32| < 1e-3  (absolute; final latent
+    absmax is ~62 with untrained weights, so this is ~1.6e-5 relative), and the fp64 oracle as
+    tie-breaker:  |gpu - f64| <= max(1e-3, 2 * |f32 - f64|)
+  * u8 image: <= 1 LSB (the reference truncates, stablediffusion/mod.rs:96)
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from stable_diffusion_burn_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def sd_full():
+    from stable_diffusion_burn_amd import ModelConfig, StableDiffusion
+    sd = StableDiffusion(ModelConfig())
+    sd.load_weights(syn.SyntheticWeights())
+    yield sd
+    sd.close()
+
+
+def _inputs():
+    return syn.initial_latent(0)[None], syn.cond_context(0)[None], syn.uncond_context()
+
+
+def test_unet_forward_full(sd_full):
+    """One UNet::forward (unet/mod.rs:109-143) at t = 999 and t = 49, T = 77."""
+    g = np.load(GOLD / "sd14_synth_unet.npz")
+    lat, ctx, _ = _inputs()
+    for t in (999, 49):
+        got = sd_full.unet.forward(lat, [t], ctx)[0].astype(np.float64)
+        e32 = np.abs(got - g[f"eps32_t{t}"]).max()
+        e64 = np.abs(got - g[f"eps64_t{t}"]).max()
+        ref_gap = np.abs(g[f"eps32_t{t}"].astype(np.float64) - g[f"eps64_t{t}"]).max()
+        print(f"unet t={t}: |gpu-f32|={e32:.2e} |gpu-f64|={e64:.2e} |f32-f64|={ref_gap:.2e}")
+        assert e64 < 2e-5, f"t={t}: {e64}"
+
+
+def test_config1_one_step(sd_full):
+    """configs[0]: 1 DDIM step, guidance 1.0 ("CFG off" still runs both forwards, Q: forward_diffuser)."""
+    g = np.load(GOLD / "sd14_synth_cfg1.npz")
+    lat, ctx, unc = _inputs()
+    got = sd_full.sample_latent(ctx, unc, 1.0, 1, init_latent=lat)[0].astype(np.float64)
+    assert np.abs(got - g["latent32"]).max() < 1e-3
+    assert np.abs(got - g["latent64"]).max() < 1e-3
+    img = sd_full.latent_to_image(g["latent32"][None])[0]
+    assert np.abs(img.astype(np.int16) - g["rgb_u8"].astype(np.int16)).max() <= 1
+
+
+def test_config2_20_steps_cfg(sd_full):
+    """configs[1]: 20-step DDIM, CFG 7.5, batch 1 fp32 -- the benchmarked configuration."""
+    g = np.load(GOLD / "sd14_synth_cfg2.npz")
+    lat, ctx, unc = _inputs()
+    got = sd_full.sample_latent(ctx, unc, 7.5, 20, init_latent=lat)[0].astype(np.float64)
+    ref32 = g["latents32"][-1].astype(np.float64)
+    ref64 = g["latent64"]
+    e32, e64 = np.abs(got - ref32).max(), np.abs(got - ref64).max()
+    gap = float(g["step_err"][-1])
+    print(f"final latent: |gpu-f32|={e32:.2e} |gpu-f64|={e64:.2e} |f32-f64|={gap:.2e} absmax={np.abs(ref64).max():.1f}")
+    assert e32 < 1e-3 and e64 <= max(1e-3, 2 * gap)
+
+    # decoded float RGB on the stride-4 grid + u8 image, from the GPU's own latent (whole sample_image path)
+    rgb = sd_full.autoencoder.decode_latent((got[None] * (1.0 / 0.18215)).astype(np.float32))[0]
+    d32 = np.abs(rgb[:, ::4, ::4] - g["rgb32_s4"]).max()
+    d64 = np.abs(rgb[:, ::4, ::4].astype(np.float64) - g["rgb64_s4"]).max()
+    print(f"float RGB (stride-4 grid): |gpu-f32|={d32:.2e} |gpu-f64|={d64:.2e}")
+    assert d32 < 1e-3 and d64 < 1e-3
+    st = g["rgb32_stats"]
+    assert np.abs(rgb.mean(axis=(1, 2)) - st[0]).max() < 1e-4 and np.abs(rgb.std(axis=(1, 2)) - st[1]).max() < 1e-4
+
+    img = sd_full.sample_image(ctx, unc, 7.5, 20, init_latent=lat)[0]
+    diff = np.abs(img.astype(np.int16) - g["rgb_u8"].astype(np.int16))
+    print(f"u8 image: max diff {diff.max()} LSB, {np.count_nonzero(diff)} of {diff.size} bytes differ")
+    assert diff.max() <= 1
+
+
+def test_per_step_drift(sd_full):
+    """Latent after each of the first 3 steps stays within the oracle's own f32/f64 gap (x4)."""
+    g = np.load(GOLD / "sd14_synth_cfg2.npz")
+    lat, ctx, unc = _inputs()
+    # n_steps=20 schedule truncated is not expressible through the reference surface; instead check
+    # the 1-step-of-20 latent by running the same schedule with guidance and comparing step 0 only
+    # via the UNet forwards at t=999 (cond / uncond) recombined on the host in f64.
+    eu = sd_full.unet.forward(lat, [999], unc[None])[0].astype(np.float64)
+    ec = sd_full.unet.forward(lat, [999], ctx)[0].astype(np.float64)
+    a = syn.alphas_cumprod().astype(np.float64)
+    e = eu + (ec - eu) * 7.5
+    x0 = (lat[0] - e * np.sqrt(1 - a[999])) / np.sqrt(a[999])
+    x1 = x0 * np.sqrt(a[949]) + e * np.sqrt(1 - a[949])
+    err = np.abs(x1 - g["latents32"][0]).max()
+    print(f"step-0 latent: |gpu-f32 oracle|={err:.2e}  (oracle f32/f64 gap {g['step_err'][0]:.2e})")
+    assert err < max(1e-4, 4 * float(g["step_err"][0]))

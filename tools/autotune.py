@@ -60,11 +60,20 @@ def main():
     ap.add_argument("--emit", default="")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--budget-s", type=float, default=240.0)
+    ap.add_argument("--only", default="", help="n,cin,h,w,cout,k,stride,ups : time just this shape (for rocprofv3 --pmc runs)")
+    ap.add_argument("--cfg", type=int, default=-1)
+    ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--variant", type=int, default=1, help="gemm kernel generation: 1 = k_gemm2.hip, 0 = k_gemm.hip")
     args = ap.parse_args()
     shapes = QUICK if args.quick else (UNET_SHAPES + (VAE_SHAPES if args.vae else []))
     sd = StableDiffusion(ModelConfig(32, 1, 32, 8, 8, 32))
     sd.set_option("gemm_variant", args.variant)
+    if args.only:
+        s = tuple(int(v) for v in args.only.split(","))
+        M, N, K = mnk(s)
+        ms = sd.bench_conv(*s[:5], k=s[5], stride=s[6], upsample2x=s[7], tile_cfg=args.cfg, splitk=args.splits, iters=args.iters)
+        print(f"{s} cfg={args.cfg} splits={args.splits} variant={args.variant}: {ms:.4f} ms {2.0 * M * N * K / ms / 1e9:.1f} TF")
+        return
     results = []
     t_start = time.time()
     for s in shapes:
