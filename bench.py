@@ -123,16 +123,18 @@ def main():
                 sd.set_option("tune", line.strip())
 
     # ---- inputs: rank 0 owns the prompt embedding; ONE RCCL broadcast ------------------
-    packed = torch.empty((2, T, cfg.ctx_dim), dtype=torch.float32, device=dev)
+    from stable_diffusion_burn_amd import sharding
+    packed = torch.empty(((T + Tu) * cfg.ctx_dim,), dtype=torch.float32, device=dev)
     if rank == 0:
-        packed[0].copy_(torch.from_numpy(syn.cond_context(0, T, cfg.ctx_dim)))
-        packed[1].copy_(torch.from_numpy(syn.uncond_context(Tu, cfg.ctx_dim)))
-    if world > 1:
-        dist.broadcast(packed, src=0)
-    context = packed[0:1].repeat(B, 1, 1).contiguous()          # same prompt for every image
-    uncond = packed[1].contiguous()
-    first = rank * B                                             # global image indices of this shard
-    latent = torch.from_numpy(np.stack([syn.initial_latent(first + i, cfg.latent_h, cfg.latent_w) for i in range(B)])).to(dev)
+        p0, _, _ = sharding.pack_prompt(torch.from_numpy(syn.cond_context(0, T, cfg.ctx_dim)),
+                                        torch.from_numpy(syn.uncond_context(Tu, cfg.ctx_dim)))
+        packed.copy_(p0)
+    sharding.broadcast_prompt(packed, src=0)
+    cond, uncond = sharding.unpack_prompt(packed, T, Tu, cfg.ctx_dim)
+    context = cond[None].repeat(B, 1, 1).contiguous()            # same prompt for every image
+    uncond = uncond.contiguous()
+    mine = sharding.shard_range(B * world, rank, world)          # global image indices of this shard
+    latent = torch.from_numpy(np.stack([syn.initial_latent(i, cfg.latent_h, cfg.latent_w) for i in mine])).to(dev)
     rgb = torch.empty((B, 8 * cfg.latent_h, 8 * cfg.latent_w, 3), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 

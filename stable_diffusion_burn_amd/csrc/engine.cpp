@@ -143,6 +143,13 @@ Engine::Engine(const sdmi_config& cfg) : cfg_(cfg) {
     SDMI_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     SDMI_HIP(hipEventCreate(&ev0_));
     SDMI_HIP(hipEventCreate(&ev1_));
+    {   // measured per-shape tile choices (tools/autotune.py -> tuning/gfx950_fp32.txt)
+        struct Row { const char* key; int cfg; int splits; };
+        static const Row rows[] = {
+#include "tuning_table.inc"
+            {nullptr, 0, 0}};
+        for (const Row* r = rows; r->key; ++r) tuned_[r->key] = TileChoice{r->cfg, r->splits};
+    }
     build_model();
 }
 
@@ -434,6 +441,12 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     if (key == "gemm_tile") opt_force_tile_ = (value == "auto") ? -1 : std::stoi(value);
     else if (key == "splitk") opt_force_splits_ = std::stoi(value);
     else if (key == "gemm_variant") opt_gemm_variant_ = std::stoi(value);
+    else if (key == "record_shapes") { record_shapes_ = std::stoi(value) != 0; if (record_shapes_) shape_counts_.clear(); }
+    else if (key == "dump_shapes") {
+        std::ofstream f(value);
+        if (!f) throw Error(SDMI_ERR_IO, "dump_shapes: cannot write " + value);
+        for (auto& kv : shape_counts_) f << kv.first << " " << kv.second << "\n";
+    }
     else if (key == "profile") { prof_flush(); profiling_ = std::stoi(value) != 0; }
     else if (key == "profile_reset") prof_reset();
     else if (key == "tune") {
@@ -479,6 +492,11 @@ TileChoice Engine::choose_tile(int M, int N, int kt_total) const {
 
 void Engine::launch_gemm(ConvGemm& p, int force_cfg, int force_splits) {
     p.kt_total = (p.K + 31) / 32;
+    if (record_shapes_) {
+        char sk[96];
+        std::snprintf(sk, sizeof sk, "%d,%d,%d,%d,%d,%d,%d,%d", p.NB, p.Cin, p.Hs, p.Ws, p.N, p.KH, p.stride, p.ups);
+        ++shape_counts_[sk];
+    }
     TileChoice tc;
     char key[64];
     std::snprintf(key, sizeof key, "%d,%d,%d", p.M, p.N, p.K);

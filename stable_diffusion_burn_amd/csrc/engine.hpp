@@ -243,6 +243,8 @@ private:
     int opt_force_splits_ = 0;
     int opt_gemm_variant_ = 1;  // 1: k_gemm2.hip (buffer loads, swizzled LDS, pipelined), 0: k_gemm.hip
     std::map<std::string, TileChoice> tuned_;
+    bool record_shapes_ = false;
+    std::map<std::string, long long> shape_counts_;  // "n,cin,h,w,cout,k,stride,ups" -> launches
 
     long long n_kernels_ = 0;
     double flops_ = 0;

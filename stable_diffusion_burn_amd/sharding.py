@@ -1,0 +1,48 @@
+"""Multi-GPU plumbing of the sampling path: image-batch sharding + the ONE collective.
+
+SURVEY.md 8(e): the path shards naturally over independent images -- GroupNorm and attention
+are per sample, DDIM is pointwise, the timestep and the prompt are shared read-only.  So:
+
+  * one process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI; "gloo" in the
+    CPU tests);
+  * rank r owns the contiguous global image indices [r*B/R, (r+1)*B/R); the initial noise of
+    image i is keyed by its GLOBAL index, so results do not depend on the GPU count;
+  * the only data-path collective is one broadcast of the packed prompt embeddings
+    [cond (T x ctx_dim) | uncond (Tu x ctx_dim)] from rank 0 (473 088 bytes at T = Tu = 77) --
+    in the reference they come out of CLIP once per prompt (stablediffusion/mod.rs:194-211);
+  * u8 images stay on their rank (the caller gathers on the host if it wants them together).
+
+torch is used only for the process group and device buffers (plumbing).
+"""
+from __future__ import annotations
+
+
+def shard_range(global_batch: int, rank: int, world: int) -> range:
+    """Contiguous block partition of image indices; sizes differ by at most one."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, rem = divmod(global_batch, world)
+    start = rank * base + min(rank, rem)
+    return range(start, start + base + (1 if rank < rem else 0))
+
+
+def pack_prompt(cond, uncond):
+    """[cond | uncond] as one flat float32 buffer + the two row counts (torch tensors)."""
+    import torch
+    if cond.dim() != 2 or uncond.dim() != 2 or cond.shape[1] != uncond.shape[1]:
+        raise ValueError("cond [T,C] and uncond [Tu,C] expected")
+    return torch.cat([cond.reshape(-1), uncond.reshape(-1)]).contiguous().float(), cond.shape[0], uncond.shape[0]
+
+
+def broadcast_prompt(packed, src: int = 0):
+    """The single collective of the path.  No-op without an initialised process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(packed, src=src)
+    return packed
+
+
+def unpack_prompt(packed, t: int, tu: int, ctx_dim: int):
+    cond = packed[: t * ctx_dim].reshape(t, ctx_dim)
+    uncond = packed[t * ctx_dim: (t + tu) * ctx_dim].reshape(tu, ctx_dim)
+    return cond, uncond

@@ -1,0 +1,69 @@
+"""Multi-process (world_size 2, gloo, CPU) test of the N>1 path's plumbing: the single broadcast of
+the packed prompt embedding and the image sharding by global index (stable_diffusion_burn_amd/sharding.py,
+used verbatim by bench.py with backend "nccl" == RCCL on the GPU box)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from stable_diffusion_burn_amd import sharding, synthetic as syn
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, global_batch, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T, Tu, C = 7, 2, 64
+    packed = torch.zeros((T + Tu) * C)
+    if rank == 0:  # only rank 0 has the prompt embedding (CLIP output in the reference)
+        p0, _, _ = sharding.pack_prompt(torch.from_numpy(syn.cond_context(0, T, C)), torch.from_numpy(syn.uncond_context(Tu, C)))
+        packed.copy_(p0)
+    sharding.broadcast_prompt(packed, src=0)
+    cond, uncond = sharding.unpack_prompt(packed, T, Tu, C)
+    mine = list(sharding.shard_range(global_batch, rank, world))
+    lat = np.stack([syn.initial_latent(i, 8, 8) for i in mine]) if mine else np.zeros((0, 4, 8, 8), np.float32)
+    # barrier + max-over-ranks timing, as bench.py does
+    dist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    q.put((rank, mine, cond.numpy().copy(), uncond.numpy().copy(), lat, float(t.item())))
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_sharding_world2():
+    world, global_batch = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, global_batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref_c, ref_u = syn.cond_context(0, 7, 64), syn.uncond_context(2, 64)
+    covered = []
+    for rank, mine, cond, uncond, lat, tmax in got:
+        assert np.array_equal(cond, ref_c) and np.array_equal(uncond, ref_u)   # every rank has rank 0's prompt
+        assert tmax == float(world)                                             # MAX over ranks
+        for j, i in enumerate(mine):                                            # noise keyed by GLOBAL index
+            assert np.array_equal(lat[j], syn.initial_latent(i, 8, 8))
+        covered += mine
+    assert covered == list(range(global_batch))
+
+
+def test_single_process_broadcast_is_noop():
+    p = torch.arange(6, dtype=torch.float32)
+    assert sharding.broadcast_prompt(p) is p
+    c, u = sharding.unpack_prompt(p, 2, 1, 2)
+    assert c.shape == (2, 2) and u.shape == (1, 2)

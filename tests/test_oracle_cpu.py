@@ -1,0 +1,177 @@
+"""CPU tests of the oracle (oracle/sd_oracle.py): internal consistency, independent
+re-derivations of each op, the reference's quirks and the committed golden
+fixtures.  No GPU, a few seconds to ~2 minutes in total.
+"""
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sd_oracle as O
+from stable_diffusion_burn_amd import synthetic as syn
+
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+# ---- op restatements against independent implementations ------------------------------------
+def test_group_norm_matches_torch_group_norm():
+    """groupnorm/mod.rs:53-82 == torch F.group_norm with biased variance and eps inside the sqrt."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 64, 5, 7, generator=g, dtype=torch.float64)
+    gamma = torch.randn(64, generator=g, dtype=torch.float64)
+    beta = torch.randn(64, generator=g, dtype=torch.float64)
+    ref = F.group_norm(x, 32, gamma, beta, eps=1e-5)
+    assert torch.allclose(O.group_norm(x, gamma, beta, 32, 1e-5), ref, atol=1e-12)
+
+
+def test_qkv_attention_matches_sdpa():
+    """attention.rs:5-45: scaling q and k by d^-0.25 each == softmax(q k^T / sqrt(d)) v."""
+    g = torch.Generator().manual_seed(1)
+    q = torch.randn(2, 9, 64, generator=g, dtype=torch.float64)
+    k = torch.randn(2, 5, 64, generator=g, dtype=torch.float64)
+    v = torch.randn(2, 5, 64, generator=g, dtype=torch.float64)
+    got = O.qkv_attention(q, k, v, None, 4)
+    qh, kh, vh = (t.reshape(2, -1, 4, 16).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(2, 9, 64)
+    assert torch.allclose(got, ref, atol=1e-12)
+
+
+def test_qkv_attention_mask():
+    g = torch.Generator().manual_seed(2)
+    q, k, v = (torch.randn(1, 6, 32, generator=g, dtype=torch.float64) for _ in range(3))
+    mask = torch.triu(torch.full((6, 6), -math.inf, dtype=torch.float64), 1)  # attn_decoder_mask, attention.rs:47-56
+    got = O.qkv_attention(q, k, v, mask, 2)
+    qh, kh, vh = (t.reshape(1, 6, 2, 16).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh, is_causal=True).transpose(1, 2).reshape(1, 6, 32)
+    assert torch.allclose(got, ref, atol=1e-12)
+
+
+def test_gelu_is_erf_not_tanh():
+    """Q4: Burn's Gelu is the exact erf form (python/dump.py uses the tanh approximation)."""
+    x = torch.linspace(-4, 4, 101, dtype=torch.float64)
+    assert torch.allclose(O.gelu_erf(x), F.gelu(x), atol=1e-12)
+    assert (O.gelu_erf(x) - F.gelu(x, approximate="tanh")).abs().max() > 1e-4
+
+
+def test_upsample_is_nearest():
+    x = torch.arange(2 * 3 * 2 * 2, dtype=torch.float64).reshape(2, 3, 2, 2)
+    assert torch.equal(O.upsample2x(x), F.interpolate(x, scale_factor=2, mode="nearest"))
+
+
+def test_timestep_embedding_layout():
+    """unet/mod.rs:19-30: [cos | sin], freqs = exp(-ln(10000) i / half)."""
+    e = O.timestep_embedding(3, 8, 10000, torch.float64)[0].numpy()
+    f = np.exp(-math.log(10000.0) * np.arange(4) / 4)
+    assert np.allclose(e, np.concatenate([np.cos(3 * f), np.sin(3 * f)]), atol=1e-12)
+
+
+# ---- DDIM schedule quirks (stablediffusion/mod.rs:111,123) ------------------------------------
+@pytest.mark.parametrize("n_steps,first,last,count", [(1, 999, 999, 1), (20, 999, 49, 20), (50, 999, 19, 50), (30, 999, 9, 31)])
+def test_ddim_timesteps(n_steps, first, last, count):
+    """Q5: (0..1000).rev().step_by(1000/n) -> 30 steps gives 31 iterations."""
+    ts, step = O.ddim_timesteps(n_steps)
+    assert ts[0] == first and ts[-1] == last and len(ts) == count and step == 1000 // n_steps
+
+
+def test_alphas_cumprod_schedule():
+    a = syn.alphas_cumprod()
+    assert a.shape == (1000,) and a.dtype == np.float32
+    assert abs(float(a[0]) - (1 - 0.00085)) < 1e-6 and 0.004 < float(a[-1]) < 0.005 and np.all(np.diff(a) < 0)
+
+
+# ---- whole-model behaviour on the half-width model ------------------------------------------------
+@pytest.fixture(scope="module")
+def tiny(tiny_dims, synth):
+    a = syn.alphas_cumprod()
+    return (O.StableDiffusionOracle(synth, a, tiny_dims, torch.float32),
+            O.StableDiffusionOracle(synth, a, tiny_dims, torch.float64))
+
+
+def _inputs(d, n=1, T=7, Tu=2):
+    lat = torch.from_numpy(np.stack([syn.initial_latent(i, d.latent_h, d.latent_w) for i in range(n)]))
+    ctx = torch.from_numpy(np.stack([syn.cond_context(i, T, d.ctx_dim) for i in range(n)]))
+    return lat, ctx, torch.from_numpy(syn.uncond_context(Tu, d.ctx_dim))
+
+
+def test_unet_f32_vs_f64(tiny, tiny_dims):
+    lat, ctx, _ = _inputs(tiny_dims)
+    e32 = tiny[0].unet.forward(lat, 999, ctx)
+    e64 = tiny[1].unet.forward(lat, 999, ctx)
+    assert e32.shape == (1, 4, 16, 16) and (e32.double() - e64).abs().max() < 2e-5
+
+
+def test_unet_is_per_sample(tiny, tiny_dims):
+    """Q1: batch > 1 == independent samples (per-sample GroupNorm / attention)."""
+    lat, ctx, _ = _inputs(tiny_dims, n=2)
+    both = tiny[1].unet.forward(lat, 500, ctx)
+    one = tiny[1].unet.forward(lat[1:], 500, ctx[1:])
+    assert (both[1:] - one).abs().max() < 1e-10
+
+
+def test_cfg_scale_one_is_conditional(tiny, tiny_dims):
+    """"CFG off" (scale 1.0) reduces to the conditional prediction (stablediffusion/mod.rs:190-191)."""
+    lat, ctx, unc = _inputs(tiny_dims)
+    eps = tiny[1].forward_diffuser(lat.double(), 999, ctx.double(), unc.double(), 1.0)
+    cond = tiny[1].unet.forward(lat, 999, ctx)
+    assert (eps - cond).abs().max() < 1e-10
+
+
+def test_sample_latent_single_step_formula(tiny, tiny_dims):
+    """One DDIM step with alpha_prev = 1 (t < step) returns predx0 (stablediffusion/mod.rs:131-156)."""
+    lat, ctx, unc = _inputs(tiny_dims)
+    out = tiny[1].sample_latent(ctx, unc, 7.5, 1, lat)
+    a = float(syn.alphas_cumprod()[999])
+    eps = tiny[1].forward_diffuser(lat.double(), 999, ctx.double(), unc.double(), 7.5)
+    x0 = (lat.double() - eps * math.sqrt(1 - a)) / math.sqrt(a)
+    assert (out - x0).abs().max() < 1e-9
+
+
+def test_u8_conversion_truncates(tiny, tiny_dims):
+    """Q8: `as u8` truncates after clamping (stablediffusion/mod.rs:96)."""
+    z = torch.from_numpy(syn.initial_latent(3, 16, 16))[None] * 0.5
+    img, f = tiny[0].latent_to_image(z)
+    assert img.dtype == np.uint8 and img.shape == (1, 128, 128, 3)
+    assert np.array_equal(img, np.floor(np.clip(f.double().numpy(), 0, 255)).astype(np.uint8))
+
+
+def test_synthetic_weights_are_deterministic():
+    a = syn.SyntheticWeights().get("unet/conv_out/weight", (4, 320, 3, 3), "w", 2880)
+    b = syn.SyntheticWeights().get("unet/conv_out/weight", (4, 320, 3, 3), "w", 2880)
+    assert np.array_equal(a, b) and np.abs(a).max() <= 1 / math.sqrt(2880) + 1e-7
+    assert not np.array_equal(a, syn.SyntheticWeights().get("unet/conv_out/bias", (4, 320, 3, 3), "w", 2880))
+    assert np.array_equal(syn.initial_latent(5), syn.initial_latent(5)) and not np.array_equal(syn.initial_latent(5), syn.initial_latent(6))
+
+
+# ---- golden fixtures (full-size model) -------------------------------------------------------------
+def test_golden_fixtures_are_consistent():
+    """The committed vectors agree with each other (cheap structural checks; regenerating them
+    takes ~7 min of oracle time, see tests/golden/gen_golden.py)."""
+    g2 = np.load(GOLD / "sd14_synth_cfg2.npz")
+    assert g2["latents32"].shape == (20, 4, 64, 64) and g2["latent64"].shape == (4, 64, 64)
+    assert g2["rgb_u8"].shape == (512, 512, 3) and g2["rgb_u8"].dtype == np.uint8
+    # f32 vs f64 drift grows monotonically-ish and stays far below the 1e-3 bar (4.8e-5)
+    assert g2["step_err"][-1] < 2e-4 and g2["step_err"][0] < g2["step_err"][-1]
+    assert np.abs(g2["latents32"][-1] - g2["latent64"]).max() == pytest.approx(float(g2["step_err"][-1]), rel=1e-6)
+    # u8 image is the truncation of the float image on the stride-4 grid
+    f = (g2["rgb32_s4"] + 1.0) / 2.0 * 255.0
+    u8 = np.clip(f, 0, 255).astype(np.uint8).transpose(1, 2, 0)
+    assert np.abs(u8.astype(np.int16) - g2["rgb_u8"][::4, ::4].astype(np.int16)).max() <= 1
+    g1 = np.load(GOLD / "sd14_synth_cfg1.npz")
+    assert np.abs(g1["latent32"] - g1["latent64"]).max() < 1e-4
+    gu = np.load(GOLD / "sd14_synth_unet.npz")
+    assert np.abs(gu["eps32_t999"] - gu["eps64_t999"]).max() < 1e-5
+
+
+@pytest.mark.slow
+def test_oracle_reproduces_golden_unet_forward():
+    """Re-run ONE full-size UNet forward (fp32, ~30 s incl. synthetic weights) and compare with the fixture."""
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    o = O.UNetOracle(syn.SyntheticWeights(), O.Dims(), torch.float32)
+    x = torch.from_numpy(syn.initial_latent(0))[None]
+    ctx = torch.from_numpy(syn.cond_context(0))[None]
+    got = o.forward(x, 999, ctx).numpy()[0]
+    ref = np.load(GOLD / "sd14_synth_unet.npz")["eps32_t999"]
+    assert np.abs(got - ref).max() < 2e-5  # thread-count dependent summation order only

@@ -60,12 +60,22 @@ def main():
     ap.add_argument("--emit", default="")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--budget-s", type=float, default=240.0)
+    ap.add_argument("--shapes-file", default="", help="shapes recorded by the engine (option dump_shapes): 'n,cin,h,w,cout,k,stride,ups count'")
     ap.add_argument("--only", default="", help="n,cin,h,w,cout,k,stride,ups : time just this shape (for rocprofv3 --pmc runs)")
     ap.add_argument("--cfg", type=int, default=-1)
     ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--variant", type=int, default=1, help="gemm kernel generation: 1 = k_gemm2.hip, 0 = k_gemm.hip")
     args = ap.parse_args()
     shapes = QUICK if args.quick else (UNET_SHAPES + (VAE_SHAPES if args.vae else []))
+    counts = {}
+    if args.shapes_file:
+        shapes = []
+        for ln in Path(args.shapes_file).read_text().splitlines():
+            if ln.strip():
+                key, cnt = ln.split()
+                sh = tuple(int(v) for v in key.split(","))
+                shapes.append(sh)
+                counts[sh] = int(cnt)
     sd = StableDiffusion(ModelConfig(32, 1, 32, 8, 8, 32))
     sd.set_option("gemm_variant", args.variant)
     if args.only:
@@ -102,7 +112,7 @@ def main():
             continue
         best = min(cands, key=lambda c: c["ms"])
         auto_ms = sd.bench_conv(*s[:5], k=s[5], stride=s[6], upsample2x=s[7], tile_cfg=-1, splitk=0, iters=args.iters)
-        results.append({"shape": s, "M": M, "N": N, "K": K, "best": best, "heuristic_ms": auto_ms,
+        results.append({"shape": s, "count": counts.get(s, 1), "M": M, "N": N, "K": K, "best": best, "heuristic_ms": auto_ms,
                         "heuristic_tflops": flops / auto_ms / 1e9, "cands": cands})
         print(f"{str(s):44s} M={M:6d} N={N:5d} K={K:5d}  best {best['tile']:8s} x{best['splits']:<2d} "
               f"{best['ms']:8.3f} ms {best['tflops']:6.1f} TF | heuristic {auto_ms:8.3f} ms "
@@ -113,9 +123,10 @@ def main():
         with open(args.emit, "w") as f:
             for r in results:
                 f.write(f"{r['M']},{r['N']},{r['K']}={r['best']['cfg']},{r['best']['splits']}\n")
-    tot = sum(2.0 * r["M"] * r["N"] * r["K"] for r in results)
-    tb = sum(r["best"]["ms"] for r in results)
-    th = sum(r["heuristic_ms"] for r in results)
+    tot = sum(2.0 * r["M"] * r["N"] * r["K"] * r["count"] for r in results)
+    tb = sum(r["best"]["ms"] * r["count"] for r in results)
+    th = sum(r["heuristic_ms"] * r["count"] for r in results)
+    print(f"launch-weighted: best {tb:.1f} ms, heuristic/current {th:.1f} ms")
     print(f"sum over shapes: best {tot / tb / 1e9:.1f} TF/s, heuristic {tot / th / 1e9:.1f} TF/s")
 
 
