@@ -188,6 +188,11 @@ int sdmi_bench_conv(sdmi_ctx* ctx, int32_t n, int32_t cin, int32_t h, int32_t w,
                     int32_t k, int32_t stride, int32_t upsample2x, int32_t tile_cfg, int32_t splitk,
                     int32_t iters, double* ms_out);
 
+/* micro-benchmark qkv_attention on device-resident synthetic q/k/v [n, nq|nk, n_state]:
+ * average kernel ms over `iters` launches (HIP events). */
+int sdmi_bench_attention(sdmi_ctx* ctx, int32_t n, int32_t nq, int32_t nk, int32_t n_state, int32_t n_head,
+                         int32_t iters, double* ms_out);
+
 #ifdef __cplusplus
 }
 #endif

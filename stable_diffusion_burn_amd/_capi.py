@@ -65,6 +65,7 @@ SIGNATURES = {
     "sdmi_last_call_stats": (C.c_int, [_CTX, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "sdmi_profile_stats": (C.c_int, [_CTX, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sdmi_bench_conv": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
+    "sdmi_bench_attention": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
 }
 
 _lib = None

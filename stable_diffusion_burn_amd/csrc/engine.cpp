@@ -441,6 +441,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     if (key == "gemm_tile") opt_force_tile_ = (value == "auto") ? -1 : std::stoi(value);
     else if (key == "splitk") opt_force_splits_ = std::stoi(value);
     else if (key == "gemm_variant") opt_gemm_variant_ = std::stoi(value);
+    else if (key == "attn_variant") opt_attn_variant_ = std::stoi(value);
     else if (key == "record_shapes") { record_shapes_ = std::stoi(value) != 0; if (record_shapes_) shape_counts_.clear(); }
     else if (key == "dump_shapes") {
         std::ofstream f(value);
@@ -603,7 +604,7 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
         p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs; p.scale = scale;
         const double fl = 4.0 * n * n_head * (double)nq * nk * d_head;
         ProfScope ps(this, PC_ATTENTION, fl);
-        SDMI_HIP(launch_attention(p, stream_));
+        SDMI_HIP(launch_attention(p, stream_, opt_attn_variant_));
         count_kernel(fl);
         return;
     }
@@ -1052,6 +1053,24 @@ double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int str
     }
     opt_force_tile_ = save_t; opt_force_splits_ = save_s;
     release(a); release(y);
+    return (double)ms / std::max(1, iters);
+}
+
+double Engine::bench_attention(int n, int nq, int nk, int n_state, int n_head, int iters) {
+    SDMI_HIP(hipSetDevice(cfg_.device));
+    if (n <= 0 || nq <= 0 || nk <= 0 || n_head <= 0 || n_state % n_head) throw Error(SDMI_ERR_INVALID, "bench_attention: bad shape");
+    Buf q(this, (size_t)n * nq * n_state * 4), k(this, (size_t)n * nk * n_state * 4), v(this, (size_t)n * nk * n_state * 4),
+        o(this, (size_t)n * nq * n_state * 4);
+    SDMI_HIP(launch_fill_normal(q.f(), (long long)n * nq * n_state, 21, stream_));
+    SDMI_HIP(launch_fill_normal(k.f(), (long long)n * nk * n_state, 22, stream_));
+    SDMI_HIP(launch_fill_normal(v.f(), (long long)n * nk * n_state, 23, stream_));
+    qkv_attention_dev(q.f(), k.f(), v.f(), nullptr, 0, n, nq, nk, n_state, n_head, o.f());
+    float ms = 0;
+    SDMI_HIP(hipEventRecord(ev0_, stream_));
+    for (int i = 0; i < iters; ++i) qkv_attention_dev(q.f(), k.f(), v.f(), nullptr, 0, n, nq, nk, n_state, n_head, o.f());
+    SDMI_HIP(hipEventRecord(ev1_, stream_));
+    SDMI_HIP(hipEventSynchronize(ev1_));
+    SDMI_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
     return (double)ms / std::max(1, iters);
 }
 

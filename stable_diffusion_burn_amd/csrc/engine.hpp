@@ -123,6 +123,7 @@ public:
     double bench_conv(int n, int cin, int h, int w, int cout, int k, int stride, int ups, int tile_cfg, int splitk,
                       int iters);
 
+    double bench_attention(int n, int nq, int nk, int n_state, int n_head, int iters);
     void set_option(const std::string& key, const std::string& value);
     void sync();
     void begin_call();
@@ -241,6 +242,7 @@ private:
     // options
     int opt_force_tile_ = -1;
     int opt_force_splits_ = 0;
+    int opt_attn_variant_ = 1;  // 1: attn2_kernel, 0: attn_f32_kernel
     int opt_gemm_variant_ = 1;  // 1: k_gemm2.hip (buffer loads, swizzled LDS, pipelined), 0: k_gemm.hip
     std::map<std::string, TileChoice> tuned_;
     bool record_shapes_ = false;

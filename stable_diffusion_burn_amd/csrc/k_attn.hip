@@ -214,6 +214,215 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnParams p) {
     }
 }
 
+// =====================================================================================
+// v2: 4- or 8-wave workgroups, branch-free fast path, exp2 domain, permlane reductions
+// =====================================================================================
+// Changes against attn_f32_kernel (kept above as variant 0 for A/B), from its ISA + rocprof:
+//  * NW = 8 waves (128 query rows) per workgroup for long sequences: the 64x64 level has
+//    1024 4-wave workgroups for 768 resident slots (LDS-limited) -> 1.33 "rounds", a 33 %
+//    quantisation loss; 512 8-wave workgroups are all resident at once (4 waves/SIMD) and
+//    the K/V staging traffic per MFMA halves.
+//  * the additive mask is a template flag and key-length masking runs only on the last
+//    (partial) tile: v1 carried 16 exec-mask branches per tile even with mask == NULL.
+//  * scores are kept in log2 units (q pre-scaled by d^-0.5 * log2 e, K unscaled):
+//    exp(s - m) becomes one v_exp_f32, no multiply.
+//  * the two cross-lane reductions use v_permlane32_swap / v_permlane16_swap (VALU) instead
+//    of ds_bpermute round trips through the LDS crossbar.
+__device__ __forceinline__ float xlane_max4(float v) {  // max over lanes {c, c+16, c+32, c+48}
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    v = fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    auto q = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return fmaxf(__builtin_bit_cast(float, q[0]), __builtin_bit_cast(float, q[1]));
+}
+__device__ __forceinline__ float xlane_sum4(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    v = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    auto q = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return __builtin_bit_cast(float, q[0]) + __builtin_bit_cast(float, q[1]);
+}
+
+template <int D, int NW>
+struct Attn2Cfg {
+    static constexpr int NT = NW * 64;
+    static constexpr int BKV = (D > 96) ? 32 : 64;
+    static constexpr int KT = BKV / 16;
+    static constexpr int DT = (D + 15) / 16;
+    static constexpr int DC = D / 8;
+    static constexpr int LDK = D + 4;
+    static constexpr int F4_PER_TILE = BKV * (D / 4);
+    static constexpr int NLD = (F4_PER_TILE + NT - 1) / NT;
+    static constexpr int TILE_FLOATS = BKV * LDK;
+    static constexpr size_t LDS_BYTES = (size_t)(4 * TILE_FLOATS + 64) * sizeof(float);
+};
+
+template <int D, int NW, bool HAS_MASK>
+__global__ __launch_bounds__(NW * 64) void attn2_kernel(const AttnParams p) {
+    using Cfg = Attn2Cfg<D, NW>;
+    constexpr int NT = Cfg::NT, BKV = Cfg::BKV, KT = Cfg::KT, DT = Cfg::DT, DC = Cfg::DC, LDK = Cfg::LDK, NLD = Cfg::NLD;
+    constexpr float kLog2e = 1.4426950408889634f;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;
+    float* Vs = smem + 2 * Cfg::TILE_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int g = lane >> 4;
+    const int c = lane & 15;
+
+    const int b = blockIdx.y / p.n_head;
+    const int hh = blockIdx.y - b * p.n_head;
+    const int qrow = blockIdx.x * (16 * NW) + wave * 16 + c;
+    const bool q_ok = qrow < p.nq;
+
+    const float* Qb = p.q + (long long)b * p.q_bs + hh * D;
+    const float* Kb = p.k + (long long)b * p.k_bs + hh * D;
+    const float* Vb = p.v + (long long)b * p.v_bs + hh * D;
+    float* Ob = p.o + (long long)b * p.o_bs + hh * D;
+
+    const int nk = p.kv_len ? p.kv_len[b] : p.nk;
+    const int n_tiles = (nk + BKV - 1) / BKV;
+    const int n_full = nk / BKV;
+
+    const float qscale = p.scale * p.scale * kLog2e;  // (q*s)(k*s) = q k s^2, in log2 units
+    f32x2 qf[DC];
+#pragma unroll
+    for (int cc = 0; cc < DC; ++cc) {
+        f32x2 v = {0.f, 0.f};
+        if (q_ok) v = *reinterpret_cast<const f32x2*>(Qb + (long long)qrow * p.ldq + cc * 8 + g * 2);
+        qf[cc] = v * qscale;
+    }
+
+    f32x4 rk[NLD], rv[NLD];
+    auto gload = [&](int tile) {
+        const int kv0 = tile * BKV;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * NT;
+            const int row = idx / (D / 4);
+            const int c4 = idx - row * (D / 4);
+            const int key = kv0 + row;
+            f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (idx < Cfg::F4_PER_TILE && key < nk) {
+                kk = *reinterpret_cast<const f32x4*>(Kb + (long long)key * p.ldk + c4 * 4);
+                vv = *reinterpret_cast<const f32x4*>(Vb + (long long)key * p.ldv + c4 * 4);
+            }
+            rk[i] = kk;
+            rv[i] = vv;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * NT;
+            if (idx < Cfg::F4_PER_TILE) {
+                const int row = idx / (D / 4);
+                const int c4 = idx - row * (D / 4);
+                *reinterpret_cast<f32x4*>(Ks + buf * Cfg::TILE_FLOATS + row * LDK + c4 * 4) = rk[i];
+                *reinterpret_cast<f32x4*>(Vs + buf * Cfg::TILE_FLOATS + row * LDK + c4 * 4) = rv[i];
+            }
+        }
+    };
+
+    f32x4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY;
+    float l_run = 0.f;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int cur = tile & 1;
+        const bool more = (tile + 1) < n_tiles;
+        if (more) gload(tile + 1);
+
+        const float* Kt = Ks + cur * Cfg::TILE_FLOATS;
+        const float* Vt = Vs + cur * Cfg::TILE_FLOATS;
+        const int kv0 = tile * BKV;
+
+        f32x4 s[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            const float* kp = Kt + (kt * 16 + c) * LDK + g * 2;
+#pragma unroll
+            for (int cc = 0; cc < DC; ++cc) {
+                const f32x2 kf = *reinterpret_cast<const f32x2*>(kp + cc * 8);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[0], qf[cc][0], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[1], qf[cc][1], a, 0, 0, 0);
+            }
+            s[kt] = a;
+        }
+
+        if (HAS_MASK || tile >= n_full) {  // uniform: additive mask and/or the ragged last tile
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kv0 + kt * 16 + g * 4 + r;
+                    float v = s[kt][r];
+                    if (HAS_MASK) {
+                        if (q_ok && key < nk) v += p.mask[(long long)qrow * p.mask_ld + key] * kLog2e;
+                    }
+                    if (key >= nk) v = -INFINITY;
+                    s[kt][r] = v;
+                }
+            }
+        }
+
+        float mt = s[0][0];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[kt][r]);
+        mt = xlane_max4(mt);
+        const float m_new = fmaxf(m_run, mt);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(s[kt][r] - m_use);
+                s[kt][r] = e;
+                psum += e;
+            }
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
+
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* vp = Vt + (kt * 16 + g * 4 + r) * LDK + c;
+                const float pv = s[kt][r];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[dt * 16], pv, o[dt], 0, 0, 0);
+            }
+        }
+
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    const float inv = 1.0f / xlane_sum4(l_run);
+    if (q_ok) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int dcol = dt * 16 + g * 4;
+            if (dcol < D) *reinterpret_cast<f32x4*>(Ob + (long long)qrow * p.ldo + dcol) = o[dt] * inv;
+        }
+    }
+}
+
 // ---- row softmax for the unfused single-head (VAE, d = 512) attention ------------------
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* x, int rows, int cols, float scale) {
     __shared__ float red[8];
@@ -259,11 +468,43 @@ static hipError_t launch_attn_d(const AttnParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
+template <int D, int NW, bool HAS_MASK>
+static hipError_t launch_attn2_d(const AttnParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    auto k = attn2_kernel<D, NW, HAS_MASK>;
+    const size_t lds = Attn2Cfg<D, NW>::LDS_BYTES;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((p.nq + 16 * NW - 1) / (16 * NW), p.n * p.n_head);
+    hipLaunchKernelGGL(k, grid, dim3(NW * 64), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int D>
+static hipError_t launch_attn2_any(const AttnParams& p, hipStream_t stream) {
+    // 8-wave workgroups once they still fill the chip (>= 1.5 workgroups per CU), else 4-wave
+    const long long wg8 = (long long)((p.nq + 127) / 128) * p.n * p.n_head;
+    const bool big = wg8 >= 384;
+    if (p.mask) return big ? launch_attn2_d<D, 8, true>(p, stream) : launch_attn2_d<D, 4, true>(p, stream);
+    return big ? launch_attn2_d<D, 8, false>(p, stream) : launch_attn2_d<D, 4, false>(p, stream);
+}
+
+hipError_t launch_attention(const AttnParams& p, hipStream_t stream, int variant) {
+    if (variant == 0) {
+        switch (p.d_head) {
+            case 40: return launch_attn_d<40>(p, stream);
+            case 80: return launch_attn_d<80>(p, stream);
+            case 160: return launch_attn_d<160>(p, stream);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (p.d_head) {
-        case 40: return launch_attn_d<40>(p, stream);
-        case 80: return launch_attn_d<80>(p, stream);
-        case 160: return launch_attn_d<160>(p, stream);
+        case 40: return launch_attn2_any<40>(p, stream);
+        case 80: return launch_attn2_any<80>(p, stream);
+        case 160: return launch_attn2_any<160>(p, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -64,7 +64,7 @@ struct AttnParams {
     float scale;                        // d_head^-0.25 applied to q and to k (attention.rs:15-26)
 };
 bool attn_supported_head_dim(int d);
-hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
+hipError_t launch_attention(const AttnParams& p, hipStream_t stream, int variant = 1);  // 0: v1 kernel (A/B)
 // row softmax (in place) for the unfused single-head VAE attention: x[rows][cols] *= scale first
 hipError_t launch_softmax_rows(float* x, int rows, int cols, float scale, hipStream_t stream);
 

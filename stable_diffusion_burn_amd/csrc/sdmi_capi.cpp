@@ -396,4 +396,12 @@ int sdmi_bench_conv(sdmi_ctx* ctx, int32_t n, int32_t cin, int32_t h, int32_t w,
     });
 }
 
+int sdmi_bench_attention(sdmi_ctx* ctx, int32_t n, int32_t nq, int32_t nk, int32_t n_state, int32_t n_head,
+                         int32_t iters, double* ms_out) {
+    return guarded([&] {
+        if (!ms_out) throw Error(SDMI_ERR_INVALID, "bench_attention: null output");
+        *ms_out = eng(ctx).bench_attention(n, nq, nk, n_state, n_head, iters);
+    });
+}
+
 }  // extern "C"

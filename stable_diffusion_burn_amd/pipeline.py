@@ -237,6 +237,11 @@ class StableDiffusion:
                                         C.byref(ms)))
         return ms.value
 
+    def bench_attention(self, n, nq, nk, n_state, n_head, iters=10) -> float:
+        ms = C.c_double()
+        check(self._lib.sdmi_bench_attention(self._ctx, n, nq, nk, n_state, n_head, iters, C.byref(ms)))
+        return ms.value
+
     # ---- operator-level entry points (parity tests) ----------------------------------------
     def op_group_norm(self, x, gamma, beta, n_group=32, eps=1e-5, silu=False):
         x = _f32(x)

@@ -195,21 +195,27 @@ ATTN_CASES = [
     (2, 64, 2, 1280, 8),      # cross, Tu = 2 (unconditional context)
     (1, 100, 37, 160, 4),     # ragged queries and keys
     (1, 4, 4, 640, 4),        # 2x2 level of the tiny model
+    (3, 2048, 512, 320, 8),   # >= 384 8-wave workgroups -> the 8-wave instance (64x64 UNet level regime)
+    (6, 2100, 300, 160, 4),   # 8-wave, ragged queries and keys
+    (3, 2048, 77, 640, 8),    # 8-wave, d = 80, cross-attention length
     (1, 64, 64, 128, 1),      # unfused path (VAE-style single wide head)
     (1, 256, 256, 512, 1),
 ]
 
 
+@pytest.mark.parametrize("variant", [1, 0])
 @pytest.mark.parametrize("case", ATTN_CASES)
-def test_qkv_attention(sd_ops, case):
+def test_qkv_attention(sd_ops, case, variant):
     n, nq, nk, c, heads = case
+    sd_ops.set_option("attn_variant", variant)
     g = _rng(hash(case) % (2 ** 31))
     q = g.standard_normal((n, nq, c)).astype(np.float32)
     k = g.standard_normal((n, nk, c)).astype(np.float32)
     v = g.standard_normal((n, nk, c)).astype(np.float32)
     got = sd_ops.qkv_attention(q, k, v, None, heads)
+    sd_ops.set_option("attn_variant", 1)
     ref = O.qkv_attention(_t(q), _t(k), _t(v), None, heads)
-    _check(got, ref.numpy(), f"qkv_attention{case}")
+    _check(got, ref.numpy(), f"qkv_attention{case} variant={variant}")
 
 
 def test_qkv_attention_causal_mask(sd_ops):
