@@ -228,17 +228,33 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnParams p) {
 //    exp(s - m) becomes one v_exp_f32, no multiply.
 //  * the two cross-lane reductions use v_permlane32_swap / v_permlane16_swap (VALU) instead
 //    of ds_bpermute round trips through the LDS crossbar.
+// The swaps are issued as inline asm: with ROCm 7.2's hipcc the __builtin_amdgcn_permlane{16,32}_swap
+// results fed to fmaxf / fadd get folded by InstCombine into a single extractvalue (the exchange is
+// silently dropped; found by the parity tests).  "s_nop 1" covers the VALU-write -> permlane-read
+// hazard (2 wait states) that hipcc does not pad inside an asm statement.
+__device__ __forceinline__ void swap32(float a, float b, float& ra, float& rb) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    ra = a;
+    rb = b;
+}
+__device__ __forceinline__ void swap16(float a, float b, float& ra, float& rb) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    ra = a;
+    rb = b;
+}
 __device__ __forceinline__ float xlane_max4(float v) {  // max over lanes {c, c+16, c+32, c+48}
-    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    v = fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-    auto q = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return fmaxf(__builtin_bit_cast(float, q[0]), __builtin_bit_cast(float, q[1]));
+    float a, b;
+    swap32(v, v, a, b);   // a = [lo, lo], b = [hi, hi]
+    v = fmaxf(a, b);
+    swap16(v, v, a, b);   // a = [r0, r0, r2, r2], b = [r1, r1, r3, r3]
+    return fmaxf(a, b);
 }
 __device__ __forceinline__ float xlane_sum4(float v) {
-    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    v = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
-    auto q = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return __builtin_bit_cast(float, q[0]) + __builtin_bit_cast(float, q[1]);
+    float a, b;
+    swap32(v, v, a, b);
+    v = a + b;
+    swap16(v, v, a, b);
+    return a + b;
 }
 
 template <int D, int NW>
