@@ -213,6 +213,16 @@ void Engine::build_model() {
         }
     };
     auto mha = [&](MhaW& m, const std::string& path, int c, int cctx) {  // unet/mod.rs:603-653
+        if (c == cctx) {
+            // self-attention: query/key/value weights are packed into ONE [3c][c] buffer so the three
+            // projections of unet/mod.rs:645-647 run as a single GEMM with N = 3c
+            void* p = nullptr;
+            SDMI_HIP(hipMalloc(&p, (size_t)3 * c * c * sizeof(float)));
+            weight_allocs_.push_back(p);
+            m.q.bt = reinterpret_cast<float*>(p);
+            m.k.bt = m.q.bt + (size_t)c * c;
+            m.v.bt = m.q.bt + (size_t)2 * c * c;
+        }
         lin(m.q, path + "/query", c, c, false);
         lin(m.k, path + "/key", cctx, c, false);
         lin(m.v, path + "/value", cctx, c, false);
@@ -468,7 +478,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
 // depends only on (M,N,K), so a sample's result is independent of where it sits
 // in the batch only for equal M; see DESIGN.md "Determinism".
 TileChoice Engine::choose_tile(int M, int N, int kt_total) const {
-    static const double eff[kNumGemmTiles] = {0.85, 0.75, 0.60, 0.90, 0.75, 0.85, 0.75, 0.85};
+    static const double eff[kNumGemmTiles] = {0.85, 0.75, 0.60, 0.90, 0.75, 0.85, 0.75, 0.85, 0.65, 0.75};
     static const int split_opts[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
     const int n_cu = 256;
     double best = 1e300;
@@ -676,14 +686,13 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
     release(g);
     {
         Buf ln(this, (size_t)M * C * 4), q(this, (size_t)M * C * 4), a(this, (size_t)M * C * 4);
-        // self attention
+        // self attention: q, k, v in one GEMM (N = 3C) on the packed [3C][C] weight
         layer_norm(w.ln1, h.p, M, ln.f());
         {
-            Buf k(this, (size_t)M * C * 4), v(this, (size_t)M * C * 4);
-            gemm(ln.f(), (int)M, w.attn1.q.bt, nullptr, C, C, q.f(), C, nullptr, 0);
-            gemm(ln.f(), (int)M, w.attn1.k.bt, nullptr, C, C, k.f(), C, nullptr, 0);
-            gemm(ln.f(), (int)M, w.attn1.v.bt, nullptr, C, C, v.f(), C, nullptr, 0);
-            attention(q.f(), C, (long long)hw * C, k.f(), C, (long long)hw * C, v.f(), C, (long long)hw * C, a.f(), C,
+            Buf qkv(this, (size_t)M * 3 * C * 4);
+            gemm(ln.f(), (int)M, w.attn1.q.bt, nullptr, C, 3 * C, qkv.f(), 3 * C, nullptr, 0);
+            const long long bs3 = (long long)hw * 3 * C;
+            attention(qkv.f(), 3 * C, bs3, qkv.f() + C, 3 * C, bs3, qkv.f() + 2 * C, 3 * C, bs3, a.f(), C,
                       (long long)hw * C, nb, hw, hw, heads, d, nullptr, nullptr, nullptr, 0);
         }
         gemm(a.f(), (int)M, w.attn1.out.bt, w.attn1.out.bias, C, C, h.p, C, h.p, C);

@@ -348,6 +348,8 @@ static const GemmTileInfo kTiles[kNumGemmTiles] = {
     {256, 80, "256x80"},    // 5: wave 64x80
     {64, 128, "64x128"},    // 6: wave 32x64
     {128, 160, "128x160"},  // 7: wave 64x80 (2x2 waves)
+    {64, 80, "64x80"},      // 8: wave 16x80  (M = 8192, N = 320 -> 512 tiles, no split-K)
+    {64, 160, "64x160"},    // 9: wave 32x80 (2x2 waves)
 };
 
 const GemmTileInfo& gemm_tile_info(int cfg) { return kTiles[cfg]; }
@@ -389,6 +391,8 @@ hipError_t launch_conv_gemm(const ConvGemm& p, int cfg, hipStream_t stream) {
         case 5: return launch_cfg<4, 5, 4, 1>(p, lds, grid, stream);
         case 6: return launch_cfg<2, 4, 2, 2>(p, lds, grid, stream);
         case 7: return launch_cfg<4, 5, 2, 2>(p, lds, grid, stream);
+        case 8: return launch_cfg<1, 5, 4, 1>(p, lds, grid, stream);
+        case 9: return launch_cfg<2, 5, 2, 2>(p, lds, grid, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -316,6 +316,8 @@ hipError_t launch_conv_gemm2(const ConvGemm& p, int cfg, hipStream_t stream) {
         case 5: return launch_cfg2<4, 5, 4, 1>(p, lds, grid, stream);
         case 6: return launch_cfg2<2, 4, 2, 2>(p, lds, grid, stream);
         case 7: return launch_cfg2<4, 5, 2, 2>(p, lds, grid, stream);
+        case 8: return launch_cfg2<1, 5, 4, 1>(p, lds, grid, stream);
+        case 9: return launch_cfg2<2, 5, 2, 2>(p, lds, grid, stream);
     }
     return hipErrorInvalidValue;
 }

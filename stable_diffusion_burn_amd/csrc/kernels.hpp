@@ -41,7 +41,7 @@ struct ConvGemm {
 
 // tile configurations (index = tile_cfg); BM x BN per 256-thread workgroup
 struct GemmTileInfo { int bm, bn; const char* name; };
-constexpr int kNumGemmTiles = 8;
+constexpr int kNumGemmTiles = 10;
 const GemmTileInfo& gemm_tile_info(int cfg);
 size_t gemm_tile_lds_bytes(int cfg);
 hipError_t launch_conv_gemm(const ConvGemm& p, int tile_cfg, hipStream_t stream);   // v1 (k_gemm.hip)

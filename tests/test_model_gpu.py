@@ -150,3 +150,45 @@ def test_shape_errors_raise(sd_tiny, tiny_dims):
     from stable_diffusion_burn_amd import SdmiError
     with pytest.raises(SdmiError):
         sd_tiny.sample_latent(ctx, unc, 7.5, 0, init_latent=lat)  # n_steps = 0
+
+
+def test_load_weights_dir_matches_set_weight(sd_tiny, synth, tiny_dims, tmp_path):
+    """the npy-dump tree (reference format, python/save.py) read by the C++ loader
+    (sdmi_load_weights_dir <- load_stable_diffusion, stablediffusion/load.rs:16-33) gives bit-identical
+    results to feeding the same tensors through sdmi_set_weight."""
+    from stable_diffusion_burn_amd import ModelConfig, StableDiffusion, SdmiError, weights as wio
+    d = tiny_dims
+    specs = sd_tiny.weight_specs()
+    shapes = dict(specs)
+
+    def get(name, shape):
+        parent, leaf = name.rsplit("/", 1)
+        wshape = shapes.get(parent + "/weight")
+        if leaf == "weight":
+            if len(shape) == 4:
+                return synth.get(name, shape, "w", shape[1] * shape[2] * shape[3])
+            if len(shape) == 2:
+                return synth.get(name, shape, "w", shape[0])
+            return synth.get(name, shape, "gamma")
+        if wshape is not None and len(wshape) == 4:
+            return synth.get(name, shape, "b", wshape[1] * wshape[2] * wshape[3])
+        if wshape is not None and len(wshape) == 2:
+            return synth.get(name, shape, "b", wshape[0])
+        return synth.get(name, shape, "beta")
+
+    wio.write_dump_tree(tmp_path / "params", specs, get, syn.alphas_cumprod(), n_head=d.n_head)
+    sd2 = StableDiffusion(ModelConfig(d.model_channels, d.n_head, d.ctx_dim, d.latent_h, d.latent_w, d.vae_ch))
+    try:
+        sd2.load_weights_dir(tmp_path / "params")
+        lat, ctx, unc = _inputs(d, 1, 7, 2)
+        a = sd_tiny.sample_image(ctx, unc, 7.5, 2, init_latent=lat)
+        b = sd2.sample_image(ctx, unc, 7.5, 2, init_latent=lat)
+        assert np.array_equal(a, b)
+        # a missing file is a loud IO error, not a silent default
+        (tmp_path / "params/unet/conv_out/bias.npy").unlink()
+        sd3 = StableDiffusion(ModelConfig(d.model_channels, d.n_head, d.ctx_dim, d.latent_h, d.latent_w, d.vae_ch))
+        with pytest.raises(SdmiError):
+            sd3.load_weights_dir(tmp_path / "params")
+        sd3.close()
+    finally:
+        sd2.close()

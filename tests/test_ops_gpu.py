@@ -117,7 +117,7 @@ def test_conv2d(sd_ops, case, variant):
 
 
 @pytest.mark.parametrize("variant", [1, 0])
-@pytest.mark.parametrize("tile", range(8))
+@pytest.mark.parametrize("tile", range(10))
 @pytest.mark.parametrize("splitk", [1, 3])
 def test_conv2d_all_tiles(sd_ops, tile, splitk, variant):
     """Every tile configuration x split-K on one awkward shape (M, N not tile multiples)."""

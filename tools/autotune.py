@@ -17,7 +17,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 
 from stable_diffusion_burn_amd import ModelConfig, StableDiffusion  # noqa: E402
 
-TILES = ["128x128", "128x64", "64x64", "256x128", "128x80", "256x80", "64x128", "128x160"]
+TILES = ["128x128", "128x64", "64x64", "256x128", "128x80", "256x80", "64x128", "128x160", "64x80", "64x160"]
 
 # (n, cin, h, w, cout, k, stride, ups): UNet at batch 2 (cond+uncond of one image) + VAE at batch 1
 UNET_SHAPES = [
