@@ -1,16 +1,21 @@
 """CPU ORACLE for the SD v1.4 sampling hot path -- TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED (see DESIGN.md section "Oracle"): the reference
-(Gadersd/stable-diffusion-burn) is Rust on top of Burn 0.14; neither a Rust
-toolchain nor the Burn crates exist in this environment, the reference ships
-no golden vectors for this path (its only test is a tokenizer test,
-src/tokenizer.rs:205-222) and its RNG is unseeded
-(src/model/stablediffusion/mod.rs:115-121).  This file is therefore a
-*restatement* of the reference's arithmetic, written from the cited Rust lines
-(NOT from diffusers / ldm, which differ in eps, GELU flavour, context padding
-and DDIM indexing).  It is cross-checked against the reference's own Python
-model definition (python/dump.py, imported through a small tinygrad shim) by
-tests/golden/gen_from_reference_python.py.
+PARITY: PINNED TO THE REFERENCE'S PYTHON MODEL, NOT TO A RUN OF THE RUST BINARY (see DESIGN.md
+section 3).  The reference (Gadersd/stable-diffusion-burn) is Rust on top of Burn 0.14; neither a
+Rust toolchain nor the Burn crates exist in this environment, the reference ships no golden
+vectors for this path (its only test is a tokenizer test, src/tokenizer.rs:205-222) and its RNG is
+unseeded (src/model/stablediffusion/mod.rs:115-121).  This file is therefore a *restatement* of
+the reference's arithmetic, written from the cited Rust lines (NOT from diffusers / ldm, which
+differ in eps, GELU flavour, context padding and DDIM indexing).  What pins it:
+  * tests/golden/gen_from_reference_python.py imports the reference's own Python model
+    (python/dump.py, through a small tinygrad-API shim) and its exporters (python/save.py,
+    unet.py, autoencoder.py), loads the seeded synthetic weights BY THE REFERENCE'S DUMP NAMES and
+    compares: UNet forward and VAE decoder agree with this oracle to 4e-15 / 3e-15 (fp64);
+    the fixtures are committed (tests/golden/refpy_*.npz, refdump/) and checked by
+    tests/test_reference_python_cpu.py;
+  * independent re-derivations of every op and quirk in tests/test_oracle_cpu.py.
+Not pinned (unavailable here): Burn's own kernels and the Rust-only deviations from the Python
+model (exact-erf GELU Q4, unpadded context Q2, DDIM step_by Q5), restated from the Rust source.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
 import this module, and only as the checker / the reported CPU baseline --
