@@ -124,7 +124,10 @@ void Engine::prof_flush() {
 // construction / model definition
 // =============================================================================
 Engine::Engine(const sdmi_config& cfg) : cfg_(cfg) {
-    if (cfg.precision != 0) throw Error(SDMI_ERR_UNSUPPORTED, "only precision=0 (fp32) is built in this round");
+    if (cfg.precision != 0 && cfg.precision != 1) throw Error(SDMI_ERR_UNSUPPORTED, "precision must be 0 (fp32) or 1 (bf16); fp8 is not built yet");
+    bf16_ = cfg.precision == 1;
+    if (bf16_ && (cfg.model_channels % 64 || cfg.vae_ch % 64 || cfg.ctx_dim % 64))
+        throw Error(SDMI_ERR_UNSUPPORTED, "precision=1 (bf16) needs model_channels, vae_ch and ctx_dim to be multiples of 64");
     if (cfg.model_channels % 32 || cfg.model_channels <= 0) throw Error(SDMI_ERR_INVALID, "model_channels must be a positive multiple of 32");
     if (cfg.vae_ch % 32 || cfg.vae_ch <= 0) throw Error(SDMI_ERR_INVALID, "vae_ch must be a positive multiple of 32");
     if (cfg.n_head <= 0 || cfg.model_channels % cfg.n_head) throw Error(SDMI_ERR_INVALID, "n_head must divide model_channels");
@@ -164,9 +167,9 @@ Engine::~Engine() {
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
-void Engine::add_entry(const std::string& name, int kind, std::initializer_list<int64_t> dims, float** dst) {
+void Engine::add_entry(const std::string& name, int kind, std::initializer_list<int64_t> dims, float** dst, int wdt) {
     WeightEntry e;
-    e.name = name; e.kind = kind; e.ndim = (int)dims.size(); e.dst = dst;
+    e.name = name; e.kind = kind; e.ndim = (int)dims.size(); e.dst = dst; e.wdt = wdt;
     int i = 0;
     for (int k = 0; k < 4; ++k) e.dims[k] = 1;
     for (auto d : dims) e.dims[i++] = d;
@@ -179,15 +182,21 @@ void Engine::add_entry(const std::string& name, int kind, std::initializer_list<
 void Engine::build_model() {
     const int mc = cfg_.model_channels, ed = 4 * mc, cd = cfg_.ctx_dim;
     const int c1 = mc, c2 = 2 * mc, c4 = 4 * mc;
-    auto add = [](Engine* e, const std::string& n, int kind, std::initializer_list<int64_t> d, float** dst) { e->add_entry(n, kind, d, dst); };
+    auto add = [](Engine* e, const std::string& n, int kind, std::initializer_list<int64_t> d, float** dst, int wdt = 0) { e->add_entry(n, kind, d, dst, wdt); };
+    // precision = 1: weights of every layer with Cin % 64 == 0 are packed as bf16; the three Cin = 4
+    // layers and the time-embedding MLPs (M = n_steps rows, once per call) stay fp32
     auto conv = [&](ConvW& w, const std::string& path, int cin, int cout, int k) {
         w.cin = cin; w.cout = cout; w.k = k;
-        add(this, path + "/weight", 0, {cout, cin, k, k}, &w.bt);
+        w.dt = (bf16_ && cin % 64 == 0) ? 1 : 0;
+        if (bf16_ && !w.dt && cin >= 32) throw Error(SDMI_ERR_UNSUPPORTED, "bf16: conv Cin must be a multiple of 64 (or < 32)");
+        add(this, path + "/weight", 0, {cout, cin, k, k}, &w.bt, w.dt);
         add(this, path + "/bias", 2, {cout}, &w.bias);
     };
-    auto lin = [&](LinW& w, const std::string& path, int cin, int cout, bool bias) {
+    auto lin = [&](LinW& w, const std::string& path, int cin, int cout, bool bias, bool keep_f32 = false) {
         w.cin = cin; w.cout = cout;
-        add(this, path + "/weight", 1, {cin, cout}, &w.bt);
+        w.dt = (bf16_ && !keep_f32) ? 1 : 0;
+        if (w.dt && cin % 64) throw Error(SDMI_ERR_UNSUPPORTED, "bf16: linear in_features must be a multiple of 64");
+        add(this, path + "/weight", 1, {cin, cout}, &w.bt, w.dt);
         if (bias) add(this, path + "/bias", 2, {cout}, &w.bias);
     };
     auto norm = [&](NormW& w, const std::string& path, int c) {
@@ -200,7 +209,7 @@ void Engine::build_model() {
         if (unet) {  // ResBlock, unet/mod.rs:679-734; names unet/load.rs:20-25
             norm(r.norm_in, path + "/norm_in", cin);
             conv(r.conv_in, path + "/conv_in", cin, cout, 3);
-            lin(r.lin_embed, path + "/lin_embed", ed, cout, true);
+            lin(r.lin_embed, path + "/lin_embed", ed, cout, true, /*keep_f32=*/true);
             norm(r.norm_out, path + "/norm_out", cout);
             conv(r.conv_out, path + "/conv_out", cout, cout, 3);
             if (r.has_skip) conv(r.skip, path + "/skip_connection", cin, cout, 1);
@@ -217,11 +226,11 @@ void Engine::build_model() {
             // self-attention: query/key/value weights are packed into ONE [3c][c] buffer so the three
             // projections of unet/mod.rs:645-647 run as a single GEMM with N = 3c
             void* p = nullptr;
-            SDMI_HIP(hipMalloc(&p, (size_t)3 * c * c * sizeof(float)));
+            SDMI_HIP(hipMalloc(&p, (size_t)3 * c * c * esz()));
             weight_allocs_.push_back(p);
             m.q.bt = reinterpret_cast<float*>(p);
-            m.k.bt = m.q.bt + (size_t)c * c;
-            m.v.bt = m.q.bt + (size_t)2 * c * c;
+            m.k.bt = adv(m.q.bt, (long long)c * c, edt());
+            m.v.bt = adv(m.q.bt, (long long)2 * c * c, edt());
         }
         lin(m.q, path + "/query", c, c, false);
         lin(m.k, path + "/key", cctx, c, false);
@@ -246,8 +255,8 @@ void Engine::build_model() {
     add(this, "alphas_cumprod", 3, {1000}, nullptr);
 
     // ---- UNet (unet/mod.rs:36-92) ------------------------------------------------
-    lin(lin1_time_, "unet/lin1_time_embed", mc, ed, true);
-    lin(lin2_time_, "unet/lin2_time_embed", ed, ed, true);
+    lin(lin1_time_, "unet/lin1_time_embed", mc, ed, true, /*keep_f32=*/true);
+    lin(lin2_time_, "unet/lin2_time_embed", ed, ed, true, /*keep_f32=*/true);
     struct Spec { BlockKind kind; const char* name; int cin, cout; };
     const Spec in_spec[12] = {
         {BK_CONV, "conv", 4, c1},   {BK_RES_ST, "rt1", c1, c1}, {BK_RES_ST, "rt2", c1, c1}, {BK_DOWN, "d1", c1, c1},
@@ -347,7 +356,7 @@ void Engine::set_weight(const char* name, const float* data, int ndim, const int
     }
     if (!*e.dst) {
         void* p = nullptr;
-        SDMI_HIP(hipMalloc(&p, count * sizeof(float)));
+        SDMI_HIP(hipMalloc(&p, count * (e.wdt ? 2 : sizeof(float))));
         weight_allocs_.push_back(p);
         *e.dst = reinterpret_cast<float*>(p);
     }
@@ -364,9 +373,11 @@ void Engine::set_weight(const char* name, const float* data, int ndim, const int
                     (void)hipFree(stage);
                     throw Error(SDMI_ERR_UNSUPPORTED, "conv Cin must be a multiple of 32, or < 32 and a multiple of 4");
                 }
-                err = launch_pack_conv_weight((const float*)stage, *e.dst, cout, cin, k, k, stream_);
+                err = e.wdt ? launch_pack_conv_weight_bf16((const float*)stage, *e.dst, cout, cin, k, k, stream_)
+                            : launch_pack_conv_weight((const float*)stage, *e.dst, cout, cin, k, k, stream_);
             } else {
-                err = launch_pack_linear_weight((const float*)stage, *e.dst, (int)e.dims[0], (int)e.dims[1], stream_);
+                err = e.wdt ? launch_pack_linear_weight_bf16((const float*)stage, *e.dst, (int)e.dims[0], (int)e.dims[1], stream_)
+                            : launch_pack_linear_weight((const float*)stage, *e.dst, (int)e.dims[0], (int)e.dims[1], stream_);
             }
         }
         if (err == hipSuccess) err = hipStreamSynchronize(stream_);
@@ -425,8 +436,8 @@ void Engine::load_weights_dir(const char* dir) {
 // =============================================================================
 // primitive ops
 // =============================================================================
-Act Engine::new_act(int n, int h, int w, int c) {
-    Act a; a.n = n; a.h = h; a.w = w; a.c = c;
+Act Engine::new_act(int n, int h, int w, int c, int dt) {
+    Act a; a.n = n; a.h = h; a.w = w; a.c = c; a.dt = dt < 0 ? edt() : dt;
     a.p = reinterpret_cast<float*>(pool_.alloc(a.bytes()));
     return a;
 }
@@ -501,8 +512,10 @@ TileChoice Engine::choose_tile(int M, int N, int kt_total) const {
     return bc;
 }
 
-void Engine::launch_gemm(ConvGemm& p, int force_cfg, int force_splits) {
-    p.kt_total = (p.K + 31) / 32;
+void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits) {
+    const int kt_elems = in_dt ? 64 : 32;  // a k tile is 128 bytes of K per row in both storage types
+    p.kt_total = (p.K + kt_elems - 1) / kt_elems;
+    if (in_dt && (p.Cin % 64)) throw Error(SDMI_ERR_UNSUPPORTED, "bf16 GEMM: K slices must be multiples of 64");
     if (record_shapes_) {
         char sk[96];
         std::snprintf(sk, sizeof sk, "%d,%d,%d,%d,%d,%d,%d,%d", p.NB, p.Cin, p.Hs, p.Ws, p.N, p.KH, p.stride, p.ups);
@@ -511,25 +524,31 @@ void Engine::launch_gemm(ConvGemm& p, int force_cfg, int force_splits) {
     TileChoice tc;
     char key[64];
     std::snprintf(key, sizeof key, "%d,%d,%d", p.M, p.N, p.K);
-    auto it = tuned_.find(key);
+    auto it = in_dt ? tuned_.end() : tuned_.find(key);  // the measured table is for the fp32 kernel
     if (it != tuned_.end()) tc = it->second;
     else tc = choose_tile(p.M, p.N, p.kt_total);
     if (opt_force_tile_ >= 0) tc.cfg = opt_force_tile_;
     if (opt_force_splits_ > 0) tc.splits = opt_force_splits_;
     if (force_cfg >= 0) tc.cfg = force_cfg;
     if (force_splits > 0) tc.splits = force_splits;
+    if (!in_dt && p.out_mode == 2) tc.splits = 1;  // fp32 kernel emitting bf16: no split-K path
     int splits = std::max(1, std::min(tc.splits, p.kt_total));
     p.kt_per_split = (p.kt_total + splits - 1) / splits;
     splits = (p.kt_total + p.kt_per_split - 1) / p.kt_per_split;
     p.splits = splits;
     const double flops = 2.0 * p.M * (double)p.N * p.K;
     // v2 uses raw buffer loads whose range check needs 32-bit extents
-    const unsigned long long a_ext = ((unsigned long long)p.NB * p.Hs * p.Ws - 1) * (unsigned long long)p.a_ld * 4ull + (unsigned long long)p.Cin * 4ull;
-    const unsigned long long b_ext = ((unsigned long long)p.N - 1) * (unsigned long long)p.b_ld * 4ull + (unsigned long long)p.K * 4ull;
-    const bool v2 = opt_gemm_variant_ == 1 && a_ext < 0xFFFFFFE0ull && b_ext < 0xFFFFFFE0ull;
+    const unsigned long long es = in_dt ? 2ull : 4ull;
+    const unsigned long long a_ext = ((unsigned long long)p.NB * p.Hs * p.Ws - 1) * (unsigned long long)p.a_ld * es + (unsigned long long)p.Cin * es;
+    const unsigned long long b_ext = ((unsigned long long)p.N - 1) * (unsigned long long)p.b_ld * es + (unsigned long long)p.K * es;
+    if (in_dt && (a_ext >= 0xFFFFFFE0ull || b_ext >= 0xFFFFFFE0ull)) throw Error(SDMI_ERR_UNSUPPORTED, "bf16 GEMM: operand larger than 4 GiB");
+    const bool v2 = (opt_gemm_variant_ == 1 || p.out_mode == 2) && a_ext < 0xFFFFFFE0ull && b_ext < 0xFFFFFFE0ull;
     p.a_bytes = (unsigned)std::min<unsigned long long>(a_ext, 0xFFFFFFE0ull);
     p.b_bytes = (unsigned)std::min<unsigned long long>(b_ext, 0xFFFFFFE0ull);
-    auto launch = [&](const ConvGemm& q) { return v2 ? launch_conv_gemm2(q, tc.cfg, stream_) : launch_conv_gemm(q, tc.cfg, stream_); };
+    auto launch = [&](const ConvGemm& q) {
+        if (in_dt) return launch_conv_gemm_bf16(q, tc.cfg, stream_);
+        return v2 ? launch_conv_gemm2(q, tc.cfg, stream_) : launch_conv_gemm(q, tc.cfg, stream_);
+    };
     if (splits == 1) {
         p.slab_stride = 0;
         ProfScope ps(this, PC_CONV_GEMM, flops);
@@ -547,7 +566,8 @@ void Engine::launch_gemm(ConvGemm& p, int force_cfg, int force_splits) {
         count_kernel(flops);
         {
             ProfScope ps(this, PC_SPLITK_REDUCE, 0, (double)(splits + 1) * p.slab_stride * 4.0);
-            SDMI_HIP(launch_splitk_reduce(p, slab.f(), real_c, stream_));
+            if (in_dt) { p.C = real_c; SDMI_HIP(launch_splitk_reduce_bf16(p, slab.f(), stream_)); }
+            else SDMI_HIP(launch_splitk_reduce(p, slab.f(), real_c, stream_));
         }
         count_kernel();
         p.C = real_c;
@@ -568,11 +588,15 @@ void Engine::conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, con
     p.KH = w.k; p.KW = w.k; p.stride = stride; p.pad = pad; p.ups = ups;
     p.ldc = y.c; p.ldr = y.c; p.a_ld = x.c; p.b_ld = p.K; p.rowvec_stride = rowvec_stride;
     p.CS = std::min(32, w.cin);
-    launch_gemm(p);
+    if (x.dt != w.dt) throw Error(SDMI_ERR_STATE, "conv: activation / weight storage types disagree");
+    p.out_mode = x.dt ? (y.dt ? 0 : 1) : (y.dt ? 2 : 0);
+    if (resid && !x.dt && y.dt) throw Error(SDMI_ERR_STATE, "conv: residual not supported on the fp32->bf16 layers");
+    launch_gemm(p, x.dt);
 }
 
 void Engine::gemm(const float* A, int a_rows, const float* bt, const float* bias, int cin, int cout, float* C, int ldc,
-                  const float* resid, int ldr) {
+                  const float* resid, int ldr, int dt, int out_mode) {
+    if (dt < 0) dt = edt();
     if (cin % 32) throw Error(SDMI_ERR_UNSUPPORTED, "linear: in_features must be a multiple of 32");
     ConvGemm p{};
     p.A = A; p.Bt = bt; p.C = C; p.bias = bias; p.resid = resid;
@@ -580,20 +604,24 @@ void Engine::gemm(const float* A, int a_rows, const float* bt, const float* bias
     p.NB = 1; p.Hs = 1; p.Ws = a_rows; p.Cin = cin; p.Ho = 1; p.Wo = a_rows;
     p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.ups = 0;
     p.ldc = ldc; p.ldr = ldr; p.a_ld = cin; p.b_ld = cin; p.rowvec_stride = 0; p.CS = 32;
-    launch_gemm(p);
+    p.out_mode = out_mode;
+    launch_gemm(p, dt);
 }
 
 void Engine::group_norm(const NormW& w, const Act& x, Act& y, bool silu) {
     const int hw = x.h * x.w;
-    Buf part(this, gn_partials_bytes(x.n, hw, x.c));
+    if (x.dt != y.dt) throw Error(SDMI_ERR_STATE, "group_norm: in/out storage types disagree");
+    Buf part(this, x.dt ? gn_partials_bytes_bf16(x.n, hw, x.c) : gn_partials_bytes(x.n, hw, x.c));
     ProfScope ps(this, PC_GROUP_NORM, 0, 2.0 * (double)x.bytes());  // algorithmic: one read + one write
-    SDMI_HIP(launch_group_norm(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, 32, 1e-5f, silu, part.p, stream_));
+    if (x.dt) SDMI_HIP(launch_group_norm_bf16(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, 32, 1e-5f, silu, part.p, stream_));
+    else SDMI_HIP(launch_group_norm(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, 32, 1e-5f, silu, part.p, stream_));
     count_kernel(); count_kernel();
 }
 
 void Engine::layer_norm(const NormW& w, const float* x, long long rows, float* y) {
-    ProfScope ps(this, PC_LAYER_NORM, 0, 2.0 * (double)rows * w.c * 4.0);
-    SDMI_HIP(launch_layer_norm(x, y, w.gamma, w.beta, (int)rows, w.c, 1e-5f, stream_));
+    ProfScope ps(this, PC_LAYER_NORM, 0, 2.0 * (double)rows * w.c * (double)esz());
+    if (bf16_) SDMI_HIP(launch_layer_norm_bf16(x, y, w.gamma, w.beta, (int)rows, w.c, 1e-5f, stream_));
+    else SDMI_HIP(launch_layer_norm(x, y, w.gamma, w.beta, (int)rows, w.c, 1e-5f, stream_));
     count_kernel();
 }
 
@@ -603,7 +631,8 @@ void Engine::layer_norm(const NormW& w, const float* x, long long rows, float* y
 void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, int ldk, long long k_bs,
                        const float* v, int ldv, long long v_bs, float* o, int ldo, long long o_bs, int n, int nq,
                        int nk, int n_head, int d_head, const int* kv_len_dev, const int* kv_len_host,
-                       const float* mask, int mask_ld) {
+                       const float* mask, int mask_ld, int dt) {
+    if (dt < 0) dt = edt();
     if (nq <= 0 || nk <= 0) throw Error(SDMI_ERR_INVALID, "attention: empty sequence");
     const float scale = (float)std::pow((double)d_head, -0.25);
     if (attn_supported_head_dim(d_head)) {
@@ -612,38 +641,45 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
         p.n = n; p.n_head = n_head; p.nq = nq; p.nk = nk; p.d_head = d_head;
         p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
         p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs; p.scale = scale;
+        p.bf16 = dt;
+        if (dt && mask) throw Error(SDMI_ERR_UNSUPPORTED, "attention: additive mask is fp32-only");
         const double fl = 4.0 * n * n_head * (double)nq * nk * d_head;
         ProfScope ps(this, PC_ATTENTION, fl);
-        SDMI_HIP(launch_attention(p, stream_, opt_attn_variant_));
+        SDMI_HIP(launch_attention(p, stream_, dt ? 1 : opt_attn_variant_));
         count_kernel(fl);
         return;
     }
     if (mask) throw Error(SDMI_ERR_UNSUPPORTED, "attention: additive mask is only supported for head dims 40/80/160");
     if (d_head % 32) throw Error(SDMI_ERR_UNSUPPORTED, "attention: head dim must be 40/80/160 or a multiple of 32");
+    if (dt && (d_head % 64)) throw Error(SDMI_ERR_UNSUPPORTED, "bf16 attention (unfused path): head dim must be a multiple of 64");
     for (int b = 0; b < n; ++b) {
         const int nkb = kv_len_host ? kv_len_host[b] : nk;
-        if (nkb % 32) throw Error(SDMI_ERR_UNSUPPORTED, "attention (unfused path): key count must be a multiple of 32");
-        Buf s(this, (size_t)nq * nkb * sizeof(float));
-        Buf vt(this, (size_t)d_head * nkb * sizeof(float));
+        if (nkb % (dt ? 64 : 32)) throw Error(SDMI_ERR_UNSUPPORTED, "attention (unfused path): key count must be a multiple of 32 (64 for bf16)");
+        Buf s(this, (size_t)nq * nkb * sizeof(float));            // scores stay fp32 in both precisions
+        Buf pb(this, dt ? (size_t)nq * nkb * 2 : 256);             // bf16 probabilities (precision = 1)
+        Buf vt(this, (size_t)d_head * nkb * (dt ? 2 : 4));
         for (int h = 0; h < n_head; ++h) {
-            const float* qb = q + b * q_bs + h * d_head;
-            const float* kb = k + b * k_bs + h * d_head;
-            const float* vb = v + b * v_bs + h * d_head;
-            float* ob = o + b * o_bs + h * d_head;
+            const float* qb = adv(q, b * q_bs + h * d_head, dt);
+            const float* kb = adv(k, b * k_bs + h * d_head, dt);
+            const float* vb = adv(v, b * v_bs + h * d_head, dt);
+            float* ob = adv(o, b * o_bs + h * d_head, dt);
             ConvGemm g{};
             g.A = qb; g.Bt = kb; g.C = s.f();
             g.M = nq; g.N = nkb; g.K = d_head; g.NB = 1; g.Hs = 1; g.Ws = nq; g.Cin = d_head; g.Ho = 1; g.Wo = nq;
             g.KH = g.KW = 1; g.stride = 1; g.ldc = nkb; g.ldr = nkb; g.a_ld = ldq; g.b_ld = ldk; g.CS = 32;
-            launch_gemm(g);
-            SDMI_HIP(launch_softmax_rows(s.f(), nq, nkb, scale * scale, stream_));
+            g.out_mode = dt ? 1 : 0;
+            launch_gemm(g, dt);
+            if (dt) SDMI_HIP(launch_softmax_rows_f32_to_bf16(s.f(), pb.p, nq, nkb, scale * scale, stream_));
+            else SDMI_HIP(launch_softmax_rows(s.f(), nq, nkb, scale * scale, stream_));
             count_kernel();
-            SDMI_HIP(launch_transpose2d(vb, vt.f(), nkb, d_head, ldv, stream_));
+            if (dt) SDMI_HIP(launch_transpose2d_bf16(vb, vt.p, nkb, d_head, ldv, stream_));
+            else SDMI_HIP(launch_transpose2d(vb, vt.f(), nkb, d_head, ldv, stream_));
             count_kernel();
             ConvGemm g2{};
-            g2.A = s.f(); g2.Bt = vt.f(); g2.C = ob;
+            g2.A = dt ? pb.f() : s.f(); g2.Bt = vt.f(); g2.C = ob;
             g2.M = nq; g2.N = d_head; g2.K = nkb; g2.NB = 1; g2.Hs = 1; g2.Ws = nq; g2.Cin = nkb; g2.Ho = 1; g2.Wo = nq;
             g2.KH = g2.KW = 1; g2.stride = 1; g2.ldc = ldo; g2.ldr = ldo; g2.a_ld = nkb; g2.b_ld = nkb; g2.CS = 32;
-            launch_gemm(g2);
+            launch_gemm(g2, dt);
         }
     }
 }
@@ -685,14 +721,15 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
     conv(w.proj_in, g, h, 1, 0, nullptr, 0, nullptr);
     release(g);
     {
-        Buf ln(this, (size_t)M * C * 4), q(this, (size_t)M * C * 4), a(this, (size_t)M * C * 4);
+        const size_t es = esz();
+        Buf ln(this, (size_t)M * C * es), q(this, (size_t)M * C * es), a(this, (size_t)M * C * es);
         // self attention: q, k, v in one GEMM (N = 3C) on the packed [3C][C] weight
         layer_norm(w.ln1, h.p, M, ln.f());
         {
-            Buf qkv(this, (size_t)M * 3 * C * 4);
+            Buf qkv(this, (size_t)M * 3 * C * es);
             gemm(ln.f(), (int)M, w.attn1.q.bt, nullptr, C, 3 * C, qkv.f(), 3 * C, nullptr, 0);
             const long long bs3 = (long long)hw * 3 * C;
-            attention(qkv.f(), 3 * C, bs3, qkv.f() + C, 3 * C, bs3, qkv.f() + 2 * C, 3 * C, bs3, a.f(), C,
+            attention(qkv.f(), 3 * C, bs3, adv(qkv.f(), C, edt()), 3 * C, bs3, adv(qkv.f(), 2 * C, edt()), 3 * C, bs3, a.f(), C,
                       (long long)hw * C, nb, hw, hw, heads, d, nullptr, nullptr, nullptr, 0);
         }
         gemm(a.f(), (int)M, w.attn1.out.bt, w.attn1.out.bias, C, C, h.p, C, h.p, C);
@@ -706,9 +743,10 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
         // GEGLU MLP
         layer_norm(w.ln3, h.p, M, ln.f());
         {
-            Buf proj(this, (size_t)M * 8 * C * 4), u(this, (size_t)M * 4 * C * 4);
+            Buf proj(this, (size_t)M * 8 * C * es), u(this, (size_t)M * 4 * C * es);
             gemm(ln.f(), (int)M, w.geglu_proj.bt, w.geglu_proj.bias, C, 8 * C, proj.f(), 8 * C, nullptr, 0);
-            SDMI_HIP(launch_geglu(proj.f(), u.f(), M, 4 * C, stream_));
+            if (bf16_) SDMI_HIP(launch_geglu_bf16(proj.p, u.p, M, 4 * C, stream_));
+            else SDMI_HIP(launch_geglu(proj.f(), u.f(), M, 4 * C, stream_));
             count_kernel();
             gemm(u.f(), (int)M, w.mlp_lin.bt, w.mlp_lin.bias, 4 * C, C, h.p, C, h.p, C);
         }
@@ -764,33 +802,40 @@ void Engine::unet_prepare(const float* ctx_packed, int nb, int t_max, const int*
     Buf te(this, (size_t)S * mc * 4), e1(this, (size_t)S * ed * 4), e2(this, (size_t)S * ed * 4);
     SDMI_HIP(launch_timestep_embedding(t_dev, S, mc, te.f(), stream_));
     count_kernel();
-    gemm(te.f(), S, lin1_time_.bt, lin1_time_.bias, mc, ed, e1.f(), ed, nullptr, 0);
+    gemm(te.f(), S, lin1_time_.bt, lin1_time_.bias, mc, ed, e1.f(), ed, nullptr, 0, /*dt=*/0);
     SDMI_HIP(launch_silu(e1.f(), e1.f(), (long long)S * ed, stream_));
     count_kernel();
-    gemm(e1.f(), S, lin2_time_.bt, lin2_time_.bias, ed, ed, e2.f(), ed, nullptr, 0);
+    gemm(e1.f(), S, lin2_time_.bt, lin2_time_.bias, ed, ed, e2.f(), ed, nullptr, 0, /*dt=*/0);
     SDMI_HIP(launch_silu(e2.f(), e2.f(), (long long)S * ed, stream_));  // SiLU(emb), shared by all ResBlocks
     count_kernel();
     us_.temb.resize(res_list_.size());
     for (size_t i = 0; i < res_list_.size(); ++i) {
         const ResW& r = *res_list_[i];
         us_.temb[i] = (float*)own((size_t)S * r.cout * 4);
-        gemm(e2.f(), S, r.lin_embed.bt, r.lin_embed.bias, ed, r.cout, us_.temb[i], r.cout, nullptr, 0);
+        gemm(e2.f(), S, r.lin_embed.bt, r.lin_embed.bias, ed, r.cout, us_.temb[i], r.cout, nullptr, 0, /*dt=*/0);
     }
     us_.kc.resize(st_list_.size());
     us_.vc.resize(st_list_.size());
+    const float* ctx_e = ctx_packed;  // text context in the engine's storage type
+    Buf ctx_h(this, bf16_ ? (size_t)nb * t_max * cd * 2 : 256);
+    if (bf16_) {
+        SDMI_HIP(launch_f32_to_bf16(ctx_packed, ctx_h.p, (long long)nb * t_max * cd, stream_));
+        count_kernel();
+        ctx_e = ctx_h.f();
+    }
     for (size_t i = 0; i < st_list_.size(); ++i) {
         const SpatialW& s = *st_list_[i];
-        us_.kc[i] = (float*)own((size_t)nb * t_max * s.c * 4);
-        us_.vc[i] = (float*)own((size_t)nb * t_max * s.c * 4);
-        gemm(ctx_packed, nb * t_max, s.attn2.k.bt, nullptr, cd, s.c, us_.kc[i], s.c, nullptr, 0);
-        gemm(ctx_packed, nb * t_max, s.attn2.v.bt, nullptr, cd, s.c, us_.vc[i], s.c, nullptr, 0);
+        us_.kc[i] = (float*)own((size_t)nb * t_max * s.c * esz());
+        us_.vc[i] = (float*)own((size_t)nb * t_max * s.c * esz());
+        gemm(ctx_e, nb * t_max, s.attn2.k.bt, nullptr, cd, s.c, us_.kc[i], s.c, nullptr, 0);
+        gemm(ctx_e, nb * t_max, s.attn2.v.bt, nullptr, cd, s.c, us_.vc[i], s.c, nullptr, 0);
     }
 }
 
 // UNet::forward (unet/mod.rs:109-143) on NHWC activations
 void Engine::unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc) {
     const int H = cfg_.latent_h, W = cfg_.latent_w;
-    Act x; x.p = const_cast<float*>(x_nhwc); x.n = nb; x.h = H; x.w = W; x.c = 4;
+    Act x; x.p = const_cast<float*>(x_nhwc); x.n = nb; x.h = H; x.w = W; x.c = 4; x.dt = 0;  // latents stay fp32
     bool x_owned = false;
     std::vector<Act> skips;
 
@@ -831,7 +876,8 @@ void Engine::unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc) {
     for (const UBlock& b : out_blocks_) {
         Act s = skips.back(); skips.pop_back();
         Act cat = new_act(x.n, x.h, x.w, x.c + s.c);  // Tensor::cat(vec![x, saved.pop()], 1) (unet/mod.rs:134)
-        SDMI_HIP(launch_concat_channels(x.p, s.p, cat.p, x.rows(), x.c, s.c, stream_));
+        // byte-wise copy: for bf16 the channel counts are halved into "float-equivalent" units
+        SDMI_HIP(launch_concat_channels(x.p, s.p, cat.p, x.rows(), bf16_ ? x.c / 2 : x.c, bf16_ ? s.c / 2 : s.c, stream_));
         count_kernel();
         if (x_owned) release(x);
         release(s);
@@ -842,7 +888,7 @@ void Engine::unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc) {
     Act gn = new_act(x.n, x.h, x.w, x.c);
     group_norm(unet_norm_out_, x, gn, true);
     release(x);
-    Act out; out.p = out_nhwc; out.n = nb; out.h = H; out.w = W; out.c = 4;
+    Act out; out.p = out_nhwc; out.n = nb; out.h = H; out.w = W; out.c = 4; out.dt = 0;  // eps stays fp32
     conv(unet_conv_out_, gn, out, 1, 0, nullptr, 0, nullptr);
     release(gn);
 }
@@ -914,8 +960,8 @@ void Engine::sample_latent_dev(const float* context, int n, int T, const float* 
 // Autoencoder::decode_latent (autoencoder/mod.rs:68-71) -> Decoder::forward (:205-217)
 void Engine::decode_one(const float* z_nhwc, int n, Act& img) {
     const int H = cfg_.latent_h, W = cfg_.latent_w, vc = cfg_.vae_ch;
-    Act z; z.p = const_cast<float*>(z_nhwc); z.n = n; z.h = H; z.w = W; z.c = 4;
-    Act pq = new_act(n, H, W, 4);
+    Act z; z.p = const_cast<float*>(z_nhwc); z.n = n; z.h = H; z.w = W; z.c = 4; z.dt = 0;
+    Act pq = new_act(n, H, W, 4, /*dt=*/0);  // the two Cin = 4 layers run on the fp32 kernel in both precisions
     conv(post_quant_, z, pq, 1, 0, nullptr, 0, nullptr);
     Act x = new_act(n, H, W, 4 * vc);
     conv(dec_conv_in_, pq, x, 1, 0, nullptr, 0, nullptr);
@@ -959,7 +1005,7 @@ void Engine::decode_latent_dev(const float* latent_nchw, int n, float in_scale, 
         Buf z(this, lat_elems * 4);
         SDMI_HIP(launch_nchw_to_nhwc(latent_nchw + i * lat_elems, z.f(), 1, 4, H, W, in_scale, stream_));
         count_kernel();
-        Act img = new_act(1, 8 * H, 8 * W, 3);
+        Act img = new_act(1, 8 * H, 8 * W, 3, /*dt=*/0);  // RGB stays fp32 (conv_out writes fp32 in both precisions)
         decode_one(z.f(), 1, img);
         if (rgb_u8) SDMI_HIP(launch_image_to_u8(img.p, rgb_u8 + i * img_elems, (long long)img_elems, stream_));
         else SDMI_HIP(launch_nhwc_to_nchw(img.p, img_nchw + i * img_elems, 1, 3, 8 * H, 8 * W, stream_));
@@ -972,9 +1018,21 @@ void Engine::qkv_attention_dev(const float* q, const float* k, const float* v, c
                                int nq, int nk, int n_state, int n_head, float* out) {
     if (n <= 0 || nq <= 0 || nk <= 0 || n_head <= 0 || n_state % n_head) throw Error(SDMI_ERR_INVALID, "qkv_attention: bad shape");
     if (mask && mask_ld < nk) throw Error(SDMI_ERR_INVALID, "qkv_attention: mask_ld < nk");
+    const long long qe = (long long)n * nq * n_state, ke = (long long)n * nk * n_state;
+    if (bf16_ && !mask) {  // precision = 1: the boundary is fp32, the kernel sees bf16 tensors
+        Buf qh(this, qe * 2), kh(this, ke * 2), vh(this, ke * 2), oh(this, qe * 2);
+        SDMI_HIP(launch_f32_to_bf16(q, qh.p, qe, stream_));
+        SDMI_HIP(launch_f32_to_bf16(k, kh.p, ke, stream_));
+        SDMI_HIP(launch_f32_to_bf16(v, vh.p, ke, stream_));
+        attention(qh.f(), n_state, (long long)nq * n_state, kh.f(), n_state, (long long)nk * n_state, vh.f(), n_state,
+                  (long long)nk * n_state, oh.f(), n_state, (long long)nq * n_state, n, nq, nk, n_head, n_state / n_head,
+                  nullptr, nullptr, nullptr, 0, 1);
+        SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(oh.p, out, (int)((long long)n * nq), n_state, 1, 1, stream_));
+        return;
+    }
     attention(q, n_state, (long long)nq * n_state, k, n_state, (long long)nk * n_state, v, n_state,
               (long long)nk * n_state, out, n_state, (long long)nq * n_state, n, nq, nk, n_head, n_state / n_head,
-              nullptr, nullptr, mask, mask_ld);
+              nullptr, nullptr, mask, mask_ld, 0);
 }
 
 // =============================================================================
@@ -983,16 +1041,31 @@ void Engine::qkv_attention_dev(const float* q, const float* k, const float* v, c
 void Engine::op_group_norm(const float* x, const float* gamma, const float* beta, int n, int c, int h, int w,
                            int groups, float eps, bool silu, float* out) {
     if (n <= 0 || c <= 0 || h <= 0 || w <= 0 || groups <= 0 || c % groups || c % 4) throw Error(SDMI_ERR_INVALID, "group_norm: bad shape");
-    Act a = new_act(n, h, w, c), b = new_act(n, h, w, c);
-    SDMI_HIP(launch_nchw_to_nhwc(x, a.p, n, c, h, w, 1.0f, stream_));
-    Buf part(this, gn_partials_bytes(n, h * w, c));
-    SDMI_HIP(launch_group_norm(a.p, b.p, gamma, beta, n, h * w, c, groups, eps, silu, part.p, stream_));
-    SDMI_HIP(launch_nhwc_to_nchw(b.p, out, n, c, h, w, stream_));
+    const int dt = (bf16_ && c % 8 == 0) ? 1 : 0;
+    Act a = new_act(n, h, w, c, dt), b = new_act(n, h, w, c, dt);
+    if (dt) {
+        SDMI_HIP(launch_nchw_f32_to_nhwc_bf16(x, a.p, n, c, h, w, 1.0f, stream_));
+        Buf part(this, gn_partials_bytes_bf16(n, h * w, c));
+        SDMI_HIP(launch_group_norm_bf16(a.p, b.p, gamma, beta, n, h * w, c, groups, eps, silu, part.p, stream_));
+        SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(b.p, out, n, c, h, w, stream_));
+    } else {
+        SDMI_HIP(launch_nchw_to_nhwc(x, a.p, n, c, h, w, 1.0f, stream_));
+        Buf part(this, gn_partials_bytes(n, h * w, c));
+        SDMI_HIP(launch_group_norm(a.p, b.p, gamma, beta, n, h * w, c, groups, eps, silu, part.p, stream_));
+        SDMI_HIP(launch_nhwc_to_nchw(b.p, out, n, c, h, w, stream_));
+    }
     release(a); release(b);
 }
 
 void Engine::op_layer_norm(const float* x, const float* gamma, const float* beta, int rows, int c, float eps, float* out) {
     if (rows <= 0 || c <= 0) throw Error(SDMI_ERR_INVALID, "layer_norm: bad shape");
+    if (bf16_ && c % 8 == 0) {
+        Buf xh(this, (size_t)rows * c * 2), yh(this, (size_t)rows * c * 2);
+        SDMI_HIP(launch_f32_to_bf16(x, xh.p, (long long)rows * c, stream_));
+        SDMI_HIP(launch_layer_norm_bf16(xh.p, yh.p, gamma, beta, rows, c, eps, stream_));
+        SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(yh.p, out, rows, c, 1, 1, stream_));
+        return;
+    }
     SDMI_HIP(launch_layer_norm(x, out, gamma, beta, rows, c, eps, stream_));
 }
 
@@ -1002,26 +1075,48 @@ void Engine::op_conv2d(const float* x, const float* wt, const float* bias, int n
         throw Error(SDMI_ERR_UNSUPPORTED, "conv2d: only 3x3 pad 1 / 1x1 pad 0, stride 1|2 are on the hot path");
     if (!(cin % 32 == 0 || (cin < 32 && cin % 4 == 0))) throw Error(SDMI_ERR_UNSUPPORTED, "conv2d: Cin must be a multiple of 32, or < 32 and a multiple of 4");
     ConvW w; w.cin = cin; w.cout = cout; w.k = k;
+    // precision = 1 mirrors the model: Cin % 64 == 0 -> bf16 kernel, Cin < 32 -> fp32 kernel emitting bf16,
+    // <= 4 output channels (eps / RGB heads) -> fp32 output
+    w.dt = (bf16_ && cin % 64 == 0) ? 1 : 0;
+    if (bf16_ && !w.dt && cin >= 32) throw Error(SDMI_ERR_UNSUPPORTED, "bf16 conv2d: Cin must be a multiple of 64 (or < 32)");
     Buf bt(this, (size_t)cout * cin * k * k * 4);
-    SDMI_HIP(launch_pack_conv_weight(wt, bt.f(), cout, cin, k, k, stream_));
+    if (w.dt) SDMI_HIP(launch_pack_conv_weight_bf16(wt, bt.p, cout, cin, k, k, stream_));
+    else SDMI_HIP(launch_pack_conv_weight(wt, bt.f(), cout, cin, k, k, stream_));
     w.bt = bt.f(); w.bias = const_cast<float*>(bias);
-    Act a = new_act(n, h, wd, cin);
-    SDMI_HIP(launch_nchw_to_nhwc(x, a.p, n, cin, h, wd, 1.0f, stream_));
+    Act a = new_act(n, h, wd, cin, w.dt);
+    if (w.dt) SDMI_HIP(launch_nchw_f32_to_nhwc_bf16(x, a.p, n, cin, h, wd, 1.0f, stream_));
+    else SDMI_HIP(launch_nchw_to_nhwc(x, a.p, n, cin, h, wd, 1.0f, stream_));
     const int hin = h << ups, win = wd << ups;
     const int ho = (hin + 2 * pad - k) / stride + 1, wo = (win + 2 * pad - k) / stride + 1;
-    Act y = new_act(n, ho, wo, cout);
+    Act y = new_act(n, ho, wo, cout, (bf16_ && cout > 4) ? 1 : 0);
     conv(w, a, y, stride, ups, nullptr, 0, nullptr);
-    SDMI_HIP(launch_nhwc_to_nchw(y.p, out, n, cout, ho, wo, stream_));
+    if (y.dt) SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(y.p, out, n, cout, ho, wo, stream_));
+    else SDMI_HIP(launch_nhwc_to_nchw(y.p, out, n, cout, ho, wo, stream_));
     release(a); release(y);
 }
 
 void Engine::op_linear(const float* x, const float* wt, const float* bias, int rows, int cin, int cout, float* out) {
     Buf bt(this, (size_t)cin * cout * 4);
+    if (bf16_ && cin % 64 == 0) {
+        Buf xh(this, (size_t)rows * cin * 2), yh(this, (size_t)rows * cout * 2);
+        SDMI_HIP(launch_pack_linear_weight_bf16(wt, bt.p, cin, cout, stream_));
+        SDMI_HIP(launch_f32_to_bf16(x, xh.p, (long long)rows * cin, stream_));
+        gemm(xh.f(), rows, bt.f(), bias, cin, cout, yh.f(), cout, nullptr, 0, 1);
+        SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(yh.p, out, rows, cout, 1, 1, stream_));
+        return;
+    }
     SDMI_HIP(launch_pack_linear_weight(wt, bt.f(), cin, cout, stream_));
-    gemm(x, rows, bt.f(), bias, cin, cout, out, cout, nullptr, 0);
+    gemm(x, rows, bt.f(), bias, cin, cout, out, cout, nullptr, 0, 0);
 }
 
 void Engine::op_geglu(const float* proj, int rows, int hidden, float* out) {
+    if (bf16_ && hidden % 8 == 0) {
+        Buf ph(this, (size_t)rows * 2 * hidden * 2), oh(this, (size_t)rows * hidden * 2);
+        SDMI_HIP(launch_f32_to_bf16(proj, ph.p, (long long)rows * 2 * hidden, stream_));
+        SDMI_HIP(launch_geglu_bf16(ph.p, oh.p, rows, hidden, stream_));
+        SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(oh.p, out, rows, hidden, 1, 1, stream_));
+        return;
+    }
     SDMI_HIP(launch_geglu(proj, out, rows, hidden, stream_));
 }
 
@@ -1039,12 +1134,19 @@ double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int str
     const int pad = k == 3 ? 1 : 0;
     const int hin = h << ups, win = w << ups;
     const int ho = (hin + 2 * pad - k) / stride + 1, wo = (win + 2 * pad - k) / stride + 1;
-    Act a = new_act(n, h, w, cin), y = new_act(n, ho, wo, cout);
+    const int wdt = (bf16_ && cin % 64 == 0) ? 1 : 0;
+    Act a = new_act(n, h, w, cin, wdt), y = new_act(n, ho, wo, cout, (bf16_ && cout > 4) ? 1 : 0);
     Buf bt(this, (size_t)cout * cin * k * k * 4), bias(this, (size_t)cout * 4);
-    SDMI_HIP(launch_fill_normal(a.p, (long long)a.rows() * cin, 11, stream_));
-    SDMI_HIP(launch_fill_normal(bt.f(), (long long)cout * cin * k * k, 12, stream_));
+    {
+        Buf tmp(this, std::max((size_t)a.rows() * cin, (size_t)cout * cin * k * k) * 4);
+        SDMI_HIP(launch_fill_normal(wdt ? tmp.f() : a.p, (long long)a.rows() * cin, 11, stream_));
+        if (wdt) SDMI_HIP(launch_f32_to_bf16(tmp.f(), a.p, (long long)a.rows() * cin, stream_));
+        SDMI_HIP(launch_fill_normal(wdt ? tmp.f() : bt.f(), (long long)cout * cin * k * k, 12, stream_));
+        if (wdt) SDMI_HIP(launch_f32_to_bf16(tmp.f(), bt.p, (long long)cout * cin * k * k, stream_));
+        SDMI_HIP(hipStreamSynchronize(stream_));
+    }
     SDMI_HIP(launch_fill_normal(bias.f(), cout, 13, stream_));
-    ConvW cw; cw.cin = cin; cw.cout = cout; cw.k = k; cw.bt = bt.f(); cw.bias = bias.f();
+    ConvW cw; cw.cin = cin; cw.cout = cout; cw.k = k; cw.bt = bt.f(); cw.bias = bias.f(); cw.dt = wdt;
     const int save_t = opt_force_tile_, save_s = opt_force_splits_;
     opt_force_tile_ = tile_cfg; opt_force_splits_ = splitk;
     float ms = 0;
@@ -1068,15 +1170,27 @@ double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int str
 double Engine::bench_attention(int n, int nq, int nk, int n_state, int n_head, int iters) {
     SDMI_HIP(hipSetDevice(cfg_.device));
     if (n <= 0 || nq <= 0 || nk <= 0 || n_head <= 0 || n_state % n_head) throw Error(SDMI_ERR_INVALID, "bench_attention: bad shape");
-    Buf q(this, (size_t)n * nq * n_state * 4), k(this, (size_t)n * nk * n_state * 4), v(this, (size_t)n * nk * n_state * 4),
-        o(this, (size_t)n * nq * n_state * 4);
-    SDMI_HIP(launch_fill_normal(q.f(), (long long)n * nq * n_state, 21, stream_));
-    SDMI_HIP(launch_fill_normal(k.f(), (long long)n * nk * n_state, 22, stream_));
-    SDMI_HIP(launch_fill_normal(v.f(), (long long)n * nk * n_state, 23, stream_));
-    qkv_attention_dev(q.f(), k.f(), v.f(), nullptr, 0, n, nq, nk, n_state, n_head, o.f());
+    const long long qe = (long long)n * nq * n_state, ke = (long long)n * nk * n_state;
+    Buf q(this, qe * 4), k(this, ke * 4), v(this, ke * 4), o(this, qe * 4);
+    SDMI_HIP(launch_fill_normal(q.f(), qe, 21, stream_));
+    SDMI_HIP(launch_fill_normal(k.f(), ke, 22, stream_));
+    SDMI_HIP(launch_fill_normal(v.f(), ke, 23, stream_));
+    const int dt = edt();
+    Buf qh(this, dt ? qe * 2 : 256), kh(this, dt ? ke * 2 : 256), vh(this, dt ? ke * 2 : 256);
+    if (dt) {
+        SDMI_HIP(launch_f32_to_bf16(q.f(), qh.p, qe, stream_));
+        SDMI_HIP(launch_f32_to_bf16(k.f(), kh.p, ke, stream_));
+        SDMI_HIP(launch_f32_to_bf16(v.f(), vh.p, ke, stream_));
+    }
+    const float* qp = dt ? qh.f() : q.f(); const float* kp = dt ? kh.f() : k.f(); const float* vp = dt ? vh.f() : v.f();
+    auto run = [&] {
+        attention(qp, n_state, (long long)nq * n_state, kp, n_state, (long long)nk * n_state, vp, n_state, (long long)nk * n_state,
+                  o.f(), n_state, (long long)nq * n_state, n, nq, nk, n_head, n_state / n_head, nullptr, nullptr, nullptr, 0, dt);
+    };
+    run();
     float ms = 0;
     SDMI_HIP(hipEventRecord(ev0_, stream_));
-    for (int i = 0; i < iters; ++i) qkv_attention_dev(q.f(), k.f(), v.f(), nullptr, 0, n, nq, nk, n_state, n_head, o.f());
+    for (int i = 0; i < iters; ++i) run();
     SDMI_HIP(hipEventRecord(ev1_, stream_));
     SDMI_HIP(hipEventSynchronize(ev1_));
     SDMI_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));

@@ -55,15 +55,18 @@ private:
     size_t reserved_ = 0, in_use_ = 0, high_ = 0;
 };
 
+// dt: storage type of a device tensor -- 0 = fp32, 1 = bf16 (precision = 1).  `p` is typed float* for
+// historical reasons; for dt == 1 it is an opaque pointer to 2-byte elements.
 struct Act {
     float* p = nullptr;
     int n = 0, h = 0, w = 0, c = 0;
+    int dt = 0;
     long long rows() const { return (long long)n * h * w; }
-    size_t bytes() const { return (size_t)rows() * c * sizeof(float); }
+    size_t bytes() const { return (size_t)rows() * c * (dt ? 2 : 4); }
 };
 
-struct ConvW { float* bt = nullptr; float* bias = nullptr; int cin = 0, cout = 0, k = 1; };
-struct LinW { float* bt = nullptr; float* bias = nullptr; int cin = 0, cout = 0; };
+struct ConvW { float* bt = nullptr; float* bias = nullptr; int cin = 0, cout = 0, k = 1; int dt = 0; };
+struct LinW { float* bt = nullptr; float* bias = nullptr; int cin = 0, cout = 0; int dt = 0; };
 struct NormW { float* gamma = nullptr; float* beta = nullptr; int c = 0; };
 
 struct ResW {  // UNet ResBlock (unet/mod.rs:700-734) and VAE ResnetBlock (autoencoder/mod.rs:503-528)
@@ -87,6 +90,7 @@ struct WeightEntry {
     int ndim;
     int64_t dims[4];
     float** dst;  // where the device pointer lives (null for alphas)
+    int wdt = 0;  // storage type of the packed weight: 0 fp32, 1 bf16
     bool set = false;
 };
 
@@ -150,23 +154,27 @@ public:
 
 private:
     // model definition
-    void add_entry(const std::string& name, int kind, std::initializer_list<int64_t> dims, float** dst);
+    void add_entry(const std::string& name, int kind, std::initializer_list<int64_t> dims, float** dst, int wdt = 0);
     void build_model();
 
     // primitive ops on device activations (NHWC)
-    Act new_act(int n, int h, int w, int c);
+    Act new_act(int n, int h, int w, int c, int dt = -1);  // dt -1: the engine's activation type
     void release(Act& a);
     void conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, const float* rowvec, int rowvec_stride,
               const float* resid);
     void gemm(const float* A, int a_rows, const float* bt, const float* bias, int cin, int cout, float* C, int ldc,
-              const float* resid, int ldr);
-    void launch_gemm(ConvGemm& p, int force_cfg = -1, int force_splits = 0);
+              const float* resid, int ldr, int dt = -1, int out_mode = 0);
+    void launch_gemm(ConvGemm& p, int in_dt, int force_cfg = -1, int force_splits = 0);
+    int edt() const { return bf16_ ? 1 : 0; }
+    size_t esz() const { return bf16_ ? 2 : 4; }
+    // element-wise pointer advance on an activation of type dt
+    static float* adv(const float* p, long long elems, int dt) { return (float*)((char*)const_cast<float*>(p) + elems * (dt ? 2 : 4)); }
     TileChoice choose_tile(int M, int N, int kt_total) const;
     void group_norm(const NormW& w, const Act& x, Act& y, bool silu);
     void layer_norm(const NormW& w, const float* x, long long rows, float* y);
     void attention(const float* q, int ldq, long long q_bs, const float* k, int ldk, long long k_bs, const float* v,
                    int ldv, long long v_bs, float* o, int ldo, long long o_bs, int n, int nq, int nk, int n_head,
-                   int d_head, const int* kv_len_dev, const int* kv_len_host, const float* mask, int mask_ld);
+                   int d_head, const int* kv_len_dev, const int* kv_len_host, const float* mask, int mask_ld, int dt = -1);
 
     // composite blocks
     void res_block(const ResW& w, const Act& x, Act& y, int step);
@@ -203,6 +211,7 @@ private:
     std::vector<ProfPending> prof_pending_;
 
     sdmi_config cfg_;
+    bool bf16_ = false;  // precision = 1: bf16 activations / weights, fp32 accumulate
     hipStream_t stream_ = nullptr;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     DevPool pool_;

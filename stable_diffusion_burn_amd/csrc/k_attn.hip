@@ -30,6 +30,8 @@ namespace sdmi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2h __attribute__((ext_vector_type(2)));
 
 template <int D>
 struct AttnCfg {
@@ -257,7 +259,7 @@ __device__ __forceinline__ float xlane_sum4(float v) {
     return a + b;
 }
 
-template <int D, int NW>
+template <int D, int NW, bool H16 = false>
 struct Attn2Cfg {
     static constexpr int NT = NW * 64;
     static constexpr int BKV = (D > 96) ? 32 : 64;
@@ -265,15 +267,20 @@ struct Attn2Cfg {
     static constexpr int DT = (D + 15) / 16;
     static constexpr int DC = D / 8;
     static constexpr int LDK = D + 4;
-    static constexpr int F4_PER_TILE = BKV * (D / 4);
+    static constexpr int VEC = H16 ? 8 : 4;                 // elements per 16-byte global access
+    static constexpr int F4_PER_TILE = BKV * (D / VEC);       // 16-byte vectors per K (or V) tile
     static constexpr int NLD = (F4_PER_TILE + NT - 1) / NT;
     static constexpr int TILE_FLOATS = BKV * LDK;
     static constexpr size_t LDS_BYTES = (size_t)(4 * TILE_FLOATS + 64) * sizeof(float);
 };
 
-template <int D, int NW, bool HAS_MASK>
+// H16: q/k/v/o are bf16 in HBM (precision = 1); the tiles are widened to fp32 when staged into LDS and
+// all arithmetic (QK^T, softmax, PV) stays on the fp32 matrix path.
+template <int D, int NW, bool HAS_MASK, bool H16>
 __global__ __launch_bounds__(NW * 64) void attn2_kernel(const AttnParams p) {
-    using Cfg = Attn2Cfg<D, NW>;
+    using Cfg = Attn2Cfg<D, NW, H16>;
+    constexpr int VEC = Cfg::VEC;
+    typedef unsigned short h16;
     constexpr int NT = Cfg::NT, BKV = Cfg::BKV, KT = Cfg::KT, DT = Cfg::DT, DC = Cfg::DC, LDK = Cfg::LDK, NLD = Cfg::NLD;
     constexpr float kLog2e = 1.4426950408889634f;
 
@@ -296,6 +303,10 @@ __global__ __launch_bounds__(NW * 64) void attn2_kernel(const AttnParams p) {
     const float* Kb = p.k + (long long)b * p.k_bs + hh * D;
     const float* Vb = p.v + (long long)b * p.v_bs + hh * D;
     float* Ob = p.o + (long long)b * p.o_bs + hh * D;
+    const h16* Qh = reinterpret_cast<const h16*>(p.q) + (long long)b * p.q_bs + hh * D;
+    const h16* Kh = reinterpret_cast<const h16*>(p.k) + (long long)b * p.k_bs + hh * D;
+    const h16* Vh = reinterpret_cast<const h16*>(p.v) + (long long)b * p.v_bs + hh * D;
+    h16* Oh = reinterpret_cast<h16*>(p.o) + (long long)b * p.o_bs + hh * D;
 
     const int nk = p.kv_len ? p.kv_len[b] : p.nk;
     const int n_tiles = (nk + BKV - 1) / BKV;
@@ -306,7 +317,14 @@ __global__ __launch_bounds__(NW * 64) void attn2_kernel(const AttnParams p) {
 #pragma unroll
     for (int cc = 0; cc < DC; ++cc) {
         f32x2 v = {0.f, 0.f};
-        if (q_ok) v = *reinterpret_cast<const f32x2*>(Qb + (long long)qrow * p.ldq + cc * 8 + g * 2);
+        if (q_ok) {
+            if constexpr (H16) {
+                const unsigned w = *reinterpret_cast<const unsigned*>(Qh + (long long)qrow * p.ldq + cc * 8 + g * 2);
+                v = f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u)};
+            } else {
+                v = *reinterpret_cast<const f32x2*>(Qb + (long long)qrow * p.ldq + cc * 8 + g * 2);
+            }
+        }
         qf[cc] = v * qscale;
     }
 
@@ -316,13 +334,18 @@ __global__ __launch_bounds__(NW * 64) void attn2_kernel(const AttnParams p) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int idx = tid + i * NT;
-            const int row = idx / (D / 4);
-            const int c4 = idx - row * (D / 4);
+            const int row = idx / (D / VEC);
+            const int c4 = idx - row * (D / VEC);
             const int key = kv0 + row;
-            f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};  // H16: 8 raw bf16 each
             if (idx < Cfg::F4_PER_TILE && key < nk) {
-                kk = *reinterpret_cast<const f32x4*>(Kb + (long long)key * p.ldk + c4 * 4);
-                vv = *reinterpret_cast<const f32x4*>(Vb + (long long)key * p.ldv + c4 * 4);
+                if constexpr (H16) {
+                    kk = *reinterpret_cast<const f32x4*>(Kh + (long long)key * p.ldk + c4 * 8);
+                    vv = *reinterpret_cast<const f32x4*>(Vh + (long long)key * p.ldv + c4 * 8);
+                } else {
+                    kk = *reinterpret_cast<const f32x4*>(Kb + (long long)key * p.ldk + c4 * 4);
+                    vv = *reinterpret_cast<const f32x4*>(Vb + (long long)key * p.ldv + c4 * 4);
+                }
             }
             rk[i] = kk;
             rv[i] = vv;
@@ -333,10 +356,24 @@ __global__ __launch_bounds__(NW * 64) void attn2_kernel(const AttnParams p) {
         for (int i = 0; i < NLD; ++i) {
             const int idx = tid + i * NT;
             if (idx < Cfg::F4_PER_TILE) {
-                const int row = idx / (D / 4);
-                const int c4 = idx - row * (D / 4);
-                *reinterpret_cast<f32x4*>(Ks + buf * Cfg::TILE_FLOATS + row * LDK + c4 * 4) = rk[i];
-                *reinterpret_cast<f32x4*>(Vs + buf * Cfg::TILE_FLOATS + row * LDK + c4 * 4) = rv[i];
+                const int row = idx / (D / VEC);
+                const int c4 = idx - row * (D / VEC);
+                float* kd = Ks + buf * Cfg::TILE_FLOATS + row * LDK + c4 * VEC;
+                float* vd = Vs + buf * Cfg::TILE_FLOATS + row * LDK + c4 * VEC;
+                if constexpr (H16) {
+                    const u32x4h kw = __builtin_bit_cast(u32x4h, rk[i]), vw = __builtin_bit_cast(u32x4h, rv[i]);
+                    *reinterpret_cast<f32x4*>(kd) = f32x4{__uint_as_float(kw[0] << 16), __uint_as_float(kw[0] & 0xFFFF0000u),
+                                                          __uint_as_float(kw[1] << 16), __uint_as_float(kw[1] & 0xFFFF0000u)};
+                    *reinterpret_cast<f32x4*>(kd + 4) = f32x4{__uint_as_float(kw[2] << 16), __uint_as_float(kw[2] & 0xFFFF0000u),
+                                                              __uint_as_float(kw[3] << 16), __uint_as_float(kw[3] & 0xFFFF0000u)};
+                    *reinterpret_cast<f32x4*>(vd) = f32x4{__uint_as_float(vw[0] << 16), __uint_as_float(vw[0] & 0xFFFF0000u),
+                                                          __uint_as_float(vw[1] << 16), __uint_as_float(vw[1] & 0xFFFF0000u)};
+                    *reinterpret_cast<f32x4*>(vd + 4) = f32x4{__uint_as_float(vw[2] << 16), __uint_as_float(vw[2] & 0xFFFF0000u),
+                                                              __uint_as_float(vw[3] << 16), __uint_as_float(vw[3] & 0xFFFF0000u)};
+                } else {
+                    *reinterpret_cast<f32x4*>(kd) = rk[i];
+                    *reinterpret_cast<f32x4*>(vd) = rv[i];
+                }
             }
         }
     };
@@ -434,7 +471,16 @@ __global__ __launch_bounds__(NW * 64) void attn2_kernel(const AttnParams p) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int dcol = dt * 16 + g * 4;
-            if (dcol < D) *reinterpret_cast<f32x4*>(Ob + (long long)qrow * p.ldo + dcol) = o[dt] * inv;
+            if (dcol < D) {
+                const f32x4 r = o[dt] * inv;
+                if constexpr (H16) {
+                    auto bits = [](float f) { unsigned u = __float_as_uint(f); u += 0x7FFFu + ((u >> 16) & 1u); return u >> 16; };
+                    u32x2h w = {bits(r[0]) | (bits(r[1]) << 16), bits(r[2]) | (bits(r[3]) << 16)};
+                    *reinterpret_cast<u32x2h*>(Oh + (long long)qrow * p.ldo + dcol) = w;
+                } else {
+                    *reinterpret_cast<f32x4*>(Ob + (long long)qrow * p.ldo + dcol) = r;
+                }
+            }
         }
     }
 }
@@ -484,11 +530,11 @@ static hipError_t launch_attn_d(const AttnParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int D, int NW, bool HAS_MASK>
+template <int D, int NW, bool HAS_MASK, bool H16>
 static hipError_t launch_attn2_d(const AttnParams& p, hipStream_t stream) {
     static bool attr_set = false;
-    auto k = attn2_kernel<D, NW, HAS_MASK>;
-    const size_t lds = Attn2Cfg<D, NW>::LDS_BYTES;
+    auto k = attn2_kernel<D, NW, HAS_MASK, H16>;
+    const size_t lds = Attn2Cfg<D, NW, H16>::LDS_BYTES;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -504,8 +550,12 @@ static hipError_t launch_attn2_any(const AttnParams& p, hipStream_t stream) {
     // 8-wave workgroups once they still fill the chip (>= 1.5 workgroups per CU), else 4-wave
     const long long wg8 = (long long)((p.nq + 127) / 128) * p.n * p.n_head;
     const bool big = wg8 >= 384;
-    if (p.mask) return big ? launch_attn2_d<D, 8, true>(p, stream) : launch_attn2_d<D, 4, true>(p, stream);
-    return big ? launch_attn2_d<D, 8, false>(p, stream) : launch_attn2_d<D, 4, false>(p, stream);
+    if (p.bf16) {
+        if (p.mask) return hipErrorInvalidValue;  // the masked (CLIP) path is fp32 only
+        return big ? launch_attn2_d<D, 8, false, true>(p, stream) : launch_attn2_d<D, 4, false, true>(p, stream);
+    }
+    if (p.mask) return big ? launch_attn2_d<D, 8, true, false>(p, stream) : launch_attn2_d<D, 4, true, false>(p, stream);
+    return big ? launch_attn2_d<D, 8, false, false>(p, stream) : launch_attn2_d<D, 4, false, false>(p, stream);
 }
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream, int variant) {

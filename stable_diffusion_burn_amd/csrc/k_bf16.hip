@@ -1,0 +1,363 @@
+// k_bf16.hip -- bf16-storage variants of the HBM-bound kernels (precision = 1).
+//
+// Same algorithms as k_norm.hip / k_elem.hip (citations there); activations are bf16 in HBM, all
+// arithmetic is fp32, statistics are combined in fp64 in fixed order.  A 16-byte access now carries
+// 8 channels, so a thread owns one 8-channel column and the HBM traffic of every pass is halved.
+#include "kernels.hpp"
+
+namespace sdmi {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct F8 { float v[8]; };
+
+__device__ __forceinline__ F8 unpack8(u32x4 w) {
+    F8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r.v[2 * i] = __uint_as_float(w[i] << 16);
+        r.v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+    }
+    return r;
+}
+__device__ __forceinline__ unsigned bf16_bits(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ u32x4 pack8(const F8& f) {
+    u32x4 w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = bf16_bits(f.v[2 * i]) | (bf16_bits(f.v[2 * i + 1]) << 16);
+    return w;
+}
+
+static inline int blocks_for(long long work, int cap = 2048) {
+    long long b = (work + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+#define GRID_STRIDE(i, total) \
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (total); i += (long long)gridDim.x * blockDim.x)
+
+// ---- GroupNorm (+SiLU) ------------------------------------------------------------------------------
+struct GnGeomH { int cq, R, threads, chunks, rows_per_chunk; };
+
+static inline GnGeomH gn_geom_h(int hw, int c) {
+    GnGeomH g;
+    g.cq = c / 8;
+    g.R = g.cq >= 1024 ? 1 : 1024 / g.cq;
+    if (g.R > 32) g.R = 32;
+    if (g.R > hw) g.R = hw;
+    g.threads = g.cq * g.R;
+    const long long bytes = (long long)hw * c * 2;
+    long long chunks = (bytes + 65535) / 65536;
+    if (chunks > 256) chunks = 256;
+    if (chunks < 1) chunks = 1;
+    int rpc = (int)((hw + chunks - 1) / chunks);
+    rpc = (rpc + g.R - 1) / g.R * g.R;
+    g.rows_per_chunk = rpc;
+    g.chunks = (hw + rpc - 1) / rpc;
+    return g;
+}
+
+size_t gn_partials_bytes_bf16(int n, int hw, int c) { return (size_t)n * gn_geom_h(hw, c).chunks * 64 * 2 * sizeof(double); }
+
+__global__ void gn_stats_bf16_kernel(const unsigned short* __restrict__ x, int hw, int C, int G, int rows_per_chunk,
+                                     double* __restrict__ part) {
+    extern __shared__ float sh[];  // [2][R][C] floats, then [2][C] doubles
+    const int cq = C >> 3;
+    const int R = blockDim.x / cq;
+    const int tid = threadIdx.x;
+    const int c8 = tid % cq;
+    const int r0 = tid / cq;
+    const int chunk = blockIdx.x, chunks = gridDim.x, smp = blockIdx.y;
+    const int row_begin = chunk * rows_per_chunk;
+    const int row_end = min(row_begin + rows_per_chunk, hw);
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
+    const unsigned short* xb = x + (long long)smp * hw * C + c8 * 8;
+    for (int row = row_begin + r0; row < row_end; row += R) {
+        const F8 v = unpack8(*reinterpret_cast<const u32x4*>(xb + (long long)row * C));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s[i] += v.v[i]; q[i] += v.v[i] * v.v[i]; }
+    }
+    float* shs = sh;
+    float* shq = sh + R * C;
+    double* chs = reinterpret_cast<double*>(sh + 2 * R * C);
+    double* chq = chs + C;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { shs[r0 * C + c8 * 8 + i] = s[i]; shq[r0 * C + c8 * 8 + i] = q[i]; }
+    __syncthreads();
+    for (int ch = tid; ch < C; ch += blockDim.x) {
+        double ds = 0.0, dq = 0.0;
+        for (int r = 0; r < R; ++r) { ds += (double)shs[r * C + ch]; dq += (double)shq[r * C + ch]; }
+        chs[ch] = ds; chq[ch] = dq;
+    }
+    __syncthreads();
+    for (int gi = tid; gi < G; gi += blockDim.x) {
+        const int cpg = C / G;
+        double ds = 0.0, dq = 0.0;
+        for (int ch = gi * cpg; ch < (gi + 1) * cpg; ++ch) { ds += chs[ch]; dq += chq[ch]; }
+        double* o = part + ((long long)(smp * chunks + chunk) * G + gi) * 2;
+        o[0] = ds;
+        o[1] = dq;
+    }
+}
+
+template <bool SILU>
+__global__ void gn_apply_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, int hw, int C, int G,
+                                     float eps, int stat_chunks, const double* __restrict__ part, int rows_per_chunk) {
+    __shared__ float s_mean[64], s_rstd[64];
+    __shared__ double s_red[2][64][8];
+    const int cq = C >> 3;
+    const int R = blockDim.x / cq;
+    const int tid = threadIdx.x;
+    const int smp = blockIdx.y;
+    const int cpg = C / G;
+    for (int idx = tid; idx < G * 8; idx += blockDim.x) {
+        const int gi = idx >> 3, j = idx & 7;
+        double ds = 0.0, dq = 0.0;
+        const double* pp = part + ((long long)smp * stat_chunks * G + gi) * 2;
+        for (int ch = j; ch < stat_chunks; ch += 8) { ds += pp[(long long)ch * G * 2]; dq += pp[(long long)ch * G * 2 + 1]; }
+        s_red[0][gi][j] = ds;
+        s_red[1][gi][j] = dq;
+    }
+    __syncthreads();
+    for (int gi = tid; gi < G; gi += blockDim.x) {
+        double ds = 0.0, dq = 0.0;
+        for (int j = 0; j < 8; ++j) { ds += s_red[0][gi][j]; dq += s_red[1][gi][j]; }
+        const double cnt = (double)hw * cpg;
+        const double mean = ds / cnt;
+        double var = dq / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[gi] = (float)mean;
+        s_rstd[gi] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int c8 = tid % cq;
+    const int r0 = tid / cq;
+    float gm[8], bt[8], mean[8], rstd[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ch = c8 * 8 + i;
+        gm[i] = gamma[ch];
+        bt[i] = beta[ch];
+        mean[i] = s_mean[ch / cpg];
+        rstd[i] = s_rstd[ch / cpg];
+    }
+    const int row_begin = blockIdx.x * rows_per_chunk;
+    const int row_end = min(row_begin + rows_per_chunk, hw);
+    const long long base = (long long)smp * hw * C + c8 * 8;
+    for (int row = row_begin + r0; row < row_end; row += R) {
+        const long long o = base + (long long)row * C;
+        F8 v = unpack8(*reinterpret_cast<const u32x4*>(x + o));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float t = (v.v[i] - mean[i]) * rstd[i];
+            t = t * gm[i] + bt[i];
+            if (SILU) t = t / (1.0f + __expf(-t));
+            v.v[i] = t;
+        }
+        *reinterpret_cast<u32x4*>(y + o) = pack8(v);
+    }
+}
+
+hipError_t launch_group_norm_bf16(const void* x, void* y, const float* gamma, const float* beta, int n, int hw, int c,
+                                  int n_group, float eps, bool silu, void* partials, hipStream_t stream) {
+    if ((c & 7) || n_group > 64 || c % n_group || c / 8 > 1024) return hipErrorInvalidValue;
+    const GnGeomH g = gn_geom_h(hw, c);
+    double* part = reinterpret_cast<double*>(partials);
+    const size_t lds = (size_t)2 * g.R * c * sizeof(float) + (size_t)2 * c * sizeof(double);
+    auto xs = reinterpret_cast<const unsigned short*>(x);
+    auto ys = reinterpret_cast<unsigned short*>(y);
+    hipLaunchKernelGGL(gn_stats_bf16_kernel, dim3(g.chunks, n), dim3(g.threads), lds, stream, xs, hw, c, n_group, g.rows_per_chunk, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (silu)
+        hipLaunchKernelGGL(gn_apply_bf16_kernel<true>, dim3(g.chunks, n), dim3(g.threads), 0, stream, xs, ys, gamma, beta, hw, c, n_group,
+                           eps, g.chunks, part, g.rows_per_chunk);
+    else
+        hipLaunchKernelGGL(gn_apply_bf16_kernel<false>, dim3(g.chunks, n), dim3(g.threads), 0, stream, xs, ys, gamma, beta, hw, c, n_group,
+                           eps, g.chunks, part, g.rows_per_chunk);
+    return hipGetLastError();
+}
+
+// ---- LayerNorm: one wave per row, 8-channel vectors ---------------------------------------------------------
+constexpr int kLnMaxVecH = 4;  // C <= 2048
+
+__global__ __launch_bounds__(256) void layer_norm_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int rows,
+                                                              int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int cq = C >> 3;
+    const unsigned short* xr = x + (long long)row * C;
+    F8 v[kLnMaxVecH];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnMaxVecH; ++i) {
+        const int f = lane + i * 64;
+        if (f < cq) {
+            v[i] = unpack8(*reinterpret_cast<const u32x4*>(xr + f * 8));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[i].v[j];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnMaxVecH; ++i) {
+        const int f = lane + i * 64;
+        if (f < cq) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[i].v[j] - mean; sq += d * d; }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+    const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+    unsigned short* yr = y + (long long)row * C;
+#pragma unroll
+    for (int i = 0; i < kLnMaxVecH; ++i) {
+        const int f = lane + i * 64;
+        if (f < cq) {
+            F8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.v[j] = (v[i].v[j] - mean) * rstd * gamma[f * 8 + j] + beta[f * 8 + j];
+            *reinterpret_cast<u32x4*>(yr + f * 8) = pack8(o);
+        }
+    }
+}
+
+hipError_t launch_layer_norm_bf16(const void* x, void* y, const float* gamma, const float* beta, int rows, int c, float eps,
+                                  hipStream_t stream) {
+    if ((c & 7) || c > kLnMaxVecH * 512) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layer_norm_bf16_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, reinterpret_cast<const unsigned short*>(x),
+                       reinterpret_cast<unsigned short*>(y), gamma, beta, rows, c, eps);
+    return hipGetLastError();
+}
+
+// ---- elementwise ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf_h(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__global__ void geglu_bf16_kernel(const unsigned short* __restrict__ proj, unsigned short* __restrict__ out, long long rows, int hidden8) {
+    const long long total = rows * hidden8;
+    GRID_STRIDE(i, total) {
+        const long long r = i / hidden8;
+        const int c = (int)(i - r * hidden8);
+        const F8 a = unpack8(reinterpret_cast<const u32x4*>(proj)[r * 2 * hidden8 + c]);
+        const F8 g = unpack8(reinterpret_cast<const u32x4*>(proj)[r * 2 * hidden8 + hidden8 + c]);
+        F8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] = a.v[j] * gelu_erf_h(g.v[j]);
+        reinterpret_cast<u32x4*>(out)[i] = pack8(o);
+    }
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long n) {
+    GRID_STRIDE(i, n) dst[i] = (unsigned short)bf16_bits(src[i]);
+}
+
+__global__ void nhwc_bf16_to_nchw_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int n, int c, int h, int w) {
+    const long long hw = (long long)h * w, total = (long long)n * c * hw;
+    GRID_STRIDE(i, total) {
+        const long long p = i % hw;
+        const long long bc = i / hw;
+        const int ch = (int)(bc % c);
+        const long long b = bc / c;
+        dst[i] = __uint_as_float((unsigned)src[(b * hw + p) * c + ch] << 16);
+    }
+}
+
+__global__ void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int n, int c, int h, int w,
+                                             float scale) {
+    const long long hw = (long long)h * w, total = (long long)n * c * hw;
+    GRID_STRIDE(i, total) {
+        const int ch = (int)(i % c);
+        const long long px = i / c;
+        const long long b = px / hw, p = px - b * hw;
+        dst[i] = (unsigned short)bf16_bits(src[(b * c + ch) * hw + p] * scale);
+    }
+}
+
+__global__ void transpose2d_bf16_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst, int rows, int cols,
+                                        int src_ld) {
+    __shared__ unsigned short tile[32][34];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int rr = by + r, cc = bx + tx;
+        tile[r][tx] = (rr < rows && cc < cols) ? src[(long long)rr * src_ld + cc] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int cc = bx + r, rr = by + tx;
+        if (cc < cols && rr < rows) dst[(long long)cc * rows + rr] = tile[tx][r];
+    }
+}
+
+// row softmax of the fp32 score matrix of the unfused single-head (VAE) attention, bf16 probabilities out
+__global__ __launch_bounds__(256) void softmax_rows_f32_to_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y,
+                                                                       int rows, int cols, float scale) {
+    __shared__ float red[8];
+    const int row = blockIdx.x;
+    if (row >= rows) return;
+    const float* xr = x + (long long)row * cols;
+    unsigned short* yr = y + (long long)row * cols;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mx = -INFINITY;
+    for (int i = tid; i < cols; i += 256) mx = fmaxf(mx, xr[i] * scale);
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int i = tid; i < cols; i += 256) sum += __expf(xr[i] * scale - mx);
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    const float inv = 1.0f / sum;
+    for (int i = tid; i < cols; i += 256) yr[i] = (unsigned short)bf16_bits(__expf(xr[i] * scale - mx) * inv);
+}
+
+hipError_t launch_geglu_bf16(const void* proj, void* out, long long rows, int hidden, hipStream_t s) {
+    if (hidden & 7) return hipErrorInvalidValue;
+    const long long total = rows * (hidden / 8);
+    hipLaunchKernelGGL(geglu_bf16_kernel, dim3(blocks_for(total, 4096)), dim3(256), 0, s, reinterpret_cast<const unsigned short*>(proj),
+                       reinterpret_cast<unsigned short*>(out), rows, hidden / 8);
+    return hipGetLastError();
+}
+hipError_t launch_f32_to_bf16(const float* src, void* dst, long long n, hipStream_t s) {
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks_for(n)), dim3(256), 0, s, src, reinterpret_cast<unsigned short*>(dst), n);
+    return hipGetLastError();
+}
+hipError_t launch_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int n, int c, int h, int w, hipStream_t s) {
+    hipLaunchKernelGGL(nhwc_bf16_to_nchw_f32_kernel, dim3(blocks_for((long long)n * c * h * w)), dim3(256), 0, s,
+                       reinterpret_cast<const unsigned short*>(src), dst, n, c, h, w);
+    return hipGetLastError();
+}
+hipError_t launch_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, int c, int h, int w, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, dim3(blocks_for((long long)n * c * h * w)), dim3(256), 0, s, src,
+                       reinterpret_cast<unsigned short*>(dst), n, c, h, w, scale);
+    return hipGetLastError();
+}
+hipError_t launch_transpose2d_bf16(const void* src, void* dst, int rows, int cols, int src_ld, hipStream_t s) {
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+    hipLaunchKernelGGL(transpose2d_bf16_kernel, grid, dim3(256), 0, s, reinterpret_cast<const unsigned short*>(src),
+                       reinterpret_cast<unsigned short*>(dst), rows, cols, src_ld);
+    return hipGetLastError();
+}
+hipError_t launch_softmax_rows_f32_to_bf16(const float* x, void* y, int rows, int cols, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_rows_f32_to_bf16_kernel, dim3(rows), dim3(256), 0, s, x, reinterpret_cast<unsigned short*>(y), rows, cols, scale);
+    return hipGetLastError();
+}
+
+}  // namespace sdmi

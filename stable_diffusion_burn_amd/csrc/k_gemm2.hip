@@ -252,7 +252,17 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(const ConvGemm p) {
                     if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)smp * p.rowvec_stride + n);
                     if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (long long)m * p.ldr + n);
                 }
-                *reinterpret_cast<f32x4*>(Cbase + (long long)m * ldc + n) = v;
+                if (p.out_mode == 2 && !split) {  // bf16 consumer (the Cin = 4 layers of the bf16 path)
+                    unsigned short* Ch = reinterpret_cast<unsigned short*>(p.C) + (long long)m * ldc + n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        unsigned u = __float_as_uint(v[r]);
+                        u += 0x7FFFu + ((u >> 16) & 1u);
+                        Ch[r] = (unsigned short)(u >> 16);
+                    }
+                } else {
+                    *reinterpret_cast<f32x4*>(Cbase + (long long)m * ldc + n) = v;
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {

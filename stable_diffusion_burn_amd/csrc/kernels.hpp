@@ -37,6 +37,7 @@ struct ConvGemm {
     int splits;           // gridDim.z
     long long slab_stride;  // M*N when splits > 1
     unsigned a_bytes, b_bytes;  // extents of A / Bt for the buffer-load range check (v2 kernel)
+    int out_mode;               // 0: output in the kernel's storage type; 1: force fp32 (bf16 kernel); 2: bf16 from the fp32 kernel
 };
 
 // tile configurations (index = tile_cfg); BM x BN per 256-thread workgroup
@@ -46,6 +47,12 @@ const GemmTileInfo& gemm_tile_info(int cfg);
 size_t gemm_tile_lds_bytes(int cfg);
 hipError_t launch_conv_gemm(const ConvGemm& p, int tile_cfg, hipStream_t stream);   // v1 (k_gemm.hip)
 hipError_t launch_conv_gemm2(const ConvGemm& p, int tile_cfg, hipStream_t stream);  // v2 (k_gemm2.hip)
+size_t gemm2_tile_lds_bytes(int cfg);
+// bf16 storage / fp32 accumulate (k_gemm_bf16.hip); A, Bt, resid and (unless out_mode == 1) C are bf16
+hipError_t launch_conv_gemm_bf16(const ConvGemm& p, int tile_cfg, hipStream_t stream);
+hipError_t launch_splitk_reduce_bf16(const ConvGemm& p, const float* slabs, hipStream_t stream);
+hipError_t launch_pack_conv_weight_bf16(const float* w_oihw, void* bt, int cout, int cin, int kh, int kw, hipStream_t s);
+hipError_t launch_pack_linear_weight_bf16(const float* w_in_out, void* bt, int cin, int cout, hipStream_t s);
 // sums split-K slabs in fixed order and applies the epilogue
 hipError_t launch_splitk_reduce(const ConvGemm& p, const float* slabs, float* C, hipStream_t stream);
 // weight packing (done once at load)
@@ -62,6 +69,7 @@ struct AttnParams {
     int ldq, ldk, ldv, ldo;             // row strides in floats
     long long q_bs, k_bs, v_bs, o_bs;   // batch strides in floats
     float scale;                        // d_head^-0.25 applied to q and to k (attention.rs:15-26)
+    int bf16;                           // q/k/v/o are bf16 in HBM (strides in elements); v2 kernel only
 };
 bool attn_supported_head_dim(int d);
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream, int variant = 1);  // 0: v1 kernel (A/B)
@@ -98,5 +106,18 @@ hipError_t launch_dup_latent(const float* latent, float* unet_in, long long per_
 // (img+1)/2*255 -> clamp -> truncating u8, NHWC in, HWC out (stablediffusion/mod.rs:79-99)
 hipError_t launch_image_to_u8(const float* img_nhwc, uint8_t* out, long long n_elem, hipStream_t s);
 hipError_t launch_fill_normal(float* dst, long long n, uint64_t seed, hipStream_t s);
+
+// ---- bf16-storage variants (k_bf16.hip) ---------------------------------------------------------------
+size_t gn_partials_bytes_bf16(int n, int hw, int c);
+hipError_t launch_group_norm_bf16(const void* x, void* y, const float* gamma, const float* beta, int n, int hw, int c,
+                                  int n_group, float eps, bool silu, void* partials, hipStream_t stream);
+hipError_t launch_layer_norm_bf16(const void* x, void* y, const float* gamma, const float* beta, int rows, int c, float eps,
+                                  hipStream_t stream);
+hipError_t launch_geglu_bf16(const void* proj, void* out, long long rows, int hidden, hipStream_t s);
+hipError_t launch_f32_to_bf16(const float* src, void* dst, long long n, hipStream_t s);
+hipError_t launch_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int n, int c, int h, int w, hipStream_t s);
+hipError_t launch_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, int c, int h, int w, float scale, hipStream_t s);
+hipError_t launch_transpose2d_bf16(const void* src, void* dst, int rows, int cols, int src_ld, hipStream_t s);
+hipError_t launch_softmax_rows_f32_to_bf16(const float* x, void* y, int rows, int cols, float scale, hipStream_t s);
 
 }  // namespace sdmi

@@ -37,6 +37,7 @@ class ModelConfig:
     latent_h: int = 64
     latent_w: int = 64
     vae_ch: int = 128
+    precision: int = 0   # 0 = fp32 (BASELINE configs[0..1]); 1 = bf16 storage + fp32 accumulate (configs[2..3])
 
 
 def _f32(a, shape=None, name="array") -> np.ndarray:
@@ -65,6 +66,7 @@ class StableDiffusion:
         cfg.latent_h = config.latent_h
         cfg.latent_w = config.latent_w
         cfg.vae_ch = config.vae_ch
+        cfg.precision = config.precision
         self._ctx = C.c_void_p()
         check(self._lib.sdmi_create(C.byref(self._ctx), C.byref(cfg)))
         self.unet = UNet(self)

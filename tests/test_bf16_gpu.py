@@ -1,0 +1,202 @@
+"""precision = 1 (bf16 storage, fp32 accumulate; BASELINE.json configs[2..3]) parity tests.
+
+Operator level: inputs and weights are rounded to bf16 on the host first, so the comparison with the
+fp64 oracle isolates the kernel (fp32 accumulation + one bf16 rounding of the output):
+    |gpu - ref| <= 2^-8 * max(1, |ref|_inf)          (bf16 outputs; 2^-9 is half an ulp at the top binade)
+    |gpu - ref| <= 2e-4 * max(1, |ref|_inf)          (fp32 outputs of the bf16 kernels: eps / RGB heads)
+Model level (full-width UNet / decoder at an 8x8 latent): relative RMS error against the fp64 oracle on
+the un-rounded weights; bars set from the first measurements ("expect ~1e-2 bf16").
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sd_oracle as O
+from stable_diffusion_burn_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def bf16_round(a):
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a)).double()
+
+
+def _check(got, ref, what, rel):
+    ref = np.asarray(ref, np.float64)
+    got = np.asarray(got, np.float64)
+    assert got.shape == ref.shape and np.isfinite(got).all(), what
+    err = np.abs(got - ref).max()
+    bound = rel * max(1.0, np.abs(ref).max())
+    assert err <= bound, f"{what}: max|d|={err:.3e} > {bound:.3e} (rms {np.sqrt(np.mean((got - ref) ** 2)):.3e})"
+
+
+@pytest.fixture(scope="module")
+def ops16():
+    from stable_diffusion_burn_amd import ModelConfig, StableDiffusion
+    sd = StableDiffusion(ModelConfig(64, 1, 64, 8, 8, 64, precision=1))
+    yield sd
+    sd.close()
+
+
+CONV16 = [
+    (2, 320, 16, 16, 320, 3, 1, 0), (1, 640, 8, 8, 640, 3, 1, 1), (2, 320, 16, 16, 320, 3, 2, 0),
+    (2, 640, 16, 16, 320, 1, 1, 0), (1, 2560, 8, 8, 1280, 3, 1, 0), (1, 256, 24, 40, 128, 3, 1, 0),
+    (1, 320, 16, 16, 4, 3, 1, 0),     # eps head: bf16 kernel, fp32 output
+    (1, 128, 16, 16, 3, 3, 1, 0),     # RGB head: N = 3, fp32 output
+    (1, 4, 16, 16, 320, 3, 1, 0),     # conv_in: fp32 kernel (Cin = 4) emitting bf16
+    (3, 64, 5, 7, 96, 3, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV16)
+def test_conv2d_bf16(ops16, case):
+    n, cin, h, w, cout, k, stride, ups = case
+    g = np.random.default_rng(hash(case) % (2 ** 31))
+    x = g.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (g.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k)).astype(np.float32)
+    b = g.standard_normal(cout).astype(np.float32)
+    if cin % 64 == 0:   # the kernel sees bf16 operands
+        x, wt = bf16_round(x), bf16_round(wt)
+    got = ops16.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
+    xin = O.upsample2x(_t(x)) if ups else _t(x)
+    ref = O.conv2d(xin, (_t(wt), _t(b)), stride=stride, padding=1 if k == 3 else 0).numpy()
+    _check(got, ref, f"conv2d bf16 {case}", 2e-4 if cout <= 4 else 2 ** -8)
+
+
+@pytest.mark.parametrize("tile", range(10))
+@pytest.mark.parametrize("splitk", [1, 3])
+def test_conv2d_bf16_all_tiles(ops16, tile, splitk):
+    n, cin, h, w, cout = 2, 128, 13, 11, 208
+    g = np.random.default_rng(2000 + tile)
+    x = bf16_round(g.standard_normal((n, cin, h, w)))
+    wt = bf16_round(g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9))
+    b = g.standard_normal(cout).astype(np.float32)
+    try:
+        ops16.set_option("gemm_tile", tile)
+        ops16.set_option("splitk", splitk)
+        got = ops16.op_conv2d(x, wt, b)
+    finally:
+        ops16.set_option("gemm_tile", "auto")
+        ops16.set_option("splitk", 0)
+    ref = O.conv2d(_t(x), (_t(wt), _t(b)), padding=1).numpy()
+    _check(got, ref, f"conv bf16 tile={tile} splitk={splitk}", 2 ** -8)
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(154, 768, 320), (512, 320, 2560), (77, 64, 192), (1, 1280, 1280)])
+def test_linear_bf16(ops16, rows, cin, cout):
+    g = np.random.default_rng(rows + cout)
+    x = bf16_round(g.standard_normal((rows, cin)))
+    wt = bf16_round(g.standard_normal((cin, cout)) / math.sqrt(cin))
+    b = g.standard_normal(cout).astype(np.float32)
+    got = ops16.op_linear(x, wt, b)
+    _check(got, O.linear(_t(x), _t(wt), _t(b)).numpy(), f"linear bf16 ({rows},{cin},{cout})", 2 ** -8)
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 320, 16, 16), (1, 1920, 8, 8), (1, 128, 32, 32), (2, 2560, 8, 8), (2, 640, 1, 1)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_group_norm_bf16(ops16, n, c, h, w, silu):
+    g = np.random.default_rng(c + h)
+    x = bf16_round(g.standard_normal((n, c, h, w)) * 1.7 + 0.9)
+    gamma = (1 + 0.1 * g.standard_normal(c)).astype(np.float32)
+    beta = (0.1 * g.standard_normal(c)).astype(np.float32)
+    got = ops16.op_group_norm(x, gamma, beta, 32, 1e-5, silu)
+    ref = O.group_norm(_t(x), _t(gamma), _t(beta), 32, 1e-5)
+    if silu:
+        ref = O.silu(ref)
+    _check(got, ref.numpy(), f"group_norm bf16 {(n, c, h, w)} silu={silu}", 2 ** -8)
+
+
+@pytest.mark.parametrize("rows,c", [(64, 320), (257, 640), (33, 1280)])
+def test_layer_norm_bf16(ops16, rows, c):
+    g = np.random.default_rng(rows)
+    x = bf16_round(g.standard_normal((rows, c)) * 2 - 0.5)
+    gamma = (1 + 0.1 * g.standard_normal(c)).astype(np.float32)
+    beta = (0.1 * g.standard_normal(c)).astype(np.float32)
+    got = ops16.op_layer_norm(x, gamma, beta, 1e-5)
+    _check(got, O.layer_norm(_t(x), _t(gamma), _t(beta), 1e-5).numpy(), f"layer_norm bf16 ({rows},{c})", 2 ** -8)
+
+
+def test_geglu_bf16(ops16):
+    g = np.random.default_rng(3)
+    proj = bf16_round(g.standard_normal((37, 2 * 640)) * 2)
+    got = ops16.op_geglu(proj)
+    p = _t(proj)
+    _check(got, (p[:, :640] * O.gelu_erf(p[:, 640:])).numpy(), "geglu bf16", 2 ** -8)
+
+
+@pytest.mark.parametrize("case", [(2, 256, 256, 320, 8), (2, 64, 64, 640, 8), (1, 256, 256, 1280, 8), (2, 256, 77, 320, 8),
+                                  (2, 64, 2, 1280, 8), (3, 2048, 512, 320, 8), (1, 64, 64, 256, 1)])
+def test_qkv_attention_bf16(ops16, case):
+    n, nq, nk, c, heads = case
+    g = np.random.default_rng(hash(case) % (2 ** 31))
+    q, k, v = (bf16_round(g.standard_normal((n, s, c))) for s in (nq, nk, nk))
+    got = ops16.qkv_attention(q, k, v, None, heads)
+    ref = O.qkv_attention(_t(q), _t(k), _t(v), None, heads).numpy()
+    # fused path: fp32 math on bf16 inputs, bf16 output; unfused (1 head): probabilities are rounded to bf16 too
+    _check(got, ref, f"qkv_attention bf16 {case}", 2 ** -8 if heads > 1 else 2 ** -6)
+
+
+# ---- model level: full-width UNet / decoder at an 8x8 latent -----------------------------------------------------
+@pytest.fixture(scope="module")
+def sd16():
+    from stable_diffusion_burn_amd import ModelConfig, StableDiffusion
+    sd = StableDiffusion(ModelConfig(320, 8, 768, 8, 8, 64, precision=1))
+    sd.load_weights(syn.SyntheticWeights())
+    yield sd
+    sd.close()
+
+
+DIMS16 = O.Dims(320, 8, 768, 8, 8, 64)
+
+
+def _rel_rms(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return float(np.sqrt(np.mean((got - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))
+
+
+def test_unet_forward_bf16(sd16):
+    lat = np.stack([syn.initial_latent(i, 8, 8) for i in range(2)])
+    ctx = np.stack([syn.cond_context(i, 77, 768) for i in range(2)])
+    got = sd16.unet.forward(lat, [999], ctx)
+    o64 = O.UNetOracle(syn.SyntheticWeights(), DIMS16, torch.float64)
+    ref = o64.forward(torch.from_numpy(lat), 999, torch.from_numpy(ctx)).numpy()
+    r = _rel_rms(got, ref)
+    print(f"bf16 UNet forward: rel-RMS vs fp64 oracle = {r:.3e}, max|d| = {np.abs(got - ref).max():.3e} (|ref|max {np.abs(ref).max():.2f})")
+    assert np.isfinite(got).all() and r < 2e-2
+
+
+def test_sample_image_bf16(sd16):
+    lat = syn.initial_latent(0, 8, 8)[None]
+    ctx = syn.cond_context(0, 77, 768)[None]
+    unc = syn.uncond_context(77, 768)
+    a = syn.alphas_cumprod()
+    o64 = O.StableDiffusionOracle(syn.SyntheticWeights(), a, DIMS16, torch.float64)
+    got = sd16.sample_latent(ctx, unc, 7.5, 5, init_latent=lat)
+    ref = o64.sample_latent(torch.from_numpy(ctx), torch.from_numpy(unc), 7.5, 5, torch.from_numpy(lat)).numpy()
+    r = _rel_rms(got, ref)
+    print(f"bf16 sample_latent (5 steps, CFG 7.5): rel-RMS = {r:.3e}")
+    assert np.isfinite(got).all() and r < 5e-2
+    img = sd16.autoencoder.decode_latent((ref * (1.0 / 0.18215)).astype(np.float32))
+    ref_img = o64.decoder.decode_latent(torch.from_numpy(ref) * (1.0 / 0.18215)).numpy()
+    r2 = _rel_rms(img, ref_img)
+    print(f"bf16 decode_latent: rel-RMS = {r2:.3e}")
+    assert np.isfinite(img).all() and r2 < 3e-2
+    u8 = sd16.sample_image(ctx, unc, 7.5, 5, init_latent=lat)
+    assert u8.shape == (1, 64, 64, 3) and u8.dtype == np.uint8 and u8.std() > 1
+
+
+def test_bf16_batch_and_repeatability(sd16):
+    lat = np.stack([syn.initial_latent(i, 8, 8) for i in range(2)])
+    ctx = np.stack([syn.cond_context(i, 77, 768) for i in range(2)])
+    unc = syn.uncond_context(77, 768)
+    a = sd16.sample_latent(ctx, unc, 7.5, 3, init_latent=lat)
+    b = sd16.sample_latent(ctx, unc, 7.5, 3, init_latent=lat)
+    assert np.array_equal(a, b)
