@@ -35,6 +35,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA" (dense)
 F_UNET = 0.8033e12              # FLOP per UNet forward per sample, T = 77
 F_VAE = 2.5145e12               # FLOP per decoded image
 
@@ -47,6 +48,8 @@ def parse():
     ap.add_argument("--ddim-steps", type=int, default=20)
     ap.add_argument("--scale", type=float, default=7.5)
     ap.add_argument("--batch-per-gpu", type=int, default=1)
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 = BASELINE.json configs[1] (the metric's configuration, default); bf16 = configs[2..3] storage/compute")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tune-file", default=str(ROOT / "stable_diffusion_burn_amd" / "tuning" / "gfx950_fp32.txt"))
@@ -111,13 +114,14 @@ def main():
 
     B = args.batch_per_gpu
     T = Tu = 77
-    cfg = ModelConfig()
+    bf16 = args.precision == "bf16"
+    cfg = ModelConfig(precision=1 if bf16 else 0)
     sd = StableDiffusion(cfg, device=local_rank)
     weights = syn.SyntheticWeights(cache=(rank == 0 and world == 1 and not args.no_cpu_baseline))
     t0 = time.perf_counter()
     sd.load_weights(weights)
     t_load = time.perf_counter() - t0
-    if os.path.exists(args.tune_file):
+    if os.path.exists(args.tune_file) and not bf16:
         for line in Path(args.tune_file).read_text().split():
             if "=" in line and not line.startswith("#"):
                 sd.set_option("tune", line.strip())
@@ -180,9 +184,14 @@ def main():
                     traffic = json.loads(pmc.read_text()).get("conv_gemm_hbm_bytes_per_launch")
                 except Exception:  # noqa: BLE001
                     traffic = None
-            roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x4_f32)",
-                        "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+            kname = ("conv_gemm_bf16_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x32_bf16)" if bf16 else
+                     "conv_gemm2_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x4_f32)")
+            if bf16:
+                traffic = None  # the committed PMC summary is for the fp32 kernel
+            roofline = {"bound": "mfma", "kernel": kname,
+                        "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                        "frac": achieved / peak, "traffic": traffic,
                         "launches_per_image": g["launches"] / B,
                         "avg_launch_us": g["ms"] * 1e3 / g["launches"],
                         "flop_per_launch": g["flops"] / g["launches"],
@@ -200,13 +209,15 @@ def main():
             "metric": "images/sec @512x512, 20-step DDIM CFG=7.5, SD v1.4",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SD v1.4 512x512, 20-step DDIM, CFG=7.5, batch=1 per GPU, fp32 (BASELINE.json configs[1])",
+            "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "config": {"workload": (f"SD v1.4 512x512, {args.ddim_steps}-step DDIM, CFG={args.scale}, batch={B} per GPU, "
+                                    + ("bf16 storage / fp32 accumulate (BASELINE.json configs[2..3] family; NOT the headline fp32 configuration)"
+                                       if bf16 else "fp32 (BASELINE.json configs[1])")),
                        "global_batch": B * world, "ddim_steps": args.ddim_steps, "cfg_scale": args.scale,
                        "context_len": T, "parallelism": f"image-sharded x{world}, 1 RCCL broadcast of the text embedding"},
             "algorithmic_tflop_per_image": flop_per_image / 1e12,
             "whole_path_tflops_per_gpu": value / world * flop_per_image / 1e12,
-            "whole_path_frac_of_fp32_mfma_peak": value / world * flop_per_image / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            "whole_path_frac_of_mfma_peak": value / world * flop_per_image / 1e12 / (BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS),
             "kernels_per_image": stats["kernels"] / B, "weights_load_s": t_load,
             "roofline": roofline, "cpu_baseline": cpu,
         }
