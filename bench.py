@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--batch-per-gpu", type=int, default=1)
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="fp32 = BASELINE.json configs[1] (the metric's configuration, default); bf16 = configs[2..3] storage/compute")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="engine option (sdmi_set_option), repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tune-file", default=str(ROOT / "stable_diffusion_burn_amd" / "tuning" / "gfx950_fp32.txt"))
@@ -125,6 +126,9 @@ def main():
         for line in Path(args.tune_file).read_text().split():
             if "=" in line and not line.startswith("#"):
                 sd.set_option("tune", line.strip())
+    for kv in args.opt:
+        k, _, v = kv.partition("=")
+        sd.set_option(k, v)
 
     # ---- inputs: rank 0 owns the prompt embedding; ONE RCCL broadcast ------------------
     from stable_diffusion_burn_amd import sharding
