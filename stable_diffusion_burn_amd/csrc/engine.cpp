@@ -463,6 +463,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "splitk") opt_force_splits_ = std::stoi(value);
     else if (key == "gemm_variant") opt_gemm_variant_ = std::stoi(value);
     else if (key == "attn_variant") opt_attn_variant_ = std::stoi(value);
+    else if (key == "attn_bf16") opt_attn_bf16_ = std::stoi(value);
     else if (key == "record_shapes") { record_shapes_ = std::stoi(value) != 0; if (record_shapes_) shape_counts_.clear(); }
     else if (key == "dump_shapes") {
         std::ofstream f(value);
@@ -645,7 +646,8 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
         if (dt && mask) throw Error(SDMI_ERR_UNSUPPORTED, "attention: additive mask is fp32-only");
         const double fl = 4.0 * n * n_head * (double)nq * nk * d_head;
         ProfScope ps(this, PC_ATTENTION, fl);
-        SDMI_HIP(launch_attention(p, stream_, dt ? 1 : opt_attn_variant_));
+        if (dt && opt_attn_bf16_) SDMI_HIP(launch_attention_bf16(p, stream_));
+        else SDMI_HIP(launch_attention(p, stream_, dt ? 1 : opt_attn_variant_));
         count_kernel(fl);
         return;
     }

@@ -251,7 +251,8 @@ private:
     // options
     int opt_force_tile_ = -1;
     int opt_force_splits_ = 0;
-    int opt_attn_variant_ = 1;  // 1: attn2_kernel, 0: attn_f32_kernel
+    int opt_attn_variant_ = 1;
+    int opt_attn_bf16_ = 1;     // precision = 1: 1 = bf16 matrix-core attention, 0 = bf16 storage widened onto the fp32 kernel  // 1: attn2_kernel, 0: attn_f32_kernel
     int opt_gemm_variant_ = 1;  // 1: k_gemm2.hip (buffer loads, swizzled LDS, pipelined), 0: k_gemm.hip
     std::map<std::string, TileChoice> tuned_;
     bool record_shapes_ = false;

@@ -1,0 +1,301 @@
+// Flash-style attention on the bf16 matrix cores (precision = 1): qkv_attention of the UNet's
+// self/cross attention (attention.rs:5-45, head dims 40 / 80 / 160) with bf16 q/k/v/o in HBM,
+// fp32 scores, fp32 online softmax and fp32 accumulation.
+//
+// One wave owns 32 query rows and all of the head's d columns; a workgroup of NW waves shares
+// 64-key K/V tiles through double-buffered LDS.
+//
+//   S^T = K Q^T   v_mfma_f32_32x32x16_bf16, A = K fragment (m = key), B = Q fragment (n = query):
+//                 lane l then holds 16 of the 32 scores of query (l & 31) in a key tile --
+//                 keys crow(r, hi) = (r & 3) + 8 (r >> 2) + 4 hi, hi = l >> 5 -- so the softmax
+//                 is lane-local except for ONE v_permlane32_swap per tile (row max).
+//   O^T = V^T P^T the eight probabilities r = 8 s .. 8 s + 7 of a lane are, packed to bf16,
+//                 exactly the B operand (k = 8 hi + j) of a 16-key step when the contraction
+//                 index is read as key(s, hi, j) = 16 s + 8 (j >> 2) + 4 hi + (j & 3).  The A
+//                 operand V^T[d][key(s, hi, j)] is two ds_read_b64_tr_b16 (the LDS transpose
+//                 read): V stays row-major [key][d] in LDS, the way it arrives from HBM, and
+//                 there is no P round trip and no cross-lane exchange at all.
+//
+// LDS images (bf16): K rows padded to an ODD number of 16-byte chunks, so the ds_read_b128 of
+// 16 different rows at one chunk column fall in 16 different 16-byte bank slots; V rows at a
+// stride = 64 (mod 256) bytes with 64-byte row segments, so the 4 rows x 64 B a half-wave
+// transpose-read touches tile the 256-byte bank row exactly.
+// The scale d^-0.5 (q and k each carry d^-0.25, attention.rs:15-26) is applied to the fp32
+// scores inside the exponent's fma, not to the bf16 operands.
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+namespace sdmi {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short h16;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <int D, int NW>
+struct AttnBfCfg {
+    static constexpr int NT = NW * 64;
+    static constexpr int BKV = 64;
+    static constexpr int DK = (D + 15) / 16 * 16;            // contraction width of K Q^T (48 / 80 / 160)
+    static constexpr int KS = DK / 16;
+    static constexpr int NDT = (D + 31) / 32;                // 32-row tiles of O^T (2 / 3 / 5)
+    static constexpr int KCH = DK / 8;                       // 16-byte chunks per K row holding data or zeros
+    static constexpr int RSK = (KCH | 1) * 16;               // K row stride, odd chunk count (112 / 176 / 336 B)
+    static constexpr int RSV = (NDT * 64 <= 192) ? 192 : 320;  // V row stride = 64 (mod 256) bytes
+    static constexpr int K_BYTES = BKV * RSK;
+    static constexpr int V_BYTES = BKV * RSV;
+    static constexpr int CHUNKS = BKV * (D / 8);             // 16-byte chunks of one K (or V) tile in HBM
+    static constexpr int NLD = (CHUNKS + NT - 1) / NT;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)(K_BYTES + V_BYTES);
+    static_assert(NDT * 64 <= RSV, "V rows must hold every d tile");
+};
+
+__device__ __forceinline__ float partner_max(float v) {  // max with lane l ^ 32
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float partner_sum(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    const f32x2 f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));  // v_cvt_pk_bf16_f32 (RNE)
+}
+
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) {
+    using Cfg = AttnBfCfg<D, NW>;
+    constexpr int NT = Cfg::NT, BKV = Cfg::BKV, KS = Cfg::KS, NDT = Cfg::NDT, RSK = Cfg::RSK, RSV = Cfg::RSV, NLD = Cfg::NLD;
+    constexpr int CPR = D / 8;  // chunks per HBM row
+    constexpr float kLog2e = 1.4426950408889634f;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_bf[];
+    unsigned char* Ks = smem_bf;
+    unsigned char* Vs = smem_bf + 2 * Cfg::K_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int hi = lane >> 5;
+    const int c = lane & 31;
+
+    const int b = blockIdx.y / p.n_head;
+    const int hh = blockIdx.y - b * p.n_head;
+    const int qrow = blockIdx.x * (32 * NW) + wave * 32 + c;
+    const bool q_ok = qrow < p.nq;
+
+    const h16* Qh = reinterpret_cast<const h16*>(p.q) + (long long)b * p.q_bs + hh * D;
+    const h16* Kh = reinterpret_cast<const h16*>(p.k) + (long long)b * p.k_bs + hh * D;
+    const h16* Vh = reinterpret_cast<const h16*>(p.v) + (long long)b * p.v_bs + hh * D;
+    h16* Oh = reinterpret_cast<h16*>(p.o) + (long long)b * p.o_bs + hh * D;
+
+    const int nk = p.kv_len ? p.kv_len[b] : p.nk;
+    const int n_tiles = (nk + BKV - 1) / BKV;
+    const int n_full = nk / BKV;
+    const float cs = p.scale * p.scale * kLog2e;  // scores -> log2 units
+
+    if constexpr (Cfg::DK > D) {  // zero the K columns D..DK-1 once (the staging never touches them)
+        for (int i = tid; i < 2 * BKV; i += NT)
+            *reinterpret_cast<u32x4*>(Ks + (i >> 6) * Cfg::K_BYTES + (i & 63) * RSK + CPR * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    // Q^T fragments: B[k = 16 s + 8 hi + j][n = query]
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        const int col = 16 * s + 8 * hi;
+        if (q_ok && col < D) v = *reinterpret_cast<const u32x4*>(Qh + (long long)qrow * p.ldq + col);
+        qf[s] = __builtin_bit_cast(bf16x8, v);
+    }
+
+    u32x4 rk[NLD], rv[NLD];
+    auto gload = [&](int tile) {
+        const int kv0 = tile * BKV;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * NT;
+            const int row = idx / CPR;
+            const int c8 = idx - row * CPR;
+            const int key = kv0 + row;
+            u32x4 kk = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+            if (idx < Cfg::CHUNKS && key < nk) {
+                kk = *reinterpret_cast<const u32x4*>(Kh + (long long)key * p.ldk + c8 * 8);
+                vv = *reinterpret_cast<const u32x4*>(Vh + (long long)key * p.ldv + c8 * 8);
+            }
+            rk[i] = kk;
+            rv[i] = vv;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * NT;
+            if (idx < Cfg::CHUNKS) {
+                const int row = idx / CPR;
+                const int c8 = idx - row * CPR;
+                *reinterpret_cast<u32x4*>(Ks + buf * Cfg::K_BYTES + row * RSK + c8 * 16) = rk[i];
+                *reinterpret_cast<u32x4*>(Vs + buf * Cfg::V_BYTES + row * RSV + c8 * 16) = rv[i];
+            }
+        }
+    };
+
+    f32x16 o[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY;  // running row max, raw score units
+    float l_run = 0.f;        // this lane's share of the row sum
+
+    // per-lane LDS offsets: K fragment row c, chunk hi; V transpose-read row 4 hi + (i >> 2), columns 16 (G & 1) + 4 (i & 3)
+    const int k_off = c * RSK + hi * 16;
+    const int i16 = lane & 15;
+    const int v_off = (4 * hi + (i16 >> 2)) * RSV + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int cur = tile & 1;
+        const bool more = (tile + 1) < n_tiles;
+        if (more) gload(tile + 1);
+
+        const unsigned char* Kt = Ks + cur * Cfg::K_BYTES + k_off;
+        const unsigned char* Vt = Vs + cur * Cfg::V_BYTES + v_off;
+        const int kv0 = tile * BKV;
+
+        f32x16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Kt + kt * 32 * RSK + ks * 32));
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+            }
+        }
+
+        if (tile >= n_full) {  // ragged last tile (uniform)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= nk) s[kt][r] = -INFINITY;
+                }
+        }
+
+        float mt = s[0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kt][r]);
+        mt = partner_max(mt);
+        const float m_new = fmaxf(m_run, mt);
+        const float mc = m_new * cs;
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
+        m_run = m_new;
+
+        unsigned pb[4][4];  // [16-key step][4 dwords = 8 bf16]
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], cs, -mc));
+                const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r + 1], cs, -mc));
+                psum += e0 + e1;
+                pb[kt * 2 + (r >> 3)][(r & 7) >> 1] = pack_bf16(e0, e1);
+            }
+        }
+        l_run = l_run * alpha + psum;
+        if (__any(alpha != 1.0f)) {  // the running max moved somewhere in the wave
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
+        }
+
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const lds_s16x4* vp = (const lds_s16x4*)(Vt + st * 16 * RSV + dt * 64);
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_s16x4*>(vp));
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_s16x4*>((const lds_s16x4*)(Vt + (st * 16 + 8) * RSV + dt * 64)));
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+                const u32x4 pw = {pb[st][0], pb[st][1], pb[st][2], pb[st][3]};
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pw), o[dt], 0, 0, 0);
+            }
+        }
+
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    const float inv = 1.0f / partner_sum(l_run);
+    if (q_ok) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int dcol = 32 * dt + 8 * rq + 4 * hi;
+                if (dcol < D) {
+                    const u32x2 w = {pack_bf16(o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv),
+                                     pack_bf16(o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv)};
+                    *reinterpret_cast<u32x2*>(Oh + (long long)qrow * p.ldo + dcol) = w;
+                }
+            }
+        }
+    }
+}
+
+template <int D, int NW>
+static hipError_t launch_attn_bf16_d(const AttnParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    auto k = attn_bf16_kernel<D, NW>;
+    const size_t lds = AttnBfCfg<D, NW>::LDS_BYTES;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((p.nq + 32 * NW - 1) / (32 * NW), p.n * p.n_head);
+    hipLaunchKernelGGL(k, grid, dim3(NW * 64), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int D>
+static hipError_t launch_attn_bf16_any(const AttnParams& p, hipStream_t stream) {
+    // widest workgroup that still gives every CU a workgroup (256 CUs)
+    const long long bh = (long long)p.n * p.n_head;
+    if ((long long)((p.nq + 255) / 256) * bh >= 256) return launch_attn_bf16_d<D, 8>(p, stream);
+    if ((long long)((p.nq + 127) / 128) * bh >= 256) return launch_attn_bf16_d<D, 4>(p, stream);
+    return launch_attn_bf16_d<D, 2>(p, stream);
+}
+
+// bf16 matrix-core attention; p.bf16 must be set, no additive mask (the masked CLIP path is fp32)
+hipError_t launch_attention_bf16(const AttnParams& p, hipStream_t stream) {
+    if (!p.bf16 || p.mask) return hipErrorInvalidValue;
+    if ((p.ldq | p.ldk | p.ldv | p.ldo) & 7) return hipErrorInvalidValue;  // 16-byte row alignment
+    switch (p.d_head) {
+        case 40: return launch_attn_bf16_any<40>(p, stream);
+        case 80: return launch_attn_bf16_any<80>(p, stream);
+        case 160: return launch_attn_bf16_any<160>(p, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace sdmi

@@ -73,6 +73,8 @@ struct AttnParams {
 };
 bool attn_supported_head_dim(int d);
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream, int variant = 1);  // 0: v1 kernel (A/B)
+// bf16 matrix-core kernel (k_attn_bf16.hip): p.bf16 set, no additive mask
+hipError_t launch_attention_bf16(const AttnParams& p, hipStream_t stream);
 // row softmax (in place) for the unfused single-head VAE attention: x[rows][cols] *= scale first
 hipError_t launch_softmax_rows(float* x, int rows, int cols, float scale, hipStream_t stream);
 

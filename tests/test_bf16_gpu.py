@@ -133,9 +133,14 @@ def test_geglu_bf16(ops16):
 
 
 @pytest.mark.parametrize("case", [(2, 256, 256, 320, 8), (2, 64, 64, 640, 8), (1, 256, 256, 1280, 8), (2, 256, 77, 320, 8),
-                                  (2, 64, 2, 1280, 8), (3, 2048, 512, 320, 8), (1, 64, 64, 256, 1)])
-def test_qkv_attention_bf16(ops16, case):
+                                  (2, 64, 2, 1280, 8), (3, 2048, 512, 320, 8), (1, 64, 64, 256, 1),
+                                  (4, 2048, 192, 320, 8), (2, 50, 100, 640, 8), (1, 300, 333, 1280, 8), (2, 1024, 1024, 640, 8)])
+@pytest.mark.parametrize("mfma16", [1, 0])
+def test_qkv_attention_bf16(ops16, case, mfma16):
+    """mfma16 = 1: bf16 matrix-core kernel (k_attn_bf16.hip; probabilities rounded to bf16 for P V);
+    0: bf16 storage widened onto the fp32 kernel."""
     n, nq, nk, c, heads = case
+    ops16.set_option("attn_bf16", mfma16)
     g = np.random.default_rng(hash(case) % (2 ** 31))
     q, k, v = (bf16_round(g.standard_normal((n, s, c))) for s in (nq, nk, nk))
     got = ops16.qkv_attention(q, k, v, None, heads)

@@ -6,13 +6,16 @@ from stable_diffusion_burn_amd import ModelConfig, StableDiffusion  # noqa: E402
 
 SHAPES = [(2, 4096, 4096, 320, 8), (2, 1024, 1024, 640, 8), (2, 256, 256, 1280, 8), (2, 64, 64, 1280, 8),
           (2, 4096, 77, 320, 8), (2, 1024, 77, 640, 8), (2, 256, 77, 1280, 8)]
-sd = StableDiffusion(ModelConfig(32, 1, 32, 8, 8, 32))
+BF16 = "--bf16" in sys.argv
+if "--b16" in sys.argv:
+    SHAPES = [(16,) + s[1:] for s in SHAPES]
+sd = StableDiffusion(ModelConfig(64, 1, 64, 8, 8, 64, precision=1 if BF16 else 0))
 for s in SHAPES:
     n, nq, nk, c, h = s
     fl = 4.0 * n * h * nq * nk * (c // h)
     row = []
     for variant in (0, 1):
-        sd.set_option("attn_variant", variant)
+        sd.set_option("attn_bf16" if BF16 else "attn_variant", variant)
         ms = sd.bench_attention(*s, iters=10)
         row.append(f"v{variant}: {ms * 1e3:8.1f} us {fl / ms / 1e9:6.1f} TF")
     print(f"{str(s):34s} " + " | ".join(row), flush=True)
