@@ -62,8 +62,14 @@ typedef struct sdmi_config {
     int32_t latent_w;        /* 64                                              */
     int32_t vae_ch;          /* 128  (decoder channels 4c,4c,2c,c)              */
     int32_t max_batch;       /* images per call the pool is sized for           */
-    int32_t precision;       /* 0 = fp32 (only value this round)                */
-    int32_t reserved[7];
+    int32_t precision;       /* 0 = fp32; 1 = bf16 storage, fp32 accumulate     */
+    /* CLIP text encoder, CLIPConfig::new(49408, 768, 12, 77, 12) stablediffusion/mod.rs:29;
+     * its width is ctx_dim.  clip_layers = 0 builds a context without it.              */
+    int32_t clip_layers;     /* 12                                              */
+    int32_t clip_heads;      /* 12                                              */
+    int32_t clip_vocab;      /* 49408                                           */
+    int32_t clip_ctx;        /* 77                                              */
+    int32_t reserved[3];
 } sdmi_config;
 
 int sdmi_default_config(sdmi_config* cfg);
@@ -134,6 +140,38 @@ int sdmi_sample_image(sdmi_ctx* ctx, const float* context, int32_t n, int32_t T,
 int sdmi_qkv_attention(sdmi_ctx* ctx, const float* q, const float* k, const float* v,
                        const float* mask, int32_t mask_ld, int32_t n, int32_t nq, int32_t nk,
                        int32_t n_state, int32_t n_head, float* out);
+
+/* ---- prompt -> context: tokenizer + CLIP text encoder ---------
+ * The step before the hot path.  The CLIP weights (dump subtree clip/...) are an
+ * optional group: without them these two functions return SDMI_ERR_STATE and the
+ * sampling functions above work unchanged on caller-supplied embeddings. */
+typedef struct sdmi_tokenizer sdmi_tokenizer;
+
+/* SimpleTokenizer::new (src/tokenizer.rs:85-120).  The reference opens
+ * "bpe_simple_vocab_16e6.txt" in the working directory; here the path is explicit. */
+int sdmi_tokenizer_create(sdmi_tokenizer** out, const char* merges_path);
+void sdmi_tokenizer_destroy(sdmi_tokenizer* tok);
+/* number of vocabulary entries (49408 with the reference's merges file) */
+int sdmi_tokenizer_vocab_size(const sdmi_tokenizer* tok);
+/* SimpleTokenizer::encode (tokenizer.rs:168-189): UTF-8 text -> ids.  *n_ids is
+ * always set to the number of ids the text has; SDMI_ERR_INVALID if capacity is
+ * smaller (nothing is written then). */
+int sdmi_tokenizer_encode(const sdmi_tokenizer* tok, const char* text, int32_t* ids, int32_t capacity, int32_t* n_ids);
+/* SimpleTokenizer::decode (tokenizer.rs:191-196): ids -> UTF-8 (no terminator is
+ * written; *n_bytes is always set to the length). */
+int sdmi_tokenizer_decode(const sdmi_tokenizer* tok, const int32_t* ids, int32_t n, char* out, int32_t capacity, int32_t* n_bytes);
+
+/* CLIP::forward (src/model/clip/mod.rs:56-75): tokens [n, seq_len] int32 ->
+ * out [n, seq_len, ctx_dim]; seq_len <= clip_ctx; causal mask = attn_decoder_mask
+ * (src/backend.rs:130-139). */
+int sdmi_clip_forward(sdmi_ctx* ctx, const int32_t* tokens, int32_t n, int32_t seq_len, float* out);
+
+/* StableDiffusion::context (src/model/stablediffusion/mod.rs:198-210): tokenises
+ * "<|startoftext|>{text}<|endoftext|>" (no padding, no truncation: T = tokens + 2)
+ * and runs CLIP.  out holds capacity_tokens x ctx_dim floats; *T is always set;
+ * SDMI_ERR_INVALID if T > capacity_tokens or T > clip_ctx.  unconditional_context
+ * (:194-196) is context(""), T = 2. */
+int sdmi_context(sdmi_ctx* ctx, const sdmi_tokenizer* tok, const char* text, float* out, int32_t capacity_tokens, int32_t* T);
 
 /* ---- hot path, device pointers (zero-copy; same layouts) ---------------------- */
 int sdmi_sample_latent_dev(sdmi_ctx* ctx, const float* context, int32_t n, int32_t T,

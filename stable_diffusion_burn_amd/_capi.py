@@ -25,13 +25,16 @@ class SdmiConfig(C.Structure):
     _fields_ = [
         ("device", C.c_int32), ("model_channels", C.c_int32), ("n_head", C.c_int32), ("ctx_dim", C.c_int32),
         ("latent_h", C.c_int32), ("latent_w", C.c_int32), ("vae_ch", C.c_int32), ("max_batch", C.c_int32),
-        ("precision", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("precision", C.c_int32), ("clip_layers", C.c_int32), ("clip_heads", C.c_int32), ("clip_vocab", C.c_int32),
+        ("clip_ctx", C.c_int32), ("reserved", C.c_int32 * 3),
     ]
 
 
 _F = C.POINTER(C.c_float)
 _U8 = C.POINTER(C.c_uint8)
 _CTX = C.c_void_p
+_TOK = C.c_void_p
+_I32 = C.POINTER(C.c_int32)
 
 # name -> (restype, argtypes); every symbol include/sdmi.h declares
 SIGNATURES = {
@@ -52,6 +55,13 @@ SIGNATURES = {
     "sdmi_latent_to_image": (C.c_int, [_CTX, _F, C.c_int32, _U8]),
     "sdmi_sample_image": (C.c_int, [_CTX, _F, C.c_int32, C.c_int32, _F, C.c_int32, C.c_double, C.c_size_t, _F, C.c_uint64, _U8]),
     "sdmi_qkv_attention": (C.c_int, [_CTX, _F, _F, _F, _F, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F]),
+    "sdmi_tokenizer_create": (C.c_int, [C.POINTER(_TOK), C.c_char_p]),
+    "sdmi_tokenizer_destroy": (None, [_TOK]),
+    "sdmi_tokenizer_vocab_size": (C.c_int, [_TOK]),
+    "sdmi_tokenizer_encode": (C.c_int, [_TOK, C.c_char_p, _I32, C.c_int32, _I32]),
+    "sdmi_tokenizer_decode": (C.c_int, [_TOK, _I32, C.c_int32, C.c_char_p, C.c_int32, _I32]),
+    "sdmi_clip_forward": (C.c_int, [_CTX, _I32, C.c_int32, C.c_int32, _F]),
+    "sdmi_context": (C.c_int, [_CTX, _TOK, C.c_char_p, _F, C.c_int32, _I32]),
     "sdmi_sample_latent_dev": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_size_t, C.c_void_p, C.c_void_p]),
     "sdmi_latent_to_image_dev": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_void_p]),
     "sdmi_sample_image_dev": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_size_t, C.c_void_p, C.c_void_p]),

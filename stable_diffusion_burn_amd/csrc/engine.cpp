@@ -169,7 +169,7 @@ Engine::~Engine() {
 
 void Engine::add_entry(const std::string& name, int kind, std::initializer_list<int64_t> dims, float** dst, int wdt) {
     WeightEntry e;
-    e.name = name; e.kind = kind; e.ndim = (int)dims.size(); e.dst = dst; e.wdt = wdt;
+    e.name = name; e.kind = kind; e.ndim = (int)dims.size(); e.dst = dst; e.wdt = wdt; e.group = cur_group_;
     int i = 0;
     for (int k = 0; k < 4; ++k) e.dims[k] = 1;
     for (auto d : dims) e.dims[i++] = d;
@@ -326,6 +326,41 @@ void Engine::build_model() {
     }
     norm(dec_norm_out_, "autoencoder/decoder/norm_out", vc);
     conv(dec_conv_out_, "autoencoder/decoder/conv_out", vc, 3, 3);
+
+    // ---- CLIP text encoder (clip/mod.rs:18-45; dump names clip/load.rs:14-91) -- SURVEY 8f rank 2 -------------
+    // An optional weight group: the sampling path takes the text embedding as an input, so a context without
+    // CLIP weights is complete; sdmi_clip_forward / sdmi_context need the whole group.  Always fp32.
+    if (cfg_.clip_layers > 0) {
+        const int cs = cd, L = cfg_.clip_layers, H = cfg_.clip_heads;
+        if (H <= 0 || cs % H || !attn_supported_head_dim(cs / H) || cfg_.clip_vocab <= 0 || cfg_.clip_ctx <= 0 || cs % 32)
+            throw Error(SDMI_ERR_UNSUPPORTED, "CLIP: ctx_dim / clip_heads must be one of the fused attention head dims (40, 64, 80, 160)");
+        cur_group_ = 1;
+        add(this, "clip/token_embedding/weight", 2, {cfg_.clip_vocab, cs}, &clip_tok_);
+        add(this, "clip/position_embedding/weight", 2, {cfg_.clip_ctx, cs}, &clip_pos_);
+        clip_blocks_.resize(L);
+        for (int i = 0; i < L; ++i) {
+            ClipBlockW& b = clip_blocks_[i];
+            const std::string bp = "clip/blocks/" + std::to_string(i);
+            void* w = nullptr;
+            void* bias = nullptr;
+            SDMI_HIP(hipMalloc(&w, (size_t)3 * cs * cs * sizeof(float)));
+            weight_allocs_.push_back(w);
+            SDMI_HIP(hipMalloc(&bias, (size_t)3 * cs * sizeof(float)));
+            weight_allocs_.push_back(bias);
+            b.q.bt = reinterpret_cast<float*>(w); b.k.bt = b.q.bt + (size_t)cs * cs; b.v.bt = b.q.bt + (size_t)2 * cs * cs;
+            b.q.bias = reinterpret_cast<float*>(bias); b.k.bias = b.q.bias + cs; b.v.bias = b.q.bias + 2 * cs;
+            norm(b.attn_ln, bp + "/attn_ln", cs);
+            lin(b.q, bp + "/attn/query", cs, cs, true, true);   // MultiHeadSelfAttention: all four Linears carry a bias
+            lin(b.k, bp + "/attn/key", cs, cs, true, true);
+            lin(b.v, bp + "/attn/value", cs, cs, true, true);
+            lin(b.out, bp + "/attn/out", cs, cs, true, true);
+            norm(b.mlp_ln, bp + "/mlp_ln", cs);
+            lin(b.fc1, bp + "/mlp/fc1", cs, 4 * cs, true, true);
+            lin(b.fc2, bp + "/mlp/fc2", 4 * cs, cs, true, true);
+        }
+        norm(clip_ln_, "clip/layer_norm", cs);
+        cur_group_ = 0;
+    }
 }
 
 // =============================================================================
@@ -389,8 +424,20 @@ void Engine::set_weight(const char* name, const float* data, int ndim, const int
 }
 
 void Engine::finalize_weights() {
-    for (auto& e : entries_)
-        if (!e.set) throw Error(SDMI_ERR_WEIGHTS, "finalize_weights: tensor '" + e.name + "' was never set");
+    int clip_total = 0, clip_set = 0;
+    const WeightEntry* clip_missing = nullptr;
+    for (auto& e : entries_) {
+        if (e.group == 1) {
+            ++clip_total;
+            if (e.set) ++clip_set;
+            else if (!clip_missing) clip_missing = &e;
+        } else if (!e.set) {
+            throw Error(SDMI_ERR_WEIGHTS, "finalize_weights: tensor '" + e.name + "' was never set");
+        }
+    }
+    if (clip_set && clip_missing)
+        throw Error(SDMI_ERR_WEIGHTS, "finalize_weights: CLIP weights are partially set; missing '" + clip_missing->name + "'");
+    clip_ready_ = clip_total > 0 && clip_set == clip_total;
     finalized_ = true;
 }
 
@@ -421,7 +468,10 @@ static std::vector<float> read_npy_f32(const std::string& path) {
 
 void Engine::load_weights_dir(const char* dir) {
     if (!dir) throw Error(SDMI_ERR_INVALID, "load_weights_dir: null path");
+    // the CLIP subtree is read when it exists (load_stable_diffusion always has it, stablediffusion/load.rs:24)
+    const bool have_clip = std::ifstream(std::string(dir) + "/clip/token_embedding/weight.npy").good();
     for (auto& e : entries_) {
+        if (e.group == 1 && !have_clip) continue;
         const std::string path = std::string(dir) + "/" + e.name + ".npy";
         std::vector<float> raw = read_npy_f32(path);
         if ((int)raw.size() < e.ndim) throw Error(SDMI_ERR_WEIGHTS, "truncated tensor file " + path);
@@ -619,9 +669,10 @@ void Engine::group_norm(const NormW& w, const Act& x, Act& y, bool silu) {
     count_kernel(); count_kernel();
 }
 
-void Engine::layer_norm(const NormW& w, const float* x, long long rows, float* y) {
-    ProfScope ps(this, PC_LAYER_NORM, 0, 2.0 * (double)rows * w.c * (double)esz());
-    if (bf16_) SDMI_HIP(launch_layer_norm_bf16(x, y, w.gamma, w.beta, (int)rows, w.c, 1e-5f, stream_));
+void Engine::layer_norm(const NormW& w, const float* x, long long rows, float* y, int dt) {
+    if (dt < 0) dt = edt();
+    ProfScope ps(this, PC_LAYER_NORM, 0, 2.0 * (double)rows * w.c * (dt ? 2.0 : 4.0));
+    if (dt) SDMI_HIP(launch_layer_norm_bf16(x, y, w.gamma, w.beta, (int)rows, w.c, 1e-5f, stream_));
     else SDMI_HIP(launch_layer_norm(x, y, w.gamma, w.beta, (int)rows, w.c, 1e-5f, stream_));
     count_kernel();
 }
@@ -646,7 +697,7 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
         if (dt && mask) throw Error(SDMI_ERR_UNSUPPORTED, "attention: additive mask is fp32-only");
         const double fl = 4.0 * n * n_head * (double)nq * nk * d_head;
         ProfScope ps(this, PC_ATTENTION, fl);
-        if (dt && opt_attn_bf16_) SDMI_HIP(launch_attention_bf16(p, stream_));
+        if (dt && opt_attn_bf16_ && (d_head == 40 || d_head == 80 || d_head == 160)) SDMI_HIP(launch_attention_bf16(p, stream_));
         else SDMI_HIP(launch_attention(p, stream_, dt ? 1 : opt_attn_variant_));
         count_kernel(fl);
         return;
@@ -893,6 +944,35 @@ void Engine::unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc) {
     Act out; out.p = out_nhwc; out.n = nb; out.h = H; out.w = W; out.c = 4; out.dt = 0;  // eps stays fp32
     conv(unet_conv_out_, gn, out, 1, 0, nullptr, 0, nullptr);
     release(gn);
+}
+
+// CLIP::forward (clip/mod.rs:56-75) with ResidualDecoderAttentionBlock (:110-114), MultiHeadSelfAttention
+// (:158-180), MLP + QuickGELU (:207-226) and attn_decoder_mask (backend.rs:130-139).  fp32 in both precisions.
+void Engine::clip_forward_dev(const int32_t* tokens, int n, int T, float* out) {
+    if (!finalized_) throw Error(SDMI_ERR_STATE, "weights not finalized");
+    if (!clip_ready_) throw Error(SDMI_ERR_STATE, "CLIP weights are not loaded (clip/... tensors; clip_layers > 0 in the config)");
+    if (n <= 0 || T <= 0) throw Error(SDMI_ERR_INVALID, "clip_forward: n and seq_len must be positive");
+    if (T > cfg_.clip_ctx) throw Error(SDMI_ERR_INVALID, "clip_forward: sequence longer than n_ctx");  // reference: slice panics
+    const int C = cfg_.ctx_dim, H = cfg_.clip_heads;
+    const long long M = (long long)n * T;
+    Buf x(this, (size_t)M * C * 4), h(this, (size_t)M * C * 4), qkv(this, (size_t)M * 3 * C * 4), a(this, (size_t)M * C * 4);
+    Buf f(this, (size_t)M * 4 * C * 4), mask(this, (size_t)T * T * 4);
+    SDMI_HIP(launch_clip_embed(tokens, clip_tok_, clip_pos_, x.f(), n, T, C, stream_));
+    SDMI_HIP(launch_causal_mask(mask.f(), T, stream_));
+    count_kernel(); count_kernel();
+    for (const ClipBlockW& b : clip_blocks_) {
+        layer_norm(b.attn_ln, x.f(), M, h.f(), 0);
+        gemm(h.f(), (int)M, b.q.bt, b.q.bias, C, 3 * C, qkv.f(), 3 * C, nullptr, 0, 0);       // query | key | value, one GEMM
+        attention(qkv.f(), 3 * C, (long long)T * 3 * C, qkv.f() + C, 3 * C, (long long)T * 3 * C, qkv.f() + 2 * C, 3 * C,
+                  (long long)T * 3 * C, a.f(), C, (long long)T * C, n, T, T, H, C / H, nullptr, nullptr, mask.f(), T, 0);
+        gemm(a.f(), (int)M, b.out.bt, b.out.bias, C, C, x.f(), C, x.f(), C, 0);               // x += out(attn)
+        layer_norm(b.mlp_ln, x.f(), M, h.f(), 0);
+        gemm(h.f(), (int)M, b.fc1.bt, b.fc1.bias, C, 4 * C, f.f(), 4 * C, nullptr, 0, 0);
+        SDMI_HIP(launch_quick_gelu(f.f(), M * 4 * C, stream_));
+        count_kernel();
+        gemm(f.f(), (int)M, b.fc2.bt, b.fc2.bias, 4 * C, C, x.f(), C, x.f(), C, 0);           // x += fc2(gelu(fc1))
+    }
+    layer_norm(clip_ln_, x.f(), M, out, 0);
 }
 
 void Engine::unet_forward_dev(const float* x_nchw, int t, const float* context, int n, int T, float* out_nchw) {

@@ -84,6 +84,10 @@ struct UBlock { BlockKind kind; int cin, cout; ConvW conv; ResW res; SpatialW st
 struct VaeAttnW { NormW norm; ConvW q, k, v, proj_out; int c = 0; };
 struct DecBlockW { ResW res[3]; ConvW upsampler; bool has_up = false; int cin = 0, cout = 0; };
 
+// CLIP text encoder block (ResidualDecoderAttentionBlock, clip/mod.rs:95-114); q/k/v weights and biases are
+// packed for one N = 3C GEMM
+struct ClipBlockW { NormW attn_ln, mlp_ln; LinW q, k, v, out, fc1, fc2; };
+
 struct WeightEntry {
     std::string name;
     int kind;  // 0 conv (OIHW), 1 linear ([in,out]), 2 vector, 3 alphas (host)
@@ -91,6 +95,7 @@ struct WeightEntry {
     int64_t dims[4];
     float** dst;  // where the device pointer lives (null for alphas)
     int wdt = 0;  // storage type of the packed weight: 0 fp32, 1 bf16
+    int group = 0;  // 0: hot path (required); 1: CLIP text encoder (optional as a whole)
     bool set = false;
 };
 
@@ -109,6 +114,9 @@ public:
 
     // hot path (device pointers, reference layouts)
     void unet_forward_dev(const float* x_nchw, int t, const float* context, int n, int T, float* out_nchw);
+    // CLIP::forward (clip/mod.rs:56-75): int32 tokens [n, T] on the device -> [n, T, ctx_dim] fp32 (both precisions)
+    void clip_forward_dev(const int32_t* tokens, int n, int T, float* out);
+    bool clip_ready() const { return clip_ready_; }
     void sample_latent_dev(const float* context, int n, int T, const float* uncond, int Tu, double scale,
                            size_t n_steps, const float* init_latent, float* latent_out);
     void decode_latent_dev(const float* latent_nchw, int n, float in_scale, float* img_nchw, uint8_t* rgb_u8);
@@ -155,6 +163,7 @@ public:
 private:
     // model definition
     void add_entry(const std::string& name, int kind, std::initializer_list<int64_t> dims, float** dst, int wdt = 0);
+    int cur_group_ = 0;  // weight group add_entry assigns (build_model switches it to 1 for the CLIP section)
     void build_model();
 
     // primitive ops on device activations (NHWC)
@@ -171,7 +180,7 @@ private:
     static float* adv(const float* p, long long elems, int dt) { return (float*)((char*)const_cast<float*>(p) + elems * (dt ? 2 : 4)); }
     TileChoice choose_tile(int M, int N, int kt_total) const;
     void group_norm(const NormW& w, const Act& x, Act& y, bool silu);
-    void layer_norm(const NormW& w, const float* x, long long rows, float* y);
+    void layer_norm(const NormW& w, const float* x, long long rows, float* y, int dt = -1);
     void attention(const float* q, int ldq, long long q_bs, const float* k, int ldk, long long k_bs, const float* v,
                    int ldv, long long v_bs, float* o, int ldo, long long o_bs, int n, int nq, int nk, int n_head,
                    int d_head, const int* kv_len_dev, const int* kv_len_host, const float* mask, int mask_ld, int dt = -1);
@@ -237,6 +246,12 @@ private:
     VaeAttnW dec_attn_;
     DecBlockW dec_blocks_[4];
     NormW dec_norm_out_;
+    // CLIP text encoder (optional weight group)
+    float* clip_tok_ = nullptr;
+    float* clip_pos_ = nullptr;
+    std::vector<ClipBlockW> clip_blocks_;
+    NormW clip_ln_;
+    bool clip_ready_ = false;
 
     // per-call UNet state
     struct UNetState {

@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* x, int rows, i
 }
 
 // ---- host side ------------------------------------------------------------------------------
-bool attn_supported_head_dim(int d) { return d == 40 || d == 80 || d == 160; }
+bool attn_supported_head_dim(int d) { return d == 40 || d == 64 || d == 80 || d == 160; }  // 64: CLIP (768 / 12)
 
 template <int D>
 static hipError_t launch_attn_d(const AttnParams& p, hipStream_t stream) {
@@ -562,6 +562,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream, int variant
     if (variant == 0) {
         switch (p.d_head) {
             case 40: return launch_attn_d<40>(p, stream);
+            case 64: return launch_attn_d<64>(p, stream);
             case 80: return launch_attn_d<80>(p, stream);
             case 160: return launch_attn_d<160>(p, stream);
         }
@@ -569,6 +570,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream, int variant
     }
     switch (p.d_head) {
         case 40: return launch_attn2_any<40>(p, stream);
+        case 64: return launch_attn2_any<64>(p, stream);
         case 80: return launch_attn2_any<80>(p, stream);
         case 160: return launch_attn2_any<160>(p, stream);
     }

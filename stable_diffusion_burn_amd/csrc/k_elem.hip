@@ -87,6 +87,36 @@ __global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, 
     }
 }
 
+// QuickGELU (clip/mod.rs:223-225): x * sigmoid(1.702 x), in place
+__global__ void quick_gelu_kernel(float* __restrict__ x, long long n) {
+    GRID_STRIDE(i, n) {
+        const float v = x[i];
+        x[i] = v * (1.0f / (1.0f + expf(-1.702f * v)));
+    }
+}
+
+// CLIP::forward embedding (clip/mod.rs:62-67): out[b, t, :] = token_table[tokens[b, t], :] + position_table[t, :]
+__global__ void clip_embed_kernel(const int* __restrict__ tokens, const float* __restrict__ tok_table,
+                                  const float* __restrict__ pos_table, float* __restrict__ out, int n, int T, int C) {
+    const long long total = (long long)n * T * (C / 4);
+    GRID_STRIDE(i, total) {
+        const int c4 = (int)(i % (C / 4));
+        const long long row = i / (C / 4);
+        const int t = (int)(row % T);
+        const float4 a = reinterpret_cast<const float4*>(tok_table + (long long)tokens[row] * C)[c4];
+        const float4 b = reinterpret_cast<const float4*>(pos_table + (long long)t * C)[c4];
+        reinterpret_cast<float4*>(out + row * C)[c4] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
+// attn_decoder_mask (backend.rs:130-139): 0 on and below the diagonal, -inf above
+__global__ void causal_mask_kernel(float* __restrict__ mask, int T) {
+    GRID_STRIDE(i, (long long)T * T) {
+        const int r = (int)(i / T), c = (int)(i % T);
+        mask[i] = c > r ? -INFINITY : 0.f;
+    }
+}
+
 __global__ void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols,
                                    int src_ld) {
     __shared__ float tile[32][33];
@@ -194,6 +224,21 @@ hipError_t launch_geglu(const float* proj, float* out, long long rows, int hidde
 }
 hipError_t launch_silu(const float* x, float* y, long long n, hipStream_t s) {
     hipLaunchKernelGGL(silu_kernel, dim3(blocks_for(n)), dim3(256), 0, s, x, y, n);
+    return hipGetLastError();
+}
+hipError_t launch_quick_gelu(float* x, long long n, hipStream_t s) {
+    hipLaunchKernelGGL(quick_gelu_kernel, dim3(blocks_for(n)), dim3(256), 0, s, x, n);
+    return hipGetLastError();
+}
+hipError_t launch_clip_embed(const int* tokens, const float* tok_table, const float* pos_table, float* out, int n, int T, int C,
+                             hipStream_t s) {
+    if (C % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(clip_embed_kernel, dim3(blocks_for((long long)n * T * (C / 4))), dim3(256), 0, s, tokens, tok_table, pos_table,
+                       out, n, T, C);
+    return hipGetLastError();
+}
+hipError_t launch_causal_mask(float* mask, int T, hipStream_t s) {
+    hipLaunchKernelGGL(causal_mask_kernel, dim3(blocks_for((long long)T * T)), dim3(256), 0, s, mask, T);
     return hipGetLastError();
 }
 hipError_t launch_transpose2d(const float* src, float* dst, int rows, int cols, int src_ld, hipStream_t s) {

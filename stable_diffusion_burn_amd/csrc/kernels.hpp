@@ -94,6 +94,11 @@ hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h
 hipError_t launch_concat_channels(const float* a, const float* b, float* dst, long long rows, int ca, int cb, hipStream_t s);
 hipError_t launch_geglu(const float* proj, float* out, long long rows, int hidden, hipStream_t s);
 hipError_t launch_silu(const float* x, float* y, long long n, hipStream_t s);
+// CLIP text encoder pieces (clip/mod.rs): QuickGELU in place, token + position embedding, decoder mask
+hipError_t launch_quick_gelu(float* x, long long n, hipStream_t s);
+hipError_t launch_clip_embed(const int* tokens, const float* tok_table, const float* pos_table, float* out, int n, int T, int C,
+                             hipStream_t s);
+hipError_t launch_causal_mask(float* mask, int T, hipStream_t s);
 // dst[c][r] = src[r*src_ld + c]
 hipError_t launch_transpose2d(const float* src, float* dst, int rows, int cols, int src_ld, hipStream_t s);
 // out[s][0:half] = cos(t_s * f_i), out[s][half:dim] = sin(t_s * f_i)  (unet/mod.rs:19-30)

@@ -5,12 +5,17 @@
 #include <string>
 
 #include "engine.hpp"
+#include "tokenizer.hpp"
 
 using sdmi::Engine;
 using sdmi::Error;
 
 struct sdmi_ctx {
     Engine* engine;
+};
+
+struct sdmi_tokenizer {
+    sdmi::Tokenizer tok;
 };
 
 static thread_local std::string g_last_error;
@@ -74,6 +79,10 @@ int sdmi_default_config(sdmi_config* cfg) {
     cfg->vae_ch = 128;          // autoencoder/mod.rs:33-34
     cfg->max_batch = 1;
     cfg->precision = 0;
+    cfg->clip_layers = 12;      // CLIPConfig::new(49408, 768, 12, 77, 12), stablediffusion/mod.rs:29
+    cfg->clip_heads = 12;
+    cfg->clip_vocab = 49408;
+    cfg->clip_ctx = 77;
     return SDMI_OK;
 }
 
@@ -172,6 +181,68 @@ int sdmi_unet_forward(sdmi_ctx* ctx, const float* x, int32_t t, const float* con
         e.unet_forward_dev(dx.f(), t, dc.f(), n, T, dout.f());
         e.end_call();
         dout.fetch();
+    });
+}
+
+// ---- tokenizer + CLIP -----------------------------------------------------------------
+int sdmi_tokenizer_create(sdmi_tokenizer** out, const char* merges_path) {
+    if (!out || !merges_path) { g_last_error = "sdmi_tokenizer_create: null argument"; return SDMI_ERR_INVALID; }
+    *out = nullptr;
+    return guarded([&] { *out = new sdmi_tokenizer{sdmi::Tokenizer(merges_path)}; });
+}
+
+void sdmi_tokenizer_destroy(sdmi_tokenizer* tok) { delete tok; }
+
+int sdmi_tokenizer_vocab_size(const sdmi_tokenizer* tok) { return tok ? tok->tok.vocab_size() : SDMI_ERR_INVALID; }
+
+int sdmi_tokenizer_encode(const sdmi_tokenizer* tok, const char* text, int32_t* ids, int32_t capacity, int32_t* n_ids) {
+    return guarded([&] {
+        if (!tok || !text || !n_ids) throw Error(SDMI_ERR_INVALID, "tokenizer_encode: null argument");
+        const std::vector<int32_t> v = tok->tok.encode(text);
+        *n_ids = (int32_t)v.size();
+        if ((int64_t)v.size() > capacity) throw Error(SDMI_ERR_INVALID, "tokenizer_encode: capacity too small");
+        if (!v.empty() && !ids) throw Error(SDMI_ERR_INVALID, "tokenizer_encode: null output");
+        std::copy(v.begin(), v.end(), ids);
+    });
+}
+
+int sdmi_tokenizer_decode(const sdmi_tokenizer* tok, const int32_t* ids, int32_t n, char* out, int32_t capacity, int32_t* n_bytes) {
+    return guarded([&] {
+        if (!tok || !n_bytes || n < 0 || (n > 0 && !ids)) throw Error(SDMI_ERR_INVALID, "tokenizer_decode: bad argument");
+        const std::string s = tok->tok.decode(ids, (size_t)n);
+        *n_bytes = (int32_t)s.size();
+        if ((int64_t)s.size() > capacity) throw Error(SDMI_ERR_INVALID, "tokenizer_decode: capacity too small");
+        if (!s.empty() && !out) throw Error(SDMI_ERR_INVALID, "tokenizer_decode: null output");
+        std::memcpy(out, s.data(), s.size());
+    });
+}
+
+static void clip_forward_host(Engine& e, const int32_t* tokens, int n, int T, float* out) {
+    if (!tokens || !out) throw Error(SDMI_ERR_INVALID, "clip_forward: null argument");
+    if (n <= 0 || T <= 0) throw Error(SDMI_ERR_INVALID, "clip_forward: n and seq_len must be positive");
+    const int vocab = e.config().clip_vocab;
+    for (long long i = 0; i < (long long)n * T; ++i)   // the reference's embedding gather panics on an id outside the table
+        if (tokens[i] < 0 || tokens[i] >= vocab) throw Error(SDMI_ERR_INVALID, "clip_forward: token id outside the vocabulary");
+    e.begin_call();
+    DevIn dt(e, tokens, (size_t)n * T * sizeof(int32_t));
+    DevOut dout(e, out, (size_t)n * T * e.config().ctx_dim * sizeof(float));
+    e.clip_forward_dev(reinterpret_cast<const int32_t*>(dt.buf.p), n, T, dout.f());
+    e.end_call();
+    dout.fetch();
+}
+
+int sdmi_clip_forward(sdmi_ctx* ctx, const int32_t* tokens, int32_t n, int32_t seq_len, float* out) {
+    return guarded([&] { clip_forward_host(eng(ctx), tokens, n, seq_len, out); });
+}
+
+int sdmi_context(sdmi_ctx* ctx, const sdmi_tokenizer* tok, const char* text, float* out, int32_t capacity_tokens, int32_t* T) {
+    return guarded([&] {
+        if (!tok || !text || !T) throw Error(SDMI_ERR_INVALID, "context: null argument");
+        Engine& e = eng(ctx);
+        const std::vector<int32_t> ids = tok->tok.encode(std::string("<|startoftext|>") + text + "<|endoftext|>");  // mod.rs:200
+        *T = (int32_t)ids.size();
+        if ((int64_t)ids.size() > capacity_tokens) throw Error(SDMI_ERR_INVALID, "context: capacity_tokens too small");
+        clip_forward_host(e, ids.data(), 1, (int)ids.size(), out);
     });
 }
 

@@ -24,7 +24,7 @@ import numpy as np
 from . import _capi
 from ._capi import SdmiConfig, SdmiError, check, load_library
 
-__all__ = ["ModelConfig", "StableDiffusion", "UNet", "Autoencoder", "qkv_attention", "SdmiError"]
+__all__ = ["ModelConfig", "StableDiffusion", "UNet", "Autoencoder", "CLIP", "SimpleTokenizer", "qkv_attention", "SdmiError"]
 
 
 @dataclass(frozen=True)
@@ -38,6 +38,17 @@ class ModelConfig:
     latent_w: int = 64
     vae_ch: int = 128
     precision: int = 0   # 0 = fp32 (BASELINE configs[0..1]); 1 = bf16 storage + fp32 accumulate (configs[2..3])
+    # CLIP text encoder, CLIPConfig::new(49408, 768, 12, 77, 12) (stablediffusion/mod.rs:29); width = ctx_dim.
+    # 0 layers (the default here: the sampling path takes embeddings) builds the context without it.
+    clip_layers: int = 0
+    clip_heads: int = 12
+    clip_vocab: int = 49408
+    clip_ctx: int = 77
+
+    @classmethod
+    def sd_v1_4(cls, precision: int = 0, clip: bool = True) -> "ModelConfig":
+        """The reference's full StableDiffusionConfig::init (stablediffusion/mod.rs:22-39), text encoder included."""
+        return cls(precision=precision, clip_layers=12 if clip else 0)
 
 
 def _f32(a, shape=None, name="array") -> np.ndarray:
@@ -67,10 +78,15 @@ class StableDiffusion:
         cfg.latent_w = config.latent_w
         cfg.vae_ch = config.vae_ch
         cfg.precision = config.precision
+        cfg.clip_layers = config.clip_layers
+        cfg.clip_heads = config.clip_heads
+        cfg.clip_vocab = config.clip_vocab
+        cfg.clip_ctx = config.clip_ctx
         self._ctx = C.c_void_p()
         check(self._lib.sdmi_create(C.byref(self._ctx), C.byref(cfg)))
         self.unet = UNet(self)
         self.autoencoder = Autoencoder(self)
+        self.clip = CLIP(self)
 
     # ---- lifecycle -----------------------------------------------------------
     def close(self):
@@ -110,13 +126,16 @@ class StableDiffusion:
         dims = (C.c_int64 * max(1, a.ndim))(*a.shape)
         check(self._lib.sdmi_set_weight(self._ctx, name.encode(), _fp(a), a.ndim, dims))
 
-    def load_weights(self, provider) -> None:
+    def load_weights(self, provider, clip: bool = True) -> None:
         """Pull every tensor from `provider.get(name, shape, kind, fan_in)`
         (synthetic.SyntheticWeights) -- the counterpart of load_stable_diffusion
-        (stablediffusion/load.rs:16-33) for seeded synthetic parameters."""
+        (stablediffusion/load.rs:16-33) for seeded synthetic parameters.  `clip=False` leaves the
+        optional clip/... group unset (context()/clip.forward then raise)."""
         specs = self.weight_specs()
         shapes = dict(specs)
         for name, shape in specs:
+            if name.startswith("clip/") and not clip:
+                continue
             if name == "alphas_cumprod":
                 from .synthetic import alphas_cumprod
                 self.set_weight(name, alphas_cumprod(shape[0]))
@@ -139,6 +158,19 @@ class StableDiffusion:
                     arr = provider.get(name, shape, "beta")
             self.set_weight(name, arr)
         check(self._lib.sdmi_finalize_weights(self._ctx))
+
+    # ---- prompt -> context (stablediffusion/mod.rs:194-210) ----------------------
+    def context(self, tokenizer: "SimpleTokenizer", text: str) -> np.ndarray:
+        """StableDiffusion::context: CLIP embedding [1, T, ctx_dim] of "<|startoftext|>{text}<|endoftext|>", T = tokens + 2."""
+        cap = self.config.clip_ctx
+        out = np.empty((cap, self.config.ctx_dim), dtype=np.float32)
+        T = C.c_int32()
+        check(self._lib.sdmi_context(self._ctx, tokenizer._tok, text.encode("utf-8"), _fp(out), cap, C.byref(T)))
+        return out[None, :T.value].copy()
+
+    def unconditional_context(self, tokenizer: "SimpleTokenizer") -> np.ndarray:
+        """StableDiffusion::unconditional_context (:194-196): context("") squeezed to [2, ctx_dim]."""
+        return self.context(tokenizer, "")[0]
 
     def load_weights_dir(self, dump_dir: str) -> None:
         """npy-dump tree written by the reference's python/ exporters
@@ -340,6 +372,64 @@ class UNet:
         out = np.empty_like(x)
         check(sd._lib.sdmi_unet_forward(sd._ctx, _fp(x), int(ts[0]), _fp(context), n, context.shape[1], _fp(out)))
         return out
+
+
+class CLIP:
+    """`CLIP<B>` (src/model/clip/mod.rs:48-75): forward(tokens [n, T] int) -> [n, T, ctx_dim]."""
+
+    def __init__(self, sd: StableDiffusion):
+        self._sd = sd
+
+    def forward(self, tokens) -> np.ndarray:
+        sd = self._sd
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        if t.ndim != 2:
+            raise ValueError(f"tokens must be [n, seq_len], got {t.shape}")
+        out = np.empty(t.shape + (sd.config.ctx_dim,), dtype=np.float32)
+        check(sd._lib.sdmi_clip_forward(sd._ctx, t.ctypes.data_as(C.POINTER(C.c_int32)), t.shape[0], t.shape[1], _fp(out)))
+        return out
+
+
+class SimpleTokenizer:
+    """`SimpleTokenizer` (src/tokenizer.rs:74-196) -- the C++ tokenizer inside libsdmi (no GPU needed).
+
+    The reference reads "bpe_simple_vocab_16e6.txt" from the working directory; here the merges file is an argument."""
+
+    def __init__(self, merges_path):
+        self._lib = load_library()
+        self._tok = C.c_void_p()
+        check(self._lib.sdmi_tokenizer_create(C.byref(self._tok), str(merges_path).encode()))
+
+    def close(self):
+        if getattr(self, "_tok", None) is not None and self._tok.value:
+            self._lib.sdmi_tokenizer_destroy(self._tok)
+            self._tok = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def vocab_size(self) -> int:
+        return int(self._lib.sdmi_tokenizer_vocab_size(self._tok))
+
+    def encode(self, text: str):
+        data = text.encode("utf-8")
+        n = C.c_int32()
+        cap = 4 * len(data) + 8   # at most one token per byte
+        ids = (C.c_int32 * cap)()
+        check(self._lib.sdmi_tokenizer_encode(self._tok, data, ids, cap, C.byref(n)))
+        return [int(ids[i]) for i in range(n.value)]
+
+    def decode(self, tokens) -> str:
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        n = C.c_int32()
+        cap = 64 * max(1, t.size)
+        buf = C.create_string_buffer(cap)
+        check(self._lib.sdmi_tokenizer_decode(self._tok, t.ctypes.data_as(C.POINTER(C.c_int32)), t.size, buf, cap, C.byref(n)))
+        return buf.raw[:n.value].decode("utf-8", "replace")
 
 
 class Autoencoder:
