@@ -173,6 +173,10 @@ int sdmi_clip_forward(sdmi_ctx* ctx, const int32_t* tokens, int32_t n, int32_t s
  * (:194-196) is context(""), T = 2. */
 int sdmi_context(sdmi_ctx* ctx, const sdmi_tokenizer* tok, const char* text, float* out, int32_t capacity_tokens, int32_t* T);
 
+/* save_images (src/bin/sample/main.rs:118-125; image::save_buffer(.., Rgb8)): one 8-bit RGB image
+ * [height, width, 3] -> PNG file.  Host code. */
+int sdmi_write_png(const char* path, const uint8_t* rgb, int32_t width, int32_t height);
+
 /* ---- hot path, device pointers (zero-copy; same layouts) ---------------------- */
 int sdmi_sample_latent_dev(sdmi_ctx* ctx, const float* context, int32_t n, int32_t T,
                            const float* uncond, int32_t Tu, double scale, size_t n_steps,

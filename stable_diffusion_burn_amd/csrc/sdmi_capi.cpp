@@ -14,6 +14,10 @@ struct sdmi_ctx {
     Engine* engine;
 };
 
+namespace sdmi {
+void write_png_rgb8(const std::string& path, const uint8_t* rgb, int width, int height);  // png_writer.cpp
+}
+
 struct sdmi_tokenizer {
     sdmi::Tokenizer tok;
 };
@@ -243,6 +247,13 @@ int sdmi_context(sdmi_ctx* ctx, const sdmi_tokenizer* tok, const char* text, flo
         *T = (int32_t)ids.size();
         if ((int64_t)ids.size() > capacity_tokens) throw Error(SDMI_ERR_INVALID, "context: capacity_tokens too small");
         clip_forward_host(e, ids.data(), 1, (int)ids.size(), out);
+    });
+}
+
+int sdmi_write_png(const char* path, const uint8_t* rgb, int32_t width, int32_t height) {
+    return guarded([&] {
+        if (!path) throw Error(SDMI_ERR_INVALID, "write_png: null path");
+        sdmi::write_png_rgb8(path, rgb, width, height);
     });
 }
 

@@ -140,22 +140,8 @@ class StableDiffusion:
                 from .synthetic import alphas_cumprod
                 self.set_weight(name, alphas_cumprod(shape[0]))
                 continue
-            parent, leaf = name.rsplit("/", 1)
-            wshape = shapes.get(parent + "/weight")
-            if leaf == "weight":
-                if len(shape) == 4:
-                    arr = provider.get(name, shape, "w", shape[1] * shape[2] * shape[3])
-                elif len(shape) == 2:
-                    arr = provider.get(name, shape, "w", shape[0])  # Linear weight is [in, out]
-                else:
-                    arr = provider.get(name, shape, "gamma")
-            else:  # bias
-                if wshape is not None and len(wshape) == 4:
-                    arr = provider.get(name, shape, "b", wshape[1] * wshape[2] * wshape[3])
-                elif wshape is not None and len(wshape) == 2:
-                    arr = provider.get(name, shape, "b", wshape[0])
-                else:
-                    arr = provider.get(name, shape, "beta")
+            from .synthetic import named_tensor
+            arr = named_tensor(provider, name, shape, shapes)
             self.set_weight(name, arr)
         check(self._lib.sdmi_finalize_weights(self._ctx))
 

@@ -69,6 +69,24 @@ class SyntheticWeights:
         return a
 
 
+def named_tensor(provider, name: str, shape, shapes) -> np.ndarray:
+    """The synthetic tensor of dump name `name` in the dump's own layout: kind and fan-in follow from the
+    tensor's rank and its module's weight shape (`shapes`: name -> shape of every tensor of the model)."""
+    parent, leaf = name.rsplit("/", 1)
+    wshape = shapes.get(parent + "/weight")
+    if leaf == "weight":
+        if len(shape) == 4:
+            return provider.get(name, shape, "w", shape[1] * shape[2] * shape[3])
+        if len(shape) == 2:
+            return provider.get(name, shape, "w", shape[0])   # Linear [in, out] / embedding table [rows, width]
+        return provider.get(name, shape, "gamma")
+    if wshape is not None and len(wshape) == 4:
+        return provider.get(name, shape, "b", wshape[1] * wshape[2] * wshape[3])
+    if wshape is not None and len(wshape) == 2:
+        return provider.get(name, shape, "b", wshape[0])
+    return provider.get(name, shape, "beta")
+
+
 def alphas_cumprod(n: int = 1000) -> np.ndarray:
     """SD scaled-linear schedule, float32 like the reference's weight file."""
     betas = np.linspace(np.sqrt(0.00085), np.sqrt(0.012), n, dtype=np.float64) ** 2

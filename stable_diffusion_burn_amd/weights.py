@@ -90,8 +90,13 @@ def write_layer_norm(dirpath, gamma, beta, eps=1e-5) -> None:
     _save(d / "eps.npy", encode_scalar(eps))
 
 
-def write_dump_tree(dump_dir, specs, get_tensor, alphas_cumprod, n_head: int = 8) -> None:
-    """Write the hot-path subset of the dump tree.
+def write_embedding(dirpath, weight) -> None:
+    """save_embedding (python/save.py:97-99): the table as it is, [rows, width] (not transposed)."""
+    _save(Path(dirpath) / "weight.npy", encode_tensor(weight))
+
+
+def write_dump_tree(dump_dir, specs, get_tensor, alphas_cumprod, n_head: int = 8, clip_heads: int = 12) -> None:
+    """Write the hot-path subset of the dump tree (+ the clip/ subtree when `specs` lists it).
 
     specs: [(name, shape)] from StableDiffusion.weight_specs(); get_tensor(name, shape) -> ndarray in
     the dump's own layout (Linear [in,out], Conv [Cout,Cin,kh,kw]).
@@ -107,7 +112,12 @@ def write_dump_tree(dump_dir, specs, get_tensor, alphas_cumprod, n_head: int = 8
     for parent, t in modules.items():
         w = t["weight"]
         b = t.get("bias")
-        if w.ndim == 4:
+        leaf_dir = parent.rsplit("/", 1)[1]
+        if parent.startswith("clip/") and leaf_dir.endswith("_embedding"):
+            write_embedding(root / parent, w)                                   # python/clip.py:32-35
+        elif parent.startswith("clip/") and w.ndim == 1:
+            write_layer_norm(root / parent, w, b)                               # attn_ln / mlp_ln / layer_norm
+        elif w.ndim == 4:
             k = w.shape[2]
             stride = 2 if parent.rsplit("/", 1)[1] in ("d1", "d2", "d3") else 1   # Downsample (unet/mod.rs:408-427)
             write_conv2d(root / parent, w, b, stride=stride, padding=1 if k == 3 else 0)
@@ -120,7 +130,11 @@ def write_dump_tree(dump_dir, specs, get_tensor, alphas_cumprod, n_head: int = 8
         if parent.rsplit("/", 1)[1] in ("attn1", "attn2"):
             pass
     for parent in {p.rsplit("/", 1)[0] for p in modules if p.rsplit("/", 1)[1] in ("query",)}:
-        _save(root / parent / "n_head.npy", encode_scalar(n_head))                 # unet/load.rs:46
+        heads = clip_heads if parent.startswith("clip/") else n_head               # unet/load.rs:46, clip/load.rs:33
+        _save(root / parent / "n_head.npy", encode_scalar(heads))
+    clip_blocks = {p.split("/")[2] for p in modules if p.startswith("clip/blocks/")}
+    if clip_blocks:
+        _save(root / "clip" / "n_layer.npy", encode_scalar(len(clip_blocks)))      # python/clip.py:29, clip/load.rs:74
     a = np.asarray(alphas_cumprod, np.float32)
     _save(root / "n_steps.npy", encode_scalar(len(a)))                                # stablediffusion/load.rs:20
     _save(root / "alphas_cumprod.npy", encode_tensor(a))

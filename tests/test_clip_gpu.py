@@ -124,3 +124,51 @@ def test_clip_full_size_vs_reference_python():
         np.testing.assert_allclose(both[0], sd.clip.forward(toks[:1])[0], rtol=0, atol=1e-6)
     finally:
         sd.close()
+
+
+def _decode_png(path):
+    """minimal PNG reader for 8-bit RGB, filter 0 (what sdmi_write_png emits); checks every CRC"""
+    import struct
+    import zlib
+    data = Path(path).read_bytes()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + body)
+        if typ == b"IHDR":
+            w, h, depth, colour, comp, filt, inter = struct.unpack(">IIBBBBB", body)
+            assert (depth, colour, comp, filt, inter) == (8, 2, 0, 0, 0)
+        elif typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 3)
+
+
+def test_sample_cli_twin(sd_clip_tiny, tmp_path):
+    """sdmi_sample (C++ twin of src/bin/sample/main.rs, same argv) on a dump tree == the same calls through Python."""
+    import os
+    import subprocess
+    from stable_diffusion_burn_amd import SimpleTokenizer, build, weights as wio
+    specs = sd_clip_tiny.weight_specs()
+    shapes = dict(specs)
+    W = syn.SyntheticWeights()
+    wio.write_dump_tree(tmp_path / "params", specs, lambda name, shape: syn.named_tensor(W, name, shape, shapes),
+                        syn.alphas_cumprod(), n_head=4, clip_heads=1)
+    env = dict(os.environ, SDMI_BPE_VOCAB=str(MINI), SDMI_SEED="3",
+               SDMI_CONFIG=f"model_channels=160,n_head=4,ctx_dim=64,latent_h=16,latent_w=16,vae_ch=32,clip_layers=2,clip_heads=1,clip_vocab={MINI_VOCAB},clip_ctx=16")
+    out = tmp_path / "img"
+    r = subprocess.run([str(build.CLI), "dump", str(tmp_path / "params"), "7.5", "2", "a photo of a cat", str(out), "hip:0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines() == ["Loading tokenizer...", "Loading model...", "Sampling image..."]   # main.rs:85-103
+    got = _decode_png(str(out) + "0.png")
+    tok = SimpleTokenizer(MINI)
+    ref = sd_clip_tiny.sample_image(sd_clip_tiny.context(tok, "a photo of a cat"), sd_clip_tiny.unconditional_context(tok), 7.5, 2, seed=3)[0]
+    np.testing.assert_array_equal(got, ref)
+    # reference error conventions: bad arguments -> message on stderr, exit code 1 (main.rs:38-52,89-97)
+    bad = subprocess.run([str(build.CLI), "dump", str(tmp_path / "nope"), "7.5", "2", "x", str(out), "hip:0"], env=env, capture_output=True, text=True)
+    assert bad.returncode == 1 and "Error loading model dump" in bad.stderr
