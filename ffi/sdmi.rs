@@ -5,8 +5,9 @@
 //! It gives `src/bin/sample/main.rs` a `StableDiffusionMi355` with the same four method
 //! signatures it already uses on `StableDiffusion<B>` (src/model/stablediffusion/mod.rs:51-67,
 //! 69-100, 102-160) but over plain `Vec<f32>` / slices instead of Burn tensors, so the hot path
-//! (DDIM + CFG UNet loop, VAE decode) runs in the HIP library while CLIP, the tokenizer and the
-//! CLI stay Burn/Rust.  Shape errors panic, exactly like the reference's `.unwrap()`s
+//! (DDIM + CFG UNet loop, VAE decode) runs in the HIP library.  CLIP and the tokenizer can stay
+//! Burn/Rust, or -- when the dump tree holds the clip/ subtree -- run in the library too
+//! (`TokenizerMi355`, `StableDiffusionMi355::context`, mirroring stablediffusion/mod.rs:194-210).  Shape errors panic, exactly like the reference's `.unwrap()`s
 //! (stablediffusion/mod.rs:86, unet/mod.rs:134); loader errors are `Box<dyn Error>` like
 //! `load_stable_diffusion` (stablediffusion/load.rs:16-33).
 use std::error::Error;
@@ -23,7 +24,11 @@ pub struct SdmiConfig {
     pub vae_ch: i32,
     pub max_batch: i32,
     pub precision: i32,
-    pub reserved: [i32; 7],
+    pub clip_layers: i32,
+    pub clip_heads: i32,
+    pub clip_vocab: i32,
+    pub clip_ctx: i32,
+    pub reserved: [i32; 3],
 }
 
 #[link(name = "sdmi")]
@@ -42,6 +47,11 @@ extern "C" {
     fn sdmi_latent_to_image(ctx: *mut c_void, latent: *const c_float, n: i32, rgb_out: *mut u8) -> c_int;
     fn sdmi_sample_image(ctx: *mut c_void, context: *const c_float, n: i32, t_len: i32, uncond: *const c_float, tu: i32,
                          scale: c_double, n_steps: usize, init_latent: *const c_float, seed: u64, rgb_out: *mut u8) -> c_int;
+    fn sdmi_tokenizer_create(out: *mut *mut c_void, merges_path: *const c_char) -> c_int;
+    fn sdmi_tokenizer_destroy(tok: *mut c_void);
+    fn sdmi_tokenizer_encode(tok: *const c_void, text: *const c_char, ids: *mut i32, capacity: i32, n_ids: *mut i32) -> c_int;
+    fn sdmi_context(ctx: *mut c_void, tok: *const c_void, text: *const c_char, out: *mut c_float, capacity_tokens: i32, t: *mut i32) -> c_int;
+    fn sdmi_write_png(path: *const c_char, rgb: *const u8, width: i32, height: i32) -> c_int;
     fn sdmi_qkv_attention(ctx: *mut c_void, q: *const c_float, k: *const c_float, v: *const c_float, mask: *const c_float,
                           mask_ld: i32, n: i32, nq: i32, nk: i32, n_state: i32, n_head: i32, out: *mut c_float) -> c_int;
 }
@@ -56,9 +66,42 @@ fn check(status: c_int) {
     }
 }
 
+/// `SimpleTokenizer` (src/tokenizer.rs:74-196) inside the library.
+pub struct TokenizerMi355 {
+    tok: *mut c_void,
+}
+
+impl TokenizerMi355 {
+    /// `SimpleTokenizer::new()` reads "bpe_simple_vocab_16e6.txt" from the working directory (tokenizer.rs:91).
+    pub fn new(merges_path: &str) -> Result<Self, Box<dyn Error>> {
+        let p = CString::new(merges_path)?;
+        let mut tok: *mut c_void = std::ptr::null_mut();
+        if unsafe { sdmi_tokenizer_create(&mut tok, p.as_ptr()) } != 0 {
+            return Err(last_error().into());
+        }
+        Ok(Self { tok })
+    }
+
+    pub fn encode(&self, text: &str) -> Vec<u32> {
+        let t = CString::new(text).expect("prompt contains a NUL byte");
+        let cap = 4 * text.len() + 8;
+        let mut ids = vec![0i32; cap];
+        let mut n = 0i32;
+        check(unsafe { sdmi_tokenizer_encode(self.tok, t.as_ptr(), ids.as_mut_ptr(), cap as i32, &mut n) });
+        ids[..n as usize].iter().map(|&v| v as u32).collect()
+    }
+}
+
+impl Drop for TokenizerMi355 {
+    fn drop(&mut self) {
+        unsafe { sdmi_tokenizer_destroy(self.tok) }
+    }
+}
+
 pub struct StableDiffusionMi355 {
     ctx: *mut c_void,
     ctx_dim: usize,
+    clip_ctx: usize,
     latent: usize, // 4 * h * w
 }
 
@@ -79,8 +122,31 @@ impl StableDiffusionMi355 {
                 sdmi_destroy(ctx);
                 return Err(e.into());
             }
-            Ok(Self { ctx, ctx_dim: cfg.ctx_dim as usize, latent: 4 * (cfg.latent_h * cfg.latent_w) as usize })
+            Ok(Self { ctx, ctx_dim: cfg.ctx_dim as usize, clip_ctx: cfg.clip_ctx as usize,
+                      latent: 4 * (cfg.latent_h * cfg.latent_w) as usize })
         }
+    }
+
+    /// `context(&tokenizer, text)` (stablediffusion/mod.rs:198-210): `[T, ctx_dim]` row-major, T = tokens + 2.
+    /// Needs the clip/ subtree in the dump; `unconditional_context` (:194-196) is `context(tok, "")`.
+    pub fn context(&self, tokenizer: &TokenizerMi355, text: &str) -> Vec<f32> {
+        let t = CString::new(text).expect("prompt contains a NUL byte");
+        let mut out = vec![0f32; self.clip_ctx * self.ctx_dim];
+        let mut n_tok = 0i32;
+        check(unsafe { sdmi_context(self.ctx, tokenizer.tok, t.as_ptr(), out.as_mut_ptr(), self.clip_ctx as i32, &mut n_tok) });
+        out.truncate(n_tok as usize * self.ctx_dim);
+        out
+    }
+
+    /// `save_images` (src/bin/sample/main.rs:118-125) without the `image` crate.
+    pub fn save_images(images: &[Vec<u8>], basepath: &str, width: u32, height: u32) -> Result<(), Box<dyn Error>> {
+        for (index, img) in images.iter().enumerate() {
+            let p = CString::new(format!("{}{}.png", basepath, index))?;
+            if unsafe { sdmi_write_png(p.as_ptr(), img.as_ptr(), width as i32, height as i32) } != 0 {
+                return Err(last_error().into());
+            }
+        }
+        Ok(())
     }
 
     /// One tensor of a Burn record / npy dump, by its dump-tree name (unet/load.rs, autoencoder/load.rs).
