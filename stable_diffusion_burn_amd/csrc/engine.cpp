@@ -146,6 +146,9 @@ Engine::Engine(const sdmi_config& cfg) : cfg_(cfg) {
     SDMI_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     SDMI_HIP(hipEventCreate(&ev0_));
     SDMI_HIP(hipEventCreate(&ev1_));
+    SDMI_HIP(hipMalloc(&zero_page_, 256));
+    SDMI_HIP(hipMemset(zero_page_, 0, 256));
+    weight_allocs_.push_back(zero_page_);
     {   // measured per-shape tile choices (tools/autotune.py -> tuning/gfx950_fp32.txt)
         struct Row { const char* key; int cfg; int splits; };
         static const Row rows[] = {
@@ -514,6 +517,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "gemm_variant") opt_gemm_variant_ = std::stoi(value);
     else if (key == "attn_variant") opt_attn_variant_ = std::stoi(value);
     else if (key == "attn_bf16") opt_attn_bf16_ = std::stoi(value);
+    else if (key == "gemm_bf16x") opt_gemm_bf16x_ = std::stoi(value);
     else if (key == "record_shapes") { record_shapes_ = std::stoi(value) != 0; if (record_shapes_) shape_counts_.clear(); }
     else if (key == "dump_shapes") {
         std::ofstream f(value);
@@ -563,6 +567,38 @@ TileChoice Engine::choose_tile(int M, int N, int kt_total) const {
     return bc;
 }
 
+// precision = 1: the 4-wave tiles of k_gemm_bf16.hip (cfg 0..9) against the 8-wave LDS-DMA tiles of
+// k_gemm_bf16x.hip (cfg 100 + x).  Cycles per CU at 4096 bf16 flop/clk/CU; the efficiencies are measured
+// ones (tools/autotune.py --precision bf16), the per-workgroup constants cover prologue DMA latency + epilogue.
+TileChoice Engine::choose_tile_bf16(int M, int N, int kt_total) const {
+    static const double eff_old[kNumGemmTiles] = {0.31, 0.22, 0.16, 0.22, 0.20, 0.20, 0.22, 0.26, 0.15, 0.28};
+    static const double eff_x[kNumGemmTilesX] = {0.52, 0.44, 0.37, 0.47};
+    static const int split_opts[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
+    const int n_cu = 256;
+    double best = 1e300;
+    TileChoice bc{0, 1};
+    auto consider = [&](int cfg, int bm, int bn, double eff, double wg_overhead) {
+        const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+        for (int s : split_opts) {
+            if (s > 1 && kt_total / s < 4) break;
+            const int kt_per = (kt_total + s - 1) / s;
+            const long long wgs = tiles * ((kt_total + kt_per - 1) / kt_per);
+            const double per_cu = (double)((wgs + n_cu - 1) / n_cu);
+            double t = per_cu * ((double)bm * bn * kt_per * 128.0 / 4096.0 / eff + wg_overhead);
+            if (s > 1) t += 8000.0 + (double)M * N * 4.0 * (s + 1) / (5.0e12 / 2.4e9);
+            if (t < best) { best = t; bc = {cfg, s}; }
+        }
+    };
+    for (int c = 0; c < kNumGemmTiles; ++c) consider(c, gemm_tile_info(c).bm, gemm_tile_info(c).bn, eff_old[c], 3000.0);
+    if (opt_gemm_bf16x_)
+        for (int c = 0; c < kNumGemmTilesX; ++c) {
+            // one workgroup per CU (144 KB of LDS): the DMA prologue and the output tile's store are not hidden by a neighbour
+            const int bm = gemm_tile_info_x(c).bm, bn = gemm_tile_info_x(c).bn;
+            consider(100 + c, bm, bn, eff_x[c], 6000.0 + bm * bn * 2.0 / 10.0);
+        }
+    return bc;
+}
+
 void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits) {
     const int kt_elems = in_dt ? 64 : 32;  // a k tile is 128 bytes of K per row in both storage types
     p.kt_total = (p.K + kt_elems - 1) / kt_elems;
@@ -577,7 +613,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     std::snprintf(key, sizeof key, "%d,%d,%d", p.M, p.N, p.K);
     auto it = in_dt ? tuned_.end() : tuned_.find(key);  // the measured table is for the fp32 kernel
     if (it != tuned_.end()) tc = it->second;
-    else tc = choose_tile(p.M, p.N, p.kt_total);
+    else tc = in_dt ? choose_tile_bf16(p.M, p.N, p.kt_total) : choose_tile(p.M, p.N, p.kt_total);
     if (opt_force_tile_ >= 0) tc.cfg = opt_force_tile_;
     if (opt_force_splits_ > 0) tc.splits = opt_force_splits_;
     if (force_cfg >= 0) tc.cfg = force_cfg;
@@ -594,9 +630,12 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     const unsigned long long b_ext = ((unsigned long long)p.N - 1) * (unsigned long long)p.b_ld * es + (unsigned long long)p.K * es;
     if (in_dt && (a_ext >= 0xFFFFFFE0ull || b_ext >= 0xFFFFFFE0ull)) throw Error(SDMI_ERR_UNSUPPORTED, "bf16 GEMM: operand larger than 4 GiB");
     const bool v2 = (opt_gemm_variant_ == 1 || p.out_mode == 2) && a_ext < 0xFFFFFFE0ull && b_ext < 0xFFFFFFE0ull;
+    p.zero_page = zero_page_;
+    if (tc.cfg >= 100 && (!in_dt || tc.cfg - 100 >= kNumGemmTilesX)) throw Error(SDMI_ERR_INVALID, "gemm: tile cfg >= 100 is a large-tile bf16 kernel index");
     p.a_bytes = (unsigned)std::min<unsigned long long>(a_ext, 0xFFFFFFE0ull);
     p.b_bytes = (unsigned)std::min<unsigned long long>(b_ext, 0xFFFFFFE0ull);
     auto launch = [&](const ConvGemm& q) {
+        if (in_dt && tc.cfg >= 100) return launch_conv_gemm_bf16x(q, tc.cfg - 100, stream_);
         if (in_dt) return launch_conv_gemm_bf16(q, tc.cfg, stream_);
         return v2 ? launch_conv_gemm2(q, tc.cfg, stream_) : launch_conv_gemm(q, tc.cfg, stream_);
     };

@@ -267,7 +267,10 @@ private:
     int opt_force_tile_ = -1;
     int opt_force_splits_ = 0;
     int opt_attn_variant_ = 1;
-    int opt_attn_bf16_ = 1;     // precision = 1: 1 = bf16 matrix-core attention, 0 = bf16 storage widened onto the fp32 kernel  // 1: attn2_kernel, 0: attn_f32_kernel
+    int opt_attn_bf16_ = 1;
+    int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
+    void* zero_page_ = nullptr;
+    TileChoice choose_tile_bf16(int M, int N, int kt_total) const;   // cfg >= 100: k_gemm_bf16x.hip tile cfg - 100     // precision = 1: 1 = bf16 matrix-core attention, 0 = bf16 storage widened onto the fp32 kernel  // 1: attn2_kernel, 0: attn_f32_kernel
     int opt_gemm_variant_ = 1;  // 1: k_gemm2.hip (buffer loads, swizzled LDS, pipelined), 0: k_gemm.hip
     std::map<std::string, TileChoice> tuned_;
     bool record_shapes_ = false;

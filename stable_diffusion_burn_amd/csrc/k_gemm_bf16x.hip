@@ -1,0 +1,265 @@
+// k_gemm_bf16x.hip -- large-tile bf16 implicit-GEMM conv / linear for precision = 1 at batch sizes where the
+// GEMMs are big (BASELINE.json configs[2..3]: M = n*Ho*Wo in the tens of thousands).
+//
+// Why a second bf16 kernel: at the bf16 matrix rate (16 cycles per v_mfma_f32_16x16x32_bf16) the 4-wave
+// 128x128 structure inherited from the fp32 kernel is LDS-bound -- per 64-deep k tile it writes 32 KB through
+// the VGPR->LDS path (~79 B/clk) and reads 16 fragments per wave, ~670 LDS cycles against 512 MFMA cycles.
+// This kernel follows the MI355X GEMM recipe instead:
+//   * 256-row tiles, 8 waves (512 threads), one workgroup per CU: wave tiles of 128x80 / 128x64 / 64x64
+//     halve the LDS bytes per flop;
+//   * operands are staged HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction): no
+//     staging registers, no ds_write pass.  The DMA writes lane-linearly (wave base + lane*16), so the
+//     XOR swizzle that keeps the ds_read_b128 fragment reads conflict-free is applied on the SOURCE side:
+//     LDS slot (row r, chunk s) receives global chunk s ^ (r & 7) of that row -- still the same full 128-byte
+//     line per row;
+//   * zero fill (conv padding taps, M / N tails) by pointing the lane at a zero page instead of predication,
+//     so every lane always issues its DMA;
+//   * two LDS stages, one __syncthreads() per k tile: [barrier: tile t landed, stage t^1 free] -> issue the
+//     DMA of tile t+1 -> 2 x (fragment reads + MFMAs) on tile t.  The DMA is in flight during the whole MFMA
+//     phase; the barrier's vmcnt(0) retires it.
+// k order, weight packing, swapped MFMA operands (a lane holds 4 consecutive output channels), XCD-aware tile
+// map, deterministic split-K and the fused epilogue are those of k_gemm_bf16.hip.
+#include "kernels.hpp"
+
+namespace sdmi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void global_cvoid;
+
+__device__ __forceinline__ float xbf16_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float xbf16_hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
+__device__ __forceinline__ unsigned xf32_to_bf16_bits(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ unsigned xpack_bf16x2(float a, float b) { return xf32_to_bf16_bits(a) | (xf32_to_bf16_bits(b) << 16); }
+
+static const GemmTileInfo kTilesX[kNumGemmTilesX] = {
+    {256, 320, "256x320x"}, {256, 256, "256x256x"}, {256, 128, "256x128x"}, {128, 320, "128x320x"}};
+const GemmTileInfo& gemm_tile_info_x(int cfg) { return kTilesX[cfg]; }
+
+template <int MI, int NI, int WM, int WN>
+__global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) {
+    constexpr int BM = 16 * MI * WM;
+    constexpr int BN = 16 * NI * WN;
+    static_assert(WM * WN == 8, "8 waves per workgroup");
+    static_assert(BM % 64 == 0 && BN % 64 == 0, "every wave issues whole 8-row DMA pieces");
+    constexpr int NA = BM / 64;               // A pieces (8 rows x 128 B) per wave per k tile
+    constexpr int NB = BN / 64;               // B pieces per wave
+    constexpr int STAGE = (BM + BN) * 128;    // bytes of one LDS stage
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_x[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
+
+    const int MT = (p.M + BM - 1) / BM;
+    const int NT = (p.N + BN - 1) / BN;
+    const int tpx = gridDim.x >> 3;
+    const int lid = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3);
+    if (lid >= MT * NT) return;
+    const int tm = lid / NT;
+    const int tn = lid - tm * NT;
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
+
+    const int z = blockIdx.z;
+    const int kt_begin = z * p.kt_per_split;
+    const int kt_end = min(kt_begin + p.kt_per_split, p.kt_total);
+    const int n_t = kt_end - kt_begin;
+
+    const int T = p.KH * p.KW;
+    const int HoWo = p.Ho * p.Wo;
+    const int Hin = p.Hs << p.ups;
+    const int Win = p.Ws << p.ups;
+    const long long pix_bytes = (long long)p.a_ld * 2;
+    const char* Abase = reinterpret_cast<const char*>(p.A);
+    const char* Bbase = reinterpret_cast<const char*>(p.Bt);
+    const char* zero = reinterpret_cast<const char*>(p.zero_page);
+
+    // DMA piece j of a wave covers tile rows (wave + 8 j) * 8 .. + 7; lane -> row + (lane >> 3), LDS slot lane & 7,
+    // which receives global chunk (lane & 7) ^ (row & 7) = (lane & 7) ^ (lane >> 3)
+    const int sub = lane >> 3;
+    const int chunk = (lane & 7) ^ sub;
+
+    int a_iy0[NA], a_ix0[NA];
+    long long a_nboff[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int m = m0 + (wave + 8 * j) * 8 + sub;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int nb = mm / HoWo;
+        const int rem = mm - nb * HoWo;
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        a_nboff[j] = (long long)nb * (p.Hs * p.Ws) * pix_bytes + chunk * 16;
+        a_iy0[j] = ok ? oy * p.stride - p.pad : -(1 << 28);   // rows past M: never in range -> zero page
+        a_ix0[j] = ox * p.stride - p.pad;
+    }
+    const char* b_src[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + (wave + 8 * j) * 8 + sub;
+        b_src[j] = (n < p.N) ? Bbase + (long long)n * p.b_ld * 2 + chunk * 16 : nullptr;
+    }
+
+    int cs = kt_begin / T;
+    int tap0 = kt_begin - cs * T;
+    int ky = tap0 / p.KW;
+    int kx = tap0 - ky * p.KW;
+    int kt_next = kt_begin;
+
+    auto issue = [&](int buf) {   // DMA of k tile kt_next into LDS stage buf; advances (cs, ky, kx)
+        unsigned char* stage = smem_x + buf * STAGE;
+        const long long c0b = (long long)cs * 128;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int iy = a_iy0[j] + ky;
+            const int ix = a_ix0[j] + kx;
+            const bool ok = ((unsigned)iy < (unsigned)Hin) & ((unsigned)ix < (unsigned)Win);
+            const long long pix = (long long)((iy >> p.ups) * p.Ws + (ix >> p.ups));
+            const char* src = ok ? Abase + a_nboff[j] + pix * pix_bytes + c0b : zero;
+            __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(stage + (wave + 8 * j) * 1024), 16, 0, 0);
+        }
+        const long long k0b = (long long)kt_next * 128;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const char* src = b_src[j] ? b_src[j] + k0b : zero;
+            __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(stage + BM * 128 + (wave + 8 * j) * 1024), 16, 0, 0);
+        }
+        const bool wrap_x = (kx + 1 == p.KW);
+        const bool wrap_y = wrap_x && (ky + 1 == p.KH);
+        kx = wrap_x ? 0 : kx + 1;
+        ky = wrap_x ? (wrap_y ? 0 : ky + 1) : ky;
+        cs = wrap_y ? cs + 1 : cs;
+        ++kt_next;
+    };
+
+    // fragment reads: lane (c = lane & 15, g = lane >> 4) reads row base + c, chunk (4 kk + g) ^ (c & 7)
+    const int c15 = lane & 15, g4 = lane >> 4;
+    const int fr_off0 = c15 * 128 + (((0 + g4) ^ (c15 & 7)) << 4);
+    const int fr_off1 = c15 * 128 + (((4 + g4) ^ (c15 & 7)) << 4);
+    const int a_base = wm * 16 * MI * 128;
+    const int b_base = BM * 128 + wn * 16 * NI * 128;
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0);
+    for (int t = 0; t < n_t; ++t) {
+        const int cur = t & 1;
+        __syncthreads();                    // k tile t is in LDS; every wave is done with stage cur ^ 1
+        if (t + 1 < n_t) issue(cur ^ 1);
+        const unsigned char* stage = smem_x + cur * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int fo = kk ? fr_off1 : fr_off0;
+            u32x4 fb[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) fb[ni] = *reinterpret_cast<const u32x4*>(stage + b_base + ni * 2048 + fo);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const u32x4 fa = *reinterpret_cast<const u32x4*>(stage + a_base + mi * 2048 + fo);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[ni]), __builtin_bit_cast(bf16x8, fa),
+                                                                          acc[mi][ni], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: fp32 bias + time-embedding row + (bf16) residual, then bf16 or fp32 store ----------
+    const bool split = p.splits > 1;
+    const bool vec_ok = ((p.N & 3) == 0) && (((split ? p.N : p.ldc) & 3) == 0) && ((p.ldr & 3) == 0 || !p.resid);
+    const bool out_f32 = split || p.out_mode == 1;
+    float* Cf = split ? (p.C + (long long)z * p.slab_stride) : p.C;
+    unsigned short* Ch = reinterpret_cast<unsigned short*>(p.C);
+    const unsigned short* Rh = reinterpret_cast<const unsigned short*>(p.resid);
+    const int ldc = split ? p.N : p.ldc;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + (wm * MI + mi) * 16 + c15;
+        if (m >= p.M) continue;
+        const int smp = m / HoWo;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + (wn * NI + ni) * 16 + g4 * 4;
+            if (n >= p.N) continue;
+            f32x4 v = acc[mi][ni];
+            if (vec_ok) {
+                if (!split) {
+                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)smp * p.rowvec_stride + n);
+                    if (p.resid) {
+                        const u32x2 r = *reinterpret_cast<const u32x2*>(Rh + (long long)m * p.ldr + n);
+                        v[0] += xbf16_lo(r[0]); v[1] += xbf16_hi(r[0]); v[2] += xbf16_lo(r[1]); v[3] += xbf16_hi(r[1]);
+                    }
+                }
+                if (out_f32) {
+                    *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;
+                } else {
+                    u32x2 o = {xpack_bf16x2(v[0], v[1]), xpack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(Ch + (long long)m * ldc + n) = o;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r < p.N) {
+                        float s = v[r];
+                        if (!split) {
+                            if (p.bias) s += p.bias[n + r];
+                            if (p.rowvec) s += p.rowvec[(long long)smp * p.rowvec_stride + n + r];
+                            if (p.resid) s += __uint_as_float((unsigned)Rh[(long long)m * p.ldr + n + r] << 16);
+                        }
+                        if (out_f32) Cf[(long long)m * ldc + n + r] = s;
+                        else Ch[(long long)m * ldc + n + r] = (unsigned short)xf32_to_bf16_bits(s);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MI, int NI, int WM, int WN>
+static hipError_t launch_cfg_bf16x(const ConvGemm& p, dim3 grid, hipStream_t stream) {
+    static bool attr_set = false;
+    auto k = conv_gemm_bf16x_kernel<MI, NI, WM, WN>;
+    constexpr size_t lds = 2 * (size_t)(16 * MI * WM + 16 * NI * WN) * 128;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(512), lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int cfg, hipStream_t stream) {
+    if (cfg < 0 || cfg >= kNumGemmTilesX) return hipErrorInvalidValue;
+    if ((p.Cin % 64) || !p.zero_page) return hipErrorInvalidValue;
+    const int bm = kTilesX[cfg].bm, bn = kTilesX[cfg].bn;
+    const int MT = (p.M + bm - 1) / bm, NT = (p.N + bn - 1) / bn;
+    const int tiles = MT * NT;
+    dim3 grid(((tiles + 7) / 8) * 8, 1, p.splits);
+    switch (cfg) {
+        case 0: return launch_cfg_bf16x<8, 5, 2, 4>(p, grid, stream);
+        case 1: return launch_cfg_bf16x<8, 4, 2, 4>(p, grid, stream);
+        case 2: return launch_cfg_bf16x<4, 4, 4, 2>(p, grid, stream);
+        case 3: return launch_cfg_bf16x<4, 5, 2, 4>(p, grid, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace sdmi

@@ -38,6 +38,7 @@ struct ConvGemm {
     long long slab_stride;  // M*N when splits > 1
     unsigned a_bytes, b_bytes;  // extents of A / Bt for the buffer-load range check (v2 kernel)
     int out_mode;               // 0: output in the kernel's storage type; 1: force fp32 (bf16 kernel); 2: bf16 from the fp32 kernel
+    const void* zero_page;      // >= 16 readable zero bytes (large-tile bf16 kernel: source of padded / out-of-range lanes)
 };
 
 // tile configurations (index = tile_cfg); BM x BN per 256-thread workgroup
@@ -51,6 +52,10 @@ size_t gemm2_tile_lds_bytes(int cfg);
 // bf16 storage / fp32 accumulate (k_gemm_bf16.hip); A, Bt, resid and (unless out_mode == 1) C are bf16
 hipError_t launch_conv_gemm_bf16(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 hipError_t launch_splitk_reduce_bf16(const ConvGemm& p, const float* slabs, hipStream_t stream);
+// large-tile (256-row, 8-wave, LDS-DMA staged) bf16 kernel (k_gemm_bf16x.hip); its own tile list
+constexpr int kNumGemmTilesX = 4;
+const GemmTileInfo& gemm_tile_info_x(int cfg);
+hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 hipError_t launch_pack_conv_weight_bf16(const float* w_oihw, void* bt, int cout, int cin, int kh, int kw, hipStream_t s);
 hipError_t launch_pack_linear_weight_bf16(const float* w_in_out, void* bt, int cin, int cout, hipStream_t s);
 // sums split-K slabs in fixed order and applies the epilogue

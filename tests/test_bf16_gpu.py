@@ -90,6 +90,50 @@ def test_conv2d_bf16_all_tiles(ops16, tile, splitk):
     _check(got, ref, f"conv bf16 tile={tile} splitk={splitk}", 2 ** -8)
 
 
+XCASES = [
+    # (n, cin, h, w, cout, k, stride, ups): several M tiles with a ragged last one, N tails, every conv flavour
+    (2, 128, 23, 19, 320, 3, 1, 0), (1, 64, 40, 36, 200, 3, 1, 0), (2, 192, 16, 16, 640, 1, 1, 0), (1, 128, 33, 31, 128, 3, 2, 0),
+    (1, 64, 12, 20, 384, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("tile", [100, 101, 102, 103])
+@pytest.mark.parametrize("splitk", [1, 3])
+@pytest.mark.parametrize("case", XCASES)
+def test_conv2d_bf16_large_tiles(ops16, tile, splitk, case):
+    """k_gemm_bf16x.hip: 256-row, 8-wave tiles staged by LDS-DMA (tile 100 + x), incl. residual + time-embedding epilogue."""
+    n, cin, h, w, cout, k, stride, ups = case
+    g = np.random.default_rng(3000 + tile + 7 * splitk + cin + cout)
+    x = bf16_round(g.standard_normal((n, cin, h, w)))
+    wt = bf16_round(g.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k))
+    b = g.standard_normal(cout).astype(np.float32)
+    try:
+        ops16.set_option("gemm_tile", tile)
+        ops16.set_option("splitk", splitk)
+        got = ops16.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
+    finally:
+        ops16.set_option("gemm_tile", "auto")
+        ops16.set_option("splitk", 0)
+    xin = O.upsample2x(_t(x)) if ups else _t(x)
+    ref = O.conv2d(xin, (_t(wt), _t(b)), stride=stride, padding=1 if k == 3 else 0).numpy()
+    _check(got, ref, f"conv bf16 large tile={tile} splitk={splitk} {case}", 2 ** -8)
+
+
+@pytest.mark.parametrize("tile", [100, 103])
+def test_linear_bf16_large_tiles(ops16, tile):
+    g = np.random.default_rng(tile)
+    rows, cin, cout = 700, 320, 960
+    x = bf16_round(g.standard_normal((rows, cin)))
+    wt = bf16_round(g.standard_normal((cin, cout)) / math.sqrt(cin))
+    b = g.standard_normal(cout).astype(np.float32)
+    try:
+        ops16.set_option("gemm_tile", tile)
+        got = ops16.op_linear(x, wt, b)
+    finally:
+        ops16.set_option("gemm_tile", "auto")
+    _check(got, O.linear(_t(x), _t(wt), _t(b)).numpy(), f"linear bf16 large tile={tile}", 2 ** -8)
+
+
 @pytest.mark.parametrize("rows,cin,cout", [(154, 768, 320), (512, 320, 2560), (77, 64, 192), (1, 1280, 1280)])
 def test_linear_bf16(ops16, rows, cin, cout):
     g = np.random.default_rng(rows + cout)
