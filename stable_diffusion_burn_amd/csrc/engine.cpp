@@ -155,6 +155,10 @@ Engine::Engine(const sdmi_config& cfg) : cfg_(cfg) {
 #include "tuning_table.inc"
             {nullptr, 0, 0}};
         for (const Row* r = rows; r->key; ++r) tuned_[r->key] = TileChoice{r->cfg, r->splits};
+        static const Row rows16[] = {
+#include "tuning_table_bf16.inc"
+            {nullptr, 0, 0}};
+        for (const Row* r = rows16; r->key; ++r) tuned_bf16_[r->key] = TileChoice{r->cfg, r->splits};
     }
     build_model();
 }
@@ -526,15 +530,17 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     }
     else if (key == "profile") { prof_flush(); profiling_ = std::stoi(value) != 0; }
     else if (key == "profile_reset") prof_reset();
-    else if (key == "tune") {
-        // "M,N,K=cfg,splits"
+    else if (key == "tune" || key == "tune_bf16") {
+        // "M,N,K=cfg,splits" (tune_bf16: cfg 100 + x selects a k_gemm_bf16x.hip tile)
         const size_t eq = value.find('=');
         if (eq == std::string::npos) throw Error(SDMI_ERR_INVALID, "tune expects M,N,K=cfg,splits");
+        const bool b16 = key == "tune_bf16";
         TileChoice tc{0, 1};
-        if (std::sscanf(value.c_str() + eq + 1, "%d,%d", &tc.cfg, &tc.splits) != 2 || tc.cfg < 0 || tc.cfg >= kNumGemmTiles || tc.splits < 1)
+        if (std::sscanf(value.c_str() + eq + 1, "%d,%d", &tc.cfg, &tc.splits) != 2 || tc.cfg < 0 || tc.splits < 1 ||
+            !(tc.cfg < kNumGemmTiles || (b16 && tc.cfg >= 100 && tc.cfg < 100 + kNumGemmTilesX)))
             throw Error(SDMI_ERR_INVALID, "tune: bad value");
-        tuned_[value.substr(0, eq)] = tc;
-    } else if (key == "tune_clear") tuned_.clear();
+        (b16 ? tuned_bf16_ : tuned_)[value.substr(0, eq)] = tc;
+    } else if (key == "tune_clear") { tuned_.clear(); tuned_bf16_.clear(); }
     else throw Error(SDMI_ERR_INVALID, "unknown option '" + key + "'");
 }
 
@@ -611,8 +617,9 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     TileChoice tc;
     char key[64];
     std::snprintf(key, sizeof key, "%d,%d,%d", p.M, p.N, p.K);
-    auto it = in_dt ? tuned_.end() : tuned_.find(key);  // the measured table is for the fp32 kernel
-    if (it != tuned_.end()) tc = it->second;
+    const auto& table = in_dt ? tuned_bf16_ : tuned_;  // measured per storage type (tuning/gfx950_{fp32,bf16}.txt)
+    auto it = table.find(key);
+    if (it != table.end() && (it->second.cfg < 100 || opt_gemm_bf16x_)) tc = it->second;
     else tc = in_dt ? choose_tile_bf16(p.M, p.N, p.kt_total) : choose_tile(p.M, p.N, p.kt_total);
     if (opt_force_tile_ >= 0) tc.cfg = opt_force_tile_;
     if (opt_force_splits_ > 0) tc.splits = opt_force_splits_;

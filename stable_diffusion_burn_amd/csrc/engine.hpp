@@ -272,7 +272,8 @@ private:
     void* zero_page_ = nullptr;
     TileChoice choose_tile_bf16(int M, int N, int kt_total) const;   // cfg >= 100: k_gemm_bf16x.hip tile cfg - 100     // precision = 1: 1 = bf16 matrix-core attention, 0 = bf16 storage widened onto the fp32 kernel  // 1: attn2_kernel, 0: attn_f32_kernel
     int opt_gemm_variant_ = 1;  // 1: k_gemm2.hip (buffer loads, swizzled LDS, pipelined), 0: k_gemm.hip
-    std::map<std::string, TileChoice> tuned_;
+    std::map<std::string, TileChoice> tuned_;        // fp32 kernels: "M,N,K" -> (tile cfg, split-K)
+    std::map<std::string, TileChoice> tuned_bf16_;   // bf16 kernels; cfg >= 100 = k_gemm_bf16x.hip tile
     bool record_shapes_ = false;
     std::map<std::string, long long> shape_counts_;  // "n,cin,h,w,cout,k,stride,ups" -> launches
 

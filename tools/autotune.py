@@ -65,7 +65,11 @@ def main():
     ap.add_argument("--cfg", type=int, default=-1)
     ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--variant", type=int, default=1, help="gemm kernel generation: 1 = k_gemm2.hip, 0 = k_gemm.hip")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32", help="bf16: k_gemm_bf16.hip tiles 0..9 + k_gemm_bf16x.hip tiles 100..103")
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU: scales the n of every shape (the lists are for 1 image)")
+    ap.add_argument("--append", action="store_true", help="append to --emit instead of overwriting")
     args = ap.parse_args()
+    bf16 = args.precision == "bf16"
     shapes = QUICK if args.quick else (UNET_SHAPES + (VAE_SHAPES if args.vae else []))
     counts = {}
     if args.shapes_file:
@@ -76,8 +80,17 @@ def main():
                 sh = tuple(int(v) for v in key.split(","))
                 shapes.append(sh)
                 counts[sh] = int(cnt)
-    sd = StableDiffusion(ModelConfig(32, 1, 32, 8, 8, 32))
+    if args.batch > 1:
+        counts = {(sh[0] * args.batch,) + tuple(sh[1:]): c for sh, c in counts.items()}
+        shapes = [(sh[0] * args.batch,) + tuple(sh[1:]) for sh in shapes]
+    if bf16:
+        shapes = [sh for sh in shapes if sh[1] % 64 == 0]     # Cin = 4 layers run on the fp32 kernel
+    sd = StableDiffusion(ModelConfig(64, 1, 64, 8, 8, 64, precision=1) if bf16 else ModelConfig(32, 1, 32, 8, 8, 32))
     sd.set_option("gemm_variant", args.variant)
+    sd.set_option("tune_clear", 1)
+    tiles_all = dict(enumerate(TILES))
+    if bf16:
+        tiles_all.update({100: "256x320", 101: "256x256", 102: "256x128", 103: "128x320"})
     if args.only:
         s = tuple(int(v) for v in args.only.split(","))
         M, N, K = mnk(s)
@@ -89,10 +102,12 @@ def main():
     for s in shapes:
         M, N, K = mnk(s)
         flops = 2.0 * M * N * K
-        kt = (K + 31) // 32
+        kt = (K + 63) // 64 if bf16 else (K + 31) // 32
         cands = []
-        for cfg in range(len(TILES)):
-            bm, bn = map(int, TILES[cfg].split("x"))
+        for cfg in tiles_all:
+            bm, bn = map(int, tiles_all[cfg].split("x"))
+            if bf16 and cfg < 100 and M * N > (1 << 24) and cfg in (2, 8):
+                continue   # 64-row tiles on very large GEMMs: never competitive, skip the launches
             tiles = -(-M // bm) * -(-N // bn)
             split_opts = [1]
             for sp in (2, 3, 4, 6, 8, 12, 16, 24, 32):
@@ -107,7 +122,7 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     print(f"  {s} cfg={cfg} sp={sp}: {e}")
                     continue
-                cands.append({"cfg": cfg, "tile": TILES[cfg], "splits": sp, "ms": ms, "tflops": flops / ms / 1e9})
+                cands.append({"cfg": cfg, "tile": tiles_all[cfg] + ("x" if cfg >= 100 else ""), "splits": sp, "ms": ms, "tflops": flops / ms / 1e9})
         if not cands:
             continue
         best = min(cands, key=lambda c: c["ms"])
@@ -120,7 +135,7 @@ def main():
     Path(args.out).parent.mkdir(parents=True, exist_ok=True)
     Path(args.out).write_text(json.dumps(results, indent=1))
     if args.emit:
-        with open(args.emit, "w") as f:
+        with open(args.emit, "a" if args.append else "w") as f:
             for r in results:
                 f.write(f"{r['M']},{r['N']},{r['K']}={r['best']['cfg']},{r['best']['splits']}\n")
     tot = sum(2.0 * r["M"] * r["N"] * r["K"] * r["count"] for r in results)
