@@ -112,3 +112,29 @@ def test_rust_shim_matches_header():
               "sdmi_sample_image", "sdmi_sample_latent", "sdmi_latent_to_image", "sdmi_unet_forward",
               "sdmi_decode_latent", "sdmi_qkv_attention", "sdmi_last_error"):
         assert re.search(r"\bfn\s+%s\b" % s, rs), s
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/sdmi.h compiles as C (not C++) and a C caller links against libsdmi.so with no other dependency."""
+    src = tmp_path / "c_caller.c"
+    src.write_text('#include "sdmi.h"\n#include <stdio.h>\n'
+                   'int main(void) { sdmi_config c; if (sdmi_default_config(&c) != SDMI_OK) return 2;\n'
+                   '  printf("%d %d %d %s\\n", c.model_channels, c.clip_layers, (int)sizeof(sdmi_config), sdmi_version()); return 0; }\n')
+    exe = tmp_path / "c_caller"
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(exe),
+                        f"-L{PKG / 'lib'}", "-lsdmi", f"-Wl,-rpath,{PKG / 'lib'}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.split()[:3] == ["320", "12", "64"], out.stdout + out.stderr
+
+
+def test_default_config_includes_the_text_encoder(lib):
+    """CLIPConfig::new(49408, 768, 12, 77, 12), stablediffusion/mod.rs:29; the Rust shim's struct mirrors the C one."""
+    from stable_diffusion_burn_amd._capi import SdmiConfig
+    cfg = SdmiConfig()
+    assert lib.sdmi_default_config(C.byref(cfg)) == 0
+    assert (cfg.clip_vocab, cfg.ctx_dim, cfg.clip_heads, cfg.clip_ctx, cfg.clip_layers) == (49408, 768, 12, 77, 12)
+    assert C.sizeof(SdmiConfig) == 64
+    rs = (ROOT / "ffi" / "sdmi.rs").read_text()
+    fields = re.findall(r"pub (\w+): (?:i32|\[i32; \d+\])", rs.split("pub struct SdmiConfig")[1].split("}")[0])
+    assert fields == [f[0] for f in SdmiConfig._fields_]
