@@ -120,7 +120,7 @@ def main():
     sd = StableDiffusion(cfg, device=local_rank)
     weights = syn.SyntheticWeights(cache=(rank == 0 and world == 1 and not args.no_cpu_baseline))
     t0 = time.perf_counter()
-    sd.load_weights(weights)
+    sd.load_weights(weights, clip=False, vae_encoder=False)   # the timed path takes embeddings and only decodes
     t_load = time.perf_counter() - t0
     if os.path.exists(args.tune_file) and not bf16:
         for line in Path(args.tune_file).read_text().split():

@@ -124,6 +124,13 @@ int sdmi_sample_latent(sdmi_ctx* ctx, const float* context, int32_t n, int32_t T
  * latent_to_image) -> img_out [n,3,8h,8w] fp32 NCHW. */
 int sdmi_decode_latent(sdmi_ctx* ctx, const float* latent, int32_t n, float* img_out);
 
+/* Autoencoder::encode_image (src/model/autoencoder/mod.rs:60-66): img [n,3,8h,8w]
+ * fp32 NCHW -> latent_out [n,4,h,w] (Encoder::forward, quant_conv, first 4 channels = the
+ * posterior mean; the reference does not sample).  Not on the txt2img path;
+ * needs the optional weight group autoencoder/encoder/..., autoencoder/quant_conv
+ * (SDMI_ERR_STATE otherwise).  Autoencoder::forward (:56-58) = decode_latent(encode_image(x)). */
+int sdmi_encode_image(sdmi_ctx* ctx, const float* img, int32_t n, float* latent_out);
+
 /* StableDiffusion::latent_to_image (stablediffusion/mod.rs:69-100):
  * latent [n,4,h,w] -> rgb_out n x [8h,8w,3] uint8 (HWC, truncating cast). */
 int sdmi_latent_to_image(sdmi_ctx* ctx, const float* latent, int32_t n, uint8_t* rgb_out);

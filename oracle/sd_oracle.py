@@ -373,6 +373,44 @@ class DecoderOracle:
 
 
 # --------------------------------------------------------------------------
+# VAE encoder half (not reachable from `sample`)
+# --------------------------------------------------------------------------
+def padded_conv2d(x, wb, stride, pad_left, pad_right, pad_top, pad_bottom):
+    """PaddedConv2d::forward autoencoder/mod.rs:390-411: a symmetric over-padded conv followed by a slice,
+    which is the conv with the asymmetric zero padding (left, right, top, bottom)."""
+    return conv2d(F.pad(x, (pad_left, pad_right, pad_top, pad_bottom)), wb, stride=stride, padding=0)
+
+
+class EncoderOracle(DecoderOracle):
+    def enc_channels(self):
+        c = self.d.vae_ch  # autoencoder/mod.rs:31-32: [(128,128),(128,256),(256,512),(512,512)]
+        return [(c, c), (c, 2 * c), (2 * c, 4 * c), (4 * c, 4 * c)]
+
+    @torch.no_grad()
+    def encode_image(self, img):
+        """Autoencoder::encode_image :60-66 -> Encoder::forward :133-144; returns the first 4 of the 8
+        quant_conv channels (the mean of the posterior; the reference never samples it)."""
+        P, r = self.P, self.root
+        chans = self.enc_channels()
+        x = img.to(self.dtype)
+        x = conv2d(x, P.conv(f"{r}/encoder/conv_in", 3, chans[0][0], 3), padding=1)
+        for i, (cin, cout) in enumerate(chans):   # EncoderBlock::forward :257-265
+            bp = f"{r}/encoder/blocks/{i}"
+            x = self.resnet_block(f"{bp}/res1", x, cin, cout)
+            x = self.resnet_block(f"{bp}/res2", x, cout, cout)
+            if i != len(chans) - 1:               # PaddingCfg::new(0, 1, 0, 1), stride 2 (:231-236)
+                x = padded_conv2d(x, P.conv(f"{bp}/downsampler/conv", cout, cout, 3), 2, 0, 1, 0, 1)
+        c4 = chans[-1][1]
+        x = self.resnet_block(f"{r}/encoder/mid/block_1", x, c4, c4)
+        x = self.attn_block(f"{r}/encoder/mid/attn", x, c4)
+        x = self.resnet_block(f"{r}/encoder/mid/block_2", x, c4, c4)
+        x = silu(group_norm(x, *P.norm(f"{r}/encoder/norm_out", c4)))
+        x = conv2d(x, P.conv(f"{r}/encoder/conv_out", c4, 8, 3), padding=1)
+        x = conv2d(x, P.conv(f"{r}/quant_conv", 8, 8, 1))
+        return x[:, :4]
+
+
+# --------------------------------------------------------------------------
 # Pipeline (src/model/stablediffusion/mod.rs)
 # --------------------------------------------------------------------------
 def ddim_timesteps(n_steps: int, total: int = 1000):

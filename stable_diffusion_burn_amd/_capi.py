@@ -62,6 +62,7 @@ SIGNATURES = {
     "sdmi_tokenizer_decode": (C.c_int, [_TOK, _I32, C.c_int32, C.c_char_p, C.c_int32, _I32]),
     "sdmi_clip_forward": (C.c_int, [_CTX, _I32, C.c_int32, C.c_int32, _F]),
     "sdmi_context": (C.c_int, [_CTX, _TOK, C.c_char_p, _F, C.c_int32, _I32]),
+    "sdmi_encode_image": (C.c_int, [_CTX, _F, C.c_int32, _F]),
     "sdmi_write_png": (C.c_int, [C.c_char_p, _U8, C.c_int32, C.c_int32]),
     "sdmi_sample_latent_dev": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_size_t, C.c_void_p, C.c_void_p]),
     "sdmi_latent_to_image_dev": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -368,6 +368,36 @@ void Engine::build_model() {
         norm(clip_ln_, "clip/layer_norm", cs);
         cur_group_ = 0;
     }
+
+    // ---- VAE encoder (autoencoder/mod.rs:30-32,76-144,220-265; names autoencoder/load.rs:120-190) -- SURVEY 8f rank 4
+    // Optional weight group: `sample` never encodes; sdmi_encode_image needs the whole group.
+    {
+        cur_group_ = 2;
+        const int ech[4][2] = {{vc, vc}, {vc, 2 * vc}, {2 * vc, 4 * vc}, {4 * vc, 4 * vc}};
+        enc_conv_in_.cin = 4; enc_conv_in_.cout = vc; enc_conv_in_.k = 3; enc_conv_in_.dt = 0;   // RGB + one zero channel
+        add(this, "autoencoder/encoder/conv_in/weight", 0, {vc, 3, 3, 3}, &enc_conv_in_.bt);
+        add(this, "autoencoder/encoder/conv_in/bias", 2, {vc}, &enc_conv_in_.bias);
+        for (int i = 0; i < 4; ++i) {
+            EncBlockW& b = enc_blocks_[i];
+            b.cin = ech[i][0]; b.cout = ech[i][1]; b.has_down = i != 3;
+            const std::string bp = "autoencoder/encoder/blocks/" + std::to_string(i);
+            res(b.res[0], bp + "/res1", b.cin, b.cout, false);
+            res(b.res[1], bp + "/res2", b.cout, b.cout, false);
+            if (b.has_down) conv(b.down, bp + "/downsampler/conv", b.cout, b.cout, 3);   // load_padded_conv2d: "{path}/conv"
+        }
+        res(enc_mid1_, "autoencoder/encoder/mid/block_1", 4 * vc, 4 * vc, false);
+        enc_attn_.c = 4 * vc;
+        norm(enc_attn_.norm, "autoencoder/encoder/mid/attn/norm", 4 * vc);
+        conv(enc_attn_.q, "autoencoder/encoder/mid/attn/q", 4 * vc, 4 * vc, 1);
+        conv(enc_attn_.k, "autoencoder/encoder/mid/attn/k", 4 * vc, 4 * vc, 1);
+        conv(enc_attn_.v, "autoencoder/encoder/mid/attn/v", 4 * vc, 4 * vc, 1);
+        conv(enc_attn_.proj_out, "autoencoder/encoder/mid/attn/proj_out", 4 * vc, 4 * vc, 1);
+        res(enc_mid2_, "autoencoder/encoder/mid/block_2", 4 * vc, 4 * vc, false);
+        norm(enc_norm_out_, "autoencoder/encoder/norm_out", 4 * vc);
+        conv(enc_conv_out_, "autoencoder/encoder/conv_out", 4 * vc, 8, 3);
+        conv(quant_conv_, "autoencoder/quant_conv", 8, 8, 1);
+        cur_group_ = 0;
+    }
 }
 
 // =============================================================================
@@ -398,7 +428,8 @@ void Engine::set_weight(const char* name, const float* data, int ndim, const int
     }
     if (!*e.dst) {
         void* p = nullptr;
-        SDMI_HIP(hipMalloc(&p, count * (e.wdt ? 2 : sizeof(float))));
+        const size_t alloc_count = (e.kind == 0 && e.dims[1] == 3) ? count / 3 * 4 : count;
+        SDMI_HIP(hipMalloc(&p, alloc_count * (e.wdt ? 2 : sizeof(float))));
         weight_allocs_.push_back(p);
         *e.dst = reinterpret_cast<float*>(p);
     }
@@ -409,7 +440,20 @@ void Engine::set_weight(const char* name, const float* data, int ndim, const int
         SDMI_HIP(hipMalloc(&stage, count * sizeof(float)));
         hipError_t err = hipMemcpy(stage, data, count * sizeof(float), hipMemcpyHostToDevice);
         if (err == hipSuccess) {
-            if (e.kind == 0) {
+            if (e.kind == 0 && e.dims[1] == 3) {
+                // RGB conv_in of the VAE encoder: packed with a zero 4th input channel (the image is staged as NHWC4)
+                const int cout = (int)e.dims[0], k = (int)e.dims[2], T = k * k;
+                std::vector<float> padded((size_t)cout * 4 * T, 0.f);
+                for (int o = 0; o < cout; ++o)
+                    for (int c = 0; c < 3; ++c)
+                        for (int t = 0; t < T; ++t) padded[((size_t)o * 4 + c) * T + t] = data[((size_t)o * 3 + c) * T + t];
+                void* stage4 = nullptr;
+                err = hipMalloc(&stage4, padded.size() * sizeof(float));
+                if (err == hipSuccess) err = hipMemcpy(stage4, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice);
+                if (err == hipSuccess) err = launch_pack_conv_weight((const float*)stage4, *e.dst, cout, 4, k, k, stream_);
+                if (err == hipSuccess) err = hipStreamSynchronize(stream_);
+                if (stage4) (void)hipFree(stage4);
+            } else if (e.kind == 0) {
                 const int cout = (int)e.dims[0], cin = (int)e.dims[1], k = (int)e.dims[2];
                 if (!(cin % 32 == 0 || (cin < 32 && cin % 4 == 0))) {
                     (void)hipFree(stage);
@@ -431,20 +475,20 @@ void Engine::set_weight(const char* name, const float* data, int ndim, const int
 }
 
 void Engine::finalize_weights() {
-    int clip_total = 0, clip_set = 0;
-    const WeightEntry* clip_missing = nullptr;
+    int total[3] = {0, 0, 0}, set[3] = {0, 0, 0};
+    const WeightEntry* missing[3] = {nullptr, nullptr, nullptr};
     for (auto& e : entries_) {
-        if (e.group == 1) {
-            ++clip_total;
-            if (e.set) ++clip_set;
-            else if (!clip_missing) clip_missing = &e;
-        } else if (!e.set) {
-            throw Error(SDMI_ERR_WEIGHTS, "finalize_weights: tensor '" + e.name + "' was never set");
-        }
+        ++total[e.group];
+        if (e.set) ++set[e.group];
+        else if (!missing[e.group]) missing[e.group] = &e;
     }
-    if (clip_set && clip_missing)
-        throw Error(SDMI_ERR_WEIGHTS, "finalize_weights: CLIP weights are partially set; missing '" + clip_missing->name + "'");
-    clip_ready_ = clip_total > 0 && clip_set == clip_total;
+    if (missing[0]) throw Error(SDMI_ERR_WEIGHTS, "finalize_weights: tensor '" + missing[0]->name + "' was never set");
+    static const char* const kGroupName[3] = {"", "CLIP", "VAE encoder"};
+    for (int g = 1; g < 3; ++g)
+        if (set[g] && missing[g])
+            throw Error(SDMI_ERR_WEIGHTS, std::string("finalize_weights: ") + kGroupName[g] + " weights are partially set; missing '" + missing[g]->name + "'");
+    clip_ready_ = total[1] > 0 && set[1] == total[1];
+    enc_ready_ = total[2] > 0 && set[2] == total[2];
     finalized_ = true;
 }
 
@@ -477,8 +521,9 @@ void Engine::load_weights_dir(const char* dir) {
     if (!dir) throw Error(SDMI_ERR_INVALID, "load_weights_dir: null path");
     // the CLIP subtree is read when it exists (load_stable_diffusion always has it, stablediffusion/load.rs:24)
     const bool have_clip = std::ifstream(std::string(dir) + "/clip/token_embedding/weight.npy").good();
+    const bool have_enc = std::ifstream(std::string(dir) + "/autoencoder/encoder/conv_in/weight.npy").good();
     for (auto& e : entries_) {
-        if (e.group == 1 && !have_clip) continue;
+        if ((e.group == 1 && !have_clip) || (e.group == 2 && !have_enc)) continue;
         const std::string path = std::string(dir) + "/" + e.name + ".npy";
         std::vector<float> raw = read_npy_f32(path);
         if ((int)raw.size() < e.ndim) throw Error(SDMI_ERR_WEIGHTS, "truncated tensor file " + path);
@@ -672,11 +717,14 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
 }
 
 void Engine::conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, const float* rowvec, int rowvec_stride,
-                  const float* resid) {
+                  const float* resid, bool pad_br) {
     if (x.c != w.cin) throw Error(SDMI_ERR_INVALID, "conv: input channels mismatch");
-    const int pad = w.k == 3 ? 1 : 0;
+    // pad_br: rows / columns past the bottom / right edge read as zero through the kernels' range check, so the
+    // asymmetric padding is pad = 0 plus one more output row / column than a symmetric pad-0 conv has
+    const int pad = pad_br ? 0 : (w.k == 3 ? 1 : 0);
     const int hin = x.h << ups, win = x.w << ups;
-    const int ho = (hin + 2 * pad - w.k) / stride + 1, wo = (win + 2 * pad - w.k) / stride + 1;
+    const int extra = pad_br ? 1 : 0;
+    const int ho = (hin + 2 * pad + extra - w.k) / stride + 1, wo = (win + 2 * pad + extra - w.k) / stride + 1;
     if (y.n != x.n || y.h != ho || y.w != wo || y.c != w.cout) throw Error(SDMI_ERR_INVALID, "conv: output shape mismatch");
     ConvGemm p{};
     p.A = x.p; p.Bt = w.bt; p.C = y.p; p.bias = w.bias; p.rowvec = rowvec; p.resid = resid;
@@ -1120,6 +1168,58 @@ void Engine::decode_one(const float* z_nhwc, int n, Act& img) {
     release(x);
     conv(dec_conv_out_, gn, img, 1, 0, nullptr, 0, nullptr);
     release(gn);
+}
+
+// Autoencoder::encode_image (autoencoder/mod.rs:60-66): Encoder::forward (:133-144) -> quant_conv -> channels 0..3
+// (the posterior mean; the reference does not sample).  One image at a time, like the decoder.
+void Engine::encode_image_dev(const float* img_nchw, int n, float* latent_nchw) {
+    if (!finalized_) throw Error(SDMI_ERR_STATE, "weights not finalized");
+    if (!enc_ready_) throw Error(SDMI_ERR_STATE, "VAE encoder weights are not loaded (autoencoder/encoder/..., autoencoder/quant_conv)");
+    if (n <= 0) throw Error(SDMI_ERR_INVALID, "encode_image: n must be positive");
+    const int H = 8 * cfg_.latent_h, W = 8 * cfg_.latent_w;
+    const size_t img_elems = (size_t)3 * H * W, lat_elems = (size_t)4 * cfg_.latent_h * cfg_.latent_w;
+    for (int i = 0; i < n; ++i) {
+        Act rgb = new_act(1, H, W, 4, /*dt=*/0);
+        SDMI_HIP(launch_nchw3_to_nhwc4(img_nchw + i * img_elems, rgb.p, 1, H, W, stream_));
+        count_kernel();
+        Act x = new_act(1, H, W, enc_conv_in_.cout);
+        conv(enc_conv_in_, rgb, x, 1, 0, nullptr, 0, nullptr);
+        release(rgb);
+        for (int bi = 0; bi < 4; ++bi) {  // EncoderBlock::forward (:257-265)
+            const EncBlockW& b = enc_blocks_[bi];
+            for (int r = 0; r < 2; ++r) {
+                Act y = new_act(x.n, x.h, x.w, b.cout);
+                res_block(b.res[r], x, y, 0);
+                release(x);
+                x = y;
+            }
+            if (b.has_down) {
+                Act y = new_act(x.n, x.h / 2, x.w / 2, b.cout);
+                conv(b.down, x, y, 2, 0, nullptr, 0, nullptr, /*pad_br=*/true);
+                release(x);
+                x = y;
+            }
+        }
+        {   // Mid (:457-462)
+            Act a = new_act(x.n, x.h, x.w, x.c); res_block(enc_mid1_, x, a, 0); release(x);
+            Act b = new_act(a.n, a.h, a.w, a.c); vae_attn(enc_attn_, a, b); release(a);
+            Act c = new_act(b.n, b.h, b.w, b.c); res_block(enc_mid2_, b, c, 0); release(b);
+            x = c;
+        }
+        Act gn = new_act(x.n, x.h, x.w, x.c);
+        group_norm(enc_norm_out_, x, gn, true);
+        release(x);
+        Act m8 = new_act(gn.n, gn.h, gn.w, 8, /*dt=*/0);   // moments stay fp32 in both precisions
+        conv(enc_conv_out_, gn, m8, 1, 0, nullptr, 0, nullptr);
+        release(gn);
+        Act q8 = new_act(m8.n, m8.h, m8.w, 8, /*dt=*/0);
+        conv(quant_conv_, m8, q8, 1, 0, nullptr, 0, nullptr);
+        release(m8);
+        // latent.slice([0..n, 0..4]): the first 4 of the 8 channels, NHWC8 -> NCHW4
+        SDMI_HIP(launch_nhwc_to_nchw_slice(q8.p, latent_nchw + i * lat_elems, 1, 8, 4, q8.h, q8.w, stream_));
+        count_kernel();
+        release(q8);
+    }
 }
 
 // in_scale = 1/0.18215 for latent_to_image (stablediffusion/mod.rs:71), 1 for decode_latent.

@@ -95,7 +95,7 @@ struct WeightEntry {
     int64_t dims[4];
     float** dst;  // where the device pointer lives (null for alphas)
     int wdt = 0;  // storage type of the packed weight: 0 fp32, 1 bf16
-    int group = 0;  // 0: hot path (required); 1: CLIP text encoder (optional as a whole)
+    int group = 0;  // 0: hot path (required); 1: CLIP text encoder, 2: VAE encoder (each optional as a whole)
     bool set = false;
 };
 
@@ -117,6 +117,8 @@ public:
     // CLIP::forward (clip/mod.rs:56-75): int32 tokens [n, T] on the device -> [n, T, ctx_dim] fp32 (both precisions)
     void clip_forward_dev(const int32_t* tokens, int n, int T, float* out);
     bool clip_ready() const { return clip_ready_; }
+    // Autoencoder::encode_image (autoencoder/mod.rs:60-66): img [n,3,8h,8w] NCHW -> latent mean [n,4,h,w] NCHW (device pointers)
+    void encode_image_dev(const float* img_nchw, int n, float* latent_nchw);
     void sample_latent_dev(const float* context, int n, int T, const float* uncond, int Tu, double scale,
                            size_t n_steps, const float* init_latent, float* latent_out);
     void decode_latent_dev(const float* latent_nchw, int n, float in_scale, float* img_nchw, uint8_t* rgb_u8);
@@ -169,8 +171,9 @@ private:
     // primitive ops on device activations (NHWC)
     Act new_act(int n, int h, int w, int c, int dt = -1);  // dt -1: the engine's activation type
     void release(Act& a);
+    // pad_br: zero padding on the bottom / right only (PaddingCfg::new(0, 1, 0, 1), the VAE encoder's downsampler)
     void conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, const float* rowvec, int rowvec_stride,
-              const float* resid);
+              const float* resid, bool pad_br = false);
     void gemm(const float* A, int a_rows, const float* bt, const float* bias, int cin, int cout, float* C, int ldc,
               const float* resid, int ldr, int dt = -1, int out_mode = 0);
     void launch_gemm(ConvGemm& p, int in_dt, int force_cfg = -1, int force_splits = 0);
@@ -252,6 +255,14 @@ private:
     std::vector<ClipBlockW> clip_blocks_;
     NormW clip_ln_;
     bool clip_ready_ = false;
+    // VAE encoder (optional weight group)
+    struct EncBlockW { ResW res[2]; ConvW down; bool has_down = false; int cin = 0, cout = 0; };
+    ConvW enc_conv_in_, enc_conv_out_, quant_conv_;
+    EncBlockW enc_blocks_[4];
+    ResW enc_mid1_, enc_mid2_;
+    VaeAttnW enc_attn_;
+    NormW enc_norm_out_;
+    bool enc_ready_ = false;
 
     // per-call UNet state
     struct UNetState {

@@ -50,6 +50,19 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __rest
     }
 }
 
+// first c_out of c_src channels: NHWC [n,h,w,c_src] -> NCHW [n,c_out,h,w]
+__global__ void nhwc_to_nchw_slice_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int c_src, int c_out,
+                                          long long hw) {
+    const long long total = (long long)n * c_out * hw;
+    GRID_STRIDE(i, total) {
+        const long long p = i % hw;
+        const long long bc = i / hw;
+        const int ch = (int)(bc % c_out);
+        const long long b = bc / c_out;
+        dst[i] = src[(b * hw + p) * c_src + ch];
+    }
+}
+
 __global__ void concat_channels_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                        float* __restrict__ dst, long long rows, int ca4, int cb4) {
     const int ct4 = ca4 + cb4;
@@ -84,6 +97,15 @@ __global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, 
     GRID_STRIDE(i, n) {
         const float v = x[i];
         y[i] = v * (1.0f / (1.0f + expf(-v)));
+    }
+}
+
+// RGB image NCHW [n,3,h,w] -> NHWC with a zero 4th channel [n,h,w,4] (the VAE encoder's conv_in runs with Cin = 4)
+__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, long long hw) {
+    GRID_STRIDE(i, (long long)n * hw) {
+        const long long b = i / hw, p = i - b * hw;
+        const float* s = src + b * 3 * hw + p;
+        reinterpret_cast<float4*>(dst)[i] = make_float4(s[0], s[hw], s[2 * hw], 0.f);
     }
 }
 
@@ -208,6 +230,12 @@ hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks_for(total)), dim3(256), 0, s, src, dst, n, c, h, w);
     return hipGetLastError();
 }
+hipError_t launch_nhwc_to_nchw_slice(const float* src, float* dst, int n, int c_src, int c_out, int h, int w, hipStream_t s) {
+    if (c_out > c_src) return hipErrorInvalidValue;
+    const long long hw = (long long)h * w;
+    hipLaunchKernelGGL(nhwc_to_nchw_slice_kernel, dim3(blocks_for((long long)n * c_out * hw)), dim3(256), 0, s, src, dst, n, c_src, c_out, hw);
+    return hipGetLastError();
+}
 hipError_t launch_concat_channels(const float* a, const float* b, float* dst, long long rows, int ca, int cb,
                                   hipStream_t s) {
     if ((ca & 3) || (cb & 3)) return hipErrorInvalidValue;
@@ -224,6 +252,11 @@ hipError_t launch_geglu(const float* proj, float* out, long long rows, int hidde
 }
 hipError_t launch_silu(const float* x, float* y, long long n, hipStream_t s) {
     hipLaunchKernelGGL(silu_kernel, dim3(blocks_for(n)), dim3(256), 0, s, x, y, n);
+    return hipGetLastError();
+}
+hipError_t launch_nchw3_to_nhwc4(const float* src, float* dst, int n, int h, int w, hipStream_t s) {
+    const long long hw = (long long)h * w;
+    hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(blocks_for((long long)n * hw)), dim3(256), 0, s, src, dst, n, hw);
     return hipGetLastError();
 }
 hipError_t launch_quick_gelu(float* x, long long n, hipStream_t s) {

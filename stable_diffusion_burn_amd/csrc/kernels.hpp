@@ -99,6 +99,8 @@ hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h
 hipError_t launch_concat_channels(const float* a, const float* b, float* dst, long long rows, int ca, int cb, hipStream_t s);
 hipError_t launch_geglu(const float* proj, float* out, long long rows, int hidden, hipStream_t s);
 hipError_t launch_silu(const float* x, float* y, long long n, hipStream_t s);
+hipError_t launch_nhwc_to_nchw_slice(const float* src, float* dst, int n, int c_src, int c_out, int h, int w, hipStream_t s);
+hipError_t launch_nchw3_to_nhwc4(const float* src, float* dst, int n, int h, int w, hipStream_t s);
 // CLIP text encoder pieces (clip/mod.rs): QuickGELU in place, token + position embedding, decoder mask
 hipError_t launch_quick_gelu(float* x, long long n, hipStream_t s);
 hipError_t launch_clip_embed(const int* tokens, const float* tok_table, const float* pos_table, float* out, int n, int T, int C,

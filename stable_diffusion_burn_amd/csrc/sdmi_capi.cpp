@@ -250,6 +250,20 @@ int sdmi_context(sdmi_ctx* ctx, const sdmi_tokenizer* tok, const char* text, flo
     });
 }
 
+int sdmi_encode_image(sdmi_ctx* ctx, const float* img, int32_t n, float* latent_out) {
+    return guarded([&] {
+        Engine& e = eng(ctx);
+        if (n <= 0) throw Error(SDMI_ERR_INVALID, "encode_image: n must be positive");
+        const size_t lat = (size_t)n * 4 * e.latent_h() * e.latent_w() * sizeof(float);
+        e.begin_call();
+        DevIn di(e, img, lat * 48);   // 3 * 64 / 4
+        DevOut dout(e, latent_out, lat);
+        e.encode_image_dev(di.f(), n, dout.f());
+        e.end_call();
+        dout.fetch();
+    });
+}
+
 int sdmi_write_png(const char* path, const uint8_t* rgb, int32_t width, int32_t height) {
     return guarded([&] {
         if (!path) throw Error(SDMI_ERR_INVALID, "write_png: null path");

@@ -126,7 +126,7 @@ class StableDiffusion:
         dims = (C.c_int64 * max(1, a.ndim))(*a.shape)
         check(self._lib.sdmi_set_weight(self._ctx, name.encode(), _fp(a), a.ndim, dims))
 
-    def load_weights(self, provider, clip: bool = True) -> None:
+    def load_weights(self, provider, clip: bool = True, vae_encoder: bool = True) -> None:
         """Pull every tensor from `provider.get(name, shape, kind, fan_in)`
         (synthetic.SyntheticWeights) -- the counterpart of load_stable_diffusion
         (stablediffusion/load.rs:16-33) for seeded synthetic parameters.  `clip=False` leaves the
@@ -135,6 +135,8 @@ class StableDiffusion:
         shapes = dict(specs)
         for name, shape in specs:
             if name.startswith("clip/") and not clip:
+                continue
+            if (name.startswith("autoencoder/encoder/") or name.startswith("autoencoder/quant_conv/")) and not vae_encoder:
                 continue
             if name == "alphas_cumprod":
                 from .synthetic import alphas_cumprod
@@ -419,10 +421,26 @@ class SimpleTokenizer:
 
 
 class Autoencoder:
-    """Decoder half of `Autoencoder<B>` (src/model/autoencoder/mod.rs:47-71)."""
+    """`Autoencoder<B>` (src/model/autoencoder/mod.rs:47-71): decode_latent on the hot path; encode_image / forward
+    with the optional encoder weights."""
 
     def __init__(self, sd: StableDiffusion):
         self._sd = sd
+
+    def encode_image(self, x) -> np.ndarray:
+        """autoencoder/mod.rs:60-66: image [n,3,8h,8w] -> latent [n,4,h,w] (first 4 quant_conv channels)."""
+        sd = self._sd
+        h, w = sd.config.latent_h, sd.config.latent_w
+        x = _f32(x, name="x")
+        if x.ndim != 4 or x.shape[1:] != (3, 8 * h, 8 * w):
+            raise ValueError(f"x must be [n,3,{8 * h},{8 * w}], got {x.shape}")
+        out = np.empty((x.shape[0], 4, h, w), dtype=np.float32)
+        check(sd._lib.sdmi_encode_image(sd._ctx, _fp(x), x.shape[0], _fp(out)))
+        return out
+
+    def forward(self, x) -> np.ndarray:
+        """autoencoder/mod.rs:56-58: decode_latent(encode_image(x))."""
+        return self.decode_latent(self.encode_image(x))
 
     def decode_latent(self, latent) -> np.ndarray:
         sd = self._sd

@@ -117,6 +117,8 @@ def write_dump_tree(dump_dir, specs, get_tensor, alphas_cumprod, n_head: int = 8
             write_embedding(root / parent, w)                                   # python/clip.py:32-35
         elif parent.startswith("clip/") and w.ndim == 1:
             write_layer_norm(root / parent, w, b)                               # attn_ln / mlp_ln / layer_norm
+        elif w.ndim == 4 and parent.endswith("/downsampler/conv"):
+            write_conv2d(root / parent, w, b, stride=2, padding=0)              # save_padded_conv2d (python/save.py:70-77)
         elif w.ndim == 4:
             k = w.shape[2]
             stride = 2 if parent.rsplit("/", 1)[1] in ("d1", "d2", "d3") else 1   # Downsample (unet/mod.rs:408-427)
@@ -140,3 +142,5 @@ def write_dump_tree(dump_dir, specs, get_tensor, alphas_cumprod, n_head: int = 8
     _save(root / "alphas_cumprod.npy", encode_tensor(a))
     if any(n.startswith("autoencoder/decoder/blocks/") for n in shapes):
         _save(root / "autoencoder/decoder/n_block.npy", encode_scalar(4))           # autoencoder/load.rs:139
+    if any(n.startswith("autoencoder/encoder/blocks/") for n in shapes):
+        _save(root / "autoencoder/encoder/n_block.npy", encode_scalar(4))           # autoencoder/load.rs:163
