@@ -90,7 +90,7 @@ int sdmi_default_config(sdmi_config* cfg) {
     return SDMI_OK;
 }
 
-const char* sdmi_version(void) { return "sdmi 0.1 gfx950 fp32 (MI355X-native SD v1.4 sampling path)"; }
+const char* sdmi_version(void) { return "sdmi 0.2 gfx950 fp32+bf16 (MI355X-native SD v1.4: CLIP, UNet DDIM/CFG loop, VAE)"; }
 
 const char* sdmi_last_error(void) { return g_last_error.c_str(); }
 
