@@ -666,7 +666,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     auto it = table.find(key);
     if (it != table.end() && (it->second.cfg < 100 || opt_gemm_bf16x_)) tc = it->second;
     else tc = in_dt ? choose_tile_bf16(p.M, p.N, p.kt_total) : choose_tile(p.M, p.N, p.kt_total);
-    if (opt_force_tile_ >= 0) tc.cfg = opt_force_tile_;
+    if (opt_force_tile_ >= 0 && (opt_force_tile_ < 100 || in_dt)) tc.cfg = opt_force_tile_;  // 100+: bf16 GEMMs only
     if (opt_force_splits_ > 0) tc.splits = opt_force_splits_;
     if (force_cfg >= 0) tc.cfg = force_cfg;
     if (force_splits > 0) tc.splits = force_splits;

@@ -163,31 +163,126 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
         __syncthreads();                    // k tile t is in LDS; every wave is done with stage cur ^ 1
         if (t + 1 < n_t) issue(cur ^ 1);
         const unsigned char* stage = smem_x + cur * STAGE;
+        // Fragment reads run one group of rows ahead of the MFMAs that use them: the reads of rows [g+1] are issued
+        // before the MFMAs of rows [g], so the compiler's counted lgkmcnt waits find the data already there
+        // (one ds_read_b128 per 5 MFMAs; issuing them two at a time right before use stalls every 10 MFMAs).
+        constexpr int GM = (MI >= 8) ? 4 : 2;    // rows per group
+        constexpr int NG = MI / GM;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int fo = kk ? fr_off1 : fr_off0;
             u32x4 fb[NI];
+            u32x4 fa[2][GM];
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) fb[ni] = *reinterpret_cast<const u32x4*>(stage + b_base + ni * 2048 + fo);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const u32x4 fa = *reinterpret_cast<const u32x4*>(stage + a_base + mi * 2048 + fo);
+            for (int i = 0; i < GM; ++i) fa[0][i] = *reinterpret_cast<const u32x4*>(stage + a_base + i * 2048 + fo);
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[ni]), __builtin_bit_cast(bf16x8, fa),
-                                                                          acc[mi][ni], 0, 0, 0);
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) {
+#pragma unroll
+                    for (int i = 0; i < GM; ++i)
+                        fa[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(stage + a_base + ((g + 1) * GM + i) * 2048 + fo);
+                }
+#pragma unroll
+                for (int i = 0; i < GM; ++i)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[g * GM + i][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[ni]),
+                                                                                  __builtin_bit_cast(bf16x8, fa[g & 1][i]),
+                                                                                  acc[g * GM + i][ni], 0, 0, 0);
             }
+            // pin the issue order the source spells out (hipcc otherwise sinks each read next to its first use to save
+            // registers): operand B and the first row group, then one read of the next group per row of MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, NI + GM, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int i = 0; i < GM; ++i) {
+                    if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NI, 0);
+                }
         }
     }
 
     // ---- epilogue: fp32 bias + time-embedding row + (bf16) residual, then bf16 or fp32 store ----------
+    // A lane holds 4 consecutive channels of 16 different rows, so storing straight from the accumulators issues
+    // 8-byte pieces at a row stride (measured: 38k cycles for a 256x320 tile, store-issue bound).  Each wave instead
+    // transposes one 16-row fragment group at a time through its own LDS scratch (the stages are free now) and
+    // writes whole 160-byte row segments with 16-byte lanes; the residual is read the same way.
     const bool split = p.splits > 1;
-    const bool vec_ok = ((p.N & 3) == 0) && (((split ? p.N : p.ldc) & 3) == 0) && ((p.ldr & 3) == 0 || !p.resid);
     const bool out_f32 = split || p.out_mode == 1;
     float* Cf = split ? (p.C + (long long)z * p.slab_stride) : p.C;
     unsigned short* Ch = reinterpret_cast<unsigned short*>(p.C);
     const unsigned short* Rh = reinterpret_cast<const unsigned short*>(p.resid);
     const int ldc = split ? p.N : p.ldc;
+    const bool has_resid = !split && p.resid;
+    const bool vec_ok = ((p.N & 7) == 0) && ((ldc & 7) == 0) && ((p.ldr & 7) == 0 || !has_resid);
+    constexpr int WNC = 16 * NI;        // columns of a wave tile
+    constexpr int LDSW = WNC + 4;       // scratch row stride in floats (336 B for NI = 5: 16-byte aligned, rows on distinct banks)
+    if (vec_ok) {
+        __syncthreads();                // every wave is done with the last k tile
+        float* scr = reinterpret_cast<float*>(smem_x + wave * (16 * LDSW * 4));
+        const int nw0 = n0 + wn * WNC;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int mrow0 = m0 + (wm * MI + mi) * 16;
+            {
+                const int m = mrow0 + c15;
+                const int smp = (m < p.M ? m : 0) / HoWo;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int n = nw0 + ni * 16 + g4 * 4;
+                    f32x4 v = acc[mi][ni];
+                    if (!split && n < p.N) {
+                        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                        if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)smp * p.rowvec_stride + n);
+                    }
+                    *reinterpret_cast<f32x4*>(scr + c15 * LDSW + ni * 16 + g4 * 4) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (!out_f32) {
+                constexpr int CH = WNC / 8;   // 16-byte bf16 chunks per row
+#pragma unroll
+                for (int q0 = 0; q0 < 16 * CH; q0 += 64) {
+                    const int q = q0 + lane;
+                    const int row = q / CH, c8 = q - row * CH;
+                    const int m = mrow0 + row, n = nw0 + c8 * 8;
+                    if (q < 16 * CH && m < p.M && n < p.N) {
+                        f32x4 lo = *reinterpret_cast<const f32x4*>(scr + row * LDSW + c8 * 8);
+                        f32x4 hi = *reinterpret_cast<const f32x4*>(scr + row * LDSW + c8 * 8 + 4);
+                        if (has_resid) {
+                            const u32x4 r = *reinterpret_cast<const u32x4*>(Rh + (long long)m * p.ldr + n);
+                            lo[0] += xbf16_lo(r[0]); lo[1] += xbf16_hi(r[0]); lo[2] += xbf16_lo(r[1]); lo[3] += xbf16_hi(r[1]);
+                            hi[0] += xbf16_lo(r[2]); hi[1] += xbf16_hi(r[2]); hi[2] += xbf16_lo(r[3]); hi[3] += xbf16_hi(r[3]);
+                        }
+                        const u32x4 o = {xpack_bf16x2(lo[0], lo[1]), xpack_bf16x2(lo[2], lo[3]), xpack_bf16x2(hi[0], hi[1]), xpack_bf16x2(hi[2], hi[3])};
+                        *reinterpret_cast<u32x4*>(Ch + (long long)m * ldc + n) = o;
+                    }
+                }
+            } else {
+                constexpr int CH = WNC / 4;   // 16-byte fp32 chunks per row
+#pragma unroll
+                for (int q0 = 0; q0 < 16 * CH; q0 += 64) {
+                    const int q = q0 + lane;
+                    const int row = q / CH, c4 = q - row * CH;
+                    const int m = mrow0 + row, n = nw0 + c4 * 4;
+                    if (q < 16 * CH && m < p.M && n < p.N) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * LDSW + c4 * 4);
+                        if (has_resid) {
+                            const u32x2 r = *reinterpret_cast<const u32x2*>(Rh + (long long)m * p.ldr + n);
+                            v[0] += xbf16_lo(r[0]); v[1] += xbf16_hi(r[0]); v[2] += xbf16_lo(r[1]); v[3] += xbf16_hi(r[1]);
+                        }
+                        *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    // odd strides / N not a multiple of 8: element-wise stores straight from the accumulators
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + (wm * MI + mi) * 16 + c15;
@@ -197,35 +292,18 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
         for (int ni = 0; ni < NI; ++ni) {
             const int n = n0 + (wn * NI + ni) * 16 + g4 * 4;
             if (n >= p.N) continue;
-            f32x4 v = acc[mi][ni];
-            if (vec_ok) {
-                if (!split) {
-                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                    if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)smp * p.rowvec_stride + n);
-                    if (p.resid) {
-                        const u32x2 r = *reinterpret_cast<const u32x2*>(Rh + (long long)m * p.ldr + n);
-                        v[0] += xbf16_lo(r[0]); v[1] += xbf16_hi(r[0]); v[2] += xbf16_lo(r[1]); v[3] += xbf16_hi(r[1]);
-                    }
-                }
-                if (out_f32) {
-                    *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;
-                } else {
-                    u32x2 o = {xpack_bf16x2(v[0], v[1]), xpack_bf16x2(v[2], v[3])};
-                    *reinterpret_cast<u32x2*>(Ch + (long long)m * ldc + n) = o;
-                }
-            } else {
+            const f32x4 v = acc[mi][ni];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (n + r < p.N) {
-                        float s = v[r];
-                        if (!split) {
-                            if (p.bias) s += p.bias[n + r];
-                            if (p.rowvec) s += p.rowvec[(long long)smp * p.rowvec_stride + n + r];
-                            if (p.resid) s += __uint_as_float((unsigned)Rh[(long long)m * p.ldr + n + r] << 16);
-                        }
-                        if (out_f32) Cf[(long long)m * ldc + n + r] = s;
-                        else Ch[(long long)m * ldc + n + r] = (unsigned short)xf32_to_bf16_bits(s);
+            for (int r = 0; r < 4; ++r) {
+                if (n + r < p.N) {
+                    float sv = v[r];
+                    if (!split) {
+                        if (p.bias) sv += p.bias[n + r];
+                        if (p.rowvec) sv += p.rowvec[(long long)smp * p.rowvec_stride + n + r];
+                        if (p.resid) sv += __uint_as_float((unsigned)Rh[(long long)m * p.ldr + n + r] << 16);
                     }
+                    if (out_f32) Cf[(long long)m * ldc + n + r] = sv;
+                    else Ch[(long long)m * ldc + n + r] = (unsigned short)xf32_to_bf16_bits(sv);
                 }
             }
         }

@@ -222,6 +222,24 @@ def test_unet_forward_bf16(sd16):
     assert np.isfinite(got).all() and r < 2e-2
 
 
+@pytest.mark.parametrize("tile", [100, 103])
+def test_unet_forward_bf16_large_tiles_forced(sd16, tile):
+    """every bf16 GEMM of the UNet on a k_gemm_bf16x.hip tile: covers its residual / time-embedding / split-K epilogues."""
+    lat = np.stack([syn.initial_latent(i, 8, 8) for i in range(2)])
+    ctx = np.stack([syn.cond_context(i, 77, 768) for i in range(2)])
+    base = sd16.unet.forward(lat, [500], ctx)
+    try:
+        sd16.set_option("gemm_tile", tile)
+        got = sd16.unet.forward(lat, [500], ctx)
+    finally:
+        sd16.set_option("gemm_tile", "auto")
+    o64 = O.UNetOracle(syn.SyntheticWeights(), DIMS16, torch.float64)
+    ref = o64.forward(torch.from_numpy(lat), 500, torch.from_numpy(ctx)).numpy()
+    r, r0 = _rel_rms(got, ref), _rel_rms(base, ref)
+    print(f"bf16 UNet forward, tile {tile} forced: rel-RMS {r:.3e} (auto tiles {r0:.3e})")
+    assert np.isfinite(got).all() and r < 2e-2
+
+
 def test_sample_image_bf16(sd16):
     lat = syn.initial_latent(0, 8, 8)[None]
     ctx = syn.cond_context(0, 77, 768)[None]
