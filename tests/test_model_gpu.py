@@ -66,7 +66,8 @@ def test_unet_forward_batch_independent(sd_tiny, tiny_dims):
     assert np.abs(both[1:2] - one).max() <= 1e-5
 
 
-@pytest.mark.parametrize("n_steps,scale,T,Tu", [(1, 1.0, 7, 7), (4, 7.5, 7, 2), (5, 7.5, 3, 6)])
+# (3, ..): 1000 / 3 = 333 -> t = 999, 666, 333, 0: FOUR iterations (quirk Q5, step_by); (50, ..): configs[2]'s schedule
+@pytest.mark.parametrize("n_steps,scale,T,Tu", [(1, 1.0, 7, 7), (4, 7.5, 7, 2), (5, 7.5, 3, 6), (3, 7.5, 7, 2), (50, 7.5, 7, 2)])
 def test_sample_latent(sd_tiny, synth, tiny_dims, n_steps, scale, T, Tu):
     """sample_latent (stablediffusion/mod.rs:102-160): DDIM + CFG, Tc != Tu, config-1 style 1 step."""
     d = tiny_dims
