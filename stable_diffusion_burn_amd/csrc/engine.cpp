@@ -567,6 +567,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "attn_variant") opt_attn_variant_ = std::stoi(value);
     else if (key == "attn_bf16") opt_attn_bf16_ = std::stoi(value);
     else if (key == "gemm_bf16x") opt_gemm_bf16x_ = std::stoi(value);
+    else if (key == "gemm_x32") opt_gemm_x32_ = std::stoi(value);
     else if (key == "record_shapes") { record_shapes_ = std::stoi(value) != 0; if (record_shapes_) shape_counts_.clear(); }
     else if (key == "dump_shapes") {
         std::ofstream f(value);
@@ -582,7 +583,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
         const bool b16 = key == "tune_bf16";
         TileChoice tc{0, 1};
         if (std::sscanf(value.c_str() + eq + 1, "%d,%d", &tc.cfg, &tc.splits) != 2 || tc.cfg < 0 || tc.splits < 1 ||
-            !(tc.cfg < kNumGemmTiles || (b16 && tc.cfg >= 100 && tc.cfg < 100 + kNumGemmTilesX)))
+            !(tc.cfg < kNumGemmTiles || (tc.cfg >= 100 && tc.cfg < 100 + kNumGemmTilesX)))
             throw Error(SDMI_ERR_INVALID, "tune: bad value");
         (b16 ? tuned_bf16_ : tuned_)[value.substr(0, eq)] = tc;
     } else if (key == "tune_clear") { tuned_.clear(); tuned_bf16_.clear(); }
@@ -594,7 +595,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
 // measured entries ("tune" option, see tools/autotune.py).  The K-reduction order
 // depends only on (M,N,K), so a sample's result is independent of where it sits
 // in the batch only for equal M; see DESIGN.md "Determinism".
-TileChoice Engine::choose_tile(int M, int N, int kt_total) const {
+TileChoice Engine::choose_tile(int M, int N, int kt_total, bool allow_x) const {
     static const double eff[kNumGemmTiles] = {0.85, 0.75, 0.60, 0.90, 0.75, 0.85, 0.75, 0.85, 0.65, 0.75};
     static const int split_opts[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
     const int n_cu = 256;
@@ -613,6 +614,24 @@ TileChoice Engine::choose_tile(int M, int N, int kt_total) const {
             t += 3000.0 * per_cu;  // prologue / epilogue per workgroup
             if (s > 1) t += 8000.0 + (double)M * N * 4.0 * (s + 1) / (5.0e12 / 2.4e9);  // reduce launch + slab traffic
             if (t < best) { best = t; bc = {c, s}; }
+        }
+    }
+    if (allow_x && opt_gemm_x32_) {
+        // k_gemm2x.hip: 8 waves, one workgroup per CU; ~0.9 of the matrix rate in the k loop, but the DMA prologue and the
+        // output tile's store are not hidden by a neighbour
+        static const double eff_x[kNumGemmTilesX] = {0.90, 0.90, 0.88, 0.90};
+        for (int c = 0; c < kNumGemmTilesX; ++c) {
+            const int bm = gemm_tile_info_x(c).bm, bn = gemm_tile_info_x(c).bn;
+            const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+            for (int s : split_opts) {
+                if (s > 1 && kt_total / s < 4) break;
+                const int kt_per = (kt_total + s - 1) / s;
+                const long long wgs = tiles * ((kt_total + kt_per - 1) / kt_per);
+                const double per_cu = (double)((wgs + n_cu - 1) / n_cu);
+                double t = per_cu * ((double)bm * bn * kt_per * 64.0 / 256.0 / eff_x[c] + 8000.0 + bm * bn * 4.0 / 10.0);
+                if (s > 1) t += 8000.0 + (double)M * N * 4.0 * (s + 1) / (5.0e12 / 2.4e9);
+                if (t < best) { best = t; bc = {100 + c, s}; }
+            }
         }
     }
     return bc;
@@ -664,9 +683,10 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     std::snprintf(key, sizeof key, "%d,%d,%d", p.M, p.N, p.K);
     const auto& table = in_dt ? tuned_bf16_ : tuned_;  // measured per storage type (tuning/gfx950_{fp32,bf16}.txt)
     auto it = table.find(key);
-    if (it != table.end() && (it->second.cfg < 100 || opt_gemm_bf16x_)) tc = it->second;
-    else tc = in_dt ? choose_tile_bf16(p.M, p.N, p.kt_total) : choose_tile(p.M, p.N, p.kt_total);
-    if (opt_force_tile_ >= 0 && (opt_force_tile_ < 100 || in_dt)) tc.cfg = opt_force_tile_;  // 100+: bf16 GEMMs only
+    const bool x32_ok = !in_dt && p.CS == 32 && p.Cin % 32 == 0 && p.out_mode == 0;   // what k_gemm2x.hip handles
+    if (it != table.end() && (it->second.cfg < 100 || (in_dt ? opt_gemm_bf16x_ != 0 : (opt_gemm_x32_ != 0 && x32_ok)))) tc = it->second;
+    else tc = in_dt ? choose_tile_bf16(p.M, p.N, p.kt_total) : choose_tile(p.M, p.N, p.kt_total, x32_ok);
+    if (opt_force_tile_ >= 0 && (opt_force_tile_ < 100 || in_dt || x32_ok)) tc.cfg = opt_force_tile_;  // 100+: large-tile kernels, where applicable
     if (opt_force_splits_ > 0) tc.splits = opt_force_splits_;
     if (force_cfg >= 0) tc.cfg = force_cfg;
     if (force_splits > 0) tc.splits = force_splits;
@@ -683,11 +703,12 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     if (in_dt && (a_ext >= 0xFFFFFFE0ull || b_ext >= 0xFFFFFFE0ull)) throw Error(SDMI_ERR_UNSUPPORTED, "bf16 GEMM: operand larger than 4 GiB");
     const bool v2 = (opt_gemm_variant_ == 1 || p.out_mode == 2) && a_ext < 0xFFFFFFE0ull && b_ext < 0xFFFFFFE0ull;
     p.zero_page = zero_page_;
-    if (tc.cfg >= 100 && (!in_dt || tc.cfg - 100 >= kNumGemmTilesX)) throw Error(SDMI_ERR_INVALID, "gemm: tile cfg >= 100 is a large-tile bf16 kernel index");
+    if (tc.cfg >= 100 && (tc.cfg - 100 >= kNumGemmTilesX || (!in_dt && !x32_ok))) throw Error(SDMI_ERR_INVALID, "gemm: large-tile kernel index out of range or not applicable to this layer");
     p.a_bytes = (unsigned)std::min<unsigned long long>(a_ext, 0xFFFFFFE0ull);
     p.b_bytes = (unsigned)std::min<unsigned long long>(b_ext, 0xFFFFFFE0ull);
     auto launch = [&](const ConvGemm& q) {
         if (in_dt && tc.cfg >= 100) return launch_conv_gemm_bf16x(q, tc.cfg - 100, stream_);
+        if (tc.cfg >= 100) return launch_conv_gemm2x(q, tc.cfg - 100, stream_);
         if (in_dt) return launch_conv_gemm_bf16(q, tc.cfg, stream_);
         return v2 ? launch_conv_gemm2(q, tc.cfg, stream_) : launch_conv_gemm(q, tc.cfg, stream_);
     };

@@ -181,7 +181,7 @@ private:
     size_t esz() const { return bf16_ ? 2 : 4; }
     // element-wise pointer advance on an activation of type dt
     static float* adv(const float* p, long long elems, int dt) { return (float*)((char*)const_cast<float*>(p) + elems * (dt ? 2 : 4)); }
-    TileChoice choose_tile(int M, int N, int kt_total) const;
+    TileChoice choose_tile(int M, int N, int kt_total, bool allow_x = false) const;   // cfg >= 100: k_gemm2x.hip tile cfg - 100
     void group_norm(const NormW& w, const Act& x, Act& y, bool silu);
     void layer_norm(const NormW& w, const float* x, long long rows, float* y, int dt = -1);
     void attention(const float* q, int ldq, long long q_bs, const float* k, int ldk, long long k_bs, const float* v,
@@ -279,6 +279,7 @@ private:
     int opt_force_splits_ = 0;
     int opt_attn_variant_ = 1;
     int opt_attn_bf16_ = 1;
+    int opt_gemm_x32_ = 1;      // precision = 0: 1 = large-tile LDS-DMA fp32 GEMM (k_gemm2x.hip) where measured / modelled faster
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
     void* zero_page_ = nullptr;
     TileChoice choose_tile_bf16(int M, int N, int kt_total) const;   // cfg >= 100: k_gemm_bf16x.hip tile cfg - 100     // precision = 1: 1 = bf16 matrix-core attention, 0 = bf16 storage widened onto the fp32 kernel  // 1: attn2_kernel, 0: attn_f32_kernel

@@ -56,6 +56,8 @@ hipError_t launch_splitk_reduce_bf16(const ConvGemm& p, const float* slabs, hipS
 constexpr int kNumGemmTilesX = 4;
 const GemmTileInfo& gemm_tile_info_x(int cfg);
 hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
+// the same structure for fp32 storage (k_gemm2x.hip; Cin % 32 == 0, fp32 output); same tile list
+hipError_t launch_conv_gemm2x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 hipError_t launch_pack_conv_weight_bf16(const float* w_oihw, void* bt, int cout, int cin, int kh, int kw, hipStream_t s);
 hipError_t launch_pack_linear_weight_bf16(const float* w_in_out, void* bt, int cin, int cout, hipStream_t s);
 // sums split-K slabs in fixed order and applies the epilogue

@@ -139,6 +139,35 @@ def test_conv2d_all_tiles(sd_ops, tile, splitk, variant):
     _check(got, ref.numpy(), f"conv tile={tile} splitk={splitk} variant={variant}")
 
 
+XCASES = [
+    # (n, cin, h, w, cout, k, stride, ups): several M tiles with a ragged last one, N tails, every conv flavour
+    (2, 128, 23, 19, 320, 3, 1, 0), (1, 64, 40, 36, 200, 3, 1, 0), (2, 192, 16, 16, 640, 1, 1, 0), (1, 128, 33, 31, 128, 3, 2, 0),
+    (1, 64, 12, 20, 384, 3, 1, 1), (1, 96, 9, 7, 100, 3, 1, 0),
+]
+
+
+@pytest.mark.parametrize("tile", [100, 101, 102, 103])
+@pytest.mark.parametrize("splitk", [1, 3])
+@pytest.mark.parametrize("case", XCASES)
+def test_conv2d_large_tiles(sd_ops, tile, splitk, case):
+    """k_gemm2x.hip: 256-row, 8-wave fp32 tiles staged by LDS-DMA (tile 100 + x)."""
+    n, cin, h, w, cout, k, stride, ups = case
+    g = _rng(4000 + tile + 7 * splitk + cin + cout)
+    x = g.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (g.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k)).astype(np.float32)
+    b = g.standard_normal(cout).astype(np.float32)
+    try:
+        sd_ops.set_option("gemm_tile", tile)
+        sd_ops.set_option("splitk", splitk)
+        got = sd_ops.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
+    finally:
+        sd_ops.set_option("gemm_tile", "auto")
+        sd_ops.set_option("splitk", 0)
+    xin = O.upsample2x(_t(x)) if ups else _t(x)
+    ref = O.conv2d(xin, (_t(wt), _t(b)), stride=stride, padding=1 if k == 3 else 0)
+    _check(got, ref.numpy(), f"conv large tile={tile} splitk={splitk} {case}")
+
+
 def test_conv2d_asymmetric_weights_not_transposed(sd_ops):
     """A = identity-like check with an asymmetric kernel: catches tap (ky,kx) swaps."""
     x = np.zeros((1, 32, 6, 6), np.float32)

@@ -89,8 +89,7 @@ def main():
     sd.set_option("gemm_variant", args.variant)
     sd.set_option("tune_clear", 1)
     tiles_all = dict(enumerate(TILES))
-    if bf16:
-        tiles_all.update({100: "256x320", 101: "256x256", 102: "256x128", 103: "128x320"})
+    tiles_all.update({100: "256x320", 101: "256x256", 102: "256x128", 103: "128x320"})   # k_gemm_bf16x.hip / k_gemm2x.hip
     if args.only:
         s = tuple(int(v) for v in args.only.split(","))
         M, N, K = mnk(s)
@@ -108,6 +107,8 @@ def main():
             bm, bn = map(int, tiles_all[cfg].split("x"))
             if bf16 and cfg < 100 and M * N > (1 << 24) and cfg in (2, 8):
                 continue   # 64-row tiles on very large GEMMs: never competitive, skip the launches
+            if cfg >= 100 and not bf16 and s[1] % 32:
+                continue   # the large-tile fp32 kernel needs Cin % 32 == 0
             tiles = -(-M // bm) * -(-N // bn)
             split_opts = [1]
             for sp in (2, 3, 4, 6, 8, 12, 16, 24, 32):
