@@ -1,7 +1,7 @@
 // kernels.hpp -- launch interface of the gfx950 HIP kernels of libsdmi.
 //
 // Layout rules (DESIGN.md "Data layout in HBM"):
-//   activations  NHWC fp32: [NB][H][W][C]  == row-major [M = NB*H*W][C]
+//   activations  NHWC fp32 (bf16 for the *_bf16 kernels): [NB][H][W][C]  == row-major [M = NB*H*W][C]
 //   conv/linear weights pre-packed "Bt": [N = Cout][K], K ordered
 //       k = (cs * T + tap) * CS + ci   with channel c = cs*CS + ci, tap = ky*KW+kx,
 //       T = KH*KW, CS = min(32, Cin)   (channel-slice outer, taps inner: the nine
