@@ -190,7 +190,7 @@ def main():
                     traffic = None
             peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
             kname = ("conv_gemm_bf16_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x32_bf16)" if bf16 else
-                     "conv_gemm2_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x4_f32)")
+                     "conv_gemm2_kernel + conv_gemm2x_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x4_f32)")
             if bf16:
                 traffic = None  # the committed PMC summary is for the fp32 kernel
             roofline = {"bound": "mfma", "kernel": kname,
