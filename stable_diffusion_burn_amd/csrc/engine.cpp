@@ -642,7 +642,7 @@ TileChoice Engine::choose_tile(int M, int N, int kt_total, bool allow_x) const {
 // ones (tools/autotune.py --precision bf16), the per-workgroup constants cover prologue DMA latency + epilogue.
 TileChoice Engine::choose_tile_bf16(int M, int N, int kt_total) const {
     static const double eff_old[kNumGemmTiles] = {0.31, 0.22, 0.16, 0.22, 0.20, 0.20, 0.22, 0.26, 0.15, 0.28};
-    static const double eff_x[kNumGemmTilesX] = {0.52, 0.44, 0.37, 0.47};
+    static const double eff_x[kNumGemmTilesX] = {0.54, 0.46, 0.38, 0.48};
     static const int split_opts[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
     const int n_cu = 256;
     double best = 1e300;
@@ -664,7 +664,7 @@ TileChoice Engine::choose_tile_bf16(int M, int N, int kt_total) const {
         for (int c = 0; c < kNumGemmTilesX; ++c) {
             // one workgroup per CU (144 KB of LDS): the DMA prologue and the output tile's store are not hidden by a neighbour
             const int bm = gemm_tile_info_x(c).bm, bn = gemm_tile_info_x(c).bn;
-            consider(100 + c, bm, bn, eff_x[c], 6000.0 + bm * bn * 2.0 / 10.0);
+            consider(100 + c, bm, bn, eff_x[c], 6000.0 + bm * bn * 2.0 / 20.0);
         }
     return bc;
 }
