@@ -218,6 +218,11 @@ int sdmi_op_linear(sdmi_ctx* ctx, const float* x, const float* weight, const flo
 /* GEGLU gate (unet/mod.rs:579-591): proj [rows,2*hidden] -> out [rows,hidden] = a*gelu_erf(gate). */
 int sdmi_op_geglu(sdmi_ctx* ctx, const float* proj, int32_t rows, int32_t hidden, float* out);
 /* timestep_embedding (unet/mod.rs:19-30): out [dim] for timestep t. */
+/* GEGLU::forward (src/model/unet/mod.rs:579-591): x [rows, cin], weight [cin, 2*hidden] (Burn Linear layout), bias
+ * [2*hidden] or NULL -> out [rows, hidden] = a * gelu(b), a | b = the halves of x W + bias.  One fused kernel when the
+ * shape allows (engine option geglu_fuse), else projection GEMM + gate kernel. */
+int sdmi_op_geglu_forward(sdmi_ctx* ctx, const float* x, const float* weight, const float* bias, int32_t rows, int32_t cin,
+                          int32_t hidden, float* out);
 int sdmi_op_timestep_embedding(sdmi_ctx* ctx, int32_t t, int32_t dim, float* out);
 
 /* ---- tuning / introspection ---------------------------------------------------- */

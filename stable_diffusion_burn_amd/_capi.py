@@ -71,6 +71,7 @@ SIGNATURES = {
     "sdmi_op_layer_norm": (C.c_int, [_CTX, _F, _F, _F, C.c_int32, C.c_int32, C.c_float, _F]),
     "sdmi_op_conv2d": (C.c_int, [_CTX, _F, _F, _F, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _F]),
     "sdmi_op_linear": (C.c_int, [_CTX, _F, _F, _F, C.c_int32, C.c_int32, C.c_int32, _F]),
+    "sdmi_op_geglu_forward": (C.c_int, [_CTX, _F, _F, _F, C.c_int32, C.c_int32, C.c_int32, _F]),
     "sdmi_op_geglu": (C.c_int, [_CTX, _F, C.c_int32, C.c_int32, _F]),
     "sdmi_op_timestep_embedding": (C.c_int, [_CTX, C.c_int32, C.c_int32, _F]),
     "sdmi_set_option": (C.c_int, [_CTX, C.c_char_p, C.c_char_p]),

@@ -568,6 +568,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "attn_bf16") opt_attn_bf16_ = std::stoi(value);
     else if (key == "gemm_bf16x") opt_gemm_bf16x_ = std::stoi(value);
     else if (key == "gemm_x32") opt_gemm_x32_ = std::stoi(value);
+    else if (key == "geglu_fuse") opt_geglu_fuse_ = std::stoi(value);
     else if (key == "record_shapes") { record_shapes_ = std::stoi(value) != 0; if (record_shapes_) shape_counts_.clear(); }
     else if (key == "dump_shapes") {
         std::ofstream f(value);
@@ -695,11 +696,11 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     p.kt_per_split = (p.kt_total + splits - 1) / splits;
     splits = (p.kt_total + p.kt_per_split - 1) / p.kt_per_split;
     p.splits = splits;
-    const double flops = 2.0 * p.M * (double)p.N * p.K;
+    const double flops = 2.0 * p.M * (double)p.N * p.K * (p.geglu ? 2.0 : 1.0);
     // v2 uses raw buffer loads whose range check needs 32-bit extents
     const unsigned long long es = in_dt ? 2ull : 4ull;
     const unsigned long long a_ext = ((unsigned long long)p.NB * p.Hs * p.Ws - 1) * (unsigned long long)p.a_ld * es + (unsigned long long)p.Cin * es;
-    const unsigned long long b_ext = ((unsigned long long)p.N - 1) * (unsigned long long)p.b_ld * es + (unsigned long long)p.K * es;
+    const unsigned long long b_ext = ((unsigned long long)p.N * (p.geglu ? 2 : 1) - 1) * (unsigned long long)p.b_ld * es + (unsigned long long)p.K * es;
     if (in_dt && (a_ext >= 0xFFFFFFE0ull || b_ext >= 0xFFFFFFE0ull)) throw Error(SDMI_ERR_UNSUPPORTED, "bf16 GEMM: operand larger than 4 GiB");
     const bool v2 = (opt_gemm_variant_ == 1 || p.out_mode == 2) && a_ext < 0xFFFFFFE0ull && b_ext < 0xFFFFFFE0ull;
     p.zero_page = zero_page_;
@@ -772,6 +773,39 @@ void Engine::gemm(const float* A, int a_rows, const float* bt, const float* bias
     p.ldc = ldc; p.ldr = ldr; p.a_ld = cin; p.b_ld = cin; p.rowvec_stride = 0; p.CS = 32;
     p.out_mode = out_mode;
     launch_gemm(p, dt);
+}
+
+void Engine::gemm_geglu(const float* x, long long rows, const float* bt, const float* bias, int cin, int hidden, float* out, int dt) {
+    if (dt < 0) dt = edt();
+    const size_t es = dt ? 2 : 4;
+    // the fused form needs a large-tile kernel with an even fragment count per wave (256x256 or 256x128 tiles, no split-K)
+    int cfg = -1;
+    const bool eligible = opt_geglu_fuse_ && hidden % 8 == 0 && cin % (dt ? 64 : 32) == 0 && (dt ? opt_gemm_bf16x_ : opt_gemm_x32_);
+    if (eligible) {
+        const long long mt = (rows + 255) / 256;
+        const long long t256 = mt * ((hidden + 127) / 128), t128 = mt * ((hidden + 63) / 64);   // tiles with 256x256 / 256x128
+        // measured (same box, --opt geglu_fuse=0/1): at batch 1 the 256-wide tiles quantise badly against 256 CUs (320 tiles =
+        // two rounds) and the fused form LOSES 2.6 % end to end in fp32; with >= 4 rounds it wins ~1 % (bf16, batch 8)
+        if (t256 >= 1024) cfg = 101;
+        else if (t128 >= 1024 || opt_geglu_fuse_ == 2) cfg = 102;
+    }
+    if (cfg >= 0) {
+        ConvGemm p{};
+        p.A = x; p.Bt = bt; p.C = out; p.bias = bias;
+        p.M = (int)rows; p.N = hidden; p.K = cin;
+        p.NB = 1; p.Hs = 1; p.Ws = (int)rows; p.Cin = cin; p.Ho = 1; p.Wo = (int)rows;
+        p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.ups = 0;
+        p.ldc = hidden; p.ldr = hidden; p.a_ld = cin; p.b_ld = cin; p.rowvec_stride = 0; p.CS = 32;
+        p.out_mode = 0;
+        p.geglu = 1;
+        launch_gemm(p, dt, cfg, 1);
+        return;
+    }
+    Buf proj(this, (size_t)rows * 2 * hidden * es);
+    gemm(x, (int)rows, bt, bias, cin, 2 * hidden, proj.f(), 2 * hidden, nullptr, 0, dt);
+    if (dt) SDMI_HIP(launch_geglu_bf16(proj.p, out, rows, hidden, stream_));
+    else SDMI_HIP(launch_geglu(proj.f(), out, rows, hidden, stream_));
+    count_kernel();
 }
 
 void Engine::group_norm(const NormW& w, const Act& x, Act& y, bool silu) {
@@ -911,11 +945,8 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
         // GEGLU MLP
         layer_norm(w.ln3, h.p, M, ln.f());
         {
-            Buf proj(this, (size_t)M * 8 * C * es), u(this, (size_t)M * 4 * C * es);
-            gemm(ln.f(), (int)M, w.geglu_proj.bt, w.geglu_proj.bias, C, 8 * C, proj.f(), 8 * C, nullptr, 0);
-            if (bf16_) SDMI_HIP(launch_geglu_bf16(proj.p, u.p, M, 4 * C, stream_));
-            else SDMI_HIP(launch_geglu(proj.f(), u.f(), M, 4 * C, stream_));
-            count_kernel();
+            Buf u(this, (size_t)M * 4 * C * es);
+            gemm_geglu(ln.f(), M, w.geglu_proj.bt, w.geglu_proj.bias, C, 4 * C, u.f(), -1);
             gemm(u.f(), (int)M, w.mlp_lin.bt, w.mlp_lin.bias, 4 * C, C, h.p, C, h.p, C);
         }
     }
@@ -1356,6 +1387,20 @@ void Engine::op_linear(const float* x, const float* wt, const float* bias, int r
     }
     SDMI_HIP(launch_pack_linear_weight(wt, bt.f(), cin, cout, stream_));
     gemm(x, rows, bt.f(), bias, cin, cout, out, cout, nullptr, 0, 0);
+}
+
+void Engine::op_geglu_forward(const float* x, const float* wt, const float* bias, int rows, int cin, int hidden, float* out) {
+    Buf bt(this, (size_t)cin * 2 * hidden * 4);
+    if (bf16_ && cin % 64 == 0 && hidden % 8 == 0) {
+        Buf xh(this, (size_t)rows * cin * 2), yh(this, (size_t)rows * hidden * 2);
+        SDMI_HIP(launch_pack_linear_weight_bf16(wt, bt.p, cin, 2 * hidden, stream_));
+        SDMI_HIP(launch_f32_to_bf16(x, xh.p, (long long)rows * cin, stream_));
+        gemm_geglu(xh.f(), rows, bt.f(), bias, cin, hidden, yh.f(), 1);
+        SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(yh.p, out, rows, hidden, 1, 1, stream_));
+        return;
+    }
+    SDMI_HIP(launch_pack_linear_weight(wt, bt.f(), cin, 2 * hidden, stream_));
+    gemm_geglu(x, rows, bt.f(), bias, cin, hidden, out, 0);
 }
 
 void Engine::op_geglu(const float* proj, int rows, int hidden, float* out) {

@@ -133,6 +133,7 @@ public:
                    int stride, int pad, int ups, float* out);
     void op_linear(const float* x, const float* w, const float* bias, int rows, int cin, int cout, float* out);
     void op_geglu(const float* proj, int rows, int hidden, float* out);
+    void op_geglu_forward(const float* x, const float* wt, const float* bias, int rows, int cin, int hidden, float* out);
     void op_timestep_embedding(int t, int dim, float* out);
     double bench_conv(int n, int cin, int h, int w, int cout, int k, int stride, int ups, int tile_cfg, int splitk,
                       int iters);
@@ -184,6 +185,9 @@ private:
     TileChoice choose_tile(int M, int N, int kt_total, bool allow_x = false) const;   // cfg >= 100: k_gemm2x.hip tile cfg - 100
     void group_norm(const NormW& w, const Act& x, Act& y, bool silu);
     void layer_norm(const NormW& w, const float* x, long long rows, float* y, int dt = -1);
+    // GEGLU::forward (unet/mod.rs:579-591): out[rows, hidden] = (x W + b)[:, :hidden] * gelu((x W + b)[:, hidden:]); bt is the
+    // packed [2 hidden][cin] weight.  Fused into a large-tile GEMM when possible, else GEMM into `proj_scratch` + gate kernel.
+    void gemm_geglu(const float* x, long long rows, const float* bt, const float* bias, int cin, int hidden, float* out, int dt);
     void attention(const float* q, int ldq, long long q_bs, const float* k, int ldk, long long k_bs, const float* v,
                    int ldv, long long v_bs, float* o, int ldo, long long o_bs, int n, int nq, int nk, int n_head,
                    int d_head, const int* kv_len_dev, const int* kv_len_host, const float* mask, int mask_ld, int dt = -1);
@@ -279,6 +283,7 @@ private:
     int opt_force_splits_ = 0;
     int opt_attn_variant_ = 1;
     int opt_attn_bf16_ = 1;
+    int opt_geglu_fuse_ = 1;    // GEGLU gate in the projection GEMM's epilogue: 0 never, 1 where there are >= 4 rounds of tiles, 2 always
     int opt_gemm_x32_ = 1;      // precision = 0: 1 = large-tile LDS-DMA fp32 GEMM (k_gemm2x.hip) where measured / modelled faster
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
     void* zero_page_ = nullptr;

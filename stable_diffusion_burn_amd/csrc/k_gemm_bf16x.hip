@@ -61,15 +61,20 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     const int wm = wave / WN;
     const int wn = wave - wm * WN;
 
+    // GEGLU mode: a tile pairs BN/2 value columns with their BN/2 gate columns (fragment ni even = values, odd = gates of
+    // the same outputs), so a lane holds both and the epilogue emits value * gelu(gate)
+    constexpr int WNC = 16 * NI;        // columns of a wave tile
+    const bool geglu = p.geglu != 0;
+    const int BNO = geglu ? BN / 2 : BN;   // output columns per tile
     const int MT = (p.M + BM - 1) / BM;
-    const int NT = (p.N + BN - 1) / BN;
+    const int NT = (p.N + BNO - 1) / BNO;
     const int tpx = gridDim.x >> 3;
     const int lid = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3);
     if (lid >= MT * NT) return;
     const int tm = lid / NT;
     const int tn = lid - tm * NT;
     const int m0 = tm * BM;
-    const int n0 = tn * BN;
+    const int n0 = tn * BNO;
 
     const int z = blockIdx.z;
     const int kt_begin = z * p.kt_per_split;
@@ -108,8 +113,15 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     const char* b_src[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int n = n0 + (wave + 8 * j) * 8 + sub;
-        b_src[j] = (n < p.N) ? Bbase + (long long)n * p.b_ld * 2 + chunk * 16 : nullptr;
+        const int r0 = (wave + 8 * j) * 8 + sub;   // tile row of operand B
+        int n = n0 + r0;
+        long long wrow = n;
+        if (geglu) {
+            const int f = r0 >> 4, fw = f / NI, ni = f - fw * NI;
+            n = n0 + fw * (WNC / 2) + (ni >> 1) * 16 + (r0 & 15);
+            wrow = (long long)n + ((ni & 1) ? p.N : 0);
+        }
+        b_src[j] = (n < p.N) ? Bbase + wrow * p.b_ld * 2 + chunk * 16 : nullptr;
     }
 
     int cs = kt_begin / T;
@@ -218,8 +230,54 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     const int ldc = split ? p.N : p.ldc;
     const bool has_resid = !split && p.resid;
     const bool vec_ok = ((p.N & 7) == 0) && ((ldc & 7) == 0) && ((p.ldr & 7) == 0 || !has_resid);
-    constexpr int WNC = 16 * NI;        // columns of a wave tile
     constexpr int LDSW = WNC + 4;       // scratch row stride in floats (336 B for NI = 5: 16-byte aligned, rows on distinct banks)
+    if (geglu) {   // launch-side guarantees: NI even, no split-K, N % 8 == 0, ldc % 8 == 0, no rowvec / residual
+        if constexpr (NI % 2 == 0) {
+            constexpr int WNO = WNC / 2;     // output columns of a wave tile
+            constexpr int LDSW2 = WNO + 4;
+            __syncthreads();
+            float* scr = reinterpret_cast<float*>(smem_x + wave * (16 * LDSW2 * 4));
+            const int nw0 = n0 + wn * WNO;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int mrow0 = m0 + (wm * MI + mi) * 16;
+#pragma unroll
+                for (int j = 0; j < NI / 2; ++j) {
+                    const int n = nw0 + j * 16 + g4 * 4;
+                    f32x4 v = acc[mi][2 * j], g = acc[mi][2 * j + 1];
+                    if (p.bias && n < p.N) {
+                        v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                        g += *reinterpret_cast<const f32x4*>(p.bias + p.N + n);
+                    }
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = v[e] * (0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752440f)));
+                    *reinterpret_cast<f32x4*>(scr + c15 * LDSW2 + j * 16 + g4 * 4) = o;
+                }
+                __builtin_amdgcn_wave_barrier();
+                constexpr int CH = WNO / 8;
+#pragma unroll
+                for (int q0 = 0; q0 < 16 * CH; q0 += 64) {
+                    const int q = q0 + lane;
+                    const int row = q / CH, c8 = q - row * CH;
+                    const int m = mrow0 + row, n = nw0 + c8 * 8;
+                    if (q < 16 * CH && m < p.M && n < p.N) {
+                        const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + row * LDSW2 + c8 * 8);
+                        const f32x4 hi = *reinterpret_cast<const f32x4*>(scr + row * LDSW2 + c8 * 8 + 4);
+                        if (p.out_mode == 1) {
+                            *reinterpret_cast<f32x4*>(p.C + (long long)m * p.ldc + n) = lo;
+                            *reinterpret_cast<f32x4*>(p.C + (long long)m * p.ldc + n + 4) = hi;
+                        } else {
+                            const u32x4 o = {xpack_bf16x2(lo[0], lo[1]), xpack_bf16x2(lo[2], lo[3]), xpack_bf16x2(hi[0], hi[1]), xpack_bf16x2(hi[2], hi[3])};
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.C) + (long long)m * p.ldc + n) = o;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    }
     if (vec_ok) {
         __syncthreads();                // every wave is done with the last k tile
         float* scr = reinterpret_cast<float*>(smem_x + wave * (16 * LDSW * 4));
@@ -327,8 +385,10 @@ static hipError_t launch_cfg_bf16x(const ConvGemm& p, dim3 grid, hipStream_t str
 hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int cfg, hipStream_t stream) {
     if (cfg < 0 || cfg >= kNumGemmTilesX) return hipErrorInvalidValue;
     if ((p.Cin % 64) || !p.zero_page) return hipErrorInvalidValue;
+    if (p.geglu && (cfg == 0 || cfg == 3 || p.splits != 1 || (p.N & 7) || (p.ldc & 7) || p.rowvec || p.resid)) return hipErrorInvalidValue;  // needs an even NI
     const int bm = kTilesX[cfg].bm, bn = kTilesX[cfg].bn;
-    const int MT = (p.M + bm - 1) / bm, NT = (p.N + bn - 1) / bn;
+    const int bno = p.geglu ? bn / 2 : bn;
+    const int MT = (p.M + bm - 1) / bm, NT = (p.N + bno - 1) / bno;
     const int tiles = MT * NT;
     dim3 grid(((tiles + 7) / 8) * 8, 1, p.splits);
     switch (cfg) {

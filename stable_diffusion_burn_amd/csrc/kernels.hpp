@@ -38,7 +38,9 @@ struct ConvGemm {
     long long slab_stride;  // M*N when splits > 1
     unsigned a_bytes, b_bytes;  // extents of A / Bt for the buffer-load range check (v2 kernel)
     int out_mode;               // 0: output in the kernel's storage type; 1: force fp32 (bf16 kernel); 2: bf16 from the fp32 kernel
-    const void* zero_page;      // >= 16 readable zero bytes (large-tile bf16 kernel: source of padded / out-of-range lanes)
+    const void* zero_page;      // >= 16 readable zero bytes (large-tile kernels: source of padded / out-of-range lanes)
+    int geglu;                  // large-tile kernels: Bt holds 2 N rows (N value rows, then N gate rows; bias likewise) and the
+                                // epilogue writes value * gelu_erf(gate) -- GEGLU::forward (unet/mod.rs:579-591) without the [M, 2N] tensor
 };
 
 // tile configurations (index = tile_cfg); BM x BN per 256-thread workgroup

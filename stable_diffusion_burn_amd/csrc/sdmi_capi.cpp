@@ -414,6 +414,22 @@ int sdmi_op_conv2d(sdmi_ctx* ctx, const float* x, const float* weight, const flo
     });
 }
 
+int sdmi_op_geglu_forward(sdmi_ctx* ctx, const float* x, const float* weight, const float* bias, int32_t rows, int32_t cin,
+                          int32_t hidden, float* out) {
+    return guarded([&] {
+        Engine& e = eng(ctx);
+        if (rows <= 0 || cin <= 0 || hidden <= 0 || cin % 32) throw Error(SDMI_ERR_INVALID, "geglu_forward: bad shape");
+        e.begin_call();
+        DevIn dx(e, x, (size_t)rows * cin * sizeof(float)), dw(e, weight, (size_t)cin * 2 * hidden * sizeof(float));
+        Engine::Buf db(&e, (size_t)2 * hidden * sizeof(float));
+        if (bias) SDMI_HIP(hipMemcpyAsync(db.p, bias, (size_t)2 * hidden * sizeof(float), hipMemcpyHostToDevice, e.stream()));
+        DevOut dout(e, out, (size_t)rows * hidden * sizeof(float));
+        e.op_geglu_forward(dx.f(), dw.f(), bias ? db.f() : nullptr, rows, cin, hidden, dout.f());
+        e.end_call();
+        dout.fetch();
+    });
+}
+
 int sdmi_op_linear(sdmi_ctx* ctx, const float* x, const float* weight, const float* bias, int32_t rows, int32_t cin,
                    int32_t cout, float* out) {
     return guarded([&] {

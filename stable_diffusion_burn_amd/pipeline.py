@@ -311,6 +311,16 @@ class StableDiffusion:
                                        _fp(out)))
         return out
 
+    def op_geglu_forward(self, x, weight_in_out, bias, hidden):
+        """GEGLU::forward (unet/mod.rs:579-591): x [rows, cin] -> [rows, hidden]."""
+        x = _f32(x)
+        rows, cin = x.shape
+        w = _f32(weight_in_out, (cin, 2 * hidden))
+        out = np.empty((rows, hidden), dtype=np.float32)
+        b = None if bias is None else _f32(bias, (2 * hidden,))
+        check(self._lib.sdmi_op_geglu_forward(self._ctx, _fp(x), _fp(w), None if b is None else _fp(b), rows, cin, hidden, _fp(out)))
+        return out
+
     def op_geglu(self, proj):
         proj = _f32(proj)
         hidden = proj.shape[-1] // 2

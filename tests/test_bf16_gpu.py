@@ -193,6 +193,24 @@ def test_qkv_attention_bf16(ops16, case, mfma16):
     _check(got, ref, f"qkv_attention bf16 {case}", 2 ** -8 if heads > 1 else 2 ** -6)
 
 
+@pytest.mark.parametrize("rows,cin,hidden", [(700, 320, 1280), (2048, 320, 1280), (513, 128, 384)])
+@pytest.mark.parametrize("fuse", [2, 0])
+def test_geglu_forward_bf16(ops16, rows, cin, hidden, fuse):
+    g = np.random.default_rng(rows + hidden + fuse)
+    x = bf16_round(g.standard_normal((rows, cin)))
+    w = bf16_round(g.standard_normal((cin, 2 * hidden)) / math.sqrt(cin))
+    b = g.standard_normal(2 * hidden).astype(np.float32)
+    try:
+        ops16.set_option("geglu_fuse", fuse)
+        got = ops16.op_geglu_forward(x, w, b, hidden)
+    finally:
+        ops16.set_option("geglu_fuse", 1)
+    proj = _t(x) @ _t(w) + _t(b)
+    ref = (proj[:, :hidden] * O.gelu_erf(proj[:, hidden:])).numpy()
+    # unfused: the projection is rounded to bf16 before the gate (one more rounding than the fused form)
+    _check(got, ref, f"geglu_forward bf16 ({rows},{cin},{hidden}) fuse={fuse}", 2 ** -8 if fuse else 2 ** -7)
+
+
 # ---- model level: full-width UNet / decoder at an 8x8 latent -----------------------------------------------------
 @pytest.fixture(scope="module")
 def sd16():

@@ -280,3 +280,23 @@ def test_bad_arguments_fail_loudly(sd_ops):
         sd_ops.op_conv2d(x, w, None)
     with pytest.raises(SdmiError):
         sd_ops.set_option("no_such_option", 1)
+
+
+# ---- GEGLU::forward, fused into the projection GEMM's epilogue --------------------------------------------------
+@pytest.mark.parametrize("rows,cin,hidden", [(700, 320, 1280), (300, 64, 200), (2048, 320, 1280), (513, 128, 384)])
+@pytest.mark.parametrize("fuse", [2, 0])
+def test_geglu_forward(sd_ops, rows, cin, hidden, fuse):
+    """GEGLU::forward (unet/mod.rs:579-591).  fuse = 2: the gate runs in the large-tile GEMM's epilogue (value and gate
+    fragments interleaved per wave, no [rows, 2 hidden] tensor); 0: projection GEMM + gate kernel."""
+    g = _rng(rows + hidden + fuse)
+    x = g.standard_normal((rows, cin)).astype(np.float32)
+    w = (g.standard_normal((cin, 2 * hidden)) / math.sqrt(cin)).astype(np.float32)
+    b = g.standard_normal(2 * hidden).astype(np.float32)
+    try:
+        sd_ops.set_option("geglu_fuse", fuse)
+        got = sd_ops.op_geglu_forward(x, w, b, hidden)
+    finally:
+        sd_ops.set_option("geglu_fuse", 1)
+    proj = _t(x) @ _t(w) + _t(b)
+    ref = (proj[:, :hidden] * O.gelu_erf(proj[:, hidden:])).numpy()
+    _check(got, ref, f"geglu_forward ({rows},{cin},{hidden}) fuse={fuse}")
