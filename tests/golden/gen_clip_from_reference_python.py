@@ -109,7 +109,8 @@ def main():
         p.t = t.t().contiguous() if transposed else t
 
     g = np.random.default_rng(7)
-    seqs = {"t2": np.array([49406, 49407]),
+    seqs = {"probe": np.array([3, 1]),            # the commented probe of dump.py:603-611: clip(Tensor([3, 1]).unsqueeze(0))
+            "t2": np.array([49406, 49407]),
             "t17": np.array([49406, 320, 1125, 539, 550, 18376, 6765, 320, 4558, 267, 847, 713, 14124, 272, 273, 274, 49407]),
             "t77": np.concatenate(([49406], g.integers(0, 49406, 75), [49407]))}
     out = {"dump_names": np.array(sorted(mapping))}

@@ -75,7 +75,16 @@ def main():
     img = np.random.default_rng(11).uniform(-1.0, 1.0, (1, 3, 64, 64)).astype(np.float32)
     lat = ae.quant_conv(ae.encoder(shim.Tensor(img)))[:, 0:4].numpy()
     print(f"reference-python encoder: latent {lat.shape}, absmax {np.abs(lat).max():.3f}")
-    np.savez_compressed(HERE / "refpy_encoder.npz", image=img, latent=lat.astype(np.float64), dump_names=np.array(enc_names))
+    # the commented probe of dump.py:613-619: autoencoder(Tensor.zeros((1, 3, 10, 10))) -- encode (10 -> 5 -> 3 -> 2), first four
+    # moment channels, post_quant_conv, decode (2 -> 16); needs the decoder weights too
+    for name in mapping:
+        if name not in enc_names:
+            p, dims = mapping[name]
+            p.t = torch.from_numpy(np.ascontiguousarray(synth_for(name, dims, shapes, W))).to(shim.DTYPE)
+    probe = ae(shim.Tensor(np.zeros((1, 3, 10, 10), np.float32))).numpy()
+    print(f"reference-python autoencoder probe: output {probe.shape}, absmax {np.abs(probe).max():.3f}")
+    np.savez_compressed(HERE / "refpy_encoder.npz", image=img, latent=lat.astype(np.float64), dump_names=np.array(enc_names),
+                        probe_zeros_10x10=probe.astype(np.float64))
     print("wrote refpy_encoder.npz")
 
 

@@ -40,7 +40,7 @@ def test_clip_oracle_matches_reference_python():
     """oracle CLIP forward == python/dump.py CLIPTextTransformer on the same dump-named weights (fp64)."""
     g = np.load(GOLD / "refpy_clip.npz")
     o = CO.CLIPOracle(syn.SyntheticWeights(), CO.ClipDims(), torch.float64)
-    for key in ("t2", "t17", "t77"):
+    for key in ("probe", "t2", "t17", "t77"):   # "probe": dump.py:603-611, clip(Tensor([3, 1]))
         y = o.forward(g[f"{key}_tokens"][None]).numpy()[0]
         ref = g[f"{key}_out"]
         got = y[::8] if key == "t77" else y

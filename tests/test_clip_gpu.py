@@ -113,7 +113,7 @@ def test_clip_full_size_vs_reference_python():
     sd = StableDiffusion(ModelConfig(64, 1, 768, 8, 8, 64, clip_layers=12))
     try:
         sd.load_weights(syn.SyntheticWeights())
-        for key in ("t2", "t17", "t77"):
+        for key in ("probe", "t2", "t17", "t77"):
             got = sd.clip.forward(g[f"{key}_tokens"][None])[0]
             ref = g[f"{key}_out"]
             err = _close(got[::8] if key == "t77" else got, ref, f"clip full {key}")

@@ -20,6 +20,15 @@ def test_encoder_oracle_matches_reference_python():
     assert lat.shape == (1, 4, 8, 8) and err < 1e-12
 
 
+def test_autoencoder_probe_of_dump_py():
+    """the commented probe of python/dump.py:613-619: autoencoder(zeros [1, 3, 10, 10]) -> [1, 3, 8, 8] (Autoencoder::forward)."""
+    g = np.load(GOLD / "refpy_encoder.npz")
+    o = O.EncoderOracle(syn.SyntheticWeights(), O.Dims(), torch.float64)
+    out = o.decode_latent(o.encode_image(torch.zeros(1, 3, 10, 10))).numpy()
+    assert out.shape == (1, 3, 8, 8)
+    assert np.abs(out - g["probe_zeros_10x10"]).max() < 1e-12
+
+
 def test_encoder_dump_names_are_the_reference_exporters():
     g = np.load(GOLD / "refpy_encoder.npz")
     ref_names = set(str(s) for s in g["dump_names"])
