@@ -236,7 +236,6 @@ private:
     std::vector<void*> weight_allocs_;
     bool finalized_ = false;
     std::vector<float> alphas_;
-    float* alphas_slot_ = nullptr;  // unused device slot (keeps entry handling uniform)
 
     // UNet
     LinW lin1_time_, lin2_time_;
