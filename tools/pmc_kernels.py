@@ -1,0 +1,55 @@
+"""Per-kernel summary of a `rocprofv3 --pmc ... --output-format csv` run (the *_counter_collection.csv).
+
+usage: python tools/pmc_kernels.py <dir> [name-substring ...]
+
+For every kernel (optionally only those whose name contains one of the substrings): dispatches, mean duration, the
+mean of every collected counter, and -- when SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE were collected --
+    mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)
+(GRBM_GUI_ACTIVE is summed over the 8 XCDs on gfx950) and the effective shader clock GRBM_GUI_ACTIVE / 8 / duration.
+"""
+import csv
+import glob
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name: str) -> str:
+    name = re.sub(r"\(.*", "", name)
+    return name.replace("void sdmi::", "").replace("sdmi::", "")
+
+
+def main():
+    d = sys.argv[1]
+    subs = sys.argv[2:]
+    acc = defaultdict(lambda: defaultdict(float))
+    disp = defaultdict(set)
+    dur = defaultdict(float)
+    for path in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                k = short(row["Kernel_Name"])
+                if subs and not any(s in k for s in subs):
+                    continue
+                acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
+                did = row["Dispatch_Id"]
+                if did not in disp[k]:
+                    disp[k].add(did)
+                    dur[k] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+    for k in sorted(acc, key=lambda n: -dur[n]):
+        n = len(disp[k])
+        c = {name: v / n for name, v in acc[k].items()}
+        us = dur[k] / n / 1e3
+        line = f"{k:58s} n={n:5d} {us:9.1f} us"
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE"):
+            gui = c["GRBM_GUI_ACTIVE"] / 8.0
+            line += f"  mfma_busy {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * gui) * 100:5.1f} %  clock {gui / us / 1e3:4.2f} GHz"
+        if "SQ_LDS_BANK_CONFLICT" in c:
+            line += f"  lds_conflict_cycles {c['SQ_LDS_BANK_CONFLICT']:.3g}"
+        if "SQ_WAIT_INST_ANY" in c and c.get("SQ_WAVE_CYCLES"):
+            line += f"  wait_inst/wave_cycles {c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES'] * 100:4.1f} %"
+        print(line)
+
+
+if __name__ == "__main__":
+    main()
