@@ -360,18 +360,21 @@ __global__ __launch_bounds__(NW * 64) void attn2_kernel(const AttnParams p) {
                 const int c4 = idx - row * (D / VEC);
                 float* kd = Ks + buf * Cfg::TILE_FLOATS + row * LDK + c4 * VEC;
                 float* vd = Vs + buf * Cfg::TILE_FLOATS + row * LDK + c4 * VEC;
+                const bool sw = (row & 8) != 0;   // see the K fragment read
                 if constexpr (H16) {
                     const u32x4h kw = __builtin_bit_cast(u32x4h, rk[i]), vw = __builtin_bit_cast(u32x4h, rv[i]);
-                    *reinterpret_cast<f32x4*>(kd) = f32x4{__uint_as_float(kw[0] << 16), __uint_as_float(kw[0] & 0xFFFF0000u),
-                                                          __uint_as_float(kw[1] << 16), __uint_as_float(kw[1] & 0xFFFF0000u)};
-                    *reinterpret_cast<f32x4*>(kd + 4) = f32x4{__uint_as_float(kw[2] << 16), __uint_as_float(kw[2] & 0xFFFF0000u),
-                                                              __uint_as_float(kw[3] << 16), __uint_as_float(kw[3] & 0xFFFF0000u)};
+                    const f32x4 k0 = {__uint_as_float(kw[0] << 16), __uint_as_float(kw[0] & 0xFFFF0000u),
+                                      __uint_as_float(kw[1] << 16), __uint_as_float(kw[1] & 0xFFFF0000u)};
+                    const f32x4 k1 = {__uint_as_float(kw[2] << 16), __uint_as_float(kw[2] & 0xFFFF0000u),
+                                      __uint_as_float(kw[3] << 16), __uint_as_float(kw[3] & 0xFFFF0000u)};
+                    *reinterpret_cast<f32x4*>(kd) = sw ? f32x4{k0[2], k0[3], k0[0], k0[1]} : k0;
+                    *reinterpret_cast<f32x4*>(kd + 4) = sw ? f32x4{k1[2], k1[3], k1[0], k1[1]} : k1;
                     *reinterpret_cast<f32x4*>(vd) = f32x4{__uint_as_float(vw[0] << 16), __uint_as_float(vw[0] & 0xFFFF0000u),
                                                           __uint_as_float(vw[1] << 16), __uint_as_float(vw[1] & 0xFFFF0000u)};
                     *reinterpret_cast<f32x4*>(vd + 4) = f32x4{__uint_as_float(vw[2] << 16), __uint_as_float(vw[2] & 0xFFFF0000u),
                                                               __uint_as_float(vw[3] << 16), __uint_as_float(vw[3] & 0xFFFF0000u)};
                 } else {
-                    *reinterpret_cast<f32x4*>(kd) = rk[i];
+                    *reinterpret_cast<f32x4*>(kd) = sw ? f32x4{rk[i][2], rk[i][3], rk[i][0], rk[i][1]} : rk[i];
                     *reinterpret_cast<f32x4*>(vd) = rv[i];
                 }
             }
@@ -401,7 +404,10 @@ __global__ __launch_bounds__(NW * 64) void attn2_kernel(const AttnParams p) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            const float* kp = Kt + (kt * 16 + c) * LDK + g * 2;
+            // K rows 8..15 of every 16 are stored with the two halves of each 4-float chunk swapped (lstore): hipcc merges
+            // these loads into ds_read2_b64, which banks 16 lanes at a time modulo 32 dwords, where rows c and c + 8
+            // (8 LDK = 0 mod 32 for any 16-byte-aligned row stride) would otherwise collide 2-way (measured: 8 % of CU cycles)
+            const float* kp = Kt + (kt * 16 + c) * LDK + ((g * 2) ^ ((c >> 3) << 1));
 #pragma unroll
             for (int cc = 0; cc < DC; ++cc) {
                 const f32x2 kf = *reinterpret_cast<const f32x2*>(kp + cc * 8);
