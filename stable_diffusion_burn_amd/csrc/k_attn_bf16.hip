@@ -43,7 +43,9 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 template <int D, int NW>
 struct AttnBfCfg {
     static constexpr int NT = NW * 64;
-    static constexpr int BKV = 64;
+    static constexpr int BKV = (D <= 40) ? 128 : 64;          // keys per tile: d = 40 is softmax-bound, fewer / longer iterations
+    static constexpr int KT = BKV / 32;                      // 32-key score tiles per K/V tile
+    static constexpr int ST = BKV / 16;                      // 16-key steps of P V
     static constexpr int DK = (D + 15) / 16 * 16;            // contraction width of K Q^T (48 / 80 / 160)
     static constexpr int KS = DK / 16;
     static constexpr int NDT = (D + 31) / 32;                // 32-row tiles of O^T (2 / 3 / 5)
@@ -77,6 +79,7 @@ template <int D, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) {
     using Cfg = AttnBfCfg<D, NW>;
     constexpr int NT = Cfg::NT, BKV = Cfg::BKV, KS = Cfg::KS, NDT = Cfg::NDT, RSK = Cfg::RSK, RSV = Cfg::RSV, NLD = Cfg::NLD;
+    constexpr int KT = Cfg::KT, ST = Cfg::ST;
     constexpr int CPR = D / 8;  // chunks per HBM row
     constexpr float kLog2e = 1.4426950408889634f;
 
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) 
 
     if constexpr (Cfg::DK > D) {  // zero the K columns D..DK-1 once (the staging never touches them)
         for (int i = tid; i < 2 * BKV; i += NT)
-            *reinterpret_cast<u32x4*>(Ks + (i >> 6) * Cfg::K_BYTES + (i & 63) * RSK + CPR * 16) = u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(Ks + (i / BKV) * Cfg::K_BYTES + (i % BKV) * RSK + CPR * 16) = u32x4{0u, 0u, 0u, 0u};
     }
 
     // Q^T fragments: B[k = 16 s + 8 hi + j][n = query]
@@ -177,9 +180,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) 
         const unsigned char* Vt = Vs + cur * Cfg::V_BYTES + v_off;
         const int kv0 = tile * BKV;
 
-        f32x16 s[2];
+        f32x16 s[KT];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) 
 
         if (tile >= n_full) {  // ragged last tile (uniform)
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) 
 
         float mt = s[0][0];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kt][r]);
         mt = partner_max(mt);
@@ -210,10 +213,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) 
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
         m_run = m_new;
 
-        unsigned pb[4][4];  // [16-key step][4 dwords = 8 bf16]
+        unsigned pb[ST][4];  // [16-key step][4 dwords = 8 bf16]
         float psum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], cs, -mc));
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) 
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
+            for (int st = 0; st < ST; ++st) {
                 const lds_s16x4* vp = (const lds_s16x4*)(Vt + st * 16 * RSV + dt * 64);
                 const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_s16x4*>(vp));
                 const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_s16x4*>((const lds_s16x4*)(Vt + (st * 16 + 8) * RSV + dt * 64)));
