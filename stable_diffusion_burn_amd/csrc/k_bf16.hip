@@ -54,7 +54,7 @@ static inline GnGeomH gn_geom_h(int hw, int c) {
     if (g.R > hw) g.R = hw;
     g.threads = g.cq * g.R;
     const long long bytes = (long long)hw * c * 2;
-    long long chunks = (bytes + 65535) / 65536;
+    long long chunks = (bytes + 32767) / 32768;   // 32 KB of bf16 = as many rows (and workgroups) per chunk as the fp32 kernels' 64 KB
     if (chunks > 256) chunks = 256;
     if (chunks < 1) chunks = 1;
     int rpc = (int)((hw + chunks - 1) / chunks);
