@@ -85,7 +85,7 @@ int main(int argc, char** argv) {
 
     std::printf("Loading model...\n");
     if (model_type == "burn") {
-        std::fprintf(stderr, "Error loading model: Burn .mpk records are not read by this build; export a dump (python/dump.py) and pass `dump <dir>`\n");
+        std::fprintf(stderr, "Error loading model: Burn .mpk records are not read by this binary; convert the record with tools/mpk_to_dump.py (or export a dump with python/dump.py) and pass `dump <dir>`\n");
         return 1;
     }
     sdmi_ctx* ctx = nullptr;
