@@ -786,7 +786,7 @@ void Engine::gemm_geglu(const float* x, long long rows, const float* bt, const f
         const long long t256 = mt * ((hidden + 127) / 128), t128 = mt * ((hidden + 63) / 64);   // tiles with 256x256 / 256x128
         // measured (same box, --opt geglu_fuse=0/1): at batch 1 the 256-wide tiles quantise badly against 256 CUs (320 tiles =
         // two rounds) and the fused form LOSES 2.6 % end to end in fp32; with >= 4 rounds it wins ~1 % (bf16, batch 8)
-        if (t256 >= 1024) cfg = 101;
+        if (t256 >= 1024 || opt_geglu_fuse_ == 3) cfg = 101;
         else if (t128 >= 1024 || opt_geglu_fuse_ == 2) cfg = 102;
     }
     if (cfg >= 0) {

@@ -282,7 +282,7 @@ private:
     int opt_force_splits_ = 0;
     int opt_attn_variant_ = 1;
     int opt_attn_bf16_ = 1;
-    int opt_geglu_fuse_ = 1;    // GEGLU gate in the projection GEMM's epilogue: 0 never, 1 where there are >= 4 rounds of tiles, 2 always
+    int opt_geglu_fuse_ = 1;    // GEGLU gate in the projection GEMM's epilogue: 0 never, 1 where there are >= 4 rounds of tiles, 2 / 3 always (256x128 / 256x256 tiles; tests)
     int opt_gemm_x32_ = 1;      // precision = 0: 1 = large-tile LDS-DMA fp32 GEMM (k_gemm2x.hip) where measured / modelled faster
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
     void* zero_page_ = nullptr;

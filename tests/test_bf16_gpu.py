@@ -194,7 +194,7 @@ def test_qkv_attention_bf16(ops16, case, mfma16):
 
 
 @pytest.mark.parametrize("rows,cin,hidden", [(700, 320, 1280), (2048, 320, 1280), (513, 128, 384)])
-@pytest.mark.parametrize("fuse", [2, 0])
+@pytest.mark.parametrize("fuse", [2, 3, 0])   # 2 / 3: fused, 256x128 / 256x256 tiles; 0: GEMM + gate kernel
 def test_geglu_forward_bf16(ops16, rows, cin, hidden, fuse):
     g = np.random.default_rng(rows + hidden + fuse)
     x = bf16_round(g.standard_normal((rows, cin)))

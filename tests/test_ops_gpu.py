@@ -284,7 +284,7 @@ def test_bad_arguments_fail_loudly(sd_ops):
 
 # ---- GEGLU::forward, fused into the projection GEMM's epilogue --------------------------------------------------
 @pytest.mark.parametrize("rows,cin,hidden", [(700, 320, 1280), (300, 64, 200), (2048, 320, 1280), (513, 128, 384)])
-@pytest.mark.parametrize("fuse", [2, 0])
+@pytest.mark.parametrize("fuse", [2, 3, 0])   # 2 / 3: fused, 256x128 / 256x256 tiles; 0: GEMM + gate kernel
 def test_geglu_forward(sd_ops, rows, cin, hidden, fuse):
     """GEGLU::forward (unet/mod.rs:579-591).  fuse = 2: the gate runs in the large-tile GEMM's epilogue (value and gate
     fragments interleaved per wave, no [rows, 2 hidden] tensor); 0: projection GEMM + gate kernel."""
