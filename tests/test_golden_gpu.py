@@ -101,3 +101,30 @@ def test_per_step_drift(sd_full):
     err = np.abs(x1 - g["latents32"][0]).max()
     print(f"step-0 latent: |gpu-f32 oracle|={err:.2e}  (oracle f32/f64 gap {g['step_err'][0]:.2e})")
     assert err < max(1e-4, 4 * float(g["step_err"][0]))
+
+
+def test_bf16_full_size_against_the_fp64_fixtures():
+    """precision = 1 at the full SD v1.4 size with the shipped bf16 tile table (large-tile LDS-DMA GEMMs, bf16 matrix-core
+    attention): relative RMS against the fp64 golden vectors -- one UNet forward, the 20-step CFG latent, decoded RGB.
+    Bars as in test_bf16_gpu.py ("expect ~1e-2 bf16")."""
+    from stable_diffusion_burn_amd import ModelConfig, StableDiffusion
+    sd = StableDiffusion(ModelConfig(precision=1))
+    try:
+        sd.load_weights(syn.SyntheticWeights(), clip=False, vae_encoder=False)
+        lat, ctx, unc = _inputs()
+
+        def rel_rms(a, b):
+            a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+            return float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+
+        gu = np.load(GOLD / "sd14_synth_unet.npz")
+        r_unet = rel_rms(sd.unet.forward(lat, [999], ctx)[0], gu["eps64_t999"])
+        g2 = np.load(GOLD / "sd14_synth_cfg2.npz")
+        got = sd.sample_latent(ctx, unc, 7.5, 20, init_latent=lat)[0]
+        r_lat = rel_rms(got, g2["latent64"])
+        rgb = sd.autoencoder.decode_latent((g2["latent64"][None] * (1.0 / 0.18215)).astype(np.float32))[0]
+        r_rgb = rel_rms(rgb[:, ::4, ::4], g2["rgb64_s4"])
+        print(f"bf16 full size: rel-RMS UNet forward {r_unet:.3e}, 20-step CFG latent {r_lat:.3e}, decoded RGB {r_rgb:.3e}")
+        assert np.isfinite(got).all() and r_unet < 2e-2 and r_lat < 5e-2 and r_rgb < 3e-2
+    finally:
+        sd.close()
