@@ -47,6 +47,17 @@ def test_unet_forward_full(sd_full):
         assert e64 < 2e-5, f"t={t}: {e64}"
 
 
+def test_unet_forward_full_batch4(sd_full):
+    """batch 4 (M = 16384 ... 256 rows: GEMM shapes outside the measured batch-1 tile table, chosen by the cost model incl. the
+    large-tile kernel): every sample equals the batch-1 golden vector."""
+    g = np.load(GOLD / "sd14_synth_unet.npz")
+    lat, ctx, _ = _inputs()
+    got = sd_full.unet.forward(np.repeat(lat, 4, axis=0), [999], np.repeat(ctx, 4, axis=0)).astype(np.float64)
+    for i in range(4):
+        assert np.abs(got[i] - g["eps64_t999"]).max() < 2e-5, i
+    assert np.array_equal(got[0], got[3])   # position in the batch does not matter
+
+
 def test_config1_one_step(sd_full):
     """configs[0]: 1 DDIM step, guidance 1.0 ("CFG off" still runs both forwards, Q: forward_diffuser)."""
     g = np.load(GOLD / "sd14_synth_cfg1.npz")
