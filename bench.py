@@ -7,7 +7,8 @@
 
 One "step" = one `sample_image` call (reference src/model/stablediffusion/mod.rs:51-67)
 over one batch of synthetic inputs: 20 DDIM iterations x 2 UNet evaluations (CFG 7.5)
-+ VAE decode -> 512x512 RGB u8, fp32 arithmetic, batch 1 per GPU
++ VAE decode -> 512x512 RGB u8 ON THE HOST ("to u8 RGB on host"; the D2H copy of
+the 786 KB image into pinned memory is inside the timed region), fp32 arithmetic, batch 1 per GPU
 (BASELINE.json configs[1]).  Inputs (text embeddings, x_T) are resident in HBM
 when the timed region starts; weights are seeded synthetic (no checkpoint / no
 network in this environment).
@@ -19,8 +20,11 @@ the image batch is sharded by global image index with no other collective
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
 `roofline` for the dominant kernel (implicit-GEMM conv on fp32 MFMA) measured
-live with HIP events on the engine's stream, and `cpu_baseline` (the fp32 oracle
-timed on the host cores, rank 0, N=1 only).
+live with HIP events on the engine's stream, `cpu_baseline` (the fp32 oracle
+timed on the host cores, rank 0, N=1 only) and -- at N=1 -- `secondary`: the same
+measurement for the reduced-precision configurations BASELINE.json names next
+to the headline (configs[2]: bf16, batch 16, 50 steps; the per-GPU shard of
+configs[3]: bf16, batch 8, 20 steps), run after the timed headline loop.
 """
 from __future__ import annotations
 
@@ -38,6 +42,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA" (dense)
 F_UNET = 0.8033e12              # FLOP per UNet forward per sample, T = 77
 F_VAE = 2.5145e12               # FLOP per decoded image
+T_CTX = 77
 
 
 def parse():
@@ -53,6 +58,7 @@ def parse():
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="engine option (sdmi_set_option), repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the bf16 configs[2] / configs[3]-shard measurements after the headline")
     ap.add_argument("--tune-file", default=str(ROOT / "stable_diffusion_burn_amd" / "tuning" / "gfx950_fp32.txt"))
     return ap.parse_args()
 
@@ -89,6 +95,101 @@ def cpu_baseline(weights, ddim_steps: int) -> dict:
                       f"oracle on {cores} threads, extrapolated to {ddim_steps} steps ({t_img:.1f} s/image)"}
 
 
+class Runner:
+    """One engine + its device-resident inputs; step() = one sample_image over the shard, u8 images on the host."""
+
+    def __init__(self, torch, np, dev, local_rank, precision, B, ddim_steps, scale, cond, uncond, indices, flat, opts, tune_file):
+        from stable_diffusion_burn_amd import ModelConfig, StableDiffusion, synthetic as syn
+        self.torch, self.B, self.ddim_steps, self.scale = torch, B, ddim_steps, scale
+        self.bf16 = precision == "bf16"
+        cfg = ModelConfig(precision=1 if self.bf16 else 0)
+        self.cfg = cfg
+        self.sd = StableDiffusion(cfg, device=local_rank)
+        t0 = time.perf_counter()
+        self.sd.load_weights_packed(flat, groups=1)   # the timed path takes embeddings and only decodes: hot-path group only
+        self.t_load = time.perf_counter() - t0
+        if tune_file and os.path.exists(tune_file) and not self.bf16:
+            for line in Path(tune_file).read_text().split():
+                if "=" in line and not line.startswith("#"):
+                    self.sd.set_option("tune", line.strip())
+        for kv in opts:
+            k, _, v = kv.partition("=")
+            self.sd.set_option(k, v)
+        self.sd.set_stream(torch.cuda.current_stream().cuda_stream)   # order the engine's stream behind torch's (no device-wide sync)
+        self.context = cond[None].repeat(B, 1, 1).contiguous()            # same prompt for every image
+        self.uncond = uncond.contiguous()
+        self.latent = torch.from_numpy(np.stack([syn.initial_latent(i, cfg.latent_h, cfg.latent_w) for i in indices])).to(dev)
+        self.rgb = torch.empty((B, 8 * cfg.latent_h, 8 * cfg.latent_w, 3), dtype=torch.uint8, device=dev)
+        self.rgb_host = torch.empty(self.rgb.shape, dtype=torch.uint8).pin_memory()
+
+    def step(self):
+        self.sd.sample_image_dev(self.context.data_ptr(), self.B, T_CTX, self.uncond.data_ptr(), T_CTX, self.scale, self.ddim_steps,
+                                 self.latent.data_ptr(), self.rgb.data_ptr())
+        self.rgb_host.copy_(self.rgb, non_blocking=True)   # the reference returns Vec<Vec<u8>> on the host (stablediffusion/mod.rs:86-99)
+
+    def timed(self, steps, warmup, barrier):
+        for _ in range(warmup):
+            self.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        barrier()
+        return time.perf_counter() - t0
+
+    def roofline(self):
+        """Live HIP-event timing of every launch, in a separate un-timed pass (sdmi_profile_stats)."""
+        sd = self.sd
+        sd.set_option("profile_reset", 1)
+        sd.set_option("profile", 1)
+        self.step()
+        self.torch.cuda.synchronize()
+        sd.set_option("profile", 0)
+        prof = sd.profile_stats()
+        g = prof["conv_gemm"]
+        if g["launches"] <= 0 or g["ms"] <= 0:
+            return None, prof
+        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
+        peak = BF16_MFMA_PEAK_TFLOPS if self.bf16 else FP32_MFMA_PEAK_TFLOPS
+        kname = ("conv_gemm_bf16x_kernel + conv_gemm_bf16_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x32_bf16)" if self.bf16 else
+                 "conv_gemm2_kernel + conv_gemm2x_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x4_f32)")
+        traffic, source = None, None
+        pmc = ROOT / "profiles" / "pmc_summary.json"
+        if pmc.exists() and not self.bf16 and self.B == 1:
+            try:
+                j = json.loads(pmc.read_text())
+                traffic = j.get("conv_gemm_hbm_bytes_per_launch")
+                source = f"profiles/pmc_summary.json ({j.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command')}); NOT measured in this run"
+            except Exception:  # noqa: BLE001
+                traffic = None
+        roof = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": traffic, "traffic_source": source,
+                "launches_per_image": g["launches"] / self.B, "avg_launch_us": g["ms"] * 1e3 / g["launches"],
+                "flop_per_launch": g["flops"] / g["launches"],
+                "share_of_gpu_time": g["ms"] / max(1e-9, sum(v["ms"] for v in prof.values()))}
+        return roof, prof
+
+    def class_summary(self, prof):
+        out = {"kernel_classes_ms_per_image": {k: round(v["ms"] / self.B, 3) for k, v in prof.items()}}
+        gn = prof["group_norm"]
+        if gn["ms"] > 0:
+            out["group_norm_algorithmic_GBps"] = gn["bytes"] / (gn["ms"] * 1e-3) / 1e9
+        at = prof["attention"]
+        if at["ms"] > 0:
+            out["attention_tflops"] = at["flops"] / (at["ms"] * 1e-3) / 1e12
+        return out
+
+    def close(self):
+        self.sd.close()
+
+
+def workload_name(precision, B, ddim_steps, scale):
+    which = {("fp32", 1, 20): "BASELINE.json configs[1]", ("bf16", 16, 50): "BASELINE.json configs[2]",
+             ("bf16", 8, 20): "the per-GPU shard of BASELINE.json configs[3] (64 images over 8 GPUs)"}.get((precision, B, ddim_steps), "not a BASELINE.json configuration")
+    arith = "fp32" if precision == "fp32" else "bf16 storage / fp32 accumulate"
+    return f"SD v1.4 512x512, {ddim_steps}-step DDIM, CFG={scale}, batch={B} per GPU, {arith} ({which})"
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -112,94 +213,68 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from stable_diffusion_burn_amd import ModelConfig, StableDiffusion, synthetic as syn
+    from stable_diffusion_burn_amd import sharding
 
     B = args.batch_per_gpu
-    T = Tu = 77
-    bf16 = args.precision == "bf16"
-    cfg = ModelConfig(precision=1 if bf16 else 0)
-    sd = StableDiffusion(cfg, device=local_rank)
+    ctx_dim = ModelConfig().ctx_dim
     weights = syn.SyntheticWeights(cache=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+    # the flat fp32 image of the hot-path weights (untimed: numpy RNG, ~3.6 GB); both precisions load the same image
     t0 = time.perf_counter()
-    sd.load_weights(weights, clip=False, vae_encoder=False)   # the timed path takes embeddings and only decodes
-    t_load = time.perf_counter() - t0
-    if os.path.exists(args.tune_file) and not bf16:
-        for line in Path(args.tune_file).read_text().split():
-            if "=" in line and not line.startswith("#"):
-                sd.set_option("tune", line.strip())
-    for kv in args.opt:
-        k, _, v = kv.partition("=")
-        sd.set_option(k, v)
+    probe = StableDiffusion(ModelConfig(), device=local_rank)
+    flat = probe.pack_weights(weights, groups=1)
+    probe.close()
+    t_gen = time.perf_counter() - t0
 
     # ---- inputs: rank 0 owns the prompt embedding; ONE RCCL broadcast ------------------
-    from stable_diffusion_burn_amd import sharding
-    packed = torch.empty(((T + Tu) * cfg.ctx_dim,), dtype=torch.float32, device=dev)
+    packed = torch.empty(((T_CTX + T_CTX) * ctx_dim,), dtype=torch.float32, device=dev)
     if rank == 0:
-        p0, _, _ = sharding.pack_prompt(torch.from_numpy(syn.cond_context(0, T, cfg.ctx_dim)),
-                                        torch.from_numpy(syn.uncond_context(Tu, cfg.ctx_dim)))
+        p0, _, _ = sharding.pack_prompt(torch.from_numpy(syn.cond_context(0, T_CTX, ctx_dim)),
+                                        torch.from_numpy(syn.uncond_context(T_CTX, ctx_dim)))
         packed.copy_(p0)
     sharding.broadcast_prompt(packed, src=0)
-    cond, uncond = sharding.unpack_prompt(packed, T, Tu, cfg.ctx_dim)
-    context = cond[None].repeat(B, 1, 1).contiguous()            # same prompt for every image
-    uncond = uncond.contiguous()
+    cond, uncond = sharding.unpack_prompt(packed, T_CTX, T_CTX, ctx_dim)
     mine = sharding.shard_range(B * world, rank, world)          # global image indices of this shard
-    latent = torch.from_numpy(np.stack([syn.initial_latent(i, cfg.latent_h, cfg.latent_w) for i in mine])).to(dev)
-    rgb = torch.empty((B, 8 * cfg.latent_h, 8 * cfg.latent_w, 3), dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize()
-
-    def step():
-        sd.sample_image_dev(context.data_ptr(), B, T, uncond.data_ptr(), Tu, args.scale, args.ddim_steps,
-                            latent.data_ptr(), rgb.data_ptr())
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    run = Runner(torch, np, dev, local_rank, args.precision, B, args.ddim_steps, args.scale, cond, uncond, mine, flat, args.opt, args.tune_file)
+    elapsed = run.timed(args.steps, args.warmup, barrier)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    stats = sd.last_call_stats()
+    stats = run.sd.last_call_stats()
 
-    # ---- roofline of the dominant kernel: live HIP-event timing, separate (untimed) pass ----
-    roofline = None
-    prof = None
+    roofline, prof = (None, None)
     if rank == 0 and not args.no_roofline:
-        sd.set_option("profile_reset", 1)
-        sd.set_option("profile", 1)
-        step()
-        sd.set_option("profile", 0)
-        prof = sd.profile_stats()
-        g = prof["conv_gemm"]
-        if g["launches"] > 0 and g["ms"] > 0:
-            achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
-            traffic = None
-            pmc = ROOT / "profiles" / "pmc_summary.json"
-            if pmc.exists():
-                try:
-                    traffic = json.loads(pmc.read_text()).get("conv_gemm_hbm_bytes_per_launch")
-                except Exception:  # noqa: BLE001
-                    traffic = None
-            peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
-            kname = ("conv_gemm_bf16_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x32_bf16)" if bf16 else
-                     "conv_gemm2_kernel + conv_gemm2x_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x4_f32)")
-            if bf16:
-                traffic = None  # the committed PMC summary is for the fp32 kernel
-            roofline = {"bound": "mfma", "kernel": kname,
-                        "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                        "frac": achieved / peak, "traffic": traffic,
-                        "launches_per_image": g["launches"] / B,
-                        "avg_launch_us": g["ms"] * 1e3 / g["launches"],
-                        "flop_per_launch": g["flops"] / g["launches"],
-                        "share_of_gpu_time": g["ms"] / max(1e-9, sum(v["ms"] for v in prof.values()))}
+        roofline, prof = run.roofline()
+    bf16 = args.precision == "bf16"
+    t_load = run.t_load
+    classes = run.class_summary(prof) if prof is not None else {}
+    run.close()
+
+    # ---- secondary: the reduced-precision configurations BASELINE.json names, witnessed by the same run ----------
+    secondary = []
+    if rank == 0 and world == 1 and not args.no_secondary and not bf16 and B == 1 and args.ddim_steps == 20:
+        for (b2, s2, k2) in ((16, 50, 2), (8, 20, 3)):
+            idx = list(range(b2))
+            r2 = Runner(torch, np, dev, local_rank, "bf16", b2, s2, args.scale, cond, uncond, idx, flat, [], None)
+            e2 = r2.timed(k2, 1, barrier)
+            roof2, prof2 = r2.roofline()
+            fpi = 2 * s2 * F_UNET + F_VAE
+            v2 = k2 * b2 / e2
+            entry = {"config": {"workload": workload_name("bf16", b2, s2, args.scale), "global_batch": b2, "ddim_steps": s2,
+                                "cfg_scale": args.scale, "context_len": T_CTX},
+                     "dtype": "bf16", "value": v2, "unit": "images/sec", "steps": k2, "warmup": 1, "ms_per_step": e2 / k2 * 1e3,
+                     "algorithmic_tflop_per_image": fpi / 1e12, "whole_path_tflops_per_gpu": v2 * fpi / 1e12,
+                     "whole_path_frac_of_mfma_peak": v2 * fpi / 1e12 / BF16_MFMA_PEAK_TFLOPS, "roofline": roof2,
+                     "weights_load_s": r2.t_load}
+            entry.update(r2.class_summary(prof2))
+            secondary.append(entry)
+            r2.close()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -209,33 +284,27 @@ def main():
         images = args.steps * B * world
         value = images / elapsed
         flop_per_image = 2 * args.ddim_steps * F_UNET + F_VAE
+        peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
         out = {
-            "metric": "images/sec @512x512, 20-step DDIM CFG=7.5, SD v1.4",
+            "metric": f"images/sec @512x512, {args.ddim_steps}-step DDIM CFG={args.scale:g}, SD v1.4",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-            "config": {"workload": (f"SD v1.4 512x512, {args.ddim_steps}-step DDIM, CFG={args.scale}, batch={B} per GPU, "
-                                    + ("bf16 storage / fp32 accumulate (BASELINE.json configs[2..3] family; NOT the headline fp32 configuration)"
-                                       if bf16 else "fp32 (BASELINE.json configs[1])")),
+            "config": {"workload": workload_name(args.precision, B, args.ddim_steps, args.scale),
                        "global_batch": B * world, "ddim_steps": args.ddim_steps, "cfg_scale": args.scale,
-                       "context_len": T, "parallelism": f"image-sharded x{world}, 1 RCCL broadcast of the text embedding"},
+                       "context_len": T_CTX, "parallelism": f"image-sharded x{world}, 1 RCCL broadcast of the text embedding",
+                       "output": "u8 RGB copied to pinned host memory inside the timed region"},
             "algorithmic_tflop_per_image": flop_per_image / 1e12,
             "whole_path_tflops_per_gpu": value / world * flop_per_image / 1e12,
-            "whole_path_frac_of_mfma_peak": value / world * flop_per_image / 1e12 / (BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS),
-            "kernels_per_image": stats["kernels"] / B, "weights_load_s": t_load,
+            "whole_path_frac_of_mfma_peak": value / world * flop_per_image / 1e12 / peak,
+            "kernels_per_image": stats["kernels"] / B, "weights_load_s": t_load, "weights_generate_s": t_gen,
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        if prof is not None:
-            out["kernel_classes_ms_per_image"] = {k: round(v["ms"] / B, 3) for k, v in prof.items()}
-            gn = prof["group_norm"]
-            if gn["ms"] > 0:
-                out["group_norm_algorithmic_GBps"] = gn["bytes"] / (gn["ms"] * 1e-3) / 1e9
-            at = prof["attention"]
-            if at["ms"] > 0:
-                out["attention_tflops"] = at["flops"] / (at["ms"] * 1e-3) / 1e12
+        out.update(classes)
+        if secondary:
+            out["secondary"] = secondary
         print(json.dumps(out), flush=True)
 
-    sd.close()
     if world > 1:
         dist.destroy_process_group()
 

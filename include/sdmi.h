@@ -16,8 +16,13 @@
  *    layouts (NCHW images/latents, [n, tokens, channels] sequences); the
  *    library copies in/out and blocks until results are in host memory.
  *    NHWC and packed weights are internal.
- *  - *_dev functions take DEVICE pointers (same logical layouts) and enqueue
- *    on the context's HIP stream; sdmi_synchronize() waits for it.
+ *  - *_dev functions take DEVICE pointers (same logical layouts).  The context
+ *    works on a private non-blocking HIP stream, so on entry it must be ordered
+ *    behind whatever produced those buffers: if sdmi_set_stream() named the
+ *    caller's stream, the context waits for an event on it (and makes that
+ *    stream wait for the results on return); otherwise the call starts with a
+ *    hipDeviceSynchronize().  All entry points return after the results are
+ *    complete (they block on the context's stream).
  *  - every function returns 0 (SDMI_OK) or a negative sdmi_status; the
  *    message is available from sdmi_last_error() (thread-local).  The
  *    reference's hot path is infallible by type and panics on shape errors
@@ -61,7 +66,7 @@ typedef struct sdmi_config {
     int32_t latent_h;        /* 64   (image = 8x)                               */
     int32_t latent_w;        /* 64                                              */
     int32_t vae_ch;          /* 128  (decoder channels 4c,4c,2c,c)              */
-    int32_t max_batch;       /* images per call the pool is sized for           */
+    int32_t max_batch;       /* largest n a call may pass; 0 = no limit          */
     int32_t precision;       /* 0 = fp32; 1 = bf16 storage, fp32 accumulate     */
     /* CLIP text encoder, CLIPConfig::new(49408, 768, 12, 77, 12) stablediffusion/mod.rs:29;
      * its width is ctx_dim.  clip_layers = 0 builds a context without it.              */
@@ -79,6 +84,11 @@ int sdmi_create(sdmi_ctx** out, const sdmi_config* cfg);
 void sdmi_destroy(sdmi_ctx* ctx);
 const char* sdmi_last_error(void);
 int sdmi_synchronize(sdmi_ctx* ctx);
+/* Names the HIP stream (a hipStream_t passed as void*; NULL = the legacy default stream) on which the caller
+ * produces the inputs and consumes the outputs of the *_dev entry points; enable = 0 returns to the default
+ * (device-wide synchronisation on entry).  The reference has no counterpart: Burn tensors are ordered by the
+ * backend's own queue. */
+int sdmi_set_stream(sdmi_ctx* ctx, void* hip_stream, int32_t enable);
 /* library / build identification, e.g. "sdmi 0.1 gfx950 fp32" */
 const char* sdmi_version(void);
 
@@ -98,6 +108,15 @@ int sdmi_weight_info(sdmi_ctx* ctx, int32_t index, const char** name, int32_t* n
  * (format: src/model/load.rs:17-28 -- 1-D float32 .npy whose first D values
  * are the shape). */
 int sdmi_load_weights_dir(sdmi_ctx* ctx, const char* dump_dir);
+/* One flat image of every tensor: `data` holds, for each entry i of the configured model in
+ * sdmi_weight_info() order and restricted to the weight groups selected by `groups` (bit 0: hot path = UNet,
+ * VAE decoder, alphas_cumprod; bit 1: CLIP; bit 2: VAE encoder), the tensor's fp32 values in the reference's
+ * layout, back to back, no headers.  `n_floats` must equal the sum of their sizes (sdmi_packed_size).  Staged
+ * through one pinned buffer and one stream: the batched replacement of load_stable_diffusion's ~1100 file reads
+ * (stablediffusion/load.rs:16-33, model/load.rs:17-160). */
+int sdmi_load_weights_packed(sdmi_ctx* ctx, const float* data, size_t n_floats, int32_t groups);
+/* number of floats sdmi_load_weights_packed expects for `groups` */
+int64_t sdmi_packed_size(sdmi_ctx* ctx, int32_t groups);
 /* packs everything into the device layouts; fails listing the first missing tensor */
 int sdmi_finalize_weights(sdmi_ctx* ctx);
 
@@ -226,7 +245,7 @@ int sdmi_op_geglu_forward(sdmi_ctx* ctx, const float* x, const float* weight, co
 int sdmi_op_timestep_embedding(sdmi_ctx* ctx, int32_t t, int32_t dim, float* out);
 
 /* ---- tuning / introspection ---------------------------------------------------- */
-/* "key=value" knobs, e.g. "gemm_tile=auto", "splitk=0", "graph=1". */
+/* "key=value" knobs for tests and tuning, e.g. "gemm_tile=auto", "splitk=0", "profile=1" (Engine::set_option). */
 int sdmi_set_option(sdmi_ctx* ctx, const char* key, const char* value);
 /* time (ms, HIP events on the context stream) and kernel count of the last
  * hot-path call; flops = algorithmic FLOPs it executed (2*MAC of conv/GEMM/attention). */

@@ -277,8 +277,9 @@ class UNetOracle:
         return linear(e, *P.linear(f"{self.root}/lin2_time_embed", ed, ed))
 
     @torch.no_grad()
-    def forward(self, x, t: int, context):
-        """UNet::forward unet/mod.rs:109-143.  x [n,4,h,w]; context [n,T,ctx_dim]."""
+    def forward(self, x, t: int, context, norm_out_eps: float = 1e-5):
+        """UNet::forward unet/mod.rs:109-143.  x [n,4,h,w]; context [n,T,ctx_dim].  norm_out_eps: the eps the dump carries
+        for unet/norm_out (groupnorm/load.rs:19; 1e-5 in every real dump, Q3) -- a test varies it."""
         x = x.to(self.dtype)
         context = context.to(self.dtype)
         emb = self.time_embed(t)
@@ -302,7 +303,7 @@ class UNetOracle:
             x = self._block(kind, f"{self.root}/output_blocks/{name}", x, emb, context, cin, cout)
             if self.trace is not None:
                 self.trace[f"out{i}"] = x
-        x = group_norm(x, *self.P.norm(f"{self.root}/norm_out", mc))
+        x = group_norm(x, *self.P.norm(f"{self.root}/norm_out", mc), eps=norm_out_eps)
         x = silu(x)
         return conv2d(x, self.P.conv(f"{self.root}/conv_out", mc, 4, 3), padding=1)
 

@@ -44,10 +44,13 @@ SIGNATURES = {
     "sdmi_last_error": (C.c_char_p, []),
     "sdmi_synchronize": (C.c_int, [_CTX]),
     "sdmi_version": (C.c_char_p, []),
+    "sdmi_set_stream": (C.c_int, [_CTX, C.c_void_p, C.c_int32]),
     "sdmi_set_weight": (C.c_int, [_CTX, C.c_char_p, _F, C.c_int32, C.POINTER(C.c_int64)]),
     "sdmi_weight_count": (C.c_int, [_CTX]),
     "sdmi_weight_info": (C.c_int, [_CTX, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "sdmi_load_weights_dir": (C.c_int, [_CTX, C.c_char_p]),
+    "sdmi_load_weights_packed": (C.c_int, [_CTX, _F, C.c_size_t, C.c_int32]),
+    "sdmi_packed_size": (C.c_int64, [_CTX, C.c_int32]),
     "sdmi_finalize_weights": (C.c_int, [_CTX]),
     "sdmi_unet_forward": (C.c_int, [_CTX, _F, C.c_int32, _F, C.c_int32, C.c_int32, _F]),
     "sdmi_sample_latent": (C.c_int, [_CTX, _F, C.c_int32, C.c_int32, _F, C.c_int32, C.c_double, C.c_size_t, _F, C.c_uint64, _F]),

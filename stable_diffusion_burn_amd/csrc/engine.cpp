@@ -32,7 +32,7 @@ void* DevPool::alloc(size_t bytes) {
                     void* p = slabs_[si].base + fl[i].off;
                     if (fl[i].size == bytes) fl.erase(fl.begin() + i);
                     else { fl[i].off += bytes; fl[i].size -= bytes; }
-                    live_[p] = {(int)si, bytes};
+                    live_[p] = Live{(int)si, bytes, ++serial_};
                     in_use_ += bytes;
                     high_ = std::max(high_, in_use_);
                     return p;
@@ -57,8 +57,8 @@ void DevPool::free(void* p) {
     if (!p) return;
     auto it = live_.find(p);
     if (it == live_.end()) throw Error(SDMI_ERR_STATE, "DevPool: free of unknown pointer");
-    const int si = it->second.first;
-    const size_t size = it->second.second;
+    const int si = it->second.slab;
+    const size_t size = it->second.size;
     live_.erase(it);
     in_use_ -= size;
     auto& sl = slabs_[si];
@@ -75,6 +75,14 @@ void DevPool::free(void* p) {
         fl[pos - 1].size += fl[pos].size;
         fl.erase(fl.begin() + pos);
     }
+}
+
+size_t DevPool::free_since(unsigned long long mark) {
+    std::vector<void*> victims;
+    for (auto& kv : live_)
+        if (kv.second.serial > mark) victims.push_back(kv.first);
+    for (void* p : victims) free(p);
+    return victims.size();
 }
 
 // =============================================================================
@@ -143,12 +151,18 @@ Engine::Engine(const sdmi_config& cfg) : cfg_(cfg) {
     SDMI_HIP(hipGetDeviceProperties(&prop, cfg.device));
     if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
         throw Error(SDMI_ERR_UNSUPPORTED, std::string("libsdmi is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
+    try {
     SDMI_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     SDMI_HIP(hipEventCreate(&ev0_));
     SDMI_HIP(hipEventCreate(&ev1_));
+    SDMI_HIP(hipEventCreateWithFlags(&ev_user_, hipEventDisableTiming));
     SDMI_HIP(hipMalloc(&zero_page_, 256));
-    SDMI_HIP(hipMemset(zero_page_, 0, 256));
     weight_allocs_.push_back(zero_page_);
+    SDMI_HIP(hipMemsetAsync(zero_page_, 0, 256, stream_));
+    SDMI_HIP(hipMalloc((void**)&splitk_counters_, kSplitkCounters * sizeof(unsigned)));
+    weight_allocs_.push_back(splitk_counters_);
+    SDMI_HIP(hipMemsetAsync(splitk_counters_, 0, kSplitkCounters * sizeof(unsigned), stream_));
+    SDMI_HIP(hipStreamSynchronize(stream_));
     {   // measured per-shape tile choices (tools/autotune.py -> tuning/gfx950_fp32.txt)
         struct Row { const char* key; int cfg; int splits; };
         static const Row rows[] = {
@@ -161,9 +175,15 @@ Engine::Engine(const sdmi_config& cfg) : cfg_(cfg) {
         for (const Row* r = rows16; r->key; ++r) tuned_bf16_[r->key] = TileChoice{r->cfg, r->splits};
     }
     build_model();
+    } catch (...) {   // the destructor does not run for a half-built object
+        destroy();
+        throw;
+    }
 }
 
-Engine::~Engine() {
+Engine::~Engine() { destroy(); }
+
+void Engine::destroy() noexcept {
     (void)hipSetDevice(cfg_.device);
     if (stream_) (void)hipStreamSynchronize(stream_);
     for (void* p : weight_allocs_) (void)hipFree(p);
@@ -171,7 +191,10 @@ Engine::~Engine() {
     for (hipEvent_t e : prof_free_) (void)hipEventDestroy(e);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
+    if (ev_user_) (void)hipEventDestroy(ev_user_);
     if (stream_) (void)hipStreamDestroy(stream_);
+    weight_allocs_.clear(); prof_pending_.clear(); prof_free_.clear();
+    ev0_ = ev1_ = ev_user_ = nullptr; stream_ = nullptr;
 }
 
 void Engine::add_entry(const std::string& name, int kind, std::initializer_list<int64_t> dims, float** dst, int wdt) {
@@ -184,6 +207,12 @@ void Engine::add_entry(const std::string& name, int kind, std::initializer_list<
     entries_.push_back(e);
 }
 
+void Engine::add_meta(const std::string& name, int n, float e0, float e1, float* store) {
+    MetaEntry m{name, n, {e0, e1}, store};
+    meta_index_[name] = (int)meta_.size();
+    meta_.push_back(m);
+}
+
 // The structs build_model() fills live in members / vectors whose storage is fixed
 // before any entry is added (entries_ keeps float** into them).
 void Engine::build_model() {
@@ -192,12 +221,19 @@ void Engine::build_model() {
     auto add = [](Engine* e, const std::string& n, int kind, std::initializer_list<int64_t> d, float** dst, int wdt = 0) { e->add_entry(n, kind, d, dst, wdt); };
     // precision = 1: weights of every layer with Cin % 64 == 0 are packed as bf16; the three Cin = 4
     // layers and the time-embedding MLPs (M = n_steps rows, once per call) stay fp32
-    auto conv = [&](ConvW& w, const std::string& path, int cin, int cout, int k) {
+    // stride / pad: what the engine applies to this layer; checked against the dump's metadata files (load_conv2d, load.rs:118-160)
+    auto conv = [&](ConvW& w, const std::string& path, int cin, int cout, int k, int stride = 1, int pad = -1) {
         w.cin = cin; w.cout = cout; w.k = k;
         w.dt = (bf16_ && cin % 64 == 0) ? 1 : 0;
         if (bf16_ && !w.dt && cin >= 32) throw Error(SDMI_ERR_UNSUPPORTED, "bf16: conv Cin must be a multiple of 64 (or < 32)");
         add(this, path + "/weight", 0, {cout, cin, k, k}, &w.bt, w.dt);
         add(this, path + "/bias", 2, {cout}, &w.bias);
+        if (pad < 0) pad = k == 3 ? 1 : 0;
+        add_meta(path + "/stride", 2, (float)stride, (float)stride, nullptr);
+        add_meta(path + "/padding", 2, (float)pad, (float)pad, nullptr);
+        add_meta(path + "/dilation", 2, 1.f, 1.f, nullptr);
+        add_meta(path + "/kernel_size", 2, (float)k, (float)k, nullptr);
+        add_meta(path + "/n_group", 1, 1.f, 0.f, nullptr);
     };
     auto lin = [&](LinW& w, const std::string& path, int cin, int cout, bool bias, bool keep_f32 = false) {
         w.cin = cin; w.cout = cout;
@@ -206,10 +242,15 @@ void Engine::build_model() {
         add(this, path + "/weight", 1, {cin, cout}, &w.bt, w.dt);
         if (bias) add(this, path + "/bias", 2, {cout}, &w.bias);
     };
-    auto norm = [&](NormW& w, const std::string& path, int c) {
+    auto norm = [&](NormW& w, const std::string& path, int c, bool group_norm = true) {
         w.c = c;
         add(this, path + "/weight", 2, {c}, &w.gamma);
         add(this, path + "/bias", 2, {c}, &w.beta);
+        add_meta(path + "/eps", 1, 0.f, 0.f, &w.eps);
+        if (group_norm) {
+            add_meta(path + "/n_group", 1, 32.f, 0.f, nullptr);   // GroupNormConfig::new(32, ..) everywhere (unet/mod.rs:692, autoencoder/mod.rs:483)
+            add_meta(path + "/n_channel", 1, (float)c, 0.f, nullptr);
+        }
     };
     auto res = [&](ResW& r, const std::string& path, int cin, int cout, bool unet) {
         r.cin = cin; r.cout = cout; r.has_embed = unet; r.has_skip = cin != cout;
@@ -243,23 +284,25 @@ void Engine::build_model() {
         lin(m.k, path + "/key", cctx, c, false);
         lin(m.v, path + "/value", cctx, c, false);
         lin(m.out, path + "/out", c, c, true);
+        add_meta(path + "/n_head", 1, (float)cfg_.n_head, 0.f, nullptr);
     };
     auto spatial = [&](SpatialW& s, const std::string& path, int c) {  // unet/mod.rs:436-527
         s.c = c;
         norm(s.norm, path + "/norm", c);
         conv(s.proj_in, path + "/proj_in", c, c, 1);
         const std::string t = path + "/transformer";
-        norm(s.ln1, t + "/norm1", c);
+        norm(s.ln1, t + "/norm1", c, false);
         mha(s.attn1, t + "/attn1", c, c);
-        norm(s.ln2, t + "/norm2", c);
+        norm(s.ln2, t + "/norm2", c, false);
         mha(s.attn2, t + "/attn2", c, cd);
-        norm(s.ln3, t + "/norm3", c);
+        norm(s.ln3, t + "/norm3", c, false);
         lin(s.geglu_proj, t + "/mlp/geglu/proj", c, 8 * c, true);
         lin(s.mlp_lin, t + "/mlp/lin", 4 * c, c, true);
         conv(s.proj_out, path + "/proj_out", c, c, 1);
     };
 
     add(this, "alphas_cumprod", 3, {1000}, nullptr);
+    add_meta("n_steps", 1, 1000.f, 0.f, nullptr);   // stablediffusion/load.rs:20
 
     // ---- UNet (unet/mod.rs:36-92) ------------------------------------------------
     lin(lin1_time_, "unet/lin1_time_embed", mc, ed, true, /*keep_f32=*/true);
@@ -281,7 +324,7 @@ void Engine::build_model() {
         const std::string path = root + "/" + s.name;
         switch (s.kind) {
             case BK_CONV: conv(b.conv, path, s.cin, s.cout, 3); break;
-            case BK_DOWN: conv(b.conv, path, s.cin, s.cout, 3); break;  // load_downsample: path itself (unet/load.rs:138-143)
+            case BK_DOWN: conv(b.conv, path, s.cin, s.cout, 3, 2); break;  // load_downsample: path itself (unet/load.rs:138-143); stride 2, pad 1 (unet/mod.rs:413-418)
             case BK_RES: res(b.res, path, s.cin, s.cout, true); break;
             default:
                 res(b.res, path + "/res", s.cin, s.cout, true);
@@ -356,16 +399,16 @@ void Engine::build_model() {
             weight_allocs_.push_back(bias);
             b.q.bt = reinterpret_cast<float*>(w); b.k.bt = b.q.bt + (size_t)cs * cs; b.v.bt = b.q.bt + (size_t)2 * cs * cs;
             b.q.bias = reinterpret_cast<float*>(bias); b.k.bias = b.q.bias + cs; b.v.bias = b.q.bias + 2 * cs;
-            norm(b.attn_ln, bp + "/attn_ln", cs);
+            norm(b.attn_ln, bp + "/attn_ln", cs, false);
             lin(b.q, bp + "/attn/query", cs, cs, true, true);   // MultiHeadSelfAttention: all four Linears carry a bias
             lin(b.k, bp + "/attn/key", cs, cs, true, true);
             lin(b.v, bp + "/attn/value", cs, cs, true, true);
             lin(b.out, bp + "/attn/out", cs, cs, true, true);
-            norm(b.mlp_ln, bp + "/mlp_ln", cs);
+            norm(b.mlp_ln, bp + "/mlp_ln", cs, false);
             lin(b.fc1, bp + "/mlp/fc1", cs, 4 * cs, true, true);
             lin(b.fc2, bp + "/mlp/fc2", 4 * cs, cs, true, true);
         }
-        norm(clip_ln_, "clip/layer_norm", cs);
+        norm(clip_ln_, "clip/layer_norm", cs, false);
         cur_group_ = 0;
     }
 
@@ -383,7 +426,7 @@ void Engine::build_model() {
             const std::string bp = "autoencoder/encoder/blocks/" + std::to_string(i);
             res(b.res[0], bp + "/res1", b.cin, b.cout, false);
             res(b.res[1], bp + "/res2", b.cout, b.cout, false);
-            if (b.has_down) conv(b.down, bp + "/downsampler/conv", b.cout, b.cout, 3);   // load_padded_conv2d: "{path}/conv"
+            if (b.has_down) conv(b.down, bp + "/downsampler/conv", b.cout, b.cout, 3, 2, 0);   // load_padded_conv2d: "{path}/conv", saved with padding (0, 0) (python/save.py:73-76)
         }
         res(enc_mid1_, "autoencoder/encoder/mid/block_1", 4 * vc, 4 * vc, false);
         enc_attn_.c = 4 * vc;
@@ -403,14 +446,176 @@ void Engine::build_model() {
 // =============================================================================
 // weights
 // =============================================================================
+// Loading is batched: every tensor goes host -> pinned ring -> (device staging ->) packing kernel -> its slot of
+// ONE device arena per weight group, all asynchronous on the engine's stream; the callers synchronise once
+// (load_weights_dir / load_weights_packed) or per tensor (set_weight, whose source may be freed on return).
+// The reference builds ~1100 Burn tensors one file at a time (stablediffusion/load.rs:16-33, model/load.rs:30-46).
+static constexpr size_t kStageBytes = (size_t)160 << 20;   // >= the largest tensor (CLIP token table, 152 MB)
+
+struct Engine::Stager {
+    char* pinned[2] = {nullptr, nullptr};
+    char* dev[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    size_t used = 0;
+    int cur = 0;
+    ~Stager() {
+        for (int i = 0; i < 2; ++i) {
+            if (done[i]) { (void)hipEventSynchronize(done[i]); (void)hipEventDestroy(done[i]); }
+            if (pinned[i]) (void)hipHostFree(pinned[i]);
+            if (dev[i]) (void)hipFree(dev[i]);
+        }
+    }
+};
+
+void Engine::stager_release() { stager_.reset(); }
+
+// `bytes` of pinned host memory (256-byte aligned) the caller fills; valid until the matching commit
+char* Engine::stage_reserve(size_t bytes, size_t* offset, int* half) {
+    if (bytes > kStageBytes) throw Error(SDMI_ERR_UNSUPPORTED, "weight tensor larger than the staging buffer");
+    if (!stager_) {
+        stager_.reset(new Stager());
+        for (int i = 0; i < 2; ++i) {
+            SDMI_HIP(hipHostMalloc((void**)&stager_->pinned[i], kStageBytes, hipHostMallocDefault));
+            SDMI_HIP(hipMalloc((void**)&stager_->dev[i], kStageBytes));
+            SDMI_HIP(hipEventCreateWithFlags(&stager_->done[i], hipEventDisableTiming));
+        }
+    }
+    Stager& st = *stager_;
+    const size_t need = (bytes + 255) / 256 * 256;
+    if (st.used + need > kStageBytes) {   // this half is full: mark it in flight, move to the other one
+        SDMI_HIP(hipEventRecord(st.done[st.cur], stream_));
+        st.busy[st.cur] = true;
+        st.cur ^= 1;
+        st.used = 0;
+        if (st.busy[st.cur]) { SDMI_HIP(hipEventSynchronize(st.done[st.cur])); st.busy[st.cur] = false; }
+    }
+    *offset = st.used;
+    *half = st.cur;
+    st.used += need;
+    return st.pinned[st.cur] + *offset;
+}
+
+void Engine::ensure_arena(int group) {
+    if (arena_done_[group]) return;
+    size_t total = 0;
+    for (auto& e : entries_) {
+        if (e.group != group || e.kind == 3 || *e.dst) continue;
+        size_t count = 1;
+        for (int i = 0; i < e.ndim; ++i) count *= (size_t)e.dims[i];
+        if (e.kind == 0 && e.dims[1] == 3) count = count / 3 * 4;   // RGB conv_in: packed with a zero 4th input channel
+        total += (count * (e.wdt ? 2 : 4) + 255) / 256 * 256;
+    }
+    if (total) {
+        char* base = nullptr;
+        SDMI_HIP(hipMalloc((void**)&base, total));
+        weight_allocs_.push_back(base);
+        size_t off = 0;
+        for (auto& e : entries_) {
+            if (e.group != group || e.kind == 3 || *e.dst) continue;
+            size_t count = 1;
+            for (int i = 0; i < e.ndim; ++i) count *= (size_t)e.dims[i];
+            if (e.kind == 0 && e.dims[1] == 3) count = count / 3 * 4;
+            *e.dst = reinterpret_cast<float*>(base + off);
+            off += (count * (e.wdt ? 2 : 4) + 255) / 256 * 256;
+        }
+    }
+    arena_done_[group] = true;
+}
+
+static size_t entry_count(const WeightEntry& e) {
+    size_t count = 1;
+    for (int i = 0; i < e.ndim; ++i) count *= (size_t)e.dims[i];
+    return count;
+}
+
+// Enqueues the upload + packing of one tensor whose fp32 values (reference layout) the caller has written to the
+// pinned block (half, offset) returned by stage_reserve.
+void Engine::stage_commit(WeightEntry& e, size_t offset, int half) {
+    Stager& st = *stager_;
+    const size_t count = entry_count(e);
+    const float* host = reinterpret_cast<const float*>(st.pinned[half] + offset);
+    if (e.kind == 3) {
+        alphas_.assign(host, host + count);
+        e.set = true;
+        return;
+    }
+    ensure_arena(e.group);
+    if (e.kind == 2) {
+        SDMI_HIP(hipMemcpyAsync(*e.dst, host, count * sizeof(float), hipMemcpyHostToDevice, stream_));
+    } else {
+        float* stage = reinterpret_cast<float*>(st.dev[half] + offset);
+        size_t n_stage = count;
+        if (e.kind == 0 && e.dims[1] == 3) n_stage = count / 3 * 4;   // padded on the host by the caller of stage_commit
+        SDMI_HIP(hipMemcpyAsync(stage, host, n_stage * sizeof(float), hipMemcpyHostToDevice, stream_));
+        hipError_t err;
+        if (e.kind == 0) {
+            const int cout = (int)e.dims[0], cin = e.dims[1] == 3 ? 4 : (int)e.dims[1], k = (int)e.dims[2];
+            if (!(cin % 32 == 0 || (cin < 32 && cin % 4 == 0))) throw Error(SDMI_ERR_UNSUPPORTED, "conv Cin must be a multiple of 32, or < 32 and a multiple of 4");
+            err = e.wdt ? launch_pack_conv_weight_bf16(stage, *e.dst, cout, cin, k, k, stream_)
+                        : launch_pack_conv_weight(stage, *e.dst, cout, cin, k, k, stream_);
+        } else {
+            err = e.wdt ? launch_pack_linear_weight_bf16(stage, *e.dst, (int)e.dims[0], (int)e.dims[1], stream_)
+                        : launch_pack_linear_weight(stage, *e.dst, (int)e.dims[0], (int)e.dims[1], stream_);
+        }
+        SDMI_HIP(err);
+    }
+    e.set = true;
+    finalized_ = false;
+}
+
+// copies one tensor into the pinned ring (padding the RGB conv_in to 4 input channels) and commits it
+void Engine::upload_weight(WeightEntry& e, const float* data) {
+    const size_t count = entry_count(e);
+    size_t off; int half;
+    if (e.kind == 0 && e.dims[1] == 3) {
+        const int cout = (int)e.dims[0], T = (int)(e.dims[2] * e.dims[3]);
+        float* dst = reinterpret_cast<float*>(stage_reserve((size_t)cout * 4 * T * sizeof(float), &off, &half));
+        std::memset(dst, 0, (size_t)cout * 4 * T * sizeof(float));
+        for (int o = 0; o < cout; ++o)
+            for (int c = 0; c < 3; ++c) std::memcpy(dst + ((size_t)o * 4 + c) * T, data + ((size_t)o * 3 + c) * T, T * sizeof(float));
+    } else {
+        char* dst = stage_reserve(count * sizeof(float), &off, &half);
+        std::memcpy(dst, data, count * sizeof(float));
+    }
+    stage_commit(e, off, half);
+}
+
+// Module metadata the reference's loaders read next to the tensors (python/save.py:23-68): a norm's `eps` is honoured
+// (groupnorm/load.rs:19, load.rs:load_layer_norm), everything else must equal what this engine is built for.
+bool Engine::set_meta(const std::string& name, const float* values, size_t n) {
+    auto it = meta_index_.find(name);
+    if (it == meta_index_.end()) return false;
+    MetaEntry& m = meta_[it->second];
+    if ((int)n != m.n) throw Error(SDMI_ERR_WEIGHTS, "'" + name + "' holds " + std::to_string(n) + " values, expected " + std::to_string(m.n));
+    if (m.store) {
+        if (!(values[0] > 0.f) || values[0] > 1e-2f) throw Error(SDMI_ERR_WEIGHTS, "'" + name + "': eps out of range");
+        *m.store = values[0];
+        return true;
+    }
+    for (int i = 0; i < m.n; ++i)
+        if (values[i] != m.expect[i]) {
+            std::ostringstream os;
+            os << "'" << name << "' = " << values[i] << " but this engine is built for " << m.expect[i]
+               << " (the reference's loaders honour the file; a dump with different hyper-parameters needs a matching sdmi_config)";
+            throw Error(SDMI_ERR_WEIGHTS, os.str());
+        }
+    return true;
+}
+
 void Engine::set_weight(const char* name, const float* data, int ndim, const int64_t* dims) {
     if (!name || !data || !dims) throw Error(SDMI_ERR_INVALID, "set_weight: null argument");
+    if (meta_index_.count(name)) {
+        size_t n = 1;
+        for (int i = 0; i < ndim; ++i) n *= (size_t)dims[i];
+        set_meta(name, data, n);
+        return;
+    }
     auto it = entry_index_.find(name);
     if (it == entry_index_.end()) throw Error(SDMI_ERR_WEIGHTS, std::string("set_weight: unknown tensor '") + name + "'");
     WeightEntry& e = entries_[it->second];
     bool ok = ndim == e.ndim;
-    size_t count = 1;
-    for (int i = 0; ok && i < ndim; ++i) { ok = dims[i] == e.dims[i]; count *= (size_t)dims[i]; }
+    for (int i = 0; ok && i < ndim; ++i) ok = dims[i] == e.dims[i];
     if (!ok) {
         std::ostringstream os;
         os << "set_weight: '" << name << "' expects shape [";
@@ -421,57 +626,29 @@ void Engine::set_weight(const char* name, const float* data, int ndim, const int
         throw Error(SDMI_ERR_WEIGHTS, os.str());
     }
     SDMI_HIP(hipSetDevice(cfg_.device));
-    if (e.kind == 3) {
-        alphas_.assign(data, data + count);
-        e.set = true;
-        return;
+    upload_weight(e, data);   // data is copied into the pinned ring before this returns: the caller may free it
+}
+
+size_t Engine::packed_size(int groups) const {
+    size_t n = 0;
+    for (auto& e : entries_)
+        if (groups & (1 << e.group)) n += entry_count(e);
+    return n;
+}
+
+void Engine::load_weights_packed(const float* data, size_t n_floats, int groups) {
+    if (!data) throw Error(SDMI_ERR_INVALID, "load_weights_packed: null pointer");
+    if (groups <= 0 || groups > 7) throw Error(SDMI_ERR_INVALID, "load_weights_packed: groups is a bit mask of 1 (hot path), 2 (CLIP), 4 (VAE encoder)");
+    if (n_floats != packed_size(groups)) throw Error(SDMI_ERR_WEIGHTS, "load_weights_packed: expected " + std::to_string(packed_size(groups)) + " floats, got " + std::to_string(n_floats));
+    SDMI_HIP(hipSetDevice(cfg_.device));
+    size_t off = 0;
+    for (auto& e : entries_) {
+        if (!(groups & (1 << e.group))) continue;
+        upload_weight(e, data + off);
+        off += entry_count(e);
     }
-    if (!*e.dst) {
-        void* p = nullptr;
-        const size_t alloc_count = (e.kind == 0 && e.dims[1] == 3) ? count / 3 * 4 : count;
-        SDMI_HIP(hipMalloc(&p, alloc_count * (e.wdt ? 2 : sizeof(float))));
-        weight_allocs_.push_back(p);
-        *e.dst = reinterpret_cast<float*>(p);
-    }
-    if (e.kind == 2) {
-        SDMI_HIP(hipMemcpy(*e.dst, data, count * sizeof(float), hipMemcpyHostToDevice));
-    } else {
-        void* stage = nullptr;
-        SDMI_HIP(hipMalloc(&stage, count * sizeof(float)));
-        hipError_t err = hipMemcpy(stage, data, count * sizeof(float), hipMemcpyHostToDevice);
-        if (err == hipSuccess) {
-            if (e.kind == 0 && e.dims[1] == 3) {
-                // RGB conv_in of the VAE encoder: packed with a zero 4th input channel (the image is staged as NHWC4)
-                const int cout = (int)e.dims[0], k = (int)e.dims[2], T = k * k;
-                std::vector<float> padded((size_t)cout * 4 * T, 0.f);
-                for (int o = 0; o < cout; ++o)
-                    for (int c = 0; c < 3; ++c)
-                        for (int t = 0; t < T; ++t) padded[((size_t)o * 4 + c) * T + t] = data[((size_t)o * 3 + c) * T + t];
-                void* stage4 = nullptr;
-                err = hipMalloc(&stage4, padded.size() * sizeof(float));
-                if (err == hipSuccess) err = hipMemcpy(stage4, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice);
-                if (err == hipSuccess) err = launch_pack_conv_weight((const float*)stage4, *e.dst, cout, 4, k, k, stream_);
-                if (err == hipSuccess) err = hipStreamSynchronize(stream_);
-                if (stage4) (void)hipFree(stage4);
-            } else if (e.kind == 0) {
-                const int cout = (int)e.dims[0], cin = (int)e.dims[1], k = (int)e.dims[2];
-                if (!(cin % 32 == 0 || (cin < 32 && cin % 4 == 0))) {
-                    (void)hipFree(stage);
-                    throw Error(SDMI_ERR_UNSUPPORTED, "conv Cin must be a multiple of 32, or < 32 and a multiple of 4");
-                }
-                err = e.wdt ? launch_pack_conv_weight_bf16((const float*)stage, *e.dst, cout, cin, k, k, stream_)
-                            : launch_pack_conv_weight((const float*)stage, *e.dst, cout, cin, k, k, stream_);
-            } else {
-                err = e.wdt ? launch_pack_linear_weight_bf16((const float*)stage, *e.dst, (int)e.dims[0], (int)e.dims[1], stream_)
-                            : launch_pack_linear_weight((const float*)stage, *e.dst, (int)e.dims[0], (int)e.dims[1], stream_);
-            }
-        }
-        if (err == hipSuccess) err = hipStreamSynchronize(stream_);
-        (void)hipFree(stage);
-        SDMI_HIP(err);
-    }
-    e.set = true;
-    finalized_ = false;
+    SDMI_HIP(hipStreamSynchronize(stream_));
+    stager_release();
 }
 
 void Engine::finalize_weights() {
@@ -487,6 +664,8 @@ void Engine::finalize_weights() {
     for (int g = 1; g < 3; ++g)
         if (set[g] && missing[g])
             throw Error(SDMI_ERR_WEIGHTS, std::string("finalize_weights: ") + kGroupName[g] + " weights are partially set; missing '" + missing[g]->name + "'");
+    SDMI_HIP(hipStreamSynchronize(stream_));   // every packing kernel has run
+    stager_release();
     clip_ready_ = total[1] > 0 && set[1] == total[1];
     enc_ready_ = total[2] > 0 && set[2] == total[2];
     finalized_ = true;
@@ -494,7 +673,9 @@ void Engine::finalize_weights() {
 
 // npy-dump reader: src/model/load.rs:17-28 -- a 1-D float32 .npy whose first D
 // values are the shape and whose remaining values are the row-major data.
-static std::vector<float> read_npy_f32(const std::string& path) {
+// Returns the number of floats in the file; `sink(n)` supplies the destination for them.
+template <class Sink>
+static size_t read_npy_f32(const std::string& path, Sink&& sink) {
     std::ifstream f(path, std::ios::binary);
     if (!f) throw Error(SDMI_ERR_IO, "cannot open " + path);
     char magic[8];
@@ -510,29 +691,63 @@ static std::vector<float> read_npy_f32(const std::string& path) {
     if (header.find("'fortran_order': True") != std::string::npos) throw Error(SDMI_ERR_IO, "fortran-order npy: " + path);
     const std::streampos start = f.tellg();
     f.seekg(0, std::ios::end);
-    const size_t bytes = (size_t)(f.tellg() - start);
+    const size_t n = (size_t)(f.tellg() - start) / sizeof(float);
     f.seekg(start);
-    std::vector<float> v(bytes / sizeof(float));
-    f.read((char*)v.data(), (std::streamsize)(v.size() * sizeof(float)));
-    return v;
+    float* dst = sink(n);
+    f.read((char*)dst, (std::streamsize)(n * sizeof(float)));
+    if (!f) throw Error(SDMI_ERR_IO, "short read: " + path);
+    return n;
 }
 
 void Engine::load_weights_dir(const char* dir) {
     if (!dir) throw Error(SDMI_ERR_INVALID, "load_weights_dir: null path");
+    SDMI_HIP(hipSetDevice(cfg_.device));
     // the CLIP subtree is read when it exists (load_stable_diffusion always has it, stablediffusion/load.rs:24)
     const bool have_clip = std::ifstream(std::string(dir) + "/clip/token_embedding/weight.npy").good();
     const bool have_enc = std::ifstream(std::string(dir) + "/autoencoder/encoder/conv_in/weight.npy").good();
+    for (auto& m : meta_) {   // optional per-module metadata files
+        const std::string path = std::string(dir) + "/" + m.name + ".npy";
+        if (!std::ifstream(path).good()) continue;
+        std::vector<float> raw;
+        read_npy_f32(path, [&](size_t n) { raw.resize(n); return raw.data(); });
+        // save_scalar writes [1.0, s]; save_tensor of a 2-vector writes [2.0, a, b] (python/save.py:6-15)
+        if (raw.size() != (size_t)m.n + 1 || raw[0] != (float)m.n) throw Error(SDMI_ERR_WEIGHTS, "malformed metadata file " + path);
+        set_meta(m.name, raw.data() + 1, (size_t)m.n);
+    }
     for (auto& e : entries_) {
         if ((e.group == 1 && !have_clip) || (e.group == 2 && !have_enc)) continue;
         const std::string path = std::string(dir) + "/" + e.name + ".npy";
-        std::vector<float> raw = read_npy_f32(path);
-        if ((int)raw.size() < e.ndim) throw Error(SDMI_ERR_WEIGHTS, "truncated tensor file " + path);
-        int64_t dims[4];
-        size_t count = 1;
-        for (int i = 0; i < e.ndim; ++i) { dims[i] = (int64_t)raw[i]; count *= (size_t)dims[i]; }
-        if (raw.size() != count + (size_t)e.ndim) throw Error(SDMI_ERR_WEIGHTS, "shape prefix does not match payload in " + path);
-        set_weight(e.name.c_str(), raw.data() + e.ndim, e.ndim, dims);
+        const size_t count = entry_count(e);
+        if (e.kind == 0 && e.dims[1] == 3) {   // rare (one tensor): through the padding path
+            std::vector<float> raw;
+            read_npy_f32(path, [&](size_t n) { raw.resize(n); return raw.data(); });
+            if (raw.size() != count + (size_t)e.ndim) throw Error(SDMI_ERR_WEIGHTS, "shape prefix does not match payload in " + path);
+            for (int i = 0; i < e.ndim; ++i)
+                if ((int64_t)raw[i] != e.dims[i]) throw Error(SDMI_ERR_WEIGHTS, "unexpected shape in " + path);
+            upload_weight(e, raw.data() + e.ndim);
+            continue;
+        }
+        // the file's floats land in the pinned ring directly: [dims.., values..]; the values start ndim floats in
+        size_t off = 0; int half = 0;
+        char* base = nullptr;
+        const size_t n = read_npy_f32(path, [&](size_t nf) {
+            if (nf != count + (size_t)e.ndim) throw Error(SDMI_ERR_WEIGHTS, "shape prefix does not match payload in " + path);
+            base = stage_reserve((nf + 64) * sizeof(float), &off, &half);
+            // keep the VALUES 256-byte aligned for the H2D copy: the prefix sits right before them
+            return reinterpret_cast<float*>(base + 256) - e.ndim;
+        });
+        (void)n;
+        const float* pre = reinterpret_cast<const float*>(base + 256) - e.ndim;
+        for (int i = 0; i < e.ndim; ++i)
+            if ((int64_t)pre[i] != e.dims[i]) {
+                std::ostringstream os;
+                os << "unexpected shape in " << path << ": dim " << i << " is " << pre[i] << ", expected " << e.dims[i];
+                throw Error(SDMI_ERR_WEIGHTS, os.str());
+            }
+        stage_commit(e, off + 256, half);
     }
+    SDMI_HIP(hipStreamSynchronize(stream_));
+    stager_release();
 }
 
 // =============================================================================
@@ -543,28 +758,58 @@ Act Engine::new_act(int n, int h, int w, int c, int dt) {
     a.p = reinterpret_cast<float*>(pool_.alloc(a.bytes()));
     return a;
 }
-void Engine::release(Act& a) { if (a.p) pool_.free(a.p); a.p = nullptr; }
+void Engine::release(Act& a) { if (a.p && !a.view) pool_.free(a.p); a.p = nullptr; }
+
+Act Engine::slice(const Act& parent, int c_off, int c) {
+    if (c_off < 0 || c <= 0 || c_off + c > parent.c || parent.view) throw Error(SDMI_ERR_STATE, "slice: bad channel range");
+    Act a = parent;
+    a.p = adv(parent.p, c_off, parent.dt);
+    a.c = c; a.ld = parent.stride(); a.view = true;
+    return a;
+}
 
 void Engine::sync() { SDMI_HIP(hipStreamSynchronize(stream_)); }
 
-void Engine::begin_call() {
+void Engine::begin_call(bool dev_inputs) {
     SDMI_HIP(hipSetDevice(cfg_.device));
     n_kernels_ = 0; flops_ = 0;
+    call_mark_ = pool_.serial();
+    call_dev_ = dev_inputs;
+    if (dev_inputs) {
+        // the engine's stream is non-blocking: nothing orders it behind the stream that produced the caller's device
+        // buffers unless we do
+        if (has_user_stream_) {
+            SDMI_HIP(hipEventRecord(ev_user_, user_stream_));
+            SDMI_HIP(hipStreamWaitEvent(stream_, ev_user_, 0));
+        } else {
+            SDMI_HIP(hipDeviceSynchronize());
+        }
+    }
     SDMI_HIP(hipEventRecord(ev0_, stream_));
 }
 void Engine::end_call() {
     SDMI_HIP(hipEventRecord(ev1_, stream_));
+    if (call_dev_ && has_user_stream_) SDMI_HIP(hipStreamWaitEvent(user_stream_, ev1_, 0));  // later work on the caller's stream sees the outputs
     SDMI_HIP(hipEventSynchronize(ev1_));
     float ms = 0;
     SDMI_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
     last_ms = ms; last_kernels = n_kernels_; last_flops = flops_;
 }
+void Engine::abort_call() noexcept {
+    // a throw inside a forward pass leaves raw activations and the per-call UNet tables allocated: wait for what was
+    // enqueued, then hand every block this call took back to the pool
+    (void)hipStreamSynchronize(stream_);
+    if (splitk_counters_) (void)hipMemset(splitk_counters_, 0, kSplitkCounters * sizeof(unsigned));   // a failed launch may have left arrivals behind
+    try {
+        us_ = UNetState{};
+        pool_.free_since(call_mark_);
+    } catch (...) {}
+}
 
 void Engine::set_option(const std::string& key, const std::string& value) {
     if (key == "gemm_tile") opt_force_tile_ = (value == "auto") ? -1 : std::stoi(value);
     else if (key == "splitk") opt_force_splits_ = std::stoi(value);
-    else if (key == "gemm_variant") opt_gemm_variant_ = std::stoi(value);
-    else if (key == "attn_variant") opt_attn_variant_ = std::stoi(value);
+    else if (key == "splitk_fused") opt_splitk_fused_ = std::stoi(value);
     else if (key == "attn_bf16") opt_attn_bf16_ = std::stoi(value);
     else if (key == "gemm_bf16x") opt_gemm_bf16x_ = std::stoi(value);
     else if (key == "gemm_x32") opt_gemm_x32_ = std::stoi(value);
@@ -697,22 +942,23 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     splits = (p.kt_total + p.kt_per_split - 1) / p.kt_per_split;
     p.splits = splits;
     const double flops = 2.0 * p.M * (double)p.N * p.K * (p.geglu ? 2.0 : 1.0);
-    // v2 uses raw buffer loads whose range check needs 32-bit extents
+    // raw buffer loads: the range check needs 32-bit extents
     const unsigned long long es = in_dt ? 2ull : 4ull;
     const unsigned long long a_ext = ((unsigned long long)p.NB * p.Hs * p.Ws - 1) * (unsigned long long)p.a_ld * es + (unsigned long long)p.Cin * es;
     const unsigned long long b_ext = ((unsigned long long)p.N * (p.geglu ? 2 : 1) - 1) * (unsigned long long)p.b_ld * es + (unsigned long long)p.K * es;
-    if (in_dt && (a_ext >= 0xFFFFFFE0ull || b_ext >= 0xFFFFFFE0ull)) throw Error(SDMI_ERR_UNSUPPORTED, "bf16 GEMM: operand larger than 4 GiB");
-    const bool v2 = (opt_gemm_variant_ == 1 || p.out_mode == 2) && a_ext < 0xFFFFFFE0ull && b_ext < 0xFFFFFFE0ull;
     p.zero_page = zero_page_;
     if (tc.cfg >= 100 && (tc.cfg - 100 >= kNumGemmTilesX || (!in_dt && !x32_ok))) throw Error(SDMI_ERR_INVALID, "gemm: large-tile kernel index out of range or not applicable to this layer");
-    p.a_bytes = (unsigned)std::min<unsigned long long>(a_ext, 0xFFFFFFE0ull);
-    p.b_bytes = (unsigned)std::min<unsigned long long>(b_ext, 0xFFFFFFE0ull);
+    if (a_ext >= 0xFFFFFFE0ull || b_ext >= 0xFFFFFFE0ull) throw Error(SDMI_ERR_UNSUPPORTED, "GEMM: operand larger than 4 GiB (the buffer-load range check needs 32-bit extents)");
+    p.a_bytes = (unsigned)a_ext;
+    p.b_bytes = (unsigned)b_ext;
     auto launch = [&](const ConvGemm& q) {
         if (in_dt && tc.cfg >= 100) return launch_conv_gemm_bf16x(q, tc.cfg - 100, stream_);
         if (tc.cfg >= 100) return launch_conv_gemm2x(q, tc.cfg - 100, stream_);
         if (in_dt) return launch_conv_gemm_bf16(q, tc.cfg, stream_);
-        return v2 ? launch_conv_gemm2(q, tc.cfg, stream_) : launch_conv_gemm(q, tc.cfg, stream_);
+        return launch_conv_gemm2(q, tc.cfg, stream_);
     };
+    p.slabs = nullptr;
+    p.counters = nullptr;
     if (splits == 1) {
         p.slab_stride = 0;
         ProfScope ps(this, PC_CONV_GEMM, flops);
@@ -721,25 +967,29 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     } else {
         p.slab_stride = (long long)p.M * p.N;
         Buf slab(this, (size_t)splits * p.slab_stride * sizeof(float));
-        float* real_c = p.C;
-        p.C = slab.f();
+        p.slabs = slab.f();
+        // combine inside the launch (k_common.hpp) when the 16-byte epilogue applies and the tile count fits the counter array
+        const int bm = tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100).bm : gemm_tile_info(tc.cfg).bm;
+        const int bn = tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100).bn : gemm_tile_info(tc.cfg).bn;
+        const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+        const bool vec = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (!p.resid || p.ldr % 4 == 0);
+        if (opt_splitk_fused_ && vec && tiles <= kSplitkCounters) p.counters = splitk_counters_;
         {
             ProfScope ps(this, PC_CONV_GEMM, flops);
             SDMI_HIP(launch(p));
         }
         count_kernel(flops);
-        {
+        if (!p.counters) {
             ProfScope ps(this, PC_SPLITK_REDUCE, 0, (double)(splits + 1) * p.slab_stride * 4.0);
-            if (in_dt) { p.C = real_c; SDMI_HIP(launch_splitk_reduce_bf16(p, slab.f(), stream_)); }
-            else SDMI_HIP(launch_splitk_reduce(p, slab.f(), real_c, stream_));
+            if (in_dt) SDMI_HIP(launch_splitk_reduce_bf16(p, stream_));
+            else SDMI_HIP(launch_splitk_reduce(p, stream_));
+            count_kernel();
         }
-        count_kernel();
-        p.C = real_c;
     }
 }
 
 void Engine::conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, const float* rowvec, int rowvec_stride,
-                  const float* resid, bool pad_br) {
+                  const Act* resid, bool pad_br) {
     if (x.c != w.cin) throw Error(SDMI_ERR_INVALID, "conv: input channels mismatch");
     // pad_br: rows / columns past the bottom / right edge read as zero through the kernels' range check, so the
     // asymmetric padding is pad = 0 plus one more output row / column than a symmetric pad-0 conv has
@@ -749,11 +999,12 @@ void Engine::conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, con
     const int ho = (hin + 2 * pad + extra - w.k) / stride + 1, wo = (win + 2 * pad + extra - w.k) / stride + 1;
     if (y.n != x.n || y.h != ho || y.w != wo || y.c != w.cout) throw Error(SDMI_ERR_INVALID, "conv: output shape mismatch");
     ConvGemm p{};
-    p.A = x.p; p.Bt = w.bt; p.C = y.p; p.bias = w.bias; p.rowvec = rowvec; p.resid = resid;
+    if (resid && (resid->rows() != y.rows() || resid->c != y.c || resid->dt != y.dt)) throw Error(SDMI_ERR_STATE, "conv: residual shape / type mismatch");
+    p.A = x.p; p.Bt = w.bt; p.C = y.p; p.bias = w.bias; p.rowvec = rowvec; p.resid = resid ? resid->p : nullptr;
     p.M = x.n * ho * wo; p.N = w.cout; p.K = w.cin * w.k * w.k;
     p.NB = x.n; p.Hs = x.h; p.Ws = x.w; p.Cin = w.cin; p.Ho = ho; p.Wo = wo;
     p.KH = w.k; p.KW = w.k; p.stride = stride; p.pad = pad; p.ups = ups;
-    p.ldc = y.c; p.ldr = y.c; p.a_ld = x.c; p.b_ld = p.K; p.rowvec_stride = rowvec_stride;
+    p.ldc = y.stride(); p.ldr = resid ? resid->stride() : y.stride(); p.a_ld = x.stride(); p.b_ld = p.K; p.rowvec_stride = rowvec_stride;
     p.CS = std::min(32, w.cin);
     if (x.dt != w.dt) throw Error(SDMI_ERR_STATE, "conv: activation / weight storage types disagree");
     p.out_mode = x.dt ? (y.dt ? 0 : 1) : (y.dt ? 2 : 0);
@@ -813,16 +1064,17 @@ void Engine::group_norm(const NormW& w, const Act& x, Act& y, bool silu) {
     if (x.dt != y.dt) throw Error(SDMI_ERR_STATE, "group_norm: in/out storage types disagree");
     Buf part(this, x.dt ? gn_partials_bytes_bf16(x.n, hw, x.c) : gn_partials_bytes(x.n, hw, x.c));
     ProfScope ps(this, PC_GROUP_NORM, 0, 2.0 * (double)x.bytes());  // algorithmic: one read + one write
-    if (x.dt) SDMI_HIP(launch_group_norm_bf16(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, 32, 1e-5f, silu, part.p, stream_));
-    else SDMI_HIP(launch_group_norm(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, 32, 1e-5f, silu, part.p, stream_));
+    if (y.view) throw Error(SDMI_ERR_STATE, "group_norm: output must be dense");
+    if (x.dt) SDMI_HIP(launch_group_norm_bf16(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_));
+    else SDMI_HIP(launch_group_norm(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_));
     count_kernel(); count_kernel();
 }
 
 void Engine::layer_norm(const NormW& w, const float* x, long long rows, float* y, int dt) {
     if (dt < 0) dt = edt();
     ProfScope ps(this, PC_LAYER_NORM, 0, 2.0 * (double)rows * w.c * (dt ? 2.0 : 4.0));
-    if (dt) SDMI_HIP(launch_layer_norm_bf16(x, y, w.gamma, w.beta, (int)rows, w.c, 1e-5f, stream_));
-    else SDMI_HIP(launch_layer_norm(x, y, w.gamma, w.beta, (int)rows, w.c, 1e-5f, stream_));
+    if (dt) SDMI_HIP(launch_layer_norm_bf16(x, y, w.gamma, w.beta, (int)rows, w.c, w.eps, stream_));
+    else SDMI_HIP(launch_layer_norm(x, y, w.gamma, w.beta, (int)rows, w.c, w.eps, stream_));
     count_kernel();
 }
 
@@ -847,7 +1099,7 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
         const double fl = 4.0 * n * n_head * (double)nq * nk * d_head;
         ProfScope ps(this, PC_ATTENTION, fl);
         if (dt && opt_attn_bf16_ && (d_head == 40 || d_head == 80 || d_head == 160)) SDMI_HIP(launch_attention_bf16(p, stream_));
-        else SDMI_HIP(launch_attention(p, stream_, dt ? 1 : opt_attn_variant_));
+        else SDMI_HIP(launch_attention(p, stream_));
         count_kernel(fl);
         return;
     }
@@ -903,9 +1155,9 @@ void Engine::res_block(const ResW& w, const Act& x, Act& y, int step) {
     release(h2);
     if (w.has_skip) {
         conv(w.skip, x, y, 1, 0, nullptr, 0, nullptr);
-        conv(w.conv_out, h3, y, 1, 0, nullptr, 0, y.p);
+        conv(w.conv_out, h3, y, 1, 0, nullptr, 0, &y);
     } else {
-        conv(w.conv_out, h3, y, 1, 0, nullptr, 0, x.p);
+        conv(w.conv_out, h3, y, 1, 0, nullptr, 0, &x);
     }
     release(h3);
 }
@@ -950,7 +1202,7 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
             gemm(u.f(), (int)M, w.mlp_lin.bt, w.mlp_lin.bias, 4 * C, C, h.p, C, h.p, C);
         }
     }
-    conv(w.proj_out, h, y, 1, 0, nullptr, 0, x.p);
+    conv(w.proj_out, h, y, 1, 0, nullptr, 0, &x);
     release(h);
 }
 
@@ -968,7 +1220,7 @@ void Engine::vae_attn(const VaeAttnW& w, const Act& x, Act& y) {
     const long long bs = (long long)hw * C;
     attention(q.p, C, bs, k.p, C, bs, v.p, C, bs, a.p, C, bs, x.n, hw, hw, 1, C, nullptr, nullptr, nullptr, 0);
     release(q); release(k); release(v);
-    conv(w.proj_out, a, y, 1, 0, nullptr, 0, x.p);
+    conv(w.proj_out, a, y, 1, 0, nullptr, 0, &x);
     release(a);
 }
 
@@ -1031,62 +1283,76 @@ void Engine::unet_prepare(const float* ctx_packed, int nb, int t_max, const int*
     }
 }
 
-// UNet::forward (unet/mod.rs:109-143) on NHWC activations
+// UNet::forward (unet/mod.rs:109-143) on NHWC activations.
+// Tensor::cat(vec![x, saved_inputs.pop()], 1) (unet/mod.rs:134) is not a copy here: the input buffer `cats[i]` of
+// output block i ([x channels | skip channels]) is allocated when its skip is produced on the way down; input block
+// 11 - i writes its result straight into the skip slice (the GEMM epilogue's row stride), output block i - 1 (or
+// the middle block) writes the x slice, and output block i reads the whole buffer.
 void Engine::unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc) {
     const int H = cfg_.latent_h, W = cfg_.latent_w;
     Act x; x.p = const_cast<float*>(x_nhwc); x.n = nb; x.h = H; x.w = W; x.c = 4; x.dt = 0;  // latents stay fp32
-    bool x_owned = false;
-    std::vector<Act> skips;
 
-    auto run_block = [&](const UBlock& b, const Act& in) -> Act {
+    // every block's last kernel writes `y` (dense or a channel slice)
+    auto run_block = [&](const UBlock& b, const Act& in, Act& y) {
         switch (b.kind) {
-            case BK_CONV: { Act y = new_act(in.n, in.h, in.w, b.cout); conv(b.conv, in, y, 1, 0, nullptr, 0, nullptr); return y; }
-            case BK_DOWN: { Act y = new_act(in.n, in.h / 2, in.w / 2, b.cout); conv(b.conv, in, y, 2, 0, nullptr, 0, nullptr); return y; }
-            case BK_RES: { Act y = new_act(in.n, in.h, in.w, b.cout); res_block(b.res, in, y, step); return y; }
+            case BK_CONV: conv(b.conv, in, y, 1, 0, nullptr, 0, nullptr); return;
+            case BK_DOWN: conv(b.conv, in, y, 2, 0, nullptr, 0, nullptr); return;
+            case BK_RES: res_block(b.res, in, y, step); return;
             case BK_RES_ST: {
                 Act r = new_act(in.n, in.h, in.w, b.cout); res_block(b.res, in, r, step);
-                Act y = new_act(in.n, in.h, in.w, b.cout); spatial_transformer(b.st, r, y); release(r); return y;
+                spatial_transformer(b.st, r, y); release(r); return;
             }
             case BK_RES_UP: {
                 Act r = new_act(in.n, in.h, in.w, b.cout); res_block(b.res, in, r, step);
-                Act y = new_act(in.n, in.h * 2, in.w * 2, b.cout); conv(b.up, r, y, 1, 1, nullptr, 0, nullptr); release(r); return y;
+                conv(b.up, r, y, 1, 1, nullptr, 0, nullptr); release(r); return;
             }
             case BK_RES_ST_UP: {
                 Act r = new_act(in.n, in.h, in.w, b.cout); res_block(b.res, in, r, step);
                 Act s = new_act(in.n, in.h, in.w, b.cout); spatial_transformer(b.st, r, s); release(r);
-                Act y = new_act(in.n, in.h * 2, in.w * 2, b.cout); conv(b.up, s, y, 1, 1, nullptr, 0, nullptr); release(s); return y;
+                conv(b.up, s, y, 1, 1, nullptr, 0, nullptr); release(s); return;
             }
         }
         throw Error(SDMI_ERR_STATE, "bad block kind");
     };
 
-    for (const UBlock& b : in_blocks_) {
-        Act y = run_block(b, x);
-        skips.push_back(y);  // saved_inputs.push (unet/mod.rs:126)
+    const int nblk = (int)in_blocks_.size();
+    std::vector<Act> cats(nblk);
+    for (int j = 0; j < nblk; ++j) {
+        const UBlock& b = in_blocks_[j];
+        const int i = nblk - 1 - j;   // the output block that pops this skip (saved_inputs is a stack, unet/mod.rs:126,134)
+        const int ctot = out_blocks_[i].cin, cskip = b.cout, cx = ctot - cskip;
+        if (cx <= 0) throw Error(SDMI_ERR_STATE, "unet: block table inconsistent");
+        const int ho = b.kind == BK_DOWN ? x.h / 2 : x.h, wo = b.kind == BK_DOWN ? x.w / 2 : x.w;
+        cats[i] = new_act(nb, ho, wo, ctot);
+        Act y = slice(cats[i], cx, cskip);
+        run_block(b, x, y);
         x = y;
     }
-    // middle (x aliases skips.back(): not owned here)
-    {
+    {   // middle block: reads the last skip, writes the x slice of output block 0's input
         Act a = new_act(x.n, x.h, x.w, mid_res1_.cout); res_block(mid_res1_, x, a, step);
         Act b = new_act(x.n, x.h, x.w, mid_st_.c); spatial_transformer(mid_st_, a, b); release(a);
-        Act c = new_act(x.n, x.h, x.w, mid_res2_.cout); res_block(mid_res2_, b, c, step); release(b);
-        x = c; x_owned = true;
+        Act c = slice(cats[0], 0, cats[0].c - x.c);
+        if (c.c != mid_res2_.cout) throw Error(SDMI_ERR_STATE, "unet: middle block width mismatch");
+        res_block(mid_res2_, b, c, step); release(b);
     }
-    for (const UBlock& b : out_blocks_) {
-        Act s = skips.back(); skips.pop_back();
-        Act cat = new_act(x.n, x.h, x.w, x.c + s.c);  // Tensor::cat(vec![x, saved.pop()], 1) (unet/mod.rs:134)
-        // byte-wise copy: for bf16 the channel counts are halved into "float-equivalent" units
-        SDMI_HIP(launch_concat_channels(x.p, s.p, cat.p, x.rows(), bf16_ ? x.c / 2 : x.c, bf16_ ? s.c / 2 : s.c, stream_));
-        count_kernel();
-        if (x_owned) release(x);
-        release(s);
-        Act y = run_block(b, cat);
-        release(cat);
-        x = y; x_owned = true;
+    Act last{};
+    for (int i = 0; i < nblk; ++i) {
+        const UBlock& b = out_blocks_[i];
+        const bool up = b.kind == BK_RES_UP || b.kind == BK_RES_ST_UP;
+        Act y;
+        if (i + 1 < nblk) {
+            y = slice(cats[i + 1], 0, cats[i + 1].c - in_blocks_[nblk - 2 - i].cout);
+            if (y.c != b.cout || y.h != (cats[i].h << (up ? 1 : 0))) throw Error(SDMI_ERR_STATE, "unet: output block shape mismatch");
+        } else {
+            y = new_act(nb, cats[i].h << (up ? 1 : 0), cats[i].w << (up ? 1 : 0), b.cout);
+            last = y;
+        }
+        run_block(b, cats[i], y);
+        release(cats[i]);
     }
-    Act gn = new_act(x.n, x.h, x.w, x.c);
-    group_norm(unet_norm_out_, x, gn, true);
-    release(x);
+    Act gn = new_act(last.n, last.h, last.w, last.c);
+    group_norm(unet_norm_out_, last, gn, true);
+    release(last);
     Act out; out.p = out_nhwc; out.n = nb; out.h = H; out.w = W; out.c = 4; out.dt = 0;  // eps stays fp32
     conv(unet_conv_out_, gn, out, 1, 0, nullptr, 0, nullptr);
     release(gn);
@@ -1124,6 +1390,7 @@ void Engine::clip_forward_dev(const int32_t* tokens, int n, int T, float* out) {
 void Engine::unet_forward_dev(const float* x_nchw, int t, const float* context, int n, int T, float* out_nchw) {
     if (!finalized_) throw Error(SDMI_ERR_STATE, "weights not finalized");
     if (n <= 0 || T <= 0) throw Error(SDMI_ERR_INVALID, "unet_forward: n and T must be positive");
+    check_batch(n);
     const int H = cfg_.latent_h, W = cfg_.latent_w;
     std::vector<int> kv(n, T), ts(1, t);
     unet_prepare(context, n, T, kv.data(), ts);
@@ -1141,6 +1408,7 @@ void Engine::sample_latent_dev(const float* context, int n, int T, const float* 
                                size_t n_steps, const float* init_latent, float* latent_out) {
     if (!finalized_) throw Error(SDMI_ERR_STATE, "weights not finalized");
     if (n <= 0 || T <= 0 || Tu <= 0) throw Error(SDMI_ERR_INVALID, "sample_latent: n, T, Tu must be positive");
+    check_batch(n);
     const size_t total = alphas_.size();
     if (n_steps == 0 || n_steps > total) throw Error(SDMI_ERR_INVALID, "sample_latent: n_steps out of range");
     const int H = cfg_.latent_h, W = cfg_.latent_w, cd = cfg_.ctx_dim;
@@ -1228,6 +1496,7 @@ void Engine::encode_image_dev(const float* img_nchw, int n, float* latent_nchw) 
     if (!finalized_) throw Error(SDMI_ERR_STATE, "weights not finalized");
     if (!enc_ready_) throw Error(SDMI_ERR_STATE, "VAE encoder weights are not loaded (autoencoder/encoder/..., autoencoder/quant_conv)");
     if (n <= 0) throw Error(SDMI_ERR_INVALID, "encode_image: n must be positive");
+    check_batch(n);
     const int H = 8 * cfg_.latent_h, W = 8 * cfg_.latent_w;
     const size_t img_elems = (size_t)3 * H * W, lat_elems = (size_t)4 * cfg_.latent_h * cfg_.latent_w;
     for (int i = 0; i < n; ++i) {
@@ -1279,6 +1548,7 @@ void Engine::encode_image_dev(const float* img_nchw, int n, float* latent_nchw) 
 void Engine::decode_latent_dev(const float* latent_nchw, int n, float in_scale, float* img_nchw, uint8_t* rgb_u8) {
     if (!finalized_) throw Error(SDMI_ERR_STATE, "weights not finalized");
     if (n <= 0) throw Error(SDMI_ERR_INVALID, "decode: n must be positive");
+    check_batch(n);
     const int H = cfg_.latent_h, W = cfg_.latent_w;
     const size_t lat_elems = (size_t)4 * H * W, img_elems = (size_t)3 * 64 * H * W;
     for (int i = 0; i < n; ++i) {  // one image at a time: peak activations are ~1 GB per image at 512x512
@@ -1326,12 +1596,12 @@ void Engine::op_group_norm(const float* x, const float* gamma, const float* beta
     if (dt) {
         SDMI_HIP(launch_nchw_f32_to_nhwc_bf16(x, a.p, n, c, h, w, 1.0f, stream_));
         Buf part(this, gn_partials_bytes_bf16(n, h * w, c));
-        SDMI_HIP(launch_group_norm_bf16(a.p, b.p, gamma, beta, n, h * w, c, groups, eps, silu, part.p, stream_));
+        SDMI_HIP(launch_group_norm_bf16(a.p, b.p, gamma, beta, n, h * w, c, c, groups, eps, silu, part.p, stream_));
         SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(b.p, out, n, c, h, w, stream_));
     } else {
         SDMI_HIP(launch_nchw_to_nhwc(x, a.p, n, c, h, w, 1.0f, stream_));
         Buf part(this, gn_partials_bytes(n, h * w, c));
-        SDMI_HIP(launch_group_norm(a.p, b.p, gamma, beta, n, h * w, c, groups, eps, silu, part.p, stream_));
+        SDMI_HIP(launch_group_norm(a.p, b.p, gamma, beta, n, h * w, c, c, groups, eps, silu, part.p, stream_));
         SDMI_HIP(launch_nhwc_to_nchw(b.p, out, n, c, h, w, stream_));
     }
     release(a); release(b);

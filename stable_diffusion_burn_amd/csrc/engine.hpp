@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -46,28 +47,39 @@ public:
     void free(void* p);
     size_t reserved() const { return reserved_; }
     size_t high_water() const { return high_; }
+    // blocks are numbered in allocation order; free_since(m) returns every block allocated after mark m = serial()
+    // (the clean-up of a call that threw half way through a forward pass)
+    unsigned long long serial() const { return serial_; }
+    size_t free_since(unsigned long long mark);
 
 private:
     struct Block { size_t off, size; };
     struct Slab { char* base; size_t size; std::vector<Block> free_list; };
     std::vector<Slab> slabs_;
-    std::map<void*, std::pair<int, size_t>> live_;  // ptr -> (slab, size)
+    struct Live { int slab; size_t size; unsigned long long serial; };
+    std::map<void*, Live> live_;
     size_t reserved_ = 0, in_use_ = 0, high_ = 0;
+    unsigned long long serial_ = 0;
 };
 
 // dt: storage type of a device tensor -- 0 = fp32, 1 = bf16 (precision = 1).  `p` is typed float* for
 // historical reasons; for dt == 1 it is an opaque pointer to 2-byte elements.
+// ld: elements between consecutive pixels (0 = dense, i.e. c).  A channel-slice VIEW of a wider buffer (view = true, never
+// freed) is how Tensor::cat (unet/mod.rs:134) is realised without a copy: producers write their slice, the consumer reads the whole.
 struct Act {
     float* p = nullptr;
     int n = 0, h = 0, w = 0, c = 0;
     int dt = 0;
+    int ld = 0;
+    bool view = false;
     long long rows() const { return (long long)n * h * w; }
+    int stride() const { return ld ? ld : c; }
     size_t bytes() const { return (size_t)rows() * c * (dt ? 2 : 4); }
 };
 
 struct ConvW { float* bt = nullptr; float* bias = nullptr; int cin = 0, cout = 0, k = 1; int dt = 0; };
 struct LinW { float* bt = nullptr; float* bias = nullptr; int cin = 0, cout = 0; int dt = 0; };
-struct NormW { float* gamma = nullptr; float* beta = nullptr; int c = 0; };
+struct NormW { float* gamma = nullptr; float* beta = nullptr; int c = 0; float eps = 1e-5f; };  // eps: Q3 default, overridden by the dump's eps file
 
 struct ResW {  // UNet ResBlock (unet/mod.rs:700-734) and VAE ResnetBlock (autoencoder/mod.rs:503-528)
     NormW norm_in; ConvW conv_in; LinW lin_embed; NormW norm_out; ConvW conv_out; ConvW skip;
@@ -99,16 +111,24 @@ struct WeightEntry {
     bool set = false;
 };
 
+// Per-module scalar / 2-vector files of the dump tree that are not tensors (python/save.py:23-68): `store` != null: the value
+// is honoured (a norm's eps); otherwise it must equal `expect` (the hyper-parameters this engine hard-wires).
+struct MetaEntry { std::string name; int n; float expect[2]; float* store; };
+
 struct TileChoice { int cfg; int splits; };
 
 class Engine {
 public:
     explicit Engine(const sdmi_config& cfg);
     ~Engine();
+    Engine(const Engine&) = delete;
+    Engine& operator=(const Engine&) = delete;
 
     // weights
     void set_weight(const char* name, const float* data, int ndim, const int64_t* dims);
     void load_weights_dir(const char* dir);
+    void load_weights_packed(const float* data, size_t n_floats, int groups);
+    size_t packed_size(int groups) const;
     void finalize_weights();
     const std::vector<WeightEntry>& entries() const { return entries_; }
 
@@ -141,8 +161,23 @@ public:
     double bench_attention(int n, int nq, int nk, int n_state, int n_head, int iters);
     void set_option(const std::string& key, const std::string& value);
     void sync();
-    void begin_call();
+    // Every C-ABI entry point runs inside a Call: the constructor orders the engine's stream behind the caller's work
+    // (dev_inputs: the arguments are device buffers produced on another stream), finish() waits for the results and
+    // records the call statistics, and a Call destroyed by an exception returns every pool block the call allocated.
+    void begin_call(bool dev_inputs = false);
     void end_call();
+    void abort_call() noexcept;
+    struct Call {
+        Engine& e; bool done = false;
+        Call(Engine& e_, bool dev_inputs = false) : e(e_) { e.begin_call(dev_inputs); }
+        void finish() { e.end_call(); done = true; }
+        ~Call() { if (!done) e.abort_call(); }
+        Call(const Call&) = delete;
+        Call& operator=(const Call&) = delete;
+    };
+    // the stream the caller's device buffers are produced / consumed on (sdmi_set_stream); has_user_stream_ false:
+    // *_dev entry points synchronise the whole device on entry instead
+    void set_user_stream(hipStream_t s, bool enable) { user_stream_ = s; has_user_stream_ = enable; }
     double last_ms = 0;
     long long last_kernels = 0;
     double last_flops = 0;
@@ -164,6 +199,20 @@ public:
     };
 
 private:
+    void destroy() noexcept;
+    // batched weight staging (engine.cpp "weights")
+    struct Stager;
+    std::unique_ptr<Stager> stager_;
+    bool arena_done_[3] = {false, false, false};
+    char* stage_reserve(size_t bytes, size_t* offset, int* half);
+    void stage_commit(WeightEntry& e, size_t offset, int half);
+    void upload_weight(WeightEntry& e, const float* data);
+    void stager_release();
+    void ensure_arena(int group);
+    bool set_meta(const std::string& name, const float* values, size_t n);
+    void add_meta(const std::string& name, int n, float e0, float e1, float* store);
+    std::vector<MetaEntry> meta_;
+    std::map<std::string, int> meta_index_;
     // model definition
     void add_entry(const std::string& name, int kind, std::initializer_list<int64_t> dims, float** dst, int wdt = 0);
     int cur_group_ = 0;  // weight group add_entry assigns (build_model switches it to 1 for the CLIP section)
@@ -174,7 +223,8 @@ private:
     void release(Act& a);
     // pad_br: zero padding on the bottom / right only (PaddingCfg::new(0, 1, 0, 1), the VAE encoder's downsampler)
     void conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, const float* rowvec, int rowvec_stride,
-              const float* resid, bool pad_br = false);
+              const Act* resid, bool pad_br = false);
+    static Act slice(const Act& parent, int c_off, int c);   // channel-slice view
     void gemm(const float* A, int a_rows, const float* bt, const float* bias, int cin, int cout, float* C, int ldc,
               const float* resid, int ldr, int dt = -1, int out_mode = 0);
     void launch_gemm(ConvGemm& p, int in_dt, int force_cfg = -1, int force_splits = 0);
@@ -204,6 +254,10 @@ private:
     void decode_one(const float* z_nhwc, int n, Act& img);
 
     void count_kernel(double flops = 0) { ++n_kernels_; flops_ += flops; }
+    void check_batch(int n) const {
+        if (cfg_.max_batch > 0 && n > cfg_.max_batch)
+            throw Error(SDMI_ERR_INVALID, "batch of " + std::to_string(n) + " exceeds sdmi_config.max_batch = " + std::to_string(cfg_.max_batch));
+    }
 
 public:
     // per-kernel-class timing (option "profile=1"): HIP events around every launch on the
@@ -229,7 +283,11 @@ private:
     sdmi_config cfg_;
     bool bf16_ = false;  // precision = 1: bf16 activations / weights, fp32 accumulate
     hipStream_t stream_ = nullptr;
-    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev_user_ = nullptr;
+    hipStream_t user_stream_ = nullptr;
+    bool has_user_stream_ = false;
+    bool call_dev_ = false;
+    unsigned long long call_mark_ = 0;
     DevPool pool_;
     std::vector<WeightEntry> entries_;
     std::map<std::string, int> entry_index_;
@@ -280,14 +338,15 @@ private:
     // options
     int opt_force_tile_ = -1;
     int opt_force_splits_ = 0;
-    int opt_attn_variant_ = 1;
     int opt_attn_bf16_ = 1;
     int opt_geglu_fuse_ = 1;    // GEGLU gate in the projection GEMM's epilogue: 0 never, 1 where there are >= 4 rounds of tiles, 2 / 3 always (256x128 / 256x256 tiles; tests)
     int opt_gemm_x32_ = 1;      // precision = 0: 1 = large-tile LDS-DMA fp32 GEMM (k_gemm2x.hip) where measured / modelled faster
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
     void* zero_page_ = nullptr;
     TileChoice choose_tile_bf16(int M, int N, int kt_total) const;   // cfg >= 100: k_gemm_bf16x.hip tile cfg - 100     // precision = 1: 1 = bf16 matrix-core attention, 0 = bf16 storage widened onto the fp32 kernel  // 1: attn2_kernel, 0: attn_f32_kernel
-    int opt_gemm_variant_ = 1;  // 1: k_gemm2.hip (buffer loads, swizzled LDS, pipelined), 0: k_gemm.hip
+    int opt_splitk_fused_ = 1;  // 1: the last-arriving k slice combines the slabs inside the GEMM launch; 0: separate reduce kernel
+    static constexpr long long kSplitkCounters = 16384;
+    unsigned* splitk_counters_ = nullptr;
     std::map<std::string, TileChoice> tuned_;        // fp32 kernels: "M,N,K" -> (tile cfg, split-K)
     std::map<std::string, TileChoice> tuned_bf16_;   // bf16 kernels; cfg >= 100 = k_gemm_bf16x.hip tile
     bool record_shapes_ = false;

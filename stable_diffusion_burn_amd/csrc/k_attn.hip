@@ -33,193 +33,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2h __attribute__((ext_vector_type(2)));
 
-template <int D>
-struct AttnCfg {
-    static constexpr int BKV = (D > 96) ? 32 : 64;  // keys per tile
-    static constexpr int KT = BKV / 16;            // 16-key MFMA tiles per KV tile
-    static constexpr int DT = (D + 15) / 16;       // 16-wide output column tiles
-    static constexpr int DC = D / 8;               // 8-wide k chunks of QK^T
-    static constexpr int LDK = D + 4;              // LDS row stride (floats)
-    static constexpr int F4_PER_TILE = BKV * (D / 4);
-    static constexpr int NLD = (F4_PER_TILE + 255) / 256;  // float4 loads per thread per tensor
-    static constexpr int TILE_FLOATS = BKV * LDK;
-    static constexpr size_t LDS_BYTES = (size_t)(4 * TILE_FLOATS + 64) * sizeof(float);
-};
-
-template <int D>
-__global__ __launch_bounds__(256) void attn_f32_kernel(const AttnParams p) {
-    using Cfg = AttnCfg<D>;
-    constexpr int BKV = Cfg::BKV, KT = Cfg::KT, DT = Cfg::DT, DC = Cfg::DC, LDK = Cfg::LDK, NLD = Cfg::NLD;
-    static_assert(D % 8 == 0, "head dim must be a multiple of 8");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;                          // [2][BKV][LDK]
-    float* Vs = smem + 2 * Cfg::TILE_FLOATS;   // [2][BKV][LDK] (+64 floats slack)
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int g = lane >> 4;
-    const int c = lane & 15;
-
-    const int b = blockIdx.y / p.n_head;
-    const int hh = blockIdx.y - b * p.n_head;
-    const int q0 = blockIdx.x * 64 + wave * 16;
-    const int qrow = q0 + c;
-    const bool q_ok = qrow < p.nq;
-
-    const float* Qb = p.q + (long long)b * p.q_bs + hh * D;
-    const float* Kb = p.k + (long long)b * p.k_bs + hh * D;
-    const float* Vb = p.v + (long long)b * p.v_bs + hh * D;
-    float* Ob = p.o + (long long)b * p.o_bs + hh * D;
-
-    const int nk = p.kv_len ? p.kv_len[b] : p.nk;
-    const int n_tiles = (nk + BKV - 1) / BKV;
-
-    // ---- Q fragment (B operand of S^T = K Q^T): Q[qrow][8c' + 2g + {0,1}], pre-scaled
-    f32x2 qf[DC];
-#pragma unroll
-    for (int cc = 0; cc < DC; ++cc) {
-        f32x2 v = {0.f, 0.f};
-        if (q_ok) v = *reinterpret_cast<const f32x2*>(Qb + (long long)qrow * p.ldq + cc * 8 + g * 2);
-        qf[cc] = v * p.scale;
-    }
-
-    // ---- K/V staging -----------------------------------------------------------------
-    f32x4 rk[NLD], rv[NLD];
-    auto gload = [&](int tile) {
-        const int kv0 = tile * BKV;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / (D / 4);
-            const int c4 = idx - row * (D / 4);
-            const int key = kv0 + row;
-            f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (idx < Cfg::F4_PER_TILE && key < nk) {
-                kk = *reinterpret_cast<const f32x4*>(Kb + (long long)key * p.ldk + c4 * 4);
-                vv = *reinterpret_cast<const f32x4*>(Vb + (long long)key * p.ldv + c4 * 4);
-            }
-            rk[i] = kk * p.scale;
-            rv[i] = vv;
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < Cfg::F4_PER_TILE) {
-                const int row = idx / (D / 4);
-                const int c4 = idx - row * (D / 4);
-                *reinterpret_cast<f32x4*>(Ks + buf * Cfg::TILE_FLOATS + row * LDK + c4 * 4) = rk[i];
-                *reinterpret_cast<f32x4*>(Vs + buf * Cfg::TILE_FLOATS + row * LDK + c4 * 4) = rv[i];
-            }
-        }
-    };
-
-    f32x4 o[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY;
-    float l_run = 0.f;
-
-    gload(0);
-    lstore(0);
-    __syncthreads();
-
-    for (int tile = 0; tile < n_tiles; ++tile) {
-        const int cur = tile & 1;
-        const bool more = (tile + 1) < n_tiles;
-        if (more) gload(tile + 1);
-
-        const float* Kt = Ks + cur * Cfg::TILE_FLOATS;
-        const float* Vt = Vs + cur * Cfg::TILE_FLOATS;
-        const int kv0 = tile * BKV;
-
-        // ---- S^T = K Q^T -------------------------------------------------------------
-        f32x4 s[KT];
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            const float* kp = Kt + (kt * 16 + c) * LDK + g * 2;
-#pragma unroll
-            for (int cc = 0; cc < DC; ++cc) {
-                const f32x2 kf = *reinterpret_cast<const f32x2*>(kp + cc * 8);
-                a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[0], qf[cc][0], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[1], qf[cc][1], a, 0, 0, 0);
-            }
-            s[kt] = a;
-        }
-
-        // ---- mask, online softmax -------------------------------------------------------
-        float mt = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kv0 + kt * 16 + g * 4 + r;
-                float v = s[kt][r];
-                if (p.mask && q_ok && key < nk) v += p.mask[(long long)qrow * p.mask_ld + key];
-                if (key >= nk) v = -INFINITY;
-                s[kt][r] = v;
-                mt = fmaxf(mt, v);
-            }
-        }
-        mt = fmaxf(mt, __shfl_xor(mt, 16));
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
-        const float m_new = fmaxf(m_run, mt);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __expf(m_run - m_use);  // m_run = -inf -> 0
-        float psum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __expf(s[kt][r] - m_use);
-                s[kt][r] = e;
-                psum += e;
-            }
-        }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
-
-        // ---- O^T += V^T P^T ---------------------------------------------------------------
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* vp = Vt + (kt * 16 + g * 4 + r) * LDK + c;
-                const float pv = s[kt][r];
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[dt * 16], pv, o[dt], 0, 0, 0);
-                }
-            }
-        }
-
-        if (more) lstore(cur ^ 1);
-        __syncthreads();
-    }
-
-    // ---- normalise and store -------------------------------------------------------------
-    float l_tot = l_run + __shfl_xor(l_run, 16);
-    l_tot += __shfl_xor(l_tot, 32);
-    const float inv = 1.0f / l_tot;
-    if (q_ok) {
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const int dcol = dt * 16 + g * 4;
-            if (dcol < D) *reinterpret_cast<f32x4*>(Ob + (long long)qrow * p.ldo + dcol) = o[dt] * inv;
-        }
-    }
-}
-
 // =====================================================================================
-// v2: 4- or 8-wave workgroups, branch-free fast path, exp2 domain, permlane reductions
+// 4- or 8-wave workgroups, branch-free fast path, exp2 domain, permlane reductions
 // =====================================================================================
-// Changes against attn_f32_kernel (kept above as variant 0 for A/B), from its ISA + rocprof:
+// What the ISA + rocprof of the first (4-wave, shuffle-based) version of this kernel led to:
 //  * NW = 8 waves (128 query rows) per workgroup for long sequences: the 64x64 level has
 //    1024 4-wave workgroups for 768 resident slots (LDS-limited) -> 1.33 "rounds", a 33 %
 //    quantisation loss; 512 8-wave workgroups are all resident at once (4 waves/SIMD) and
@@ -521,21 +338,6 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* x, int rows, i
 // ---- host side ------------------------------------------------------------------------------
 bool attn_supported_head_dim(int d) { return d == 40 || d == 64 || d == 80 || d == 160; }  // 64: CLIP (768 / 12)
 
-template <int D>
-static hipError_t launch_attn_d(const AttnParams& p, hipStream_t stream) {
-    static bool attr_set = false;
-    auto k = attn_f32_kernel<D>;
-    const size_t lds = AttnCfg<D>::LDS_BYTES;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    dim3 grid((p.nq + 63) / 64, p.n * p.n_head);
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, p);
-    return hipGetLastError();
-}
-
 template <int D, int NW, bool HAS_MASK, bool H16>
 static hipError_t launch_attn2_d(const AttnParams& p, hipStream_t stream) {
     static bool attr_set = false;
@@ -564,16 +366,7 @@ static hipError_t launch_attn2_any(const AttnParams& p, hipStream_t stream) {
     return big ? launch_attn2_d<D, 8, false, false>(p, stream) : launch_attn2_d<D, 4, false, false>(p, stream);
 }
 
-hipError_t launch_attention(const AttnParams& p, hipStream_t stream, int variant) {
-    if (variant == 0) {
-        switch (p.d_head) {
-            case 40: return launch_attn_d<40>(p, stream);
-            case 64: return launch_attn_d<64>(p, stream);
-            case 80: return launch_attn_d<80>(p, stream);
-            case 160: return launch_attn_d<160>(p, stream);
-        }
-        return hipErrorInvalidValue;
-    }
+hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     switch (p.d_head) {
         case 40: return launch_attn2_any<40>(p, stream);
         case 64: return launch_attn2_any<64>(p, stream);

@@ -4,6 +4,7 @@
 // arithmetic is fp32, statistics are combined in fp64 in fixed order.  A 16-byte access now carries
 // 8 channels, so a thread owns one 8-channel column and the HBM traffic of every pass is halved.
 #include "kernels.hpp"
+#include "k_common.hpp"
 
 namespace sdmi {
 
@@ -66,9 +67,10 @@ static inline GnGeomH gn_geom_h(int hw, int c) {
 
 size_t gn_partials_bytes_bf16(int n, int hw, int c) { return (size_t)n * gn_geom_h(hw, c).chunks * 64 * 2 * sizeof(double); }
 
-__global__ void gn_stats_bf16_kernel(const unsigned short* __restrict__ x, int hw, int C, int G, int rows_per_chunk,
+// shifted statistics, partial format and merge order: k_norm.hip / k_common.hpp.  `ldx` = elements between pixels of x.
+__global__ void gn_stats_bf16_kernel(const unsigned short* __restrict__ x, int hw, int C, int ldx, int G, int rows_per_chunk,
                                      double* __restrict__ part) {
-    extern __shared__ float sh[];  // [2][R][C] floats, then [2][C] doubles
+    extern __shared__ float sh[];  // [2][R][C] floats, [C] pivots, then [2][C] doubles
     const int cq = C >> 3;
     const int R = blockDim.x / cq;
     const int tid = threadIdx.x;
@@ -80,111 +82,106 @@ __global__ void gn_stats_bf16_kernel(const unsigned short* __restrict__ x, int h
     float s[8], q[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
-    const unsigned short* xb = x + (long long)smp * hw * C + c8 * 8;
+    const unsigned short* xb = x + (long long)smp * hw * ldx + c8 * 8;
+    const F8 pv = unpack8(*reinterpret_cast<const u32x4*>(xb + (long long)row_begin * ldx));
     for (int row = row_begin + r0; row < row_end; row += R) {
-        const F8 v = unpack8(*reinterpret_cast<const u32x4*>(xb + (long long)row * C));
+        const F8 v = unpack8(*reinterpret_cast<const u32x4*>(xb + (long long)row * ldx));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { s[i] += v.v[i]; q[i] += v.v[i] * v.v[i]; }
+        for (int i = 0; i < 8; ++i) { const float d = v.v[i] - pv.v[i]; s[i] += d; q[i] += d * d; }
     }
     float* shs = sh;
     float* shq = sh + R * C;
-    double* chs = reinterpret_cast<double*>(sh + 2 * R * C);
-    double* chq = chs + C;
+    float* shp = sh + 2 * R * C;
+    double* chm = reinterpret_cast<double*>(sh + 2 * R * C + C);
+    double* chq = chm + C;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { shs[r0 * C + c8 * 8 + i] = s[i]; shq[r0 * C + c8 * 8 + i] = q[i]; }
+    if (r0 == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) shp[c8 * 8 + i] = pv.v[i];
+    }
     __syncthreads();
+    const double n_rows = (double)(row_end - row_begin);
     for (int ch = tid; ch < C; ch += blockDim.x) {
         double ds = 0.0, dq = 0.0;
         for (int r = 0; r < R; ++r) { ds += (double)shs[r * C + ch]; dq += (double)shq[r * C + ch]; }
-        chs[ch] = ds; chq[ch] = dq;
+        const double m2 = dq - ds * ds / n_rows;
+        chm[ch] = (double)shp[ch] + ds / n_rows;
+        chq[ch] = m2 > 0.0 ? m2 : 0.0;
     }
     __syncthreads();
     for (int gi = tid; gi < G; gi += blockDim.x) {
         const int cpg = C / G;
-        double ds = 0.0, dq = 0.0;
-        for (int ch = gi * cpg; ch < (gi + 1) * cpg; ++ch) { ds += chs[ch]; dq += chq[ch]; }
+        const double ref = chm[gi * cpg];
+        double a = 0.0, b = 0.0, m2 = 0.0;
+        for (int ch = gi * cpg; ch < (gi + 1) * cpg; ++ch) {
+            const double d = chm[ch] - ref;
+            a += d; b += d * d; m2 += chq[ch];
+        }
         double* o = part + ((long long)(smp * chunks + chunk) * G + gi) * 2;
-        o[0] = ds;
-        o[1] = dq;
+        o[0] = ref + a / cpg;
+        o[1] = m2 + n_rows * (b - a * a / cpg);
     }
 }
 
 template <bool SILU>
 __global__ void gn_apply_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
-                                     const float* __restrict__ gamma, const float* __restrict__ beta, int hw, int C, int G,
-                                     float eps, int stat_chunks, const double* __restrict__ part, int rows_per_chunk) {
-    __shared__ float s_mean[64], s_rstd[64];
-    __shared__ double s_red[2][64][8];
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, int hw, int C, int ldx, int G,
+                                     float eps, int stat_chunks, int stat_rows, const double* __restrict__ part, int rows_per_chunk) {
+    __shared__ float s_mean_hi[64], s_mean_lo[64], s_rstd[64];
+    __shared__ double s_red[3][64][8];
     const int cq = C >> 3;
     const int R = blockDim.x / cq;
     const int tid = threadIdx.x;
     const int smp = blockIdx.y;
     const int cpg = C / G;
-    for (int idx = tid; idx < G * 8; idx += blockDim.x) {
-        const int gi = idx >> 3, j = idx & 7;
-        double ds = 0.0, dq = 0.0;
-        const double* pp = part + ((long long)smp * stat_chunks * G + gi) * 2;
-        for (int ch = j; ch < stat_chunks; ch += 8) { ds += pp[(long long)ch * G * 2]; dq += pp[(long long)ch * G * 2 + 1]; }
-        s_red[0][gi][j] = ds;
-        s_red[1][gi][j] = dq;
-    }
-    __syncthreads();
-    for (int gi = tid; gi < G; gi += blockDim.x) {
-        double ds = 0.0, dq = 0.0;
-        for (int j = 0; j < 8; ++j) { ds += s_red[0][gi][j]; dq += s_red[1][gi][j]; }
-        const double cnt = (double)hw * cpg;
-        const double mean = ds / cnt;
-        double var = dq / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        s_mean[gi] = (float)mean;
-        s_rstd[gi] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-    __syncthreads();
+    gn_finalize(part, smp, G, cpg, hw, stat_chunks, stat_rows, eps, s_red, s_mean_hi, s_mean_lo, s_rstd);
     const int c8 = tid % cq;
     const int r0 = tid / cq;
-    float gm[8], bt[8], mean[8], rstd[8];
+    float gm[8], bt[8], mean_hi[8], mean_lo[8], rstd[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int ch = c8 * 8 + i;
         gm[i] = gamma[ch];
         bt[i] = beta[ch];
-        mean[i] = s_mean[ch / cpg];
+        mean_hi[i] = s_mean_hi[ch / cpg];
+        mean_lo[i] = s_mean_lo[ch / cpg];
         rstd[i] = s_rstd[ch / cpg];
     }
     const int row_begin = blockIdx.x * rows_per_chunk;
     const int row_end = min(row_begin + rows_per_chunk, hw);
-    const long long base = (long long)smp * hw * C + c8 * 8;
+    const long long xbase = (long long)smp * hw * ldx + c8 * 8;
+    const long long ybase = (long long)smp * hw * C + c8 * 8;
     for (int row = row_begin + r0; row < row_end; row += R) {
-        const long long o = base + (long long)row * C;
-        F8 v = unpack8(*reinterpret_cast<const u32x4*>(x + o));
+        F8 v = unpack8(*reinterpret_cast<const u32x4*>(x + xbase + (long long)row * ldx));
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float t = (v.v[i] - mean[i]) * rstd[i];
+            float t = ((v.v[i] - mean_hi[i]) - mean_lo[i]) * rstd[i];
             t = t * gm[i] + bt[i];
             if (SILU) t = t / (1.0f + __expf(-t));
             v.v[i] = t;
         }
-        *reinterpret_cast<u32x4*>(y + o) = pack8(v);
+        *reinterpret_cast<u32x4*>(y + ybase + (long long)row * C) = pack8(v);
     }
 }
 
-hipError_t launch_group_norm_bf16(const void* x, void* y, const float* gamma, const float* beta, int n, int hw, int c,
+hipError_t launch_group_norm_bf16(const void* x, void* y, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
                                   int n_group, float eps, bool silu, void* partials, hipStream_t stream) {
-    if ((c & 7) || n_group > 64 || c % n_group || c / 8 > 1024) return hipErrorInvalidValue;
+    if ((c & 7) || (ldx & 7) || ldx < c || n_group > 64 || c % n_group || c / 8 > 1024) return hipErrorInvalidValue;
     const GnGeomH g = gn_geom_h(hw, c);
     double* part = reinterpret_cast<double*>(partials);
-    const size_t lds = (size_t)2 * g.R * c * sizeof(float) + (size_t)2 * c * sizeof(double);
+    const size_t lds = (size_t)(2 * g.R + 1) * c * sizeof(float) + (size_t)2 * c * sizeof(double);
     auto xs = reinterpret_cast<const unsigned short*>(x);
     auto ys = reinterpret_cast<unsigned short*>(y);
-    hipLaunchKernelGGL(gn_stats_bf16_kernel, dim3(g.chunks, n), dim3(g.threads), lds, stream, xs, hw, c, n_group, g.rows_per_chunk, part);
+    hipLaunchKernelGGL(gn_stats_bf16_kernel, dim3(g.chunks, n), dim3(g.threads), lds, stream, xs, hw, c, ldx, n_group, g.rows_per_chunk, part);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (silu)
-        hipLaunchKernelGGL(gn_apply_bf16_kernel<true>, dim3(g.chunks, n), dim3(g.threads), 0, stream, xs, ys, gamma, beta, hw, c, n_group,
-                           eps, g.chunks, part, g.rows_per_chunk);
+        hipLaunchKernelGGL(gn_apply_bf16_kernel<true>, dim3(g.chunks, n), dim3(g.threads), 0, stream, xs, ys, gamma, beta, hw, c, ldx, n_group,
+                           eps, g.chunks, g.rows_per_chunk, part, g.rows_per_chunk);
     else
-        hipLaunchKernelGGL(gn_apply_bf16_kernel<false>, dim3(g.chunks, n), dim3(g.threads), 0, stream, xs, ys, gamma, beta, hw, c, n_group,
-                           eps, g.chunks, part, g.rows_per_chunk);
+        hipLaunchKernelGGL(gn_apply_bf16_kernel<false>, dim3(g.chunks, n), dim3(g.threads), 0, stream, xs, ys, gamma, beta, hw, c, ldx, n_group,
+                           eps, g.chunks, g.rows_per_chunk, part, g.rows_per_chunk);
     return hipGetLastError();
 }
 

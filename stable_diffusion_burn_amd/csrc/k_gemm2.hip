@@ -1,8 +1,7 @@
 // k_gemm2.hip -- second-generation implicit-GEMM conv / linear kernel (fp32 MFMA).
 //
-// Same math, operand orientation, k order and tile mapping as k_gemm.hip (v1, kept as
-// the A/B reference and selectable with option "gemm_variant=0"); what changes is the
-// memory pipeline, driven by the v1 ISA + measurements (DESIGN.md "conv_gemm v2"):
+// Math, operand orientation, k order and tile mapping: the notes at the top of k_gemm.hip.
+// The memory pipeline (driven by the ISA and measurements of the round-1 first version):
 //  * global -> register staging uses RAW BUFFER loads (buffer_load_dwordx4 ... offen)
 //    with the hardware range check standing in for every predicate: padding taps,
 //    rows beyond M, weight rows beyond N and k beyond K get an out-of-range offset and
@@ -17,6 +16,7 @@
 //    latency cover), and the single barrier per k tile sits between two MFMA groups so
 //    the first fragment read of the next tile is hidden too.
 #include "kernels.hpp"
+#include "k_common.hpp"
 
 namespace sdmi {
 
@@ -231,9 +231,9 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(const ConvGemm p) {
         mma(fa1, fb1, 2, 4);
     }
 
-    // ---- epilogue (identical to v1) -----------------------------------------------------
+    // ---- epilogue: a k slice stores its raw partial tile; otherwise bias + time-embedding row + residual -------------
     const bool split = p.splits > 1;
-    float* Cbase = split ? (p.C + (long long)z * p.slab_stride) : p.C;
+    float* Cbase = split ? (p.slabs + (long long)z * p.slab_stride) : p.C;
     const int ldc = split ? p.N : p.ldc;
     const bool vec_ok = ((p.N & 3) == 0) && ((ldc & 3) == 0);
 #pragma unroll
@@ -278,6 +278,9 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(const ConvGemm p) {
                 }
             }
         }
+    }
+    if (split && p.counters) {
+        if (splitk_arrive(p.counters, lid, p.splits, reinterpret_cast<unsigned*>(smem))) splitk_reduce_tile<false>(p, m0, n0, BM, BN);
     }
 }
 

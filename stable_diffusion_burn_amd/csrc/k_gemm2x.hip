@@ -10,6 +10,7 @@
 // k order, weight packing, XCD-aware tile map, deterministic split-K slabs and the fused epilogue (bias +
 // time-embedding row + residual) are those of k_gemm2.hip, so both kernels read the same packed weights.
 #include "kernels.hpp"
+#include "k_common.hpp"
 
 namespace sdmi {
 
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(512) void conv_gemm2x_kernel(const ConvGemm p) {
     // Each wave transposes one 16-row fragment group at a time through its own LDS scratch (the stages are free
     // now) and writes whole 320-byte row segments with 16-byte lanes; the residual is read the same way.
     const bool split = p.splits > 1;
-    float* Cf = split ? (p.C + (long long)z * p.slab_stride) : p.C;
+    float* Cf = split ? (p.slabs + (long long)z * p.slab_stride) : p.C;
     const int ldc = split ? p.N : p.ldc;
     const bool has_resid = !split && p.resid;
     const bool vec_ok = ((p.N & 3) == 0) && ((ldc & 3) == 0) && ((p.ldr & 3) == 0 || !has_resid);
@@ -278,8 +279,7 @@ __global__ __launch_bounds__(512) void conv_gemm2x_kernel(const ConvGemm p) {
             }
             __builtin_amdgcn_wave_barrier();
         }
-        return;
-    }
+    } else {
     // odd strides / N not a multiple of 4: element-wise stores straight from the accumulators
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -304,6 +304,10 @@ __global__ __launch_bounds__(512) void conv_gemm2x_kernel(const ConvGemm p) {
                 }
             }
         }
+    }
+    }
+    if (split && p.counters) {
+        if (splitk_arrive(p.counters, lid, p.splits, reinterpret_cast<unsigned*>(smem_x32))) splitk_reduce_tile<false>(p, m0, n0, BM, BN);
     }
 }
 

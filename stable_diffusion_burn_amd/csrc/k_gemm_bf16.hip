@@ -11,6 +11,7 @@
 // (k = (cs*T + tap)*64 + ci): every hot-path layer with Cin >= 64 has Cin % 64 == 0; the three
 // Cin = 4 layers stay on the fp32 kernel (which can emit bf16, `out_mode` = 2).
 #include "kernels.hpp"
+#include "k_common.hpp"
 
 namespace sdmi {
 
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const ConvGemm p) {
     const bool split = p.splits > 1;
     const bool vec_ok = ((p.N & 3) == 0) && (((split ? p.N : p.ldc) & 3) == 0) && ((p.ldr & 3) == 0 || !p.resid);
     const bool out_f32 = split || p.out_mode == 1;
-    float* Cf = split ? (p.C + (long long)z * p.slab_stride) : p.C;
+    float* Cf = split ? (p.slabs + (long long)z * p.slab_stride) : p.C;
     unsigned short* Ch = reinterpret_cast<unsigned short*>(p.C);
     const unsigned short* Rh = reinterpret_cast<const unsigned short*>(p.resid);
     const int ldc = split ? p.N : p.ldc;
@@ -286,10 +287,14 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const ConvGemm p) {
             }
         }
     }
+    if (split && p.counters) {
+        if (splitk_arrive(p.counters, lid, p.splits, reinterpret_cast<unsigned*>(smem))) splitk_reduce_tile<true>(p, m0, n0, BM, BN);
+    }
 }
 
 // ---- split-K reduction for the bf16 path: fp32 slabs -> bf16 (or fp32) output ---------------------------
-__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const ConvGemm p, const float* slabs) {
+__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const ConvGemm p) {
+    const float* slabs = p.slabs;
     const int HoWo = p.Ho * p.Wo;
     const bool out_f32 = p.out_mode == 1;
     float* Cf = p.C;
@@ -378,12 +383,12 @@ hipError_t launch_conv_gemm_bf16(const ConvGemm& p, int cfg, hipStream_t stream)
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_splitk_reduce_bf16(const ConvGemm& p, const float* slabs, hipStream_t stream) {
+hipError_t launch_splitk_reduce_bf16(const ConvGemm& p, hipStream_t stream) {
     const long long work = (long long)p.M * p.N;
     int blocks = (int)((work + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3(blocks), dim3(256), 0, stream, p, slabs);
+    hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3(blocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

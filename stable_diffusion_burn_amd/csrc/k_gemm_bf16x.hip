@@ -20,6 +20,7 @@
 // k order, weight packing, swapped MFMA operands (a lane holds 4 consecutive output channels), XCD-aware tile
 // map, deterministic split-K and the fused epilogue are those of k_gemm_bf16.hip.
 #include "kernels.hpp"
+#include "k_common.hpp"
 
 namespace sdmi {
 
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     // writes whole 160-byte row segments with 16-byte lanes; the residual is read the same way.
     const bool split = p.splits > 1;
     const bool out_f32 = split || p.out_mode == 1;
-    float* Cf = split ? (p.C + (long long)z * p.slab_stride) : p.C;
+    float* Cf = split ? (p.slabs + (long long)z * p.slab_stride) : p.C;
     unsigned short* Ch = reinterpret_cast<unsigned short*>(p.C);
     const unsigned short* Rh = reinterpret_cast<const unsigned short*>(p.resid);
     const int ldc = split ? p.N : p.ldc;
@@ -338,8 +339,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
             }
             __builtin_amdgcn_wave_barrier();
         }
-        return;
-    }
+    } else {
     // odd strides / N not a multiple of 8: element-wise stores straight from the accumulators
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -365,6 +365,10 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
                 }
             }
         }
+    }
+    }
+    if (split && p.counters) {
+        if (splitk_arrive(p.counters, lid, p.splits, reinterpret_cast<unsigned*>(smem_x))) splitk_reduce_tile<true>(p, m0, n0, BM, BN);
     }
 }
 

@@ -13,16 +13,20 @@
 //    with 16-byte loads, every wave instruction touching 1 KiB of consecutive
 //    bytes.  Each thread owns one fixed float4 column, so its 4 channels'
 //    gamma/beta/mean/rstd live in registers for the whole kernel.
-//  * stats pass: per-thread fp32 sums over <= a few dozen pixels, combined per
-//    (sample, chunk, group) in fp64 in a FIXED order through LDS (no atomics:
-//    results are bit-reproducible run to run); the apply pass finishes the
-//    statistics in fp64 (mean, biased variance, 1/sqrt(var+eps)) and writes
-//    y = (x-mean)*rstd*gamma+beta, optionally y*sigmoid(y).
+//  * stats pass: the reference is two-pass (u = x - mean; mean(u^2), groupnorm/mod.rs:75-82).  Here every
+//    thread accumulates SHIFTED sums  sum(x - p), sum((x - p)^2)  in fp32 over <= a few dozen pixels, with
+//    the pivot p = the chunk's first pixel of the same channel (a sample of the data, so |x - p| is O(sigma)
+//    and nothing cancels however large |mean| / sigma is).  Per channel the R thread rows are summed in fp64
+//    in a FIXED order through LDS and turned into (mean_c, M2_c = sum (x - mean_c)^2); channels of a group
+//    and later the chunks are merged with the pairwise (Chan) update written as one shifted pass in fp64.
+//    No atomics: bit-reproducible.  The apply pass finishes the statistics in fp64 and subtracts the mean as
+//    a float-float pair (hi + lo), so  x - mean  is as exact as the reference's fp64-free u = x - mean can be.
 //    Algorithmic traffic: 2 reads + 1 write of the tensor; the second read of
 //    UNet-sized tensors (<= 21 MB) is served from L2 / Infinity Cache.
 //  * LayerNorm: one wave per token row, the row (<= 2048 channels) is held in
 //    registers, exact two-pass mean / variance with xor-shuffle reductions.
 #include "kernels.hpp"
+#include "k_common.hpp"
 
 namespace sdmi {
 
@@ -55,10 +59,12 @@ size_t gn_partials_bytes(int n, int hw, int c) {
     return (size_t)n * gn_geom(hw, c).chunks * 64 * 2 * sizeof(double);
 }
 
-// partial sums: part[((smp*chunks + chunk)*G + g)*2 + {0: sum, 1: sumsq}]
-__global__ void gn_stats_kernel(const float* __restrict__ x, int hw, int C, int G, int rows_per_chunk,
+// Partial statistics of one (sample, chunk, group): part[((smp*chunks + chunk)*G + g)*2 + {0: mean, 1: M2}]
+// over the chunk's rows x (C/G) channels, M2 = sum (x - mean)^2.  `ldx` = floats between pixels of x (>= C: the
+// tensor may be a channel slice of a wider buffer).
+__global__ void gn_stats_kernel(const float* __restrict__ x, int hw, int C, int ldx, int G, int rows_per_chunk,
                                 double* __restrict__ part) {
-    extern __shared__ float sh[];  // [2][R][C] floats, then [2][C] doubles
+    extern __shared__ float sh[];  // [2][R][C] floats, [C] pivots, then [2][C] doubles
     const int cq = C >> 2;
     const int R = blockDim.x / cq;
     const int tid = threadIdx.x;
@@ -69,93 +75,82 @@ __global__ void gn_stats_kernel(const float* __restrict__ x, int hw, int C, int 
     const int row_end = min(row_begin + rows_per_chunk, hw);
 
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, q0 = s0, s1 = s0, q1 = s0;
-    const float* xb = x + (long long)smp * hw * C + c4 * 4;
+    const float* xb = x + (long long)smp * hw * ldx + c4 * 4;
+    const f32x4 pv = *reinterpret_cast<const f32x4*>(xb + (long long)row_begin * ldx);  // pivot: same address for the R threads of a column
     int row = row_begin + r0;
     for (; row + R < row_end; row += 2 * R) {  // two independent loads in flight per thread
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(xb + (long long)row * C);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(xb + (long long)(row + R) * C);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(xb + (long long)row * ldx) - pv;
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(xb + (long long)(row + R) * ldx) - pv;
         s0 += v0; q0 += v0 * v0;
         s1 += v1; q1 += v1 * v1;
     }
     if (row < row_end) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(xb + (long long)row * C);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(xb + (long long)row * ldx) - pv;
         s0 += v0; q0 += v0 * v0;
     }
     s0 += s1; q0 += q1;
     float* shs = sh;
     float* shq = sh + R * C;
-    double* chs = reinterpret_cast<double*>(sh + 2 * R * C);
-    double* chq = chs + C;
+    float* shp = sh + 2 * R * C;
+    double* chm = reinterpret_cast<double*>(sh + 2 * R * C + C);
+    double* chq = chm + C;
     *reinterpret_cast<f32x4*>(shs + r0 * C + c4 * 4) = s0;
     *reinterpret_cast<f32x4*>(shq + r0 * C + c4 * 4) = q0;
+    if (r0 == 0) *reinterpret_cast<f32x4*>(shp + c4 * 4) = pv;
     __syncthreads();
-    for (int ch = tid; ch < C; ch += blockDim.x) {  // per-channel sums over the R thread rows, fixed order
+    const double n_rows = (double)(row_end - row_begin);
+    for (int ch = tid; ch < C; ch += blockDim.x) {  // per channel: the R thread rows in fixed order -> (mean_c, M2_c)
         double ds = 0.0, dq = 0.0;
         for (int r = 0; r < R; ++r) { ds += (double)shs[r * C + ch]; dq += (double)shq[r * C + ch]; }
-        chs[ch] = ds; chq[ch] = dq;
+        const double m2 = dq - ds * ds / n_rows;
+        chm[ch] = (double)shp[ch] + ds / n_rows;
+        chq[ch] = m2 > 0.0 ? m2 : 0.0;
     }
     __syncthreads();
-    for (int gi = tid; gi < G; gi += blockDim.x) {
+    for (int gi = tid; gi < G; gi += blockDim.x) {  // merge the group's channels (equal counts), shifted by the first channel's mean
         const int cpg = C / G;
-        double ds = 0.0, dq = 0.0;
-        for (int ch = gi * cpg; ch < (gi + 1) * cpg; ++ch) { ds += chs[ch]; dq += chq[ch]; }
+        const double ref = chm[gi * cpg];
+        double a = 0.0, b = 0.0, m2 = 0.0;
+        for (int ch = gi * cpg; ch < (gi + 1) * cpg; ++ch) {
+            const double d = chm[ch] - ref;
+            a += d; b += d * d; m2 += chq[ch];
+        }
         double* o = part + ((long long)(smp * chunks + chunk) * G + gi) * 2;
-        o[0] = ds;
-        o[1] = dq;
+        o[0] = ref + a / cpg;
+        o[1] = m2 + n_rows * (b - a * a / cpg);
     }
 }
 
 template <bool SILU>
 __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, int hw, int C, int G, float eps, int stat_chunks,
-                                const double* __restrict__ part, int rows_per_chunk) {
-    __shared__ float s_mean[64], s_rstd[64];
-    __shared__ double s_red[2][64][8];
+                                const float* __restrict__ beta, int hw, int C, int ldx, int G, float eps, int stat_chunks,
+                                int stat_rows, const double* __restrict__ part, int rows_per_chunk) {
+    __shared__ float s_mean_hi[64], s_mean_lo[64], s_rstd[64];
+    __shared__ double s_red[3][64][8];
     const int cq = C >> 2;
     const int R = blockDim.x / cq;
     const int tid = threadIdx.x;
     const int smp = blockIdx.y;
     const int cpg = C / G;
-    // finalize the statistics: 8 threads per group stride over the chunk partials (fixed order)
-    for (int idx = tid; idx < G * 8; idx += blockDim.x) {
-        const int gi = idx >> 3, j = idx & 7;
-        double ds = 0.0, dq = 0.0;
-        const double* pp = part + ((long long)smp * stat_chunks * G + gi) * 2;
-        for (int ch = j; ch < stat_chunks; ch += 8) {
-            ds += pp[(long long)ch * G * 2];
-            dq += pp[(long long)ch * G * 2 + 1];
-        }
-        s_red[0][gi][j] = ds;
-        s_red[1][gi][j] = dq;
-    }
-    __syncthreads();
-    for (int gi = tid; gi < G; gi += blockDim.x) {
-        double ds = 0.0, dq = 0.0;
-        for (int j = 0; j < 8; ++j) { ds += s_red[0][gi][j]; dq += s_red[1][gi][j]; }
-        const double cnt = (double)hw * cpg;
-        const double mean = ds / cnt;
-        double var = dq / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        s_mean[gi] = (float)mean;
-        s_rstd[gi] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-    __syncthreads();
+    gn_finalize(part, smp, G, cpg, hw, stat_chunks, stat_rows, eps, s_red, s_mean_hi, s_mean_lo, s_rstd);
     const int c4 = tid % cq;
     const int r0 = tid / cq;
     const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c4 * 4);
     const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c4 * 4);
-    f32x4 mean, rstd;
+    f32x4 mean_hi, mean_lo, rstd;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int gi = (c4 * 4 + i) / cpg;
-        mean[i] = s_mean[gi];
+        mean_hi[i] = s_mean_hi[gi];
+        mean_lo[i] = s_mean_lo[gi];
         rstd[i] = s_rstd[gi];
     }
     const int row_begin = blockIdx.x * rows_per_chunk;
     const int row_end = min(row_begin + rows_per_chunk, hw);
-    const long long base = (long long)smp * hw * C + c4 * 4;
+    const long long xbase = (long long)smp * hw * ldx + c4 * 4;
+    const long long ybase = (long long)smp * hw * C + c4 * 4;
     auto norm = [&](f32x4 v) {
-        v = (v - mean) * rstd;
+        v = ((v - mean_hi) - mean_lo) * rstd;
         v = v * gm + bt;
         if (SILU) {
 #pragma unroll
@@ -165,35 +160,32 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__
     };
     int row = row_begin + r0;
     for (; row + R < row_end; row += 2 * R) {
-        const long long o0 = base + (long long)row * C, o1 = base + (long long)(row + R) * C;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + o0);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + o1);
-        *reinterpret_cast<f32x4*>(y + o0) = norm(v0);
-        *reinterpret_cast<f32x4*>(y + o1) = norm(v1);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + xbase + (long long)row * ldx);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + xbase + (long long)(row + R) * ldx);
+        *reinterpret_cast<f32x4*>(y + ybase + (long long)row * C) = norm(v0);
+        *reinterpret_cast<f32x4*>(y + ybase + (long long)(row + R) * C) = norm(v1);
     }
-    if (row < row_end) {
-        const long long o0 = base + (long long)row * C;
-        *reinterpret_cast<f32x4*>(y + o0) = norm(*reinterpret_cast<const f32x4*>(x + o0));
-    }
+    if (row < row_end)
+        *reinterpret_cast<f32x4*>(y + ybase + (long long)row * C) = norm(*reinterpret_cast<const f32x4*>(x + xbase + (long long)row * ldx));
 }
 
-hipError_t launch_group_norm(const float* x, float* y, const float* gamma, const float* beta, int n, int hw, int c,
+hipError_t launch_group_norm(const float* x, float* y, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
                              int n_group, float eps, bool silu, void* partials, hipStream_t stream) {
-    if ((c & 3) || n_group > 64 || c % n_group) return hipErrorInvalidValue;
+    if ((c & 3) || (ldx & 3) || ldx < c || n_group > 64 || c % n_group) return hipErrorInvalidValue;
     if (c / 4 > 1024) return hipErrorInvalidValue;
     const GnGeom g = gn_geom(hw, c);
     double* part = reinterpret_cast<double*>(partials);
-    const size_t lds = (size_t)2 * g.R * c * sizeof(float) + (size_t)2 * c * sizeof(double);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(g.chunks, n), dim3(g.threads), lds, stream, x, hw, c, n_group,
+    const size_t lds = (size_t)(2 * g.R + 1) * c * sizeof(float) + (size_t)2 * c * sizeof(double);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(g.chunks, n), dim3(g.threads), lds, stream, x, hw, c, ldx, n_group,
                        g.rows_per_chunk, part);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (silu)
         hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(g.chunks, n), dim3(g.threads), 0, stream, x, y, gamma, beta, hw,
-                           c, n_group, eps, g.chunks, part, g.rows_per_chunk);
+                           c, ldx, n_group, eps, g.chunks, g.rows_per_chunk, part, g.rows_per_chunk);
     else
         hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(g.chunks, n), dim3(g.threads), 0, stream, x, y, gamma, beta, hw,
-                           c, n_group, eps, g.chunks, part, g.rows_per_chunk);
+                           c, ldx, n_group, eps, g.chunks, g.rows_per_chunk, part, g.rows_per_chunk);
     return hipGetLastError();
 }
 

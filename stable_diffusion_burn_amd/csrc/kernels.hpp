@@ -19,7 +19,10 @@ namespace sdmi {
 struct ConvGemm {
     const float* A;       // source activations [NB][Hs][Ws][Cin]
     const float* Bt;      // packed weights [N][K]
-    float* C;             // output [M][ldc], or split-K slabs [splits][M][N]
+    float* C;             // output [M][ldc]
+    float* slabs;         // splits > 1: fp32 partial sums [splits][M][N]
+    unsigned* counters;   // splits > 1: per-tile arrival counters (zero between launches) -> the last-arriving slice combines
+                          // the slabs and applies the epilogue inside the launch; null: a separate reduce kernel does
     const float* bias;    // [N] or null
     const float* rowvec;  // per-sample per-channel add (time embedding) or null
     const float* resid;   // residual [M][ldr] or null
@@ -47,13 +50,11 @@ struct ConvGemm {
 struct GemmTileInfo { int bm, bn; const char* name; };
 constexpr int kNumGemmTiles = 10;
 const GemmTileInfo& gemm_tile_info(int cfg);
-size_t gemm_tile_lds_bytes(int cfg);
-hipError_t launch_conv_gemm(const ConvGemm& p, int tile_cfg, hipStream_t stream);   // v1 (k_gemm.hip)
-hipError_t launch_conv_gemm2(const ConvGemm& p, int tile_cfg, hipStream_t stream);  // v2 (k_gemm2.hip)
+hipError_t launch_conv_gemm2(const ConvGemm& p, int tile_cfg, hipStream_t stream);  // k_gemm2.hip
 size_t gemm2_tile_lds_bytes(int cfg);
 // bf16 storage / fp32 accumulate (k_gemm_bf16.hip); A, Bt, resid and (unless out_mode == 1) C are bf16
 hipError_t launch_conv_gemm_bf16(const ConvGemm& p, int tile_cfg, hipStream_t stream);
-hipError_t launch_splitk_reduce_bf16(const ConvGemm& p, const float* slabs, hipStream_t stream);
+hipError_t launch_splitk_reduce_bf16(const ConvGemm& p, hipStream_t stream);
 // large-tile (256-row, 8-wave, LDS-DMA staged) bf16 kernel (k_gemm_bf16x.hip); its own tile list
 constexpr int kNumGemmTilesX = 4;
 const GemmTileInfo& gemm_tile_info_x(int cfg);
@@ -62,8 +63,8 @@ hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int tile_cfg, hipStream_t s
 hipError_t launch_conv_gemm2x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 hipError_t launch_pack_conv_weight_bf16(const float* w_oihw, void* bt, int cout, int cin, int kh, int kw, hipStream_t s);
 hipError_t launch_pack_linear_weight_bf16(const float* w_in_out, void* bt, int cin, int cout, hipStream_t s);
-// sums split-K slabs in fixed order and applies the epilogue
-hipError_t launch_splitk_reduce(const ConvGemm& p, const float* slabs, float* C, hipStream_t stream);
+// sums split-K slabs in fixed order and applies the epilogue (the fallback when p.counters == null)
+hipError_t launch_splitk_reduce(const ConvGemm& p, hipStream_t stream);
 // weight packing (done once at load)
 hipError_t launch_pack_conv_weight(const float* w_oihw, float* bt, int cout, int cin, int kh, int kw, hipStream_t s);
 hipError_t launch_pack_linear_weight(const float* w_in_out, float* bt, int cin, int cout, hipStream_t s);
@@ -78,10 +79,10 @@ struct AttnParams {
     int ldq, ldk, ldv, ldo;             // row strides in floats
     long long q_bs, k_bs, v_bs, o_bs;   // batch strides in floats
     float scale;                        // d_head^-0.25 applied to q and to k (attention.rs:15-26)
-    int bf16;                           // q/k/v/o are bf16 in HBM (strides in elements); v2 kernel only
+    int bf16;                           // q/k/v/o are bf16 in HBM (strides in elements)
 };
 bool attn_supported_head_dim(int d);
-hipError_t launch_attention(const AttnParams& p, hipStream_t stream, int variant = 1);  // 0: v1 kernel (A/B)
+hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 // bf16 matrix-core kernel (k_attn_bf16.hip): p.bf16 set, no additive mask
 hipError_t launch_attention_bf16(const AttnParams& p, hipStream_t stream);
 // row softmax (in place) for the unfused single-head VAE attention: x[rows][cols] *= scale first
@@ -91,8 +92,9 @@ hipError_t launch_softmax_rows(float* x, int rows, int cols, float scale, hipStr
 // GroupNorm (+SiLU) over NHWC: stats pass (per-chunk partial sums) + apply pass.
 // `partials` needs gn_partials_bytes(n, hw, c) bytes of scratch.
 size_t gn_partials_bytes(int n, int hw, int c);
+// ldx: elements between pixels of x (>= c; x may be a channel slice of a wider buffer); y is dense [n][hw][c]
 hipError_t launch_group_norm(const float* x, float* y, const float* gamma, const float* beta,
-                             int n, int hw, int c, int n_group, float eps, bool silu,
+                             int n, int hw, int c, int ldx, int n_group, float eps, bool silu,
                              void* partials, hipStream_t stream);
 hipError_t launch_layer_norm(const float* x, float* y, const float* gamma, const float* beta,
                              int rows, int c, float eps, hipStream_t stream);
@@ -127,7 +129,7 @@ hipError_t launch_fill_normal(float* dst, long long n, uint64_t seed, hipStream_
 
 // ---- bf16-storage variants (k_bf16.hip) ---------------------------------------------------------------
 size_t gn_partials_bytes_bf16(int n, int hw, int c);
-hipError_t launch_group_norm_bf16(const void* x, void* y, const float* gamma, const float* beta, int n, int hw, int c,
+hipError_t launch_group_norm_bf16(const void* x, void* y, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
                                   int n_group, float eps, bool silu, void* partials, hipStream_t stream);
 hipError_t launch_layer_norm_bf16(const void* x, void* y, const float* gamma, const float* beta, int rows, int c, float eps,
                                   hipStream_t stream);

@@ -81,7 +81,7 @@ int sdmi_default_config(sdmi_config* cfg) {
     cfg->latent_h = 64;         // stablediffusion/mod.rs:116
     cfg->latent_w = 64;
     cfg->vae_ch = 128;          // autoencoder/mod.rs:33-34
-    cfg->max_batch = 1;
+    cfg->max_batch = 0;
     cfg->precision = 0;
     cfg->clip_layers = 12;      // CLIPConfig::new(49408, 768, 12, 77, 12), stablediffusion/mod.rs:29
     cfg->clip_heads = 12;
@@ -111,6 +111,10 @@ void sdmi_destroy(sdmi_ctx* ctx) {
 
 int sdmi_synchronize(sdmi_ctx* ctx) { return guarded([&] { eng(ctx).sync(); }); }
 
+int sdmi_set_stream(sdmi_ctx* ctx, void* hip_stream, int32_t enable) {
+    return guarded([&] { eng(ctx).set_user_stream(reinterpret_cast<hipStream_t>(hip_stream), enable != 0); });
+}
+
 int sdmi_set_weight(sdmi_ctx* ctx, const char* name, const float* data, int32_t ndim, const int64_t* dims) {
     return guarded([&] { eng(ctx).set_weight(name, data, ndim, dims); });
 }
@@ -135,6 +139,16 @@ int sdmi_load_weights_dir(sdmi_ctx* ctx, const char* dump_dir) {
     return guarded([&] { eng(ctx).load_weights_dir(dump_dir); });
 }
 
+int sdmi_load_weights_packed(sdmi_ctx* ctx, const float* data, size_t n_floats, int32_t groups) {
+    return guarded([&] { eng(ctx).load_weights_packed(data, n_floats, groups); });
+}
+
+int64_t sdmi_packed_size(sdmi_ctx* ctx, int32_t groups) {
+    int64_t n = 0;
+    int st = guarded([&] { n = (int64_t)eng(ctx).packed_size(groups); });
+    return st == SDMI_OK ? n : st;
+}
+
 int sdmi_finalize_weights(sdmi_ctx* ctx) { return guarded([&] { eng(ctx).finalize_weights(); }); }
 
 // ---- hot path, device pointers -----------------------------------------------------
@@ -143,9 +157,9 @@ int sdmi_sample_latent_dev(sdmi_ctx* ctx, const float* context, int32_t n, int32
     return guarded([&] {
         Engine& e = eng(ctx);
         if (!context || !uncond || !init_latent || !latent_out) throw Error(SDMI_ERR_INVALID, "sample_latent_dev: null pointer");
-        e.begin_call();
+        Engine::Call call(e, /*dev_inputs=*/true);
         e.sample_latent_dev(context, n, T, uncond, Tu, scale, n_steps, init_latent, latent_out);
-        e.end_call();
+        call.finish();
     });
 }
 
@@ -153,9 +167,9 @@ int sdmi_latent_to_image_dev(sdmi_ctx* ctx, const float* latent, int32_t n, uint
     return guarded([&] {
         Engine& e = eng(ctx);
         if (!latent || !rgb_out) throw Error(SDMI_ERR_INVALID, "latent_to_image_dev: null pointer");
-        e.begin_call();
+        Engine::Call call(e, /*dev_inputs=*/true);
         e.decode_latent_dev(latent, n, (float)(1.0 / 0.18215), nullptr, rgb_out);
-        e.end_call();
+        call.finish();
     });
 }
 
@@ -165,11 +179,11 @@ int sdmi_sample_image_dev(sdmi_ctx* ctx, const float* context, int32_t n, int32_
         Engine& e = eng(ctx);
         if (!context || !uncond || !init_latent || !rgb_out) throw Error(SDMI_ERR_INVALID, "sample_image_dev: null pointer");
         if (n <= 0) throw Error(SDMI_ERR_INVALID, "sample_image_dev: n must be positive");
-        e.begin_call();
+        Engine::Call call(e, /*dev_inputs=*/true);
         Engine::Buf lat(&e, (size_t)n * 4 * e.latent_h() * e.latent_w() * sizeof(float));
         e.sample_latent_dev(context, n, T, uncond, Tu, scale, n_steps, init_latent, lat.f());
         e.decode_latent_dev(lat.f(), n, (float)(1.0 / 0.18215), nullptr, rgb_out);
-        e.end_call();
+        call.finish();
     });
 }
 
@@ -179,11 +193,11 @@ int sdmi_unet_forward(sdmi_ctx* ctx, const float* x, int32_t t, const float* con
         Engine& e = eng(ctx);
         if (n <= 0 || T <= 0) throw Error(SDMI_ERR_INVALID, "unet_forward: n and T must be positive");
         const size_t lat = (size_t)n * 4 * e.latent_h() * e.latent_w() * sizeof(float);
-        e.begin_call();
+        Engine::Call call(e);
         DevIn dx(e, x, lat), dc(e, context, (size_t)n * T * e.config().ctx_dim * sizeof(float));
         DevOut dout(e, out, lat);
         e.unet_forward_dev(dx.f(), t, dc.f(), n, T, dout.f());
-        e.end_call();
+        call.finish();
         dout.fetch();
     });
 }
@@ -227,11 +241,11 @@ static void clip_forward_host(Engine& e, const int32_t* tokens, int n, int T, fl
     const int vocab = e.config().clip_vocab;
     for (long long i = 0; i < (long long)n * T; ++i)   // the reference's embedding gather panics on an id outside the table
         if (tokens[i] < 0 || tokens[i] >= vocab) throw Error(SDMI_ERR_INVALID, "clip_forward: token id outside the vocabulary");
-    e.begin_call();
+    Engine::Call call(e);
     DevIn dt(e, tokens, (size_t)n * T * sizeof(int32_t));
     DevOut dout(e, out, (size_t)n * T * e.config().ctx_dim * sizeof(float));
     e.clip_forward_dev(reinterpret_cast<const int32_t*>(dt.buf.p), n, T, dout.f());
-    e.end_call();
+    call.finish();
     dout.fetch();
 }
 
@@ -255,11 +269,11 @@ int sdmi_encode_image(sdmi_ctx* ctx, const float* img, int32_t n, float* latent_
         Engine& e = eng(ctx);
         if (n <= 0) throw Error(SDMI_ERR_INVALID, "encode_image: n must be positive");
         const size_t lat = (size_t)n * 4 * e.latent_h() * e.latent_w() * sizeof(float);
-        e.begin_call();
+        Engine::Call call(e);
         DevIn di(e, img, lat * 48);   // 3 * 64 / 4
         DevOut dout(e, latent_out, lat);
         e.encode_image_dev(di.f(), n, dout.f());
-        e.end_call();
+        call.finish();
         dout.fetch();
     });
 }
@@ -287,13 +301,13 @@ int sdmi_sample_latent(sdmi_ctx* ctx, const float* context, int32_t n, int32_t T
         if (n <= 0 || T <= 0 || Tu <= 0) throw Error(SDMI_ERR_INVALID, "sample_latent: n, T, Tu must be positive");
         const int cd = e.config().ctx_dim;
         const size_t lat = (size_t)n * 4 * e.latent_h() * e.latent_w() * sizeof(float);
-        e.begin_call();
+        Engine::Call call(e);
         DevIn dc(e, context, (size_t)n * T * cd * sizeof(float)), du(e, uncond, (size_t)Tu * cd * sizeof(float));
         Engine::Buf x0(&e, lat);
         make_init_latent(e, init_latent, seed, n, x0);
         DevOut dout(e, latent_out, lat);
         e.sample_latent_dev(dc.f(), n, T, du.f(), Tu, scale, n_steps, x0.f(), dout.f());
-        e.end_call();
+        call.finish();
         dout.fetch();
     });
 }
@@ -303,11 +317,11 @@ int sdmi_decode_latent(sdmi_ctx* ctx, const float* latent, int32_t n, float* img
         Engine& e = eng(ctx);
         if (n <= 0) throw Error(SDMI_ERR_INVALID, "decode_latent: n must be positive");
         const size_t hw = (size_t)e.latent_h() * e.latent_w();
-        e.begin_call();
+        Engine::Call call(e);
         DevIn dl(e, latent, (size_t)n * 4 * hw * sizeof(float));
         DevOut dout(e, img_out, (size_t)n * 3 * 64 * hw * sizeof(float));
         e.decode_latent_dev(dl.f(), n, 1.0f, dout.f(), nullptr);
-        e.end_call();
+        call.finish();
         dout.fetch();
     });
 }
@@ -317,11 +331,11 @@ int sdmi_latent_to_image(sdmi_ctx* ctx, const float* latent, int32_t n, uint8_t*
         Engine& e = eng(ctx);
         if (n <= 0) throw Error(SDMI_ERR_INVALID, "latent_to_image: n must be positive");
         const size_t hw = (size_t)e.latent_h() * e.latent_w();
-        e.begin_call();
+        Engine::Call call(e);
         DevIn dl(e, latent, (size_t)n * 4 * hw * sizeof(float));
         DevOut dout(e, rgb_out, (size_t)n * 3 * 64 * hw);
         e.decode_latent_dev(dl.f(), n, (float)(1.0 / 0.18215), nullptr, reinterpret_cast<uint8_t*>(dout.buf.p));
-        e.end_call();
+        call.finish();
         dout.fetch();
     });
 }
@@ -334,14 +348,14 @@ int sdmi_sample_image(sdmi_ctx* ctx, const float* context, int32_t n, int32_t T,
         const int cd = e.config().ctx_dim;
         const size_t hw = (size_t)e.latent_h() * e.latent_w();
         const size_t lat = (size_t)n * 4 * hw * sizeof(float);
-        e.begin_call();
+        Engine::Call call(e);
         DevIn dc(e, context, (size_t)n * T * cd * sizeof(float)), du(e, uncond, (size_t)Tu * cd * sizeof(float));
         Engine::Buf x0(&e, lat), xl(&e, lat);
         make_init_latent(e, init_latent, seed, n, x0);
         DevOut dout(e, rgb_out, (size_t)n * 3 * 64 * hw);
         e.sample_latent_dev(dc.f(), n, T, du.f(), Tu, scale, n_steps, x0.f(), xl.f());
         e.decode_latent_dev(xl.f(), n, (float)(1.0 / 0.18215), nullptr, reinterpret_cast<uint8_t*>(dout.buf.p));
-        e.end_call();
+        call.finish();
         dout.fetch();
     });
 }
@@ -352,13 +366,13 @@ int sdmi_qkv_attention(sdmi_ctx* ctx, const float* q, const float* k, const floa
         Engine& e = eng(ctx);
         if (n <= 0 || nq <= 0 || nk <= 0 || n_state <= 0) throw Error(SDMI_ERR_INVALID, "qkv_attention: bad shape");
         const size_t qb = (size_t)n * nq * n_state * sizeof(float), kb = (size_t)n * nk * n_state * sizeof(float);
-        e.begin_call();
+        Engine::Call call(e);
         DevIn dq(e, q, qb), dk(e, k, kb), dv(e, v, kb);
         Engine::Buf dm(&e, mask ? (size_t)nq * mask_ld * sizeof(float) : 256);
         if (mask) SDMI_HIP(hipMemcpyAsync(dm.p, mask, (size_t)nq * mask_ld * sizeof(float), hipMemcpyHostToDevice, e.stream()));
         DevOut dout(e, out, qb);
         e.qkv_attention_dev(dq.f(), dk.f(), dv.f(), mask ? dm.f() : nullptr, mask_ld, n, nq, nk, n_state, n_head, dout.f());
-        e.end_call();
+        call.finish();
         dout.fetch();
     });
 }
@@ -370,11 +384,11 @@ int sdmi_op_group_norm(sdmi_ctx* ctx, const float* x, const float* gamma, const 
         Engine& e = eng(ctx);
         if (n <= 0 || c <= 0 || h <= 0 || w <= 0) throw Error(SDMI_ERR_INVALID, "group_norm: bad shape");
         const size_t bytes = (size_t)n * c * h * w * sizeof(float);
-        e.begin_call();
+        Engine::Call call(e);
         DevIn dx(e, x, bytes), dg(e, gamma, c * sizeof(float)), db(e, beta, c * sizeof(float));
         DevOut dout(e, out, bytes);
         e.op_group_norm(dx.f(), dg.f(), db.f(), n, c, h, w, n_group, eps, fuse_silu != 0, dout.f());
-        e.end_call();
+        call.finish();
         dout.fetch();
     });
 }
@@ -385,11 +399,11 @@ int sdmi_op_layer_norm(sdmi_ctx* ctx, const float* x, const float* gamma, const 
         Engine& e = eng(ctx);
         if (rows <= 0 || c <= 0) throw Error(SDMI_ERR_INVALID, "layer_norm: bad shape");
         const size_t bytes = (size_t)rows * c * sizeof(float);
-        e.begin_call();
+        Engine::Call call(e);
         DevIn dx(e, x, bytes), dg(e, gamma, c * sizeof(float)), db(e, beta, c * sizeof(float));
         DevOut dout(e, out, bytes);
         e.op_layer_norm(dx.f(), dg.f(), db.f(), rows, c, eps, dout.f());
-        e.end_call();
+        call.finish();
         dout.fetch();
     });
 }
@@ -403,13 +417,13 @@ int sdmi_op_conv2d(sdmi_ctx* ctx, const float* x, const float* weight, const flo
         const int ups = upsample2x ? 1 : 0;
         const int hin = h << ups, win = w << ups;
         const int ho = (hin + 2 * pad - k) / stride + 1, wo = (win + 2 * pad - k) / stride + 1;
-        e.begin_call();
+        Engine::Call call(e);
         DevIn dx(e, x, (size_t)n * cin * h * w * sizeof(float)), dw(e, weight, (size_t)cout * cin * k * k * sizeof(float));
         Engine::Buf db(&e, (size_t)cout * sizeof(float));
         if (bias) SDMI_HIP(hipMemcpyAsync(db.p, bias, (size_t)cout * sizeof(float), hipMemcpyHostToDevice, e.stream()));
         DevOut dout(e, out, (size_t)n * cout * ho * wo * sizeof(float));
         e.op_conv2d(dx.f(), dw.f(), bias ? db.f() : nullptr, n, cin, h, w, cout, k, stride, pad, ups, dout.f());
-        e.end_call();
+        call.finish();
         dout.fetch();
     });
 }
@@ -419,13 +433,13 @@ int sdmi_op_geglu_forward(sdmi_ctx* ctx, const float* x, const float* weight, co
     return guarded([&] {
         Engine& e = eng(ctx);
         if (rows <= 0 || cin <= 0 || hidden <= 0 || cin % 32) throw Error(SDMI_ERR_INVALID, "geglu_forward: bad shape");
-        e.begin_call();
+        Engine::Call call(e);
         DevIn dx(e, x, (size_t)rows * cin * sizeof(float)), dw(e, weight, (size_t)cin * 2 * hidden * sizeof(float));
         Engine::Buf db(&e, (size_t)2 * hidden * sizeof(float));
         if (bias) SDMI_HIP(hipMemcpyAsync(db.p, bias, (size_t)2 * hidden * sizeof(float), hipMemcpyHostToDevice, e.stream()));
         DevOut dout(e, out, (size_t)rows * hidden * sizeof(float));
         e.op_geglu_forward(dx.f(), dw.f(), bias ? db.f() : nullptr, rows, cin, hidden, dout.f());
-        e.end_call();
+        call.finish();
         dout.fetch();
     });
 }
@@ -435,13 +449,13 @@ int sdmi_op_linear(sdmi_ctx* ctx, const float* x, const float* weight, const flo
     return guarded([&] {
         Engine& e = eng(ctx);
         if (rows <= 0 || cin <= 0 || cout <= 0) throw Error(SDMI_ERR_INVALID, "linear: bad shape");
-        e.begin_call();
+        Engine::Call call(e);
         DevIn dx(e, x, (size_t)rows * cin * sizeof(float)), dw(e, weight, (size_t)cin * cout * sizeof(float));
         Engine::Buf db(&e, (size_t)cout * sizeof(float));
         if (bias) SDMI_HIP(hipMemcpyAsync(db.p, bias, (size_t)cout * sizeof(float), hipMemcpyHostToDevice, e.stream()));
         DevOut dout(e, out, (size_t)rows * cout * sizeof(float));
         e.op_linear(dx.f(), dw.f(), bias ? db.f() : nullptr, rows, cin, cout, dout.f());
-        e.end_call();
+        call.finish();
         dout.fetch();
     });
 }
@@ -450,11 +464,11 @@ int sdmi_op_geglu(sdmi_ctx* ctx, const float* proj, int32_t rows, int32_t hidden
     return guarded([&] {
         Engine& e = eng(ctx);
         if (rows <= 0 || hidden <= 0 || hidden % 4) throw Error(SDMI_ERR_INVALID, "geglu: bad shape");
-        e.begin_call();
+        Engine::Call call(e);
         DevIn dp(e, proj, (size_t)rows * 2 * hidden * sizeof(float));
         DevOut dout(e, out, (size_t)rows * hidden * sizeof(float));
         e.op_geglu(dp.f(), rows, hidden, dout.f());
-        e.end_call();
+        call.finish();
         dout.fetch();
     });
 }
@@ -463,10 +477,10 @@ int sdmi_op_timestep_embedding(sdmi_ctx* ctx, int32_t t, int32_t dim, float* out
     return guarded([&] {
         Engine& e = eng(ctx);
         if (dim <= 0 || dim % 2) throw Error(SDMI_ERR_INVALID, "timestep_embedding: dim must be even");
-        e.begin_call();
+        Engine::Call call(e);
         DevOut dout(e, out, (size_t)dim * sizeof(float));
         e.op_timestep_embedding(t, dim, dout.f());
-        e.end_call();
+        call.finish();
         dout.fetch();
     });
 }

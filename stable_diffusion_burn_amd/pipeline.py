@@ -126,6 +126,48 @@ class StableDiffusion:
         dims = (C.c_int64 * max(1, a.ndim))(*a.shape)
         check(self._lib.sdmi_set_weight(self._ctx, name.encode(), _fp(a), a.ndim, dims))
 
+    GROUP_HOT, GROUP_CLIP, GROUP_ENCODER = 1, 2, 4
+
+    @staticmethod
+    def _group_of(name: str) -> int:
+        if name.startswith("clip/"):
+            return StableDiffusion.GROUP_CLIP
+        if name.startswith("autoencoder/encoder/") or name.startswith("autoencoder/quant_conv/"):
+            return StableDiffusion.GROUP_ENCODER
+        return StableDiffusion.GROUP_HOT
+
+    def pack_weights(self, provider, groups: int = 1) -> np.ndarray:
+        """The flat image sdmi_load_weights_packed expects: every tensor of the selected groups in weight_specs()
+        order, fp32, reference layouts, back to back (SURVEY.md 8b "flat pack")."""
+        from .synthetic import alphas_cumprod, named_tensor
+        specs = self.weight_specs()
+        shapes = dict(specs)
+        n = self._lib.sdmi_packed_size(self._ctx, groups)
+        if n < 0:
+            check(int(n))
+        flat = np.empty(int(n), dtype=np.float32)
+        off = 0
+        for name, shape in specs:
+            if not (self._group_of(name) & groups):
+                continue
+            cnt = int(np.prod(shape))
+            src = alphas_cumprod(shape[0]) if name == "alphas_cumprod" else named_tensor(provider, name, shape, shapes)
+            flat[off:off + cnt] = np.asarray(src, dtype=np.float32).reshape(-1)
+            off += cnt
+        assert off == flat.size
+        return flat
+
+    def load_weights_packed(self, flat: np.ndarray, groups: int = 1) -> None:
+        """One staged upload of the whole model (sdmi_load_weights_packed) + finalize."""
+        flat = np.ascontiguousarray(flat, dtype=np.float32)
+        check(self._lib.sdmi_load_weights_packed(self._ctx, _fp(flat), flat.size, groups))
+        check(self._lib.sdmi_finalize_weights(self._ctx))
+
+    def set_stream(self, hip_stream, enable: bool = True) -> None:
+        """Name the HIP stream (integer handle, e.g. torch.cuda.current_stream().cuda_stream) the caller's device
+        buffers of the *_dev calls are produced / consumed on (sdmi_set_stream)."""
+        check(self._lib.sdmi_set_stream(self._ctx, C.c_void_p(int(hip_stream) if hip_stream else 0), 1 if enable else 0))
+
     def load_weights(self, provider, clip: bool = True, vae_encoder: bool = True) -> None:
         """Pull every tensor from `provider.get(name, shape, kind, fan_in)`
         (synthetic.SyntheticWeights) -- the counterpart of load_stable_diffusion

@@ -224,6 +224,10 @@ def sd16():
 DIMS16 = O.Dims(320, 8, 768, 8, 8, 64)
 
 
+# model-level bars = 1.5 x the relative RMS measured on MI355X (UNet forward 1.1e-2, 5-step CFG latent 1.7e-2, decoded RGB 0.9e-2)
+BAR_UNET, BAR_LATENT, BAR_RGB = 1.7e-2, 2.6e-2, 1.4e-2
+
+
 def _rel_rms(got, ref):
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     return float(np.sqrt(np.mean((got - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))
@@ -237,7 +241,7 @@ def test_unet_forward_bf16(sd16):
     ref = o64.forward(torch.from_numpy(lat), 999, torch.from_numpy(ctx)).numpy()
     r = _rel_rms(got, ref)
     print(f"bf16 UNet forward: rel-RMS vs fp64 oracle = {r:.3e}, max|d| = {np.abs(got - ref).max():.3e} (|ref|max {np.abs(ref).max():.2f})")
-    assert np.isfinite(got).all() and r < 2e-2
+    assert np.isfinite(got).all() and r < BAR_UNET
 
 
 @pytest.mark.parametrize("tile", [100, 103])
@@ -255,7 +259,7 @@ def test_unet_forward_bf16_large_tiles_forced(sd16, tile):
     ref = o64.forward(torch.from_numpy(lat), 500, torch.from_numpy(ctx)).numpy()
     r, r0 = _rel_rms(got, ref), _rel_rms(base, ref)
     print(f"bf16 UNet forward, tile {tile} forced: rel-RMS {r:.3e} (auto tiles {r0:.3e})")
-    assert np.isfinite(got).all() and r < 2e-2
+    assert np.isfinite(got).all() and r < BAR_UNET
 
 
 def test_sample_image_bf16(sd16):
@@ -268,14 +272,20 @@ def test_sample_image_bf16(sd16):
     ref = o64.sample_latent(torch.from_numpy(ctx), torch.from_numpy(unc), 7.5, 5, torch.from_numpy(lat)).numpy()
     r = _rel_rms(got, ref)
     print(f"bf16 sample_latent (5 steps, CFG 7.5): rel-RMS = {r:.3e}")
-    assert np.isfinite(got).all() and r < 5e-2
+    assert np.isfinite(got).all() and r < BAR_LATENT
     img = sd16.autoencoder.decode_latent((ref * (1.0 / 0.18215)).astype(np.float32))
     ref_img = o64.decoder.decode_latent(torch.from_numpy(ref) * (1.0 / 0.18215)).numpy()
     r2 = _rel_rms(img, ref_img)
     print(f"bf16 decode_latent: rel-RMS = {r2:.3e}")
-    assert np.isfinite(img).all() and r2 < 3e-2
+    assert np.isfinite(img).all() and r2 < BAR_RGB
     u8 = sd16.sample_image(ctx, unc, 7.5, 5, init_latent=lat)
-    assert u8.shape == (1, 64, 64, 3) and u8.dtype == np.uint8 and u8.std() > 1
+    assert u8.shape == (1, 64, 64, 3) and u8.dtype == np.uint8
+    # the u8 image against the fp64 oracle's own image (truncating cast, stablediffusion/mod.rs:96): bf16 moves a pixel by a
+    # few LSB, never by a visible amount
+    ref_u8, _ = o64.latent_to_image(torch.from_numpy(ref))
+    du8 = np.abs(u8.astype(np.int16) - ref_u8.astype(np.int16))
+    print(f"bf16 u8 image vs fp64 oracle: mean |d| = {du8.mean():.2f} LSB, max = {du8.max()} LSB")
+    assert du8.mean() < 4.0 and du8.max() <= 40
 
 
 def test_bf16_batch_and_repeatability(sd16):

@@ -20,6 +20,18 @@ pytestmark = pytest.mark.gpu
 
 GOLD = Path(__file__).resolve().parent / "golden"
 
+# bf16 bars = 1.5 x the relative RMS measured on MI355X against the fp64 fixtures ("bar set after first
+# measurement"); measured: UNet forward 1.0e-2, 20-step latent 0.9e-2, 50-step latent see test output, RGB 0.9e-2
+BF16_BAR_UNET = 1.5e-2
+BF16_BAR_LATENT20 = 1.4e-2
+BF16_BAR_LATENT50 = 3.0e-2
+BF16_BAR_RGB = 1.4e-2
+
+
+def _rel_rms(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return float(np.sqrt(np.mean((got - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))
+
 
 @pytest.fixture(scope="module")
 def sd_full():
@@ -136,6 +148,54 @@ def test_bf16_full_size_against_the_fp64_fixtures():
         rgb = sd.autoencoder.decode_latent((g2["latent64"][None] * (1.0 / 0.18215)).astype(np.float32))[0]
         r_rgb = rel_rms(rgb[:, ::4, ::4], g2["rgb64_s4"])
         print(f"bf16 full size: rel-RMS UNet forward {r_unet:.3e}, 20-step CFG latent {r_lat:.3e}, decoded RGB {r_rgb:.3e}")
-        assert np.isfinite(got).all() and r_unet < 2e-2 and r_lat < 5e-2 and r_rgb < 3e-2
+        assert np.isfinite(got).all() and r_unet < BF16_BAR_UNET and r_lat < BF16_BAR_LATENT20 and r_rgb < BF16_BAR_RGB
+    finally:
+        sd.close()
+
+
+# ---- BASELINE.json configs[2]: 50 steps, batch 16, bf16 ------------------------------------------------------------
+def _cfg3_inputs(n):
+    lat = np.stack([syn.initial_latent(i) for i in range(n)])
+    ctx = np.repeat(syn.cond_context(0)[None], n, axis=0)      # one prompt for the whole batch, like bench.py
+    return lat, ctx, syn.uncond_context()
+
+
+def test_config3_50_steps_fp32(sd_full):
+    """The 50-step schedule t = 999, 979, .., 19 (stablediffusion/mod.rs:111,123) in fp32 against the fp64 fixture
+    (tests/golden/gen_golden_cfg3.py), batch 2 = the first two samples of configs[2]."""
+    g = np.load(GOLD / "sd14_synth_cfg3.npz")
+    lat, ctx, unc = _cfg3_inputs(2)
+    got = sd_full.sample_latent(ctx, unc, 7.5, 50, init_latent=lat).astype(np.float64)
+    for i in range(2):
+        e = np.abs(got[i] - g["latent64"][i]).max()
+        print(f"50-step fp32, sample {i}: |gpu-f64| = {e:.2e} (absmax {np.abs(g['latent64'][i]).max():.1f})")
+        assert e < 1e-3
+
+
+def test_config3_bf16_batch16_50_steps():
+    """configs[2] as BASELINE.json states it: batch 16, 50 DDIM steps, CFG 7.5, bf16 on one GPU.  Samples 0 and 1 are
+    compared with the fp64 oracle's batch-1 runs (the reference defines batch > 1 as independent samples, SURVEY Q1);
+    the bars are 1.5x the values measured on MI355X (printed).  Samples 2..15 must be finite and must not depend on the
+    batch position: sample 0's latent is reproduced bit-exactly when it is also placed at position 15."""
+    from stable_diffusion_burn_amd import ModelConfig, StableDiffusion
+    g = np.load(GOLD / "sd14_synth_cfg3.npz")
+    sd = StableDiffusion(ModelConfig(precision=1))
+    try:
+        sd.load_weights(syn.SyntheticWeights(), clip=False, vae_encoder=False)
+        lat, ctx, unc = _cfg3_inputs(16)
+        lat[15] = lat[0]
+        got = sd.sample_latent(ctx, unc, 7.5, 50, init_latent=lat)
+        assert np.isfinite(got).all()
+        assert np.array_equal(got[0], got[15])
+        for i in range(2):
+            r = _rel_rms(got[i], g["latent64"][i])
+            steps = []
+            print(f"bf16 B=16 S=50, sample {i}: rel-RMS of the final latent vs fp64 = {r:.3e}")
+            assert r < BF16_BAR_LATENT50
+        rgb = sd.autoencoder.decode_latent((g["latent64"][:2] * (1.0 / 0.18215)).astype(np.float32))
+        for i in range(2):
+            r = _rel_rms(rgb[i][:, ::4, ::4], g["rgb64_s4"][i])
+            print(f"bf16 decode of the fp64 latent, sample {i}: rel-RMS RGB = {r:.3e}")
+            assert r < BF16_BAR_RGB
     finally:
         sd.close()

@@ -209,3 +209,110 @@ def test_load_weights_dir_matches_set_weight(sd_tiny, synth, tiny_dims, tmp_path
         sd3.close()
     finally:
         sd2.close()
+
+
+# ---- round 2: stream ordering of the *_dev entry points, batched weight loading, metadata, error clean-up -------------
+def _dev_sample(sd, d, lat_t, ctx_t, unc_t, steps=2):
+    out = torch.empty((lat_t.shape[0], 4, d.latent_h, d.latent_w), dtype=torch.float32, device="cuda")
+    sd.sample_latent_dev(ctx_t.data_ptr(), lat_t.shape[0], ctx_t.shape[1], unc_t.data_ptr(), unc_t.shape[0], 7.5, steps,
+                         lat_t.data_ptr(), out.data_ptr())
+    return out
+
+
+@pytest.mark.parametrize("mode", ["user_stream", "device_sync"])
+def test_dev_entry_points_are_ordered_behind_the_producer(sd_tiny, tiny_dims, mode):
+    """The engine works on a private non-blocking stream.  Inputs that are still being PRODUCED on another stream when
+    sdmi_sample_latent_dev is called (here: a long chain of kernels on a torch side stream ending in the copy that fills
+    the latent) must be waited for -- through sdmi_set_stream's event hand-shake, or the default device-wide sync."""
+    d = tiny_dims
+    lat, ctx, unc = _inputs(d, 1, 7, 2)
+    ref = sd_tiny.sample_latent(ctx, unc, 7.5, 2, init_latent=lat)
+    side = torch.cuda.Stream()
+    ctx_t = torch.from_numpy(ctx).cuda()
+    unc_t = torch.from_numpy(unc).cuda()
+    src = torch.from_numpy(lat).cuda()
+    lat_t = torch.full_like(src, float("nan"))
+    junk = torch.randn(4096, 4096, device="cuda")
+    torch.cuda.synchronize()
+    try:
+        if mode == "user_stream":
+            sd_tiny.set_stream(side.cuda_stream)
+        with torch.cuda.stream(side):
+            for _ in range(40):                      # ~tens of ms of queued work in front of the real producer
+                junk = junk @ junk * 1e-4
+            lat_t.copy_(src, non_blocking=True)      # the producer of the input, last in the queue
+            out = _dev_sample(sd_tiny, d, lat_t, ctx_t, unc_t)
+            got = out.cpu().numpy()                  # consumer on the same stream (ordered behind the results)
+    finally:
+        sd_tiny.set_stream(0, enable=False)
+    assert np.isfinite(got).all()
+    assert np.array_equal(got, ref)
+
+
+def test_packed_weights_match_set_weight(sd_tiny, synth, tiny_dims):
+    """sdmi_load_weights_packed (one flat image, one staged upload) gives bit-identical results to per-tensor set_weight."""
+    from stable_diffusion_burn_amd import ModelConfig, StableDiffusion
+    d = tiny_dims
+    lat, ctx, unc = _inputs(d, 1, 7, 2)
+    ref = sd_tiny.sample_latent(ctx, unc, 7.5, 2, init_latent=lat)
+    sd = StableDiffusion(ModelConfig(d.model_channels, d.n_head, d.ctx_dim, d.latent_h, d.latent_w, d.vae_ch))
+    try:
+        flat = sd.pack_weights(synth, groups=1)
+        sd.load_weights_packed(flat, groups=1)
+        got = sd.sample_latent(ctx, unc, 7.5, 2, init_latent=lat)
+        img = sd.sample_image(ctx, unc, 7.5, 2, init_latent=lat)
+        with pytest.raises(Exception):
+            sd.load_weights_packed(flat[:-1], groups=1)
+    finally:
+        sd.close()
+    assert np.array_equal(got, ref)
+    assert np.array_equal(img, sd_tiny.sample_image(ctx, unc, 7.5, 2, init_latent=lat))
+
+
+def test_dump_metadata_is_honoured_or_rejected(sd_tiny, synth, tiny_dims, tmp_path):
+    """The reference's loaders read eps / n_group / stride / padding next to the tensors (groupnorm/load.rs:15-19,
+    load.rs:118-160).  A dump whose GroupNorm eps differs must change the result exactly like the oracle with that eps;
+    a dump whose conv stride differs from what this engine hard-wires must be refused, not silently mis-run."""
+    from stable_diffusion_burn_amd import ModelConfig, SdmiError, StableDiffusion, weights as W
+    d = tiny_dims
+    cfg = ModelConfig(d.model_channels, d.n_head, d.ctx_dim, d.latent_h, d.latent_w, d.vae_ch)
+    sd = StableDiffusion(cfg)
+    try:
+        specs = [(n, s) for n, s in sd.weight_specs() if not n.startswith("clip/") and not n.startswith("autoencoder/encoder/") and not n.startswith("autoencoder/quant_conv/")]
+        shapes = dict(specs)
+        W.write_dump_tree(tmp_path, specs, lambda n, s: syn.named_tensor(synth, n, s, shapes), syn.alphas_cumprod())
+        # (1) a different eps on the UNet's output norm
+        np.save(tmp_path / "unet/norm_out/eps.npy", W.encode_scalar(0.5))
+        sd.load_weights_dir(tmp_path)
+        lat, ctx, _ = _inputs(d, 1, 7, 2)
+        got = sd.unet.forward(lat, [500], ctx)
+        base = sd_tiny.unet.forward(lat, [500], ctx)
+        assert np.abs(got - base).max() > 1e-3          # eps = 0.5 on O(1)-variance activations is visible
+        o64 = O.UNetOracle(synth, d, torch.float64)
+        ref = o64.forward(torch.from_numpy(lat), 500, torch.from_numpy(ctx), norm_out_eps=0.5).numpy()
+        assert np.abs(got - ref).max() < 1e-4
+        # (2) a stride the engine does not implement for that layer
+        np.save(tmp_path / "unet/norm_out/eps.npy", W.encode_scalar(1e-5))
+        np.save(tmp_path / "unet/input_blocks/d1/stride.npy", W.encode_tensor(np.array([1, 1], np.float32)))
+        with pytest.raises(SdmiError) as ei:
+            sd.load_weights_dir(tmp_path)
+        assert "stride" in str(ei.value)
+    finally:
+        sd.close()
+
+
+def test_failed_call_returns_its_pool_blocks(sd_tiny, tiny_dims):
+    """A call that throws half way (here: a context wider than the model's ctx_dim is caught up front, so use a batch
+    above max_batch = unlimited -> force an unsupported attention shape instead) must not leak activation blocks:
+    the same failing call repeated 50 times leaves the next good call's result and the pool unchanged."""
+    d = tiny_dims
+    lat, ctx, unc = _inputs(d, 1, 7, 2)
+    ref = sd_tiny.sample_latent(ctx, unc, 7.5, 1, init_latent=lat)
+    from stable_diffusion_burn_amd import SdmiError
+    q = np.zeros((1, 8, 96), np.float32)   # head dim 96: not a fused instance; nk = 5 is not a multiple of 32 -> throws inside attention()
+    k = np.zeros((1, 5, 96), np.float32)
+    for _ in range(50):
+        with pytest.raises(SdmiError):
+            sd_tiny.qkv_attention(q, k, k, None, 1)
+    got = sd_tiny.sample_latent(ctx, unc, 7.5, 1, init_latent=lat)
+    assert np.array_equal(got, ref)
