@@ -108,6 +108,14 @@ int sdmi_weight_info(sdmi_ctx* ctx, int32_t index, const char** name, int32_t* n
  * (format: src/model/load.rs:17-28 -- 1-D float32 .npy whose first D values
  * are the shape). */
 int sdmi_load_weights_dir(sdmi_ctx* ctx, const char* dump_dir);
+/* load_stable_diffusion_model_file (src/bin/sample/main.rs:27-34): reads a Burn NamedMpkFileRecorder<FullPrecisionSettings>
+ * record (the reference's "SDv1-4.mpk") natively -- a MessagePack walker over the memory-mapped file, tensors staged
+ * straight from the mapping.  The burn 0.14 layout it assumes is spelled out in csrc/mpk_reader.hpp (UNPINNED against a
+ * real record: none exists offline).  Tensors the configured model lacks are skipped; call sdmi_finalize_weights after. */
+int sdmi_load_weights_mpk(sdmi_ctx* ctx, const char* mpk_path);
+/* Host only (no context): the tensors of a record as text, one "name<TAB>d0,d1,..<TAB>file offset" line each (dump-tree
+ * names), after a "# format=.. float=.." line.  *needed = bytes incl. the terminator; out may be NULL to query it. */
+int sdmi_mpk_list(const char* mpk_path, char* out, size_t capacity, size_t* needed);
 /* One flat image of every tensor: `data` holds, for each entry i of the configured model in
  * sdmi_weight_info() order and restricted to the weight groups selected by `groups` (bit 0: hot path = UNet,
  * VAE decoder, alphas_cumprod; bit 1: CLIP; bit 2: VAE encoder), the tensor's fp32 values in the reference's

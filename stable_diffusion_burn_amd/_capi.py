@@ -49,6 +49,8 @@ SIGNATURES = {
     "sdmi_weight_count": (C.c_int, [_CTX]),
     "sdmi_weight_info": (C.c_int, [_CTX, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "sdmi_load_weights_dir": (C.c_int, [_CTX, C.c_char_p]),
+    "sdmi_load_weights_mpk": (C.c_int, [_CTX, C.c_char_p]),
+    "sdmi_mpk_list": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sdmi_load_weights_packed": (C.c_int, [_CTX, _F, C.c_size_t, C.c_int32]),
     "sdmi_packed_size": (C.c_int64, [_CTX, C.c_int32]),
     "sdmi_finalize_weights": (C.c_int, [_CTX]),

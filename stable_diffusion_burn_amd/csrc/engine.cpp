@@ -1,6 +1,7 @@
 // engine.cpp -- see engine.hpp.  Reference citations are relative to
 // Gadersd/stable-diffusion-burn (src/model/...).
 #include "engine.hpp"
+#include "mpk_reader.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -647,6 +648,36 @@ void Engine::load_weights_packed(const float* data, size_t n_floats, int groups)
         upload_weight(e, data + off);
         off += entry_count(e);
     }
+    SDMI_HIP(hipStreamSynchronize(stream_));
+    stager_release();
+}
+
+// load_stable_diffusion_model_file (src/bin/sample/main.rs:27-34): the Burn record, read natively (mpk_reader.hpp for the
+// assumed layout).  Tensors the configured model does not have (e.g. clip/... with clip_layers = 0) are skipped.
+void Engine::load_weights_mpk(const char* path) {
+    if (!path) throw Error(SDMI_ERR_INVALID, "load_weights_mpk: null path");
+    SDMI_HIP(hipSetDevice(cfg_.device));
+    MpkFile f(path);
+    size_t used = 0;
+    for (const MpkTensor& t : f.tensors()) {
+        auto it = entry_index_.find(t.name);
+        if (it == entry_index_.end()) continue;
+        WeightEntry& e = entries_[it->second];
+        bool ok = (int)t.shape.size() == e.ndim;
+        for (int i = 0; ok && i < e.ndim; ++i) ok = t.shape[i] == e.dims[i];
+        if (!ok) {
+            std::ostringstream os;
+            os << "load_weights_mpk: '" << t.name << "' has shape [";
+            for (size_t i = 0; i < t.shape.size(); ++i) os << (i ? "," : "") << t.shape[i];
+            os << "], the configured model expects [";
+            for (int i = 0; i < e.ndim; ++i) os << (i ? "," : "") << e.dims[i];
+            os << "]";
+            throw Error(SDMI_ERR_WEIGHTS, os.str());
+        }
+        upload_weight(e, reinterpret_cast<const float*>(t.data));   // memcpy into the pinned ring: any alignment
+        ++used;
+    }
+    if (!used) throw Error(SDMI_ERR_WEIGHTS, std::string("load_weights_mpk: no tensor of ") + path + " matches the configured model");
     SDMI_HIP(hipStreamSynchronize(stream_));
     stager_release();
 }

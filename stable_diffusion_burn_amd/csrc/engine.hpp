@@ -127,6 +127,7 @@ public:
     // weights
     void set_weight(const char* name, const float* data, int ndim, const int64_t* dims);
     void load_weights_dir(const char* dir);
+    void load_weights_mpk(const char* path);
     void load_weights_packed(const float* data, size_t n_floats, int groups);
     size_t packed_size(int groups) const;
     void finalize_weights();

@@ -5,7 +5,9 @@
 //
 // It is a pure consumer of the C ABI (include/sdmi.h) -- the same calls the Rust shim (ffi/sdmi.rs) makes:
 // tokenizer -> CLIP context -> sample_image -> PNG.  Differences from the reference, all forced:
-//   * model_type "burn" (.mpk record) is not read yet; "dump" is the npy tree of python/dump.py (main.rs:94);
+//   * model_type "burn" reads the NamedMpkFileRecorder<FullPrecisionSettings> record "<model_name>.mpk" natively (the
+//     recorder sets the extension itself, main.rs:27-34; layout assumptions: csrc/mpk_reader.hpp); "dump" is the npy tree
+//     of python/dump.py (main.rs:94);
 //   * device is "hip", "hip:N" or "cuda[N]" (alias, index N); "cpu" / "mps" are refused -- there is no CPU path;
 //   * the reference's noise is unseeded; here SDMI_SEED (default 0) seeds the device generator;
 //   * the merges file is $SDMI_BPE_VOCAB, default "bpe_simple_vocab_16e6.txt" in the working directory (tokenizer.rs:91);
@@ -84,13 +86,15 @@ int main(int argc, char** argv) {
     if (sdmi_tokenizer_create(&tok, vocab ? vocab : "bpe_simple_vocab_16e6.txt") != SDMI_OK) die("Error loading tokenizer");
 
     std::printf("Loading model...\n");
-    if (model_type == "burn") {
-        std::fprintf(stderr, "Error loading model: Burn .mpk records are not read by this binary; convert the record with tools/mpk_to_dump.py (or export a dump with python/dump.py) and pass `dump <dir>`\n");
-        return 1;
-    }
     sdmi_ctx* ctx = nullptr;
     if (sdmi_create(&ctx, &cfg) != SDMI_OK) die("Error creating device context");
-    if (sdmi_load_weights_dir(ctx, model_name.c_str()) != SDMI_OK || sdmi_finalize_weights(ctx) != SDMI_OK) die("Error loading model dump");
+    if (model_type == "burn") {
+        std::string file = model_name;
+        if (file.size() < 4 || file.compare(file.size() - 4, 4, ".mpk") != 0) file += ".mpk";   // FileRecorder::load sets the extension
+        if (sdmi_load_weights_mpk(ctx, file.c_str()) != SDMI_OK || sdmi_finalize_weights(ctx) != SDMI_OK) die("Error loading model");
+    } else if (sdmi_load_weights_dir(ctx, model_name.c_str()) != SDMI_OK || sdmi_finalize_weights(ctx) != SDMI_OK) {
+        die("Error loading model dump");
+    }
 
     // sd.unconditional_context(&tokenizer); sd.context(&tokenizer, prompt)   (main.rs:100-101)
     const int cd = cfg.ctx_dim, cap = cfg.clip_ctx;

@@ -5,6 +5,7 @@
 #include <string>
 
 #include "engine.hpp"
+#include "mpk_reader.hpp"
 #include "tokenizer.hpp"
 
 using sdmi::Engine;
@@ -137,6 +138,26 @@ int sdmi_weight_info(sdmi_ctx* ctx, int32_t index, const char** name, int32_t* n
 
 int sdmi_load_weights_dir(sdmi_ctx* ctx, const char* dump_dir) {
     return guarded([&] { eng(ctx).load_weights_dir(dump_dir); });
+}
+
+int sdmi_load_weights_mpk(sdmi_ctx* ctx, const char* mpk_path) {
+    return guarded([&] { eng(ctx).load_weights_mpk(mpk_path); });
+}
+
+int sdmi_mpk_list(const char* mpk_path, char* out, size_t capacity, size_t* needed) {
+    return guarded([&] {
+        if (!mpk_path || !needed) throw Error(SDMI_ERR_INVALID, "mpk_list: null argument");
+        sdmi::MpkFile f(mpk_path);
+        std::string s = "# format=" + f.format() + " float=" + f.float_type() + "\n";
+        for (const auto& t : f.tensors()) {
+            s += t.name + "\t";
+            for (size_t i = 0; i < t.shape.size(); ++i) s += (i ? "," : "") + std::to_string(t.shape[i]);
+            s += "\t" + std::to_string(t.file_offset) + "\n";
+        }
+        *needed = s.size() + 1;
+        if (out && capacity >= s.size() + 1) std::memcpy(out, s.c_str(), s.size() + 1);
+        else if (out && capacity) throw Error(SDMI_ERR_INVALID, "mpk_list: capacity too small");
+    });
 }
 
 int sdmi_load_weights_packed(sdmi_ctx* ctx, const float* data, size_t n_floats, int32_t groups) {

@@ -24,7 +24,23 @@ import numpy as np
 from . import _capi
 from ._capi import SdmiConfig, SdmiError, check, load_library
 
-__all__ = ["ModelConfig", "StableDiffusion", "UNet", "Autoencoder", "CLIP", "SimpleTokenizer", "qkv_attention", "SdmiError"]
+def mpk_list(path) -> list:
+    """[(dump name, shape, file offset)] of a Burn .mpk record, parsed by the C++ reader (host only, no GPU)."""
+    lib = load_library()
+    need = C.c_size_t()
+    check(lib.sdmi_mpk_list(str(path).encode(), None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    check(lib.sdmi_mpk_list(str(path).encode(), buf, need.value, C.byref(need)))
+    out = []
+    for line in buf.value.decode().splitlines():
+        if line.startswith("#") or not line:
+            continue
+        name, shape, off = line.split("\t")
+        out.append((name, tuple(int(v) for v in shape.split(",")) if shape else (), int(off)))
+    return out
+
+
+__all__ = ["ModelConfig", "StableDiffusion", "mpk_list", "UNet", "Autoencoder", "CLIP", "SimpleTokenizer", "qkv_attention", "SdmiError"]
 
 
 @dataclass(frozen=True)
@@ -161,6 +177,11 @@ class StableDiffusion:
         """One staged upload of the whole model (sdmi_load_weights_packed) + finalize."""
         flat = np.ascontiguousarray(flat, dtype=np.float32)
         check(self._lib.sdmi_load_weights_packed(self._ctx, _fp(flat), flat.size, groups))
+        check(self._lib.sdmi_finalize_weights(self._ctx))
+
+    def load_weights_mpk(self, path) -> None:
+        """The reference's `burn` model type: a NamedMpkFileRecorder<FullPrecisionSettings> record (sample/main.rs:27-34)."""
+        check(self._lib.sdmi_load_weights_mpk(self._ctx, str(path).encode()))
         check(self._lib.sdmi_finalize_weights(self._ctx))
 
     def set_stream(self, hip_stream, enable: bool = True) -> None:

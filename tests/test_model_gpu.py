@@ -316,3 +316,34 @@ def test_failed_call_returns_its_pool_blocks(sd_tiny, tiny_dims):
             sd_tiny.qkv_attention(q, k, k, None, 1)
     got = sd_tiny.sample_latent(ctx, unc, 7.5, 1, init_latent=lat)
     assert np.array_equal(got, ref)
+
+
+def test_load_weights_mpk_matches_set_weight(sd_tiny, synth, tiny_dims, tmp_path):
+    """The `burn` model type (NamedMpkFileRecorder record, sample/main.rs:27-34) read by the C++ MessagePack walker and
+    staged straight from the mapping gives bit-identical results to per-tensor set_weight.  (The record is written by
+    tools/mpk_to_dump.write_record with the burn 0.14 layout of csrc/mpk_reader.hpp: UNPINNED against a real file.)"""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from tools import mpk_to_dump as M
+    from stable_diffusion_burn_amd import ModelConfig, SdmiError, StableDiffusion
+    d = tiny_dims
+    sd = StableDiffusion(ModelConfig(d.model_channels, d.n_head, d.ctx_dim, d.latent_h, d.latent_w, d.vae_ch))
+    try:
+        specs = [(n, s) for n, s in sd.weight_specs() if not n.startswith("autoencoder/encoder/") and not n.startswith("autoencoder/quant_conv/")]
+        shapes = dict(specs)
+        tensors = {n: (syn.alphas_cumprod(s[0]) if n == "alphas_cumprod" else syn.named_tensor(synth, n, s, shapes)) for n, s in specs}
+        M.write_record(tensors, tmp_path / "tiny.mpk")
+        sd.load_weights_mpk(tmp_path / "tiny.mpk")
+        lat, ctx, unc = _inputs(d, 1, 7, 2)
+        got = sd.sample_latent(ctx, unc, 7.5, 2, init_latent=lat)
+        assert np.array_equal(got, sd_tiny.sample_latent(ctx, unc, 7.5, 2, init_latent=lat))
+        # a record for a different model width is refused with the tensor's name
+        bad = dict(tensors)
+        bad["unet/conv_out/bias"] = np.zeros(5, np.float32)
+        M.write_record(bad, tmp_path / "bad.mpk")
+        with pytest.raises(SdmiError) as ei:
+            sd.load_weights_mpk(tmp_path / "bad.mpk")
+        assert "unet/conv_out/bias" in str(ei.value)
+    finally:
+        sd.close()

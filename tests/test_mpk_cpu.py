@@ -5,6 +5,7 @@ import sys
 from pathlib import Path
 
 import numpy as np
+import pytest
 import torch
 
 ROOT = Path(__file__).resolve().parents[1]
@@ -69,3 +70,74 @@ def test_legacy_data_serialize_flavour_and_names():
     names = {M.dump_name(k): v.shape for k, v in out.items()}
     assert names == {"unet/norm_out/weight": (2,), "unet/norm_out/bias": (2,), "unet/input_blocks/d1/weight": (2, 1, 2, 2),
                      "clip/position_embedding/weight": (3, 2), "clip/blocks/0/attn_ln/weight": (1,), "alphas_cumprod": (2,)}
+
+
+# ---- the native C++ reader (csrc/mpk_reader.cpp) against records written by msgpack-python --------------------------
+def _list(path):
+    from stable_diffusion_burn_amd import mpk_list
+    return mpk_list(path)
+
+
+def test_cpp_reader_indexes_the_same_tensors_as_the_python_walker(tmp_path):
+    """Names, shapes and the bytes at the reported file offsets of the C++ MessagePack walker == the Python converter's
+    view of the same record (which itself is only self-consistent: the burn 0.14 layout is UNPINNED, see mpk_reader.hpp)."""
+    d = O.Dims(32, 1, 32, 8, 8, 32)
+    cd = CO.ClipDims(n_vocab=300, n_state=32, n_head=1, n_ctx=8, n_layer=2)   # 300 x 32 floats: a bin32-sized tensor
+    want = _expected_tensors(d, cd)
+    rec = tmp_path / "model.mpk"
+    M.write_record(want, rec)
+    got = _list(rec)
+    assert {n for n, _, _ in got} == set(want)
+    raw = rec.read_bytes()
+    for name, shape, off in got:
+        a = np.asarray(want[name], dtype="<f4")
+        assert shape == a.shape, name
+        assert off > 0 and raw[off:off + a.nbytes] == a.tobytes(), name
+
+
+def test_cpp_reader_accepts_the_tolerated_variants(tmp_path):
+    """legacy {"value": [...]} tensors, dtype as an externally tagged enum, bytes as a plain integer array (no serde_bytes),
+    integer map keys, a record without the BurnRecord wrapper, constants / None as nil, unit modules as empty maps."""
+    import msgpack
+    t1 = np.arange(6, dtype="<f4").reshape(2, 3)
+    item = {"diffusion": {"norm_out": {"gamma": {"id": "a", "param": {"value": [1.0, 2.5], "shape": [2]}},
+                                       "beta": {"id": "b", "param": {"bytes": list(np.array([3, 4], "<f4").tobytes()), "shape": [2], "dtype": {"F32": None}}},
+                                       "eps": None, "n_group": None},
+                          "silu_out": {},
+                          "conv_out": {"weight": {"id": "c", "param": {"bytes": t1.tobytes(), "shape": [2, 3], "dtype": "F32"}}, "bias": None,
+                                       "stride": [None, None]}},
+            "clip": {"blocks": [{"attn_ln": {"gamma": {"id": "g", "param": {"value": [7], "shape": [1]}}}}], "position_embedding": {"id": "p", "param": {"value": [0.5] * 4, "shape": [2, 2]}}},
+            "alpha_cumulative_products": {"id": "z", "param": {"value": [0.9, 0.8, 0.7], "shape": [3]}},
+            "n_steps": None, 7: "integer key"}
+    p = tmp_path / "bare.mpk"
+    p.write_bytes(msgpack.packb(item, use_bin_type=True))
+    got = {n: s for n, s, _ in _list(p)}
+    assert got == {"unet/norm_out/weight": (2,), "unet/norm_out/bias": (2,), "unet/conv_out/weight": (2, 3),
+                   "clip/blocks/0/attn_ln/weight": (1,), "clip/position_embedding/weight": (2, 2), "alphas_cumprod": (3,)}
+
+
+@pytest.mark.parametrize("damage", ["truncate", "half_precision", "bad_length", "garbage", "empty"])
+def test_cpp_reader_rejects_bad_records(tmp_path, damage):
+    import msgpack
+    from stable_diffusion_burn_amd import SdmiError
+    good = {"metadata": {"float": "f32", "int": "i32", "format": "x", "version": "0.14.0", "settings": "FullPrecisionSettings"},
+            "item": {"diffusion": {"conv_out": {"weight": {"id": "c", "param": {"bytes": np.zeros(12, "<f4").tobytes(), "shape": [3, 4], "dtype": "F32"}}}}}}
+    blob = msgpack.packb(good, use_bin_type=True)
+    if damage == "truncate":
+        blob = blob[:-9]
+    elif damage == "half_precision":
+        good["item"]["diffusion"]["conv_out"]["weight"]["param"]["dtype"] = "F16"
+        blob = msgpack.packb(good, use_bin_type=True)
+    elif damage == "bad_length":
+        good["item"]["diffusion"]["conv_out"]["weight"]["param"]["shape"] = [3, 5]
+        blob = msgpack.packb(good, use_bin_type=True)
+    elif damage == "garbage":
+        blob = bytes([0xc1]) * 64          # 0xc1 is the one reserved MessagePack type byte
+    elif damage == "empty":
+        blob = msgpack.packb({"metadata": {}, "item": {"n_steps": None}}, use_bin_type=True)
+    p = tmp_path / "bad.mpk"
+    p.write_bytes(blob)
+    with pytest.raises(SdmiError):
+        _list(p)
+    with pytest.raises(SdmiError):
+        _list(tmp_path / "does_not_exist.mpk")
