@@ -220,6 +220,29 @@ int sdmi_sample_image_dev(sdmi_ctx* ctx, const float* context, int32_t n, int32_
                           const float* uncond, int32_t Tu, double scale, size_t n_steps,
                           const float* init_latent, uint8_t* rgb_out);
 
+/* ---- multi-GPU: the image batch sharded over the devices of one node ----------------------
+ * The reference's caller asks one StableDiffusion for n images of one prompt (src/bin/sample/main.rs:104-109).
+ * The path shards over independent images, so a multi-context is: one weights replica + stream + host thread per
+ * device inside ONE process, an RCCL communicator over the device list (ncclCommInitAll; librccl is opened
+ * lazily here, libsdmi itself links only the HIP runtime), ONE ncclBroadcast over xGMI of the packed prompt
+ * embedding [cond | uncond] from the first device per call, contiguous image ranges per device, noise keyed by
+ * the GLOBAL image index -- results do not depend on the device count -- and no other collective. */
+typedef struct sdmi_multi sdmi_multi;
+int sdmi_create_multi(sdmi_multi** out, const sdmi_config* cfg /* .device ignored */, const int32_t* devices, int32_t n_devices);
+void sdmi_destroy_multi(sdmi_multi* m);
+int32_t sdmi_multi_size(sdmi_multi* m);
+/* the per-device context (owned by m): for sdmi_set_weight / sdmi_load_weights_* / sdmi_set_option per device */
+sdmi_ctx* sdmi_multi_ctx(sdmi_multi* m, int32_t index);
+/* load_stable_diffusion / load_stable_diffusion_model_file on every device in parallel + finalize; kind = "dump" | "burn" */
+int sdmi_multi_load_weights(sdmi_multi* m, const char* kind, const char* path);
+/* StableDiffusion::sample_image for n_images of ONE prompt: context [T, ctx_dim], uncond [Tu, ctx_dim] (host);
+ * init_latents [n_images,4,h,w] or NULL (image i draws N(0,1) from stream seed + i); rgb_out n_images x [8h,8w,3] (host). */
+int sdmi_sample_image_sharded(sdmi_multi* m, const float* context, int32_t T, const float* uncond, int32_t Tu,
+                              double scale, size_t n_steps, int32_t n_images, const float* init_latents, uint64_t seed,
+                              uint8_t* rgb_out);
+/* number of RCCL broadcasts issued so far (one per sdmi_sample_image_sharded call) */
+int64_t sdmi_multi_broadcast_count(sdmi_multi* m);
+
 /* ---- operator-level entry points (parity tests, profiling) -------------------
  * Same math as the Burn primitives / reference modules named; host pointers
  * in reference layouts.  These let tests/ compare each HIP kernel with the

@@ -6,7 +6,7 @@ C++ engine, C ABI in include/sdmi.h).  It exposes the reference's
 src/model/stablediffusion/mod.rs) and nothing else; there is no CPU or PyTorch
 fallback -- importing the pipeline without a built library raises.
 """
-from .pipeline import CLIP, Autoencoder, ModelConfig, SdmiError, SimpleTokenizer, StableDiffusion, UNet, mpk_list, qkv_attention  # noqa: F401
+from .pipeline import CLIP, Autoencoder, ModelConfig, MultiStableDiffusion, SdmiError, SimpleTokenizer, StableDiffusion, UNet, mpk_list, qkv_attention  # noqa: F401
 from . import synthetic  # noqa: F401
 
-__all__ = ["StableDiffusion", "UNet", "Autoencoder", "CLIP", "SimpleTokenizer", "ModelConfig", "SdmiError", "qkv_attention", "mpk_list", "synthetic"]
+__all__ = ["StableDiffusion", "MultiStableDiffusion", "UNet", "Autoencoder", "CLIP", "SimpleTokenizer", "ModelConfig", "SdmiError", "qkv_attention", "mpk_list", "synthetic"]

@@ -590,7 +590,7 @@ bool Engine::set_meta(const std::string& name, const float* values, size_t n) {
     MetaEntry& m = meta_[it->second];
     if ((int)n != m.n) throw Error(SDMI_ERR_WEIGHTS, "'" + name + "' holds " + std::to_string(n) + " values, expected " + std::to_string(m.n));
     if (m.store) {
-        if (!(values[0] > 0.f) || values[0] > 1e-2f) throw Error(SDMI_ERR_WEIGHTS, "'" + name + "': eps out of range");
+        if (!(values[0] > 0.f) || values[0] > 1.f) throw Error(SDMI_ERR_WEIGHTS, "'" + name + "': eps out of range");
         *m.store = values[0];
         return true;
     }
@@ -990,6 +990,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     };
     p.slabs = nullptr;
     p.counters = nullptr;
+    p.slab_wt = 0;
     if (splits == 1) {
         p.slab_stride = 0;
         ProfScope ps(this, PC_CONV_GEMM, flops);
@@ -1004,7 +1005,11 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         const int bn = tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100).bn : gemm_tile_info(tc.cfg).bn;
         const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
         const bool vec = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (!p.resid || p.ldr % 4 == 0);
-        if (opt_splitk_fused_ && vec && tiles <= kSplitkCounters) p.counters = splitk_counters_;
+        const bool slab_ok = (unsigned long long)p.slab_stride * 4ull < 0xFFFFFFE0ull;   // write-through stores go through a 32-bit buffer descriptor
+        if (opt_splitk_fused_ && vec && tiles <= kSplitkCounters && (opt_splitk_fused_ != 2 || slab_ok)) {
+            p.counters = splitk_counters_;
+            p.slab_wt = opt_splitk_fused_ == 2 ? 1 : 0;
+        }
         {
             ProfScope ps(this, PC_CONV_GEMM, flops);
             SDMI_HIP(launch(p));

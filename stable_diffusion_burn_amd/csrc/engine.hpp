@@ -345,7 +345,9 @@ private:
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
     void* zero_page_ = nullptr;
     TileChoice choose_tile_bf16(int M, int N, int kt_total) const;   // cfg >= 100: k_gemm_bf16x.hip tile cfg - 100     // precision = 1: 1 = bf16 matrix-core attention, 0 = bf16 storage widened onto the fp32 kernel  // 1: attn2_kernel, 0: attn_f32_kernel
-    int opt_splitk_fused_ = 1;  // 1: the last-arriving k slice combines the slabs inside the GEMM launch; 0: separate reduce kernel
+    // split-K combine: 0 = separate reduce kernel (the measured best, profiles/README.md); 1 = inside the GEMM launch by the
+    // last-arriving k slice (plain slab stores + release fence); 2 = the same with write-through (sc1) slab stores
+    int opt_splitk_fused_ = 0;
     static constexpr long long kSplitkCounters = 16384;
     unsigned* splitk_counters_ = nullptr;
     std::map<std::string, TileChoice> tuned_;        // fp32 kernels: "M,N,K" -> (tile cfg, split-K)
@@ -357,4 +359,11 @@ private:
     double flops_ = 0;
 };
 
+void set_last_error(const std::string& msg);   // the thread-local message behind sdmi_last_error() (sdmi_capi.cpp)
+
 }  // namespace sdmi
+
+// the opaque handle of include/sdmi.h
+struct sdmi_ctx {
+    sdmi::Engine* engine;
+};

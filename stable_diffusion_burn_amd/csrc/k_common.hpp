@@ -55,12 +55,16 @@ __device__ __forceinline__ void gn_finalize(const double* __restrict__ part, int
 // per-wave vmcnt(0) -> barrier -> one lane: release fence + vmcnt(0) + relaxed agent fetch_add; last arriver: one
 // acquire fence, barrier, plain loads.  No spin anywhere: nobody waits for another workgroup.  Counters are zero
 // between launches: the last arriver resets its counter (the engine zeroes the array once at creation).
-__device__ __forceinline__ bool splitk_arrive(unsigned* counters, int tile, int splits, unsigned* lds_flag) {
+// write_through: the slab tile was stored with sc1 (write-through) stores, which are complete once vmcnt drains -- no
+// release fence, i.e. no write-back sweep of the XCD's whole L2 (buffer_wbl2) in every workgroup's tail.
+__device__ __forceinline__ bool splitk_arrive(unsigned* counters, int tile, int splits, unsigned* lds_flag, bool write_through) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler may drop the wait behind buffer_wbl2 (guide, G16 pitfall 12)
+        if (!write_through) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler may drop the wait behind buffer_wbl2 (guide, G16 pitfall 12)
+        }
         const unsigned old = __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool last = old == (unsigned)(splits - 1);
         if (last) {
@@ -75,6 +79,21 @@ __device__ __forceinline__ bool splitk_arrive(unsigned* counters, int tile, int 
 
 typedef float kc_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int kc_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int kc_u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte store of a slab element: plain, or write-through (sc1: aux bit 4 of the raw buffer store) through a descriptor
+// over this k slice's slab.  byte_off < 4 GiB (slabs are M*N*4 bytes; the launch side checks).
+struct SlabStore {
+    __amdgpu_buffer_rsrc_t rsrc;
+    float* base;
+    bool wt;
+    __device__ __forceinline__ SlabStore(float* slab, long long elems, bool write_through)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)(unsigned)(elems * 4), 0x00020000)), base(slab), wt(write_through) {}
+    __device__ __forceinline__ void store(long long elem_off, kc_f32x4 v) const {
+        if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(kc_u32x4, v), rsrc, (int)(unsigned)(elem_off * 4), 0, 16);
+        else *reinterpret_cast<kc_f32x4*>(base + elem_off) = v;
+    }
+};
 
 __device__ __forceinline__ unsigned kc_bf16_bits(float f) {
     unsigned u = __float_as_uint(f);

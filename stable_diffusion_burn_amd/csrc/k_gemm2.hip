@@ -236,6 +236,7 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(const ConvGemm p) {
     float* Cbase = split ? (p.slabs + (long long)z * p.slab_stride) : p.C;
     const int ldc = split ? p.N : p.ldc;
     const bool vec_ok = ((p.N & 3) == 0) && ((ldc & 3) == 0);
+    const SlabStore slab(Cbase, split ? p.slab_stride : 0, split && p.counters && p.slab_wt);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + (wm * MI + mi) * 16 + c15;
@@ -260,6 +261,8 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(const ConvGemm p) {
                         u += 0x7FFFu + ((u >> 16) & 1u);
                         Ch[r] = (unsigned short)(u >> 16);
                     }
+                } else if (split) {
+                    slab.store((long long)m * ldc + n, v);
                 } else {
                     *reinterpret_cast<f32x4*>(Cbase + (long long)m * ldc + n) = v;
                 }
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(const ConvGemm p) {
         }
     }
     if (split && p.counters) {
-        if (splitk_arrive(p.counters, lid, p.splits, reinterpret_cast<unsigned*>(smem))) splitk_reduce_tile<false>(p, m0, n0, BM, BN);
+        if (splitk_arrive(p.counters, lid, p.splits, reinterpret_cast<unsigned*>(smem), p.slab_wt != 0)) splitk_reduce_tile<false>(p, m0, n0, BM, BN);
     }
 }
 

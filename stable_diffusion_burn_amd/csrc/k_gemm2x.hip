@@ -243,6 +243,7 @@ __global__ __launch_bounds__(512) void conv_gemm2x_kernel(const ConvGemm p) {
         }
         return;
     }
+    const SlabStore slab(Cf, split ? p.slab_stride : 0, split && p.counters && p.slab_wt);
     if (vec_ok) {
         __syncthreads();                // every wave is done with the last k tile
         float* scr = reinterpret_cast<float*>(smem_x32 + wave * (16 * LDSW * 4));
@@ -274,7 +275,8 @@ __global__ __launch_bounds__(512) void conv_gemm2x_kernel(const ConvGemm p) {
                 if (q < 16 * CH && m < p.M && n < p.N) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * LDSW + c4 * 4);
                     if (has_resid) v += *reinterpret_cast<const f32x4*>(p.resid + (long long)m * p.ldr + n);
-                    *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;
+                    if (split) slab.store((long long)m * ldc + n, v);
+                    else *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(512) void conv_gemm2x_kernel(const ConvGemm p) {
     }
     }
     if (split && p.counters) {
-        if (splitk_arrive(p.counters, lid, p.splits, reinterpret_cast<unsigned*>(smem_x32))) splitk_reduce_tile<false>(p, m0, n0, BM, BN);
+        if (splitk_arrive(p.counters, lid, p.splits, reinterpret_cast<unsigned*>(smem_x32), p.slab_wt != 0)) splitk_reduce_tile<false>(p, m0, n0, BM, BN);
     }
 }
 

@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const ConvGemm p) {
     unsigned short* Ch = reinterpret_cast<unsigned short*>(p.C);
     const unsigned short* Rh = reinterpret_cast<const unsigned short*>(p.resid);
     const int ldc = split ? p.N : p.ldc;
+    const SlabStore slab(Cf, split ? p.slab_stride : 0, split && p.counters && p.slab_wt);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + (wm * MI + mi) * 16 + c15;
@@ -264,7 +265,9 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const ConvGemm p) {
                         v[0] += bf16_lo(r[0]); v[1] += bf16_hi(r[0]); v[2] += bf16_lo(r[1]); v[3] += bf16_hi(r[1]);
                     }
                 }
-                if (out_f32) {
+                if (split) {
+                    slab.store((long long)m * ldc + n, v);
+                } else if (out_f32) {
                     *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;
                 } else {
                     u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const ConvGemm p) {
         }
     }
     if (split && p.counters) {
-        if (splitk_arrive(p.counters, lid, p.splits, reinterpret_cast<unsigned*>(smem))) splitk_reduce_tile<true>(p, m0, n0, BM, BN);
+        if (splitk_arrive(p.counters, lid, p.splits, reinterpret_cast<unsigned*>(smem), p.slab_wt != 0)) splitk_reduce_tile<true>(p, m0, n0, BM, BN);
     }
 }
 

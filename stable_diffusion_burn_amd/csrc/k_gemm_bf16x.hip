@@ -279,6 +279,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
         }
         return;
     }
+    const SlabStore slab(Cf, split ? p.slab_stride : 0, split && p.counters && p.slab_wt);
     if (vec_ok) {
         __syncthreads();                // every wave is done with the last k tile
         float* scr = reinterpret_cast<float*>(smem_x + wave * (16 * LDSW * 4));
@@ -333,7 +334,8 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
                             const u32x2 r = *reinterpret_cast<const u32x2*>(Rh + (long long)m * p.ldr + n);
                             v[0] += xbf16_lo(r[0]); v[1] += xbf16_hi(r[0]); v[2] += xbf16_lo(r[1]); v[3] += xbf16_hi(r[1]);
                         }
-                        *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;
+                        if (split) slab.store((long long)m * ldc + n, v);
+                        else *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;
                     }
                 }
             }
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     }
     }
     if (split && p.counters) {
-        if (splitk_arrive(p.counters, lid, p.splits, reinterpret_cast<unsigned*>(smem_x))) splitk_reduce_tile<true>(p, m0, n0, BM, BN);
+        if (splitk_arrive(p.counters, lid, p.splits, reinterpret_cast<unsigned*>(smem_x), p.slab_wt != 0)) splitk_reduce_tile<true>(p, m0, n0, BM, BN);
     }
 }
 

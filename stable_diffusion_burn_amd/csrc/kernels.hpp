@@ -21,6 +21,7 @@ struct ConvGemm {
     const float* Bt;      // packed weights [N][K]
     float* C;             // output [M][ldc]
     float* slabs;         // splits > 1: fp32 partial sums [splits][M][N]
+    int slab_wt;          // with counters: slab tiles are stored write-through (sc1) and published without a release fence
     unsigned* counters;   // splits > 1: per-tile arrival counters (zero between launches) -> the last-arriving slice combines
                           // the slabs and applies the epilogue inside the launch; null: a separate reduce kernel does
     const float* bias;    // [N] or null

@@ -1,0 +1,250 @@
+// multi.cpp -- the image batch sharded over the GPUs of one node, behind the C ABI.
+//
+// The reference's caller (src/bin/sample/main.rs:104-109) asks ONE StableDiffusion for n images of one prompt.  The
+// path shards over independent images (GroupNorm, attention and DDIM are per sample), so the multi-GPU form is:
+//   * one process, one Engine (weights replica, stream, activation pool) per device, one host thread per device;
+//   * the prompt embedding lives on device 0 (where CLIP -- or the caller -- put it); ONE ncclBroadcast (RCCL over xGMI)
+//     of the packed buffer [cond (T x ctx_dim) | uncond (Tu x ctx_dim)] = 473 088 B at T = Tu = 77 hands it to the other
+//     devices, enqueued on each device's own stream inside one ncclGroupStart / ncclGroupEnd;
+//   * device r samples the contiguous global image range [r*n/R, (r+1)*n/R) with noise keyed by the GLOBAL image index
+//     (seed + i), decodes, and copies its u8 images into the caller's buffer: no other collective.
+// RCCL is opened lazily (dlopen) when a multi-context is created: libsdmi.so itself depends on libamdhip64 only, so a
+// process that already carries its own RCCL (PyTorch) and single-GPU users are unaffected.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "engine.hpp"
+
+namespace sdmi {
+
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+
+    void open() {
+        if (lib) return;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) throw Error(SDMI_ERR_UNSUPPORTED, std::string("cannot load RCCL (librccl.so.1): ") + dlerror());
+        auto sym = [&](const char* n) {
+            void* p = dlsym(lib, n);
+            if (!p) throw Error(SDMI_ERR_UNSUPPORTED, std::string("RCCL symbol missing: ") + n);
+            return p;
+        };
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        Broadcast = reinterpret_cast<decltype(Broadcast)>(sym("ncclBroadcast"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+    }
+    void check(ncclResult_t r, const char* what) const {
+        if (r != ncclSuccess) throw Error(SDMI_ERR_HIP, std::string(what) + ": " + (GetErrorString ? GetErrorString(r) : "RCCL error"));
+    }
+};
+Rccl g_rccl;
+}  // namespace
+
+// contiguous image range of shard r of R over n images (the same rule as sharding.shard_range on the Python side)
+void shard_range(int n, int r, int R, int* begin, int* end) {
+    const int base = n / R, rem = n % R;
+    *begin = r * base + (r < rem ? r : rem);
+    *end = *begin + base + (r < rem ? 1 : 0);
+}
+
+class MultiEngine {
+public:
+    MultiEngine(const sdmi_config& cfg, const int* devices, int n) {
+        if (!devices || n <= 0) throw Error(SDMI_ERR_INVALID, "create_multi: empty device list");
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < i; ++j)
+                if (devices[i] == devices[j]) throw Error(SDMI_ERR_INVALID, "create_multi: a device is listed twice");
+        devs_.assign(devices, devices + n);
+        try {
+            for (int i = 0; i < n; ++i) {
+                sdmi_config c = cfg;
+                c.device = devices[i];
+                engines_.push_back(new Engine(c));
+            }
+            g_rccl.open();
+            comms_.resize(n, nullptr);
+            g_rccl.check(g_rccl.CommInitAll(comms_.data(), n, devs_.data()), "ncclCommInitAll");
+        } catch (...) {
+            destroy();
+            throw;
+        }
+    }
+    ~MultiEngine() { destroy(); }
+    MultiEngine(const MultiEngine&) = delete;
+    MultiEngine& operator=(const MultiEngine&) = delete;
+
+    int size() const { return (int)engines_.size(); }
+    Engine& engine(int i) { return *engines_.at((size_t)i); }
+
+    // runs f(rank) on one host thread per device and rethrows the first failure in the caller's thread
+    template <class F>
+    void for_each_device(F&& f) {
+        const int R = size();
+        std::vector<std::string> msg((size_t)R);
+        std::vector<int> status((size_t)R, SDMI_OK);
+        auto body = [&](int r) {
+            try { f(r); }
+            catch (const Error& e) { status[r] = e.status; msg[r] = e.what(); }
+            catch (const std::exception& e) { status[r] = SDMI_ERR_INVALID; msg[r] = e.what(); }
+        };
+        std::vector<std::thread> th;
+        for (int r = 1; r < R; ++r) th.emplace_back(body, r);
+        body(0);
+        for (auto& t : th) t.join();
+        for (int r = 0; r < R; ++r)
+            if (status[r] != SDMI_OK) throw Error(status[r], "device " + std::to_string(devs_[r]) + ": " + msg[r]);
+    }
+
+    void sample_image(const float* context, int T, const float* uncond, int Tu, double scale, size_t n_steps, int n_images,
+                      const float* init_latents, uint64_t seed, uint8_t* rgb_out) {
+        if (!context || !uncond || !rgb_out) throw Error(SDMI_ERR_INVALID, "sample_image_sharded: null pointer");
+        if (T <= 0 || Tu <= 0 || n_images <= 0) throw Error(SDMI_ERR_INVALID, "sample_image_sharded: T, Tu and n_images must be positive");
+        const int R = size();
+        const int cd = engine(0).config().ctx_dim, H = engine(0).latent_h(), W = engine(0).latent_w();
+        const size_t n_cond = (size_t)T * cd, n_unc = (size_t)Tu * cd, n_prompt = n_cond + n_unc;
+        const size_t lat_elems = (size_t)4 * H * W, img_bytes = (size_t)3 * 64 * H * W;
+
+        // the packed prompt [cond | uncond] on every device; rank 0 holds the data
+        std::vector<Engine::Buf*> prompt((size_t)R, nullptr);
+        struct Free { std::vector<Engine::Buf*>& v; ~Free() { for (auto* b : v) delete b; } } free_prompt{prompt};
+        for (int r = 0; r < R; ++r) {
+            SDMI_HIP(hipSetDevice(devs_[r]));
+            prompt[r] = new Engine::Buf(&engine(r), n_prompt * sizeof(float));
+        }
+        SDMI_HIP(hipSetDevice(devs_[0]));
+        SDMI_HIP(hipMemcpyAsync(prompt[0]->p, context, n_cond * sizeof(float), hipMemcpyHostToDevice, engine(0).stream()));
+        SDMI_HIP(hipMemcpyAsync(prompt[0]->f() + n_cond, uncond, n_unc * sizeof(float), hipMemcpyHostToDevice, engine(0).stream()));
+        // THE collective of the path: one broadcast, each rank's part enqueued on that device's own stream
+        g_rccl.check(g_rccl.GroupStart(), "ncclGroupStart");
+        for (int r = 0; r < R; ++r)
+            g_rccl.check(g_rccl.Broadcast(prompt[r]->p, prompt[r]->p, n_prompt, ncclFloat32, 0, comms_[r], engine(r).stream()), "ncclBroadcast");
+        g_rccl.check(g_rccl.GroupEnd(), "ncclGroupEnd");
+        ++broadcasts_;
+
+        for_each_device([&](int r) {
+            int g0, g1;
+            shard_range(n_images, r, R, &g0, &g1);
+            const int n = g1 - g0;
+            Engine& e = engine(r);
+            Engine::Call call(e);          // also hipSetDevice
+            if (n > 0) {
+                Engine::Buf ctx(&e, (size_t)n * n_cond * sizeof(float)), x0(&e, (size_t)n * lat_elems * sizeof(float));
+                Engine::Buf lat(&e, (size_t)n * lat_elems * sizeof(float)), rgb(&e, (size_t)n * img_bytes);
+                for (int i = 0; i < n; ++i)   // the same prompt for every image of the shard (sample/main.rs:100-109)
+                    SDMI_HIP(hipMemcpyAsync(ctx.f() + (size_t)i * n_cond, prompt[r]->p, n_cond * sizeof(float), hipMemcpyDeviceToDevice, e.stream()));
+                if (init_latents) {
+                    SDMI_HIP(hipMemcpyAsync(x0.p, init_latents + (size_t)g0 * lat_elems, (size_t)n * lat_elems * sizeof(float), hipMemcpyHostToDevice, e.stream()));
+                } else {
+                    for (int i = 0; i < n; ++i)   // noise keyed by the global image index: independent of the device count
+                        SDMI_HIP(launch_fill_normal(x0.f() + (size_t)i * lat_elems, (long long)lat_elems, seed + (uint64_t)(g0 + i), e.stream()));
+                }
+                e.sample_latent_dev(ctx.f(), n, T, prompt[r]->f() + n_cond, Tu, scale, n_steps, x0.f(), lat.f());
+                e.decode_latent_dev(lat.f(), n, (float)(1.0 / 0.18215), nullptr, reinterpret_cast<uint8_t*>(rgb.p));
+                SDMI_HIP(hipMemcpyAsync(rgb_out + (size_t)g0 * img_bytes, rgb.p, (size_t)n * img_bytes, hipMemcpyDeviceToHost, e.stream()));
+            }
+            call.finish();   // waits for this device's stream (incl. its share of the broadcast and the D2H copy)
+        });
+    }
+
+    long long broadcasts() const { return broadcasts_; }
+
+private:
+    void destroy() noexcept {
+        for (size_t i = 0; i < comms_.size(); ++i)
+            if (comms_[i] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comms_[i]);
+        comms_.clear();
+        for (Engine* e : engines_) delete e;
+        engines_.clear();
+    }
+    std::vector<int> devs_;
+    std::vector<Engine*> engines_;
+    std::vector<ncclComm_t> comms_;
+    long long broadcasts_ = 0;
+};
+
+}  // namespace sdmi
+
+// ---- C ABI (include/sdmi.h, "multi-GPU") ---------------------------------------------------------------------------
+struct sdmi_multi {
+    sdmi::MultiEngine* m;
+    std::vector<sdmi_ctx> views;   // non-owning per-device handles for the single-device entry points (weights, options)
+};
+
+static void sdmi_set_last_error(const char* msg) { sdmi::set_last_error(msg); }
+
+extern "C" {
+
+static int multi_guard(const std::function<void()>& f) {
+    try { f(); return SDMI_OK; }
+    catch (const sdmi::Error& e) { sdmi_set_last_error(e.what()); return e.status; }
+    catch (const std::exception& e) { sdmi_set_last_error(e.what()); return SDMI_ERR_INVALID; }
+    catch (...) { sdmi_set_last_error("unknown internal error"); return SDMI_ERR_INVALID; }
+}
+
+int sdmi_create_multi(sdmi_multi** out, const sdmi_config* cfg, const int32_t* devices, int32_t n_devices) {
+    if (!out || !cfg) { sdmi_set_last_error("sdmi_create_multi: null argument"); return SDMI_ERR_INVALID; }
+    *out = nullptr;
+    return multi_guard([&] {
+        std::vector<int> devs(devices, devices + (devices && n_devices > 0 ? n_devices : 0));
+        auto* mm = new sdmi_multi{new sdmi::MultiEngine(*cfg, devs.data(), (int)devs.size()), {}};
+        for (int i = 0; i < mm->m->size(); ++i) mm->views.push_back(sdmi_ctx{&mm->m->engine(i)});
+        *out = mm;
+    });
+}
+
+void sdmi_destroy_multi(sdmi_multi* m) {
+    if (!m) return;
+    delete m->m;
+    delete m;
+}
+
+int32_t sdmi_multi_size(sdmi_multi* m) { return m ? m->m->size() : SDMI_ERR_INVALID; }
+
+sdmi_ctx* sdmi_multi_ctx(sdmi_multi* m, int32_t index) {
+    if (!m || index < 0 || index >= m->m->size()) { sdmi_set_last_error("sdmi_multi_ctx: index out of range"); return nullptr; }
+    return &m->views[(size_t)index];
+}
+
+int sdmi_multi_load_weights(sdmi_multi* m, const char* kind, const char* path) {
+    return multi_guard([&] {
+        if (!m || !kind || !path) throw sdmi::Error(SDMI_ERR_INVALID, "multi_load_weights: null argument");
+        const std::string k = kind;
+        if (k != "dump" && k != "burn") throw sdmi::Error(SDMI_ERR_INVALID, "multi_load_weights: kind must be \"dump\" or \"burn\"");
+        m->m->for_each_device([&](int r) {
+            sdmi::Engine& e = m->m->engine(r);
+            if (k == "dump") e.load_weights_dir(path); else e.load_weights_mpk(path);
+            e.finalize_weights();
+        });
+    });
+}
+
+int sdmi_sample_image_sharded(sdmi_multi* m, const float* context, int32_t T, const float* uncond, int32_t Tu, double scale,
+                              size_t n_steps, int32_t n_images, const float* init_latents, uint64_t seed, uint8_t* rgb_out) {
+    return multi_guard([&] {
+        if (!m) throw sdmi::Error(SDMI_ERR_INVALID, "null sdmi_multi");
+        m->m->sample_image(context, T, uncond, Tu, scale, n_steps, n_images, init_latents, seed, rgb_out);
+    });
+}
+
+int64_t sdmi_multi_broadcast_count(sdmi_multi* m) { return m ? m->m->broadcasts() : SDMI_ERR_INVALID; }
+
+}  // extern "C"

@@ -11,10 +11,6 @@
 using sdmi::Engine;
 using sdmi::Error;
 
-struct sdmi_ctx {
-    Engine* engine;
-};
-
 namespace sdmi {
 void write_png_rgb8(const std::string& path, const uint8_t* rgb, int width, int height);  // png_writer.cpp
 }
@@ -24,6 +20,10 @@ struct sdmi_tokenizer {
 };
 
 static thread_local std::string g_last_error;
+
+namespace sdmi {
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+}
 
 template <class F>
 static int guarded(F&& f) {

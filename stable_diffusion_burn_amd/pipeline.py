@@ -40,7 +40,7 @@ def mpk_list(path) -> list:
     return out
 
 
-__all__ = ["ModelConfig", "StableDiffusion", "mpk_list", "UNet", "Autoencoder", "CLIP", "SimpleTokenizer", "qkv_attention", "SdmiError"]
+__all__ = ["ModelConfig", "StableDiffusion", "MultiStableDiffusion", "mpk_list", "UNet", "Autoencoder", "CLIP", "SimpleTokenizer", "qkv_attention", "SdmiError"]
 
 
 @dataclass(frozen=True)
@@ -81,9 +81,16 @@ def _fp(a: np.ndarray):
 class StableDiffusion:
     """`StableDiffusion<B>` (src/model/stablediffusion/mod.rs:41-48) on one MI355X."""
 
-    def __init__(self, config: ModelConfig = ModelConfig(), device: int = 0):
+    def __init__(self, config: ModelConfig = ModelConfig(), device: int = 0, _borrowed_ctx=None):
         self._lib = load_library()
         self.config = config
+        self._owned = _borrowed_ctx is None
+        if _borrowed_ctx is not None:      # a per-device view of a MultiStableDiffusion (sdmi_multi_ctx): not ours to destroy
+            self._ctx = C.c_void_p(_borrowed_ctx)
+            self.unet = UNet(self)
+            self.autoencoder = Autoencoder(self)
+            self.clip = CLIP(self)
+            return
         cfg = SdmiConfig()
         check(self._lib.sdmi_default_config(C.byref(cfg)))
         cfg.device = device
@@ -107,7 +114,8 @@ class StableDiffusion:
     # ---- lifecycle -----------------------------------------------------------
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
-            self._lib.sdmi_destroy(self._ctx)
+            if getattr(self, "_owned", True):
+                self._lib.sdmi_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
     def __del__(self):
@@ -409,6 +417,80 @@ class StableDiffusion:
         check(self._lib.sdmi_qkv_attention(self._ctx, _fp(q), _fp(k), _fp(v), None if m is None else _fp(m),
                                            0 if m is None else m.shape[1], n, nq, nk, c, n_head, _fp(out)))
         return out
+
+
+def _make_cfg(lib, config: ModelConfig, device: int = 0) -> SdmiConfig:
+    cfg = SdmiConfig()
+    check(lib.sdmi_default_config(C.byref(cfg)))
+    cfg.device = device
+    for f in ("model_channels", "n_head", "ctx_dim", "latent_h", "latent_w", "vae_ch", "precision", "clip_layers", "clip_heads",
+              "clip_vocab", "clip_ctx"):
+        setattr(cfg, f, getattr(config, f))
+    return cfg
+
+
+class MultiStableDiffusion:
+    """`StableDiffusion::sample_image` for n images of one prompt, sharded over the GPUs of one node behind the C ABI
+    (sdmi_create_multi / sdmi_sample_image_sharded): one process, one engine + host thread per device,
+    ONE RCCL broadcast of the packed prompt embedding per call, contiguous image ranges, noise keyed by the global
+    image index."""
+
+    def __init__(self, config: ModelConfig = ModelConfig(), devices=(0,)):
+        self._lib = load_library()
+        self.config = config
+        cfg = _make_cfg(self._lib, config)
+        devs = (C.c_int32 * len(devices))(*devices)
+        self._m = C.c_void_p()
+        check(self._lib.sdmi_create_multi(C.byref(self._m), C.byref(cfg), devs, len(devices)))
+        self.devices = tuple(devices)
+
+    def close(self):
+        if getattr(self, "_m", None) is not None and self._m.value:
+            self._lib.sdmi_destroy_multi(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_view(self, index: int) -> StableDiffusion:
+        """The single-device surface of device `index` (weights, options); owned by this object."""
+        ctx = self._lib.sdmi_multi_ctx(self._m, index)
+        if not ctx:
+            check(-1)
+        return StableDiffusion(self.config, _borrowed_ctx=ctx)
+
+    def load_weights(self, provider, clip: bool = False, vae_encoder: bool = False) -> None:
+        for i in range(len(self.devices)):
+            self.device_view(i).load_weights(provider, clip=clip, vae_encoder=vae_encoder)
+
+    def load_weights_path(self, kind: str, path) -> None:
+        """kind = "dump" (npy tree) | "burn" (.mpk record), on every device in parallel."""
+        check(self._lib.sdmi_multi_load_weights(self._m, kind.encode(), str(path).encode()))
+
+    def sample_image(self, context, unconditional_context, unconditional_guidance_scale: float, n_steps: int, n_images: int,
+                     init_latents=None, seed: int = 0) -> np.ndarray:
+        cd, h, w = self.config.ctx_dim, self.config.latent_h, self.config.latent_w
+        context = _f32(context, name="context")
+        if context.ndim == 3 and context.shape[0] == 1:
+            context = context[0]
+        if context.ndim != 2 or context.shape[1] != cd:
+            raise ValueError(f"context must be [T, {cd}] (one prompt), got {context.shape}")
+        uncond = _f32(unconditional_context, name="unconditional_context")
+        if uncond.ndim != 2 or uncond.shape[1] != cd:
+            raise ValueError(f"unconditional_context must be [Tu, {cd}], got {uncond.shape}")
+        x0 = None if init_latents is None else _f32(init_latents, (n_images, 4, h, w), "init_latents")
+        out = np.empty((n_images, 8 * h, 8 * w, 3), dtype=np.uint8)
+        check(self._lib.sdmi_sample_image_sharded(self._m, _fp(context), context.shape[0], _fp(uncond), uncond.shape[0],
+                                                  float(unconditional_guidance_scale), int(n_steps), int(n_images),
+                                                  None if x0 is None else _fp(x0), int(seed),
+                                                  out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def broadcast_count(self) -> int:
+        return int(self._lib.sdmi_multi_broadcast_count(self._m))
 
 
 class UNet:

@@ -280,7 +280,7 @@ def test_dump_metadata_is_honoured_or_rejected(sd_tiny, synth, tiny_dims, tmp_pa
     try:
         specs = [(n, s) for n, s in sd.weight_specs() if not n.startswith("clip/") and not n.startswith("autoencoder/encoder/") and not n.startswith("autoencoder/quant_conv/")]
         shapes = dict(specs)
-        W.write_dump_tree(tmp_path, specs, lambda n, s: syn.named_tensor(synth, n, s, shapes), syn.alphas_cumprod())
+        W.write_dump_tree(tmp_path, specs, lambda n, s: syn.named_tensor(synth, n, s, shapes), syn.alphas_cumprod(), n_head=d.n_head)
         # (1) a different eps on the UNet's output norm
         np.save(tmp_path / "unet/norm_out/eps.npy", W.encode_scalar(0.5))
         sd.load_weights_dir(tmp_path)
@@ -347,3 +347,30 @@ def test_load_weights_mpk_matches_set_weight(sd_tiny, synth, tiny_dims, tmp_path
         assert "unet/conv_out/bias" in str(ei.value)
     finally:
         sd.close()
+
+
+def test_sharded_sample_image_through_the_c_abi(sd_tiny, synth, tiny_dims):
+    """sdmi_create_multi + sdmi_sample_image_sharded on the devices this box has (1 here; the same code drives 8):
+    one RCCL communicator, ONE broadcast of the packed prompt per call, images equal to the single-context path --
+    with explicit x_T and with noise keyed by the global image index (seed + i)."""
+    import torch as _t
+    from stable_diffusion_burn_amd import ModelConfig, MultiStableDiffusion
+    d = tiny_dims
+    n_dev = min(_t.cuda.device_count(), 2)
+    m = MultiStableDiffusion(ModelConfig(d.model_channels, d.n_head, d.ctx_dim, d.latent_h, d.latent_w, d.vae_ch), devices=tuple(range(n_dev)))
+    try:
+        m.load_weights(synth)
+        n = 3
+        lat = np.stack([syn.initial_latent(i, d.latent_h, d.latent_w) for i in range(n)])
+        ctx = syn.cond_context(0, 7, d.ctx_dim)
+        unc = syn.uncond_context(2, d.ctx_dim)
+        got = m.sample_image(ctx, unc, 7.5, 2, n, init_latents=lat)
+        ref = sd_tiny.sample_image(np.repeat(ctx[None], n, axis=0), unc, 7.5, 2, init_latent=lat)
+        assert np.array_equal(got, ref)
+        assert m.broadcast_count() == 1
+        got_seed = m.sample_image(ctx, unc, 7.5, 2, n, seed=11)
+        ref_seed = sd_tiny.sample_image(np.repeat(ctx[None], n, axis=0), unc, 7.5, 2, seed=11)
+        assert np.array_equal(got_seed, ref_seed)
+        assert m.broadcast_count() == 2
+    finally:
+        m.close()

@@ -102,7 +102,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("fused", [1, 0])   # split-K combined inside the launch (last-arriving slice) / by the reduce kernel
+@pytest.mark.parametrize("fused", [0, 1, 2])   # split-K combined by the reduce kernel / inside the launch (plain, write-through slabs)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d(sd_ops, case, fused):
     n, cin, h, w, cout, k, stride, ups = case
@@ -117,12 +117,12 @@ def test_conv2d(sd_ops, case, fused):
     xin = _t(x)
     if ups:
         xin = O.upsample2x(xin)
-    sd_ops.set_option("splitk_fused", 1)
+    sd_ops.set_option("splitk_fused", 0)
     ref = O.conv2d(xin, (_t(wt), _t(b)), stride=stride, padding=1 if k == 3 else 0)
     _check(got, ref.numpy(), f"conv2d{case} splitk_fused={fused}")
 
 
-@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("fused", [0, 1, 2])
 @pytest.mark.parametrize("tile", list(range(10)) + [100, 101, 102, 103])   # 100+: the 8-wave LDS-DMA kernel's tiles
 @pytest.mark.parametrize("splitk", [1, 3, 8])
 def test_conv2d_all_tiles(sd_ops, tile, splitk, fused):
@@ -138,7 +138,7 @@ def test_conv2d_all_tiles(sd_ops, tile, splitk, fused):
         sd_ops.set_option("splitk", splitk)
         got = sd_ops.op_conv2d(x, wt, b)
     finally:
-        sd_ops.set_option("splitk_fused", 1)
+        sd_ops.set_option("splitk_fused", 0)
         sd_ops.set_option("gemm_tile", "auto")
         sd_ops.set_option("splitk", 0)
     ref = O.conv2d(_t(x), (_t(wt), _t(b)), padding=1)
@@ -157,12 +157,14 @@ def test_conv2d_splitk_fused_repeatable(sd_ops):
     try:
         sd_ops.set_option("gemm_tile", 8)
         sd_ops.set_option("splitk", 24)
-        for i in range(20):
-            outs.append(sd_ops.op_conv2d(x, wt, b))
+        for mode in (1, 2):
+            sd_ops.set_option("splitk_fused", mode)
+            for i in range(10):
+                outs.append(sd_ops.op_conv2d(x, wt, b))
         sd_ops.set_option("splitk_fused", 0)
         sep = sd_ops.op_conv2d(x, wt, b)
     finally:
-        sd_ops.set_option("splitk_fused", 1)
+        sd_ops.set_option("splitk_fused", 0)
         sd_ops.set_option("gemm_tile", "auto")
         sd_ops.set_option("splitk", 0)
     for o in outs[1:]:
