@@ -23,8 +23,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
 live with HIP events on the engine's stream, `cpu_baseline` (the fp32 oracle
 timed on the host cores, rank 0, N=1 only) and -- at N=1 -- `secondary`: the same
 measurement for the reduced-precision configurations BASELINE.json names next
-to the headline (configs[2]: bf16, batch 16, 50 steps; the per-GPU shard of
-configs[3]: bf16, batch 8, 20 steps), run after the timed headline loop.
+to the headline (configs[2]: bf16, batch 16, 50 steps; the per-GPU shards of
+configs[3]: bf16, batch 8, 20 steps, and configs[4]: MXFP8 convs, batch 16, 20 steps),
+run after the timed headline loop.
 """
 from __future__ import annotations
 
@@ -38,6 +39,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+FP8_MFMA_PEAK_TFLOPS = 5000.0   # same table, "Peak FP8 MFMA" (dense; the MX-scaled K = 128 instruction)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA" (dense)
 F_UNET = 0.8033e12              # FLOP per UNet forward per sample, T = 77
@@ -53,7 +55,7 @@ def parse():
     ap.add_argument("--ddim-steps", type=int, default=20)
     ap.add_argument("--scale", type=float, default=7.5)
     ap.add_argument("--batch-per-gpu", type=int, default=1)
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "bf16", "fp8"], default="fp32",
                     help="fp32 = BASELINE.json configs[1] (the metric's configuration, default); bf16 = configs[2..3] storage/compute")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="engine option (sdmi_set_option), repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,8 +103,9 @@ class Runner:
     def __init__(self, torch, np, dev, local_rank, precision, B, ddim_steps, scale, cond, uncond, indices, flat, opts, tune_file):
         from stable_diffusion_burn_amd import ModelConfig, StableDiffusion, synthetic as syn
         self.torch, self.B, self.ddim_steps, self.scale = torch, B, ddim_steps, scale
-        self.bf16 = precision == "bf16"
-        cfg = ModelConfig(precision=1 if self.bf16 else 0)
+        self.bf16 = precision in ("bf16", "fp8")
+        self.fp8 = precision == "fp8"
+        cfg = ModelConfig(precision=2 if self.fp8 else 1 if self.bf16 else 0)
         self.cfg = cfg
         self.sd = StableDiffusion(cfg, device=local_rank)
         t0 = time.perf_counter()
@@ -146,12 +149,13 @@ class Runner:
         self.torch.cuda.synchronize()
         sd.set_option("profile", 0)
         prof = sd.profile_stats()
-        g = prof["conv_gemm"]
+        g = prof["conv_gemm_fp8"] if self.fp8 else prof["conv_gemm"]
         if g["launches"] <= 0 or g["ms"] <= 0:
             return None, prof
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
-        peak = BF16_MFMA_PEAK_TFLOPS if self.bf16 else FP32_MFMA_PEAK_TFLOPS
-        kname = ("conv_gemm_bf16x_kernel + conv_gemm_bf16_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x32_bf16)" if self.bf16 else
+        peak = FP8_MFMA_PEAK_TFLOPS if self.fp8 else BF16_MFMA_PEAK_TFLOPS if self.bf16 else FP32_MFMA_PEAK_TFLOPS
+        kname = ("conv_gemm_fp8x_kernel (implicit-GEMM 3x3 conv of the ResBlocks, v_mfma_scale_f32_16x16x128_f8f6f4, MXFP8)" if self.fp8 else
+                 "conv_gemm_bf16x_kernel + conv_gemm_bf16_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x32_bf16)" if self.bf16 else
                  "conv_gemm2_kernel + conv_gemm2x_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x4_f32)")
         traffic, source = None, None
         pmc = ROOT / "profiles" / "pmc_summary.json"
@@ -185,8 +189,10 @@ class Runner:
 
 def workload_name(precision, B, ddim_steps, scale):
     which = {("fp32", 1, 20): "BASELINE.json configs[1]", ("bf16", 16, 50): "BASELINE.json configs[2]",
-             ("bf16", 8, 20): "the per-GPU shard of BASELINE.json configs[3] (64 images over 8 GPUs)"}.get((precision, B, ddim_steps), "not a BASELINE.json configuration")
-    arith = "fp32" if precision == "fp32" else "bf16 storage / fp32 accumulate"
+             ("bf16", 8, 20): "the per-GPU shard of BASELINE.json configs[3] (64 images over 8 GPUs)",
+             ("fp8", 16, 20): "the per-GPU shard of BASELINE.json configs[4] (128 images over 8 GPUs)"}.get((precision, B, ddim_steps), "not a BASELINE.json configuration")
+    arith = {"fp32": "fp32", "bf16": "bf16 storage / fp32 accumulate",
+             "fp8": "bf16 storage / fp32 accumulate + the ResBlock 3x3 convs in MXFP8 (e4m3, E8M0 scales per 32 channels)"}[precision]
     return f"SD v1.4 512x512, {ddim_steps}-step DDIM, CFG={scale}, batch={B} per GPU, {arith} ({which})"
 
 
@@ -251,7 +257,7 @@ def main():
     roofline, prof = (None, None)
     if rank == 0 and not args.no_roofline:
         roofline, prof = run.roofline()
-    bf16 = args.precision == "bf16"
+    bf16 = args.precision in ("bf16", "fp8")
     t_load = run.t_load
     classes = run.class_summary(prof) if prof is not None else {}
     run.close()
@@ -259,18 +265,18 @@ def main():
     # ---- secondary: the reduced-precision configurations BASELINE.json names, witnessed by the same run ----------
     secondary = []
     if rank == 0 and world == 1 and not args.no_secondary and not bf16 and B == 1 and args.ddim_steps == 20:
-        for (b2, s2, k2) in ((16, 50, 2), (8, 20, 3)):
+        for (prec2, b2, s2, k2) in (("bf16", 16, 50, 2), ("bf16", 8, 20, 3), ("fp8", 16, 20, 2)):
             idx = list(range(b2))
-            r2 = Runner(torch, np, dev, local_rank, "bf16", b2, s2, args.scale, cond, uncond, idx, flat, [], None)
+            r2 = Runner(torch, np, dev, local_rank, prec2, b2, s2, args.scale, cond, uncond, idx, flat, [], None)
             e2 = r2.timed(k2, 1, barrier)
             roof2, prof2 = r2.roofline()
             fpi = 2 * s2 * F_UNET + F_VAE
             v2 = k2 * b2 / e2
-            entry = {"config": {"workload": workload_name("bf16", b2, s2, args.scale), "global_batch": b2, "ddim_steps": s2,
+            entry = {"config": {"workload": workload_name(prec2, b2, s2, args.scale), "global_batch": b2, "ddim_steps": s2,
                                 "cfg_scale": args.scale, "context_len": T_CTX},
-                     "dtype": "bf16", "value": v2, "unit": "images/sec", "steps": k2, "warmup": 1, "ms_per_step": e2 / k2 * 1e3,
+                     "dtype": "bf16" if prec2 == "bf16" else "fp8(e4m3, MX)+bf16", "value": v2, "unit": "images/sec", "steps": k2, "warmup": 1, "ms_per_step": e2 / k2 * 1e3,
                      "algorithmic_tflop_per_image": fpi / 1e12, "whole_path_tflops_per_gpu": v2 * fpi / 1e12,
-                     "whole_path_frac_of_mfma_peak": v2 * fpi / 1e12 / BF16_MFMA_PEAK_TFLOPS, "roofline": roof2,
+                     "whole_path_frac_of_bf16_mfma_peak": v2 * fpi / 1e12 / BF16_MFMA_PEAK_TFLOPS, "roofline": roof2,
                      "weights_load_s": r2.t_load}
             entry.update(r2.class_summary(prof2))
             secondary.append(entry)
@@ -289,7 +295,7 @@ def main():
             "metric": f"images/sec @512x512, {args.ddim_steps}-step DDIM CFG={args.scale:g}, SD v1.4",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "fp8(e4m3, MX)+bf16" if args.precision == "fp8" else "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": workload_name(args.precision, B, args.ddim_steps, args.scale),
                        "global_batch": B * world, "ddim_steps": args.ddim_steps, "cfg_scale": args.scale,
                        "context_len": T_CTX, "parallelism": f"image-sharded x{world}, 1 RCCL broadcast of the text embedding",

@@ -67,7 +67,7 @@ typedef struct sdmi_config {
     int32_t latent_w;        /* 64                                              */
     int32_t vae_ch;          /* 128  (decoder channels 4c,4c,2c,c)              */
     int32_t max_batch;       /* largest n a call may pass; 0 = no limit          */
-    int32_t precision;       /* 0 = fp32; 1 = bf16 storage, fp32 accumulate     */
+    int32_t precision;       /* 0 = fp32; 1 = bf16 storage, fp32 accumulate; 2 = 1 + the ResBlock 3x3 convs in MXFP8 */
     /* CLIP text encoder, CLIPConfig::new(49408, 768, 12, 77, 12) stablediffusion/mod.rs:29;
      * its width is ctx_dim.  clip_layers = 0 builds a context without it.              */
     int32_t clip_layers;     /* 12                                              */
@@ -253,6 +253,11 @@ int64_t sdmi_multi_broadcast_count(sdmi_multi* m);
 int sdmi_op_group_norm(sdmi_ctx* ctx, const float* x, const float* gamma, const float* beta,
                        int32_t n, int32_t c, int32_t h, int32_t w, int32_t n_group, float eps,
                        int32_t fuse_silu, float* out);
+/* precision = 2 only: the same GroupNorm(+SiLU) with its output quantised to MXFP8 (e4m3 elements, one E8M0 scale per 32
+ * channels) as the ResBlock convolutions consume it (unet/mod.rs:713-733); `out` is the DEQUANTISED tensor. */
+int sdmi_op_group_norm_fp8(sdmi_ctx* ctx, const float* x, const float* gamma, const float* beta,
+                           int32_t n, int32_t c, int32_t h, int32_t w, int32_t n_group, float eps,
+                           int32_t fuse_silu, float* out);
 /* Burn nn::LayerNorm (unet/mod.rs:523-525): x,out [rows,c]. */
 int sdmi_op_layer_norm(sdmi_ctx* ctx, const float* x, const float* gamma, const float* beta,
                        int32_t rows, int32_t c, float eps, float* out);
@@ -283,7 +288,7 @@ int sdmi_set_option(sdmi_ctx* ctx, const char* key, const char* value);
 int sdmi_last_call_stats(sdmi_ctx* ctx, double* gpu_ms, int64_t* n_kernels, double* flops);
 /* Per-kernel-class timing collected while option "profile" = "1": HIP events around every
  * launch on the context stream.  cls: 0 conv_gemm (implicit-GEMM conv/linear), 1 splitk_reduce,
- * 2 attention, 3 group_norm(+silu), 4 layer_norm.  flops / bytes are the ALGORITHMIC work of
+ * 2 attention, 3 group_norm(+silu), 4 layer_norm, 5 conv_gemm_fp8 (the MXFP8 convs of precision = 2).  flops / bytes are the ALGORITHMIC work of
  * those launches (2*M*N*K; one read + one write of the tensor).  "profile_reset" clears. */
 int sdmi_profile_stats(sdmi_ctx* ctx, int32_t cls, double* ms, int64_t* launches, double* flops, double* bytes);
 /* micro-benchmark one implicit-GEMM conv shape on device-resident synthetic

@@ -133,8 +133,9 @@ void Engine::prof_flush() {
 // construction / model definition
 // =============================================================================
 Engine::Engine(const sdmi_config& cfg) : cfg_(cfg) {
-    if (cfg.precision != 0 && cfg.precision != 1) throw Error(SDMI_ERR_UNSUPPORTED, "precision must be 0 (fp32) or 1 (bf16); fp8 is not built yet");
-    bf16_ = cfg.precision == 1;
+    if (cfg.precision < 0 || cfg.precision > 2) throw Error(SDMI_ERR_UNSUPPORTED, "precision must be 0 (fp32), 1 (bf16) or 2 (bf16 + MXFP8 ResBlock convolutions)");
+    bf16_ = cfg.precision >= 1;
+    fp8_ = cfg.precision == 2;
     if (bf16_ && (cfg.model_channels % 64 || cfg.vae_ch % 64 || cfg.ctx_dim % 64))
         throw Error(SDMI_ERR_UNSUPPORTED, "precision=1 (bf16) needs model_channels, vae_ch and ctx_dim to be multiples of 64");
     if (cfg.model_channels % 32 || cfg.model_channels <= 0) throw Error(SDMI_ERR_INVALID, "model_channels must be a positive multiple of 32");
@@ -253,6 +254,13 @@ void Engine::build_model() {
             add_meta(path + "/n_channel", 1, (float)c, 0.f, nullptr);
         }
     };
+    // precision = 2: these convs (fed by a GroupNorm + SiLU, Cin % 32 == 0, Cout % 8 == 0) also get an MXFP8 copy of their weight
+    auto fp8_copy = [&](ConvW& w, const std::string& weight_name) {
+        if (!fp8_ || w.cin % 32 || w.cout % 8 || !w.dt) return;
+        WeightEntry& e = entries_[entry_index_.at(weight_name)];
+        e.dst8 = &w.bt8;
+        e.dsts = &w.bs8;
+    };
     auto res = [&](ResW& r, const std::string& path, int cin, int cout, bool unet) {
         r.cin = cin; r.cout = cout; r.has_embed = unet; r.has_skip = cin != cout;
         if (unet) {  // ResBlock, unet/mod.rs:679-734; names unet/load.rs:20-25
@@ -262,12 +270,16 @@ void Engine::build_model() {
             norm(r.norm_out, path + "/norm_out", cout);
             conv(r.conv_out, path + "/conv_out", cout, cout, 3);
             if (r.has_skip) conv(r.skip, path + "/skip_connection", cin, cout, 1);
+            fp8_copy(r.conv_in, path + "/conv_in/weight");
+            fp8_copy(r.conv_out, path + "/conv_out/weight");
         } else {  // ResnetBlock, autoencoder/mod.rs:472-528; names autoencoder/load.rs:39-45
             norm(r.norm_in, path + "/norm1", cin);
             conv(r.conv_in, path + "/conv1", cin, cout, 3);
             norm(r.norm_out, path + "/norm2", cout);
             conv(r.conv_out, path + "/conv2", cout, cout, 3);
             if (r.has_skip) conv(r.skip, path + "/nin_shortcut", cin, cout, 1);
+            fp8_copy(r.conv_in, path + "/conv1/weight");
+            fp8_copy(r.conv_out, path + "/conv2/weight");
         }
     };
     auto mha = [&](MhaW& m, const std::string& path, int c, int cctx) {  // unet/mod.rs:603-653
@@ -555,6 +567,19 @@ void Engine::stage_commit(WeightEntry& e, size_t offset, int half) {
             if (!(cin % 32 == 0 || (cin < 32 && cin % 4 == 0))) throw Error(SDMI_ERR_UNSUPPORTED, "conv Cin must be a multiple of 32, or < 32 and a multiple of 4");
             err = e.wdt ? launch_pack_conv_weight_bf16(stage, *e.dst, cout, cin, k, k, stream_)
                         : launch_pack_conv_weight(stage, *e.dst, cout, cin, k, k, stream_);
+            if (err == hipSuccess && e.dst8) {
+                const size_t kp = (size_t)((cin + 127) / 128 * 128) * k * k;
+                if (!*e.dst8) {
+                    void *q = nullptr, *sc = nullptr;
+                    SDMI_HIP(hipMalloc(&q, (size_t)cout * kp));
+                    weight_allocs_.push_back(q);
+                    SDMI_HIP(hipMalloc(&sc, (size_t)cout * kp / 32));
+                    weight_allocs_.push_back(sc);
+                    *e.dst8 = reinterpret_cast<float*>(q);
+                    *e.dsts = reinterpret_cast<float*>(sc);
+                }
+                err = launch_pack_conv_weight_fp8(stage, *e.dst8, *e.dsts, cout, cin, k, k, stream_);
+            }
         } else {
             err = e.wdt ? launch_pack_linear_weight_bf16(stage, *e.dst, (int)e.dims[0], (int)e.dims[1], stream_)
                         : launch_pack_linear_weight(stage, *e.dst, (int)e.dims[0], (int)e.dims[1], stream_);
@@ -841,6 +866,9 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     if (key == "gemm_tile") opt_force_tile_ = (value == "auto") ? -1 : std::stoi(value);
     else if (key == "splitk") opt_force_splits_ = std::stoi(value);
     else if (key == "splitk_fused") opt_splitk_fused_ = std::stoi(value);
+    else if (key == "fp8_convs") opt_fp8_convs_ = std::stoi(value);
+    else if (key == "fp8_min_rows") opt_fp8_min_rows_ = std::stoi(value);
+    else if (key == "fp8_tile") opt_fp8_tile_ = (value == "auto") ? -1 : std::stoi(value);
     else if (key == "attn_bf16") opt_attn_bf16_ = std::stoi(value);
     else if (key == "gemm_bf16x") opt_gemm_bf16x_ = std::stoi(value);
     else if (key == "gemm_x32") opt_gemm_x32_ = std::stoi(value);
@@ -1179,23 +1207,116 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
 // =============================================================================
 // ResBlock::forward (unet/mod.rs:713-733) / ResnetBlock::forward (autoencoder/mod.rs:514-527)
 void Engine::res_block(const ResW& w, const Act& x, Act& y, int step) {
-    Act h1 = new_act(x.n, x.h, x.w, x.c);
-    group_norm(w.norm_in, x, h1, true);
     Act h2 = new_act(x.n, x.h, x.w, w.cout);
     const float* rowvec = nullptr;
     if (w.has_embed) rowvec = us_.temb.at(w.temb_index) + (size_t)step * w.cout;  // shared by the batch (one timestep)
-    conv(w.conv_in, h1, h2, 1, 0, rowvec, 0, nullptr);
-    release(h1);
-    Act h3 = new_act(x.n, x.h, x.w, w.cout);
-    group_norm(w.norm_out, h2, h3, true);
-    release(h2);
-    if (w.has_skip) {
-        conv(w.skip, x, y, 1, 0, nullptr, 0, nullptr);
-        conv(w.conv_out, h3, y, 1, 0, nullptr, 0, &y);
+    if (use_fp8(w.conv_in, x)) {   // precision = 2: the normalisation writes MXFP8, the conv runs on the MX-scaled matrix instruction
+        ActQ q1 = new_actq(x.n, x.h, x.w, x.c);
+        group_norm_fp8(w.norm_in, x, q1, true);
+        conv_fp8(w.conv_in, q1, h2, rowvec, nullptr);
+        release(q1);
     } else {
-        conv(w.conv_out, h3, y, 1, 0, nullptr, 0, &x);
+        Act h1 = new_act(x.n, x.h, x.w, x.c);
+        group_norm(w.norm_in, x, h1, true);
+        conv(w.conv_in, h1, h2, 1, 0, rowvec, 0, nullptr);
+        release(h1);
     }
-    release(h3);
+    if (w.has_skip) conv(w.skip, x, y, 1, 0, nullptr, 0, nullptr);
+    const Act* resid = w.has_skip ? &y : &x;
+    if (use_fp8(w.conv_out, h2)) {
+        ActQ q3 = new_actq(x.n, x.h, x.w, w.cout);
+        group_norm_fp8(w.norm_out, h2, q3, true);
+        release(h2);
+        conv_fp8(w.conv_out, q3, y, nullptr, resid);
+        release(q3);
+    } else {
+        Act h3 = new_act(x.n, x.h, x.w, w.cout);
+        group_norm(w.norm_out, h2, h3, true);
+        release(h2);
+        conv(w.conv_out, h3, y, 1, 0, nullptr, 0, resid);
+        release(h3);
+    }
+}
+
+// ---- precision = 2: MXFP8 GroupNorm output + 3x3 convolution (k_fp8.hip) ------------------------------------------------
+bool Engine::use_fp8(const ConvW& w, const Act& x) const {
+    return fp8_ && opt_fp8_convs_ && w.bt8 && x.dt == 1 && x.rows() >= opt_fp8_min_rows_;
+}
+
+ActQ Engine::new_actq(int n, int h, int w, int c) {
+    ActQ a; a.n = n; a.h = h; a.w = w; a.c = c; a.cp = (c + 127) / 128 * 128;
+    a.q = pool_.alloc((size_t)a.rows() * a.cp);
+    a.s = pool_.alloc((size_t)a.rows() * (a.cp / 32));
+    return a;
+}
+void Engine::release(ActQ& a) {
+    if (a.q) pool_.free(a.q);
+    if (a.s) pool_.free(a.s);
+    a.q = a.s = nullptr;
+}
+
+void Engine::group_norm_fp8(const NormW& w, const Act& x, ActQ& y, bool silu) {
+    const int hw = x.h * x.w;
+    if (x.dt != 1 || y.c != x.c) throw Error(SDMI_ERR_STATE, "group_norm_fp8: bf16 input of matching width expected");
+    Buf part(this, gn_partials_bytes_bf16(x.n, hw, x.c));
+    ProfScope ps(this, PC_GROUP_NORM, 0, (double)x.bytes() + (double)x.rows() * (y.cp + y.cp / 32));
+    SDMI_HIP(launch_group_norm_fp8(x.p, y.q, y.s, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_));
+    count_kernel(); count_kernel();
+}
+
+void Engine::conv_fp8(const ConvW& w, const ActQ& x, Act& y, const float* rowvec, const Act* resid) {
+    if (x.c != w.cin || w.k != 3 || !w.bt8) throw Error(SDMI_ERR_STATE, "conv_fp8: not an MXFP8-packed 3x3 convolution");
+    if (y.n != x.n || y.h != x.h || y.w != x.w || y.c != w.cout || y.dt != 1) throw Error(SDMI_ERR_INVALID, "conv_fp8: output shape / type mismatch");
+    if (resid && (resid->rows() != y.rows() || resid->c != y.c || resid->dt != 1)) throw Error(SDMI_ERR_STATE, "conv_fp8: residual shape / type mismatch");
+    ConvGemm p{};
+    p.A = reinterpret_cast<const float*>(x.q); p.Bt = w.bt8; p.C = y.p; p.bias = w.bias; p.rowvec = rowvec; p.resid = resid ? resid->p : nullptr;
+    p.a_scale = x.s; p.b_scale = w.bs8;
+    p.M = (int)x.rows(); p.N = w.cout; p.K = x.cp * 9;
+    p.NB = x.n; p.Hs = x.h; p.Ws = x.w; p.Cin = x.cp; p.Ho = x.h; p.Wo = x.w;
+    p.KH = 3; p.KW = 3; p.stride = 1; p.pad = 1; p.ups = 0;
+    p.ldc = y.stride(); p.ldr = resid ? resid->stride() : y.stride(); p.a_ld = x.cp; p.b_ld = p.K; p.rowvec_stride = 0; p.CS = 128;
+    p.out_mode = 0;
+    p.zero_page = zero_page_;
+    p.kt_total = p.K / 128;
+    if ((unsigned long long)p.M * x.cp >= 0xFFFFFFE0ull || (unsigned long long)p.N * p.K >= 0xFFFFFFE0ull) throw Error(SDMI_ERR_UNSUPPORTED, "conv_fp8: operand larger than 4 GiB");
+    // tile: the widest one that divides N without waste, else the widest; split K only when the tiles leave most of the chip idle
+    int cfg = opt_fp8_tile_;
+    if (cfg < 0) {
+        double best = 1e300;
+        for (int c = 0; c < kNumGemmTilesQ; ++c) {
+            const int bm = gemm_tile_info_q(c).bm, bn = gemm_tile_info_q(c).bn;
+            const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+            const double t = (double)((tiles + 255) / 256) * bm * bn + 0.01 * bn;   // rounds of workgroups x tile area
+            if (t < best) { best = t; cfg = c; }
+        }
+    }
+    if (cfg >= kNumGemmTilesQ) throw Error(SDMI_ERR_INVALID, "fp8_tile out of range");
+    const int bm = gemm_tile_info_q(cfg).bm, bn = gemm_tile_info_q(cfg).bn;
+    const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+    int splits = opt_force_splits_ > 0 ? opt_force_splits_ : 1;
+    if (opt_force_splits_ <= 0 && tiles < 128) splits = (int)std::min<long long>(p.kt_total / 4, (256 + tiles - 1) / tiles);
+    splits = std::max(1, std::min(splits, p.kt_total));
+    p.kt_per_split = (p.kt_total + splits - 1) / splits;
+    splits = (p.kt_total + p.kt_per_split - 1) / p.kt_per_split;
+    p.splits = splits;
+    const double flops = 2.0 * p.M * (double)p.N * w.cin * 9;   // algorithmic (unpadded) work
+    if (splits == 1) {
+        ProfScope ps(this, PC_CONV_FP8, flops);
+        SDMI_HIP(launch_conv_gemm_fp8x(p, cfg, stream_));
+        count_kernel(flops);
+    } else {
+        p.slab_stride = (long long)p.M * p.N;
+        Buf slab(this, (size_t)splits * p.slab_stride * sizeof(float));
+        p.slabs = slab.f();
+        {
+            ProfScope ps(this, PC_CONV_FP8, flops);
+            SDMI_HIP(launch_conv_gemm_fp8x(p, cfg, stream_));
+        }
+        count_kernel(flops);
+        ProfScope ps(this, PC_SPLITK_REDUCE, 0, (double)(splits + 1) * p.slab_stride * 4.0);
+        SDMI_HIP(launch_splitk_reduce_bf16(p, stream_));
+        count_kernel();
+    }
 }
 
 // SpatialTransformer::forward (unet/mod.rs:462-480) + TransformerBlock (:522-526) +
@@ -1643,6 +1764,22 @@ void Engine::op_group_norm(const float* x, const float* gamma, const float* beta
     release(a); release(b);
 }
 
+// GroupNorm(+SiLU) with MXFP8 output (precision = 2), returned dequantised: out [n,c,h,w] fp32
+void Engine::op_group_norm_fp8(const float* x, const float* gamma, const float* beta, int n, int c, int h, int w, int groups, float eps,
+                               bool silu, float* out) {
+    if (!fp8_) throw Error(SDMI_ERR_STATE, "group_norm_fp8 needs a precision = 2 context");
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0 || groups <= 0 || c % groups || c % 32) throw Error(SDMI_ERR_INVALID, "group_norm_fp8: bad shape");
+    Act a = new_act(n, h, w, c, 1);
+    SDMI_HIP(launch_nchw_f32_to_nhwc_bf16(x, a.p, n, c, h, w, 1.0f, stream_));
+    ActQ q = new_actq(n, h, w, c);
+    Buf part(this, gn_partials_bytes_bf16(n, h * w, c));
+    SDMI_HIP(launch_group_norm_fp8(a.p, q.q, q.s, gamma, beta, n, h * w, c, c, groups, eps, silu, part.p, stream_));
+    Act d = new_act(n, h, w, c, 0);
+    SDMI_HIP(launch_dequant_fp8(q.q, q.s, d.p, d.rows(), c, stream_));
+    SDMI_HIP(launch_nhwc_to_nchw(d.p, out, n, c, h, w, stream_));
+    release(a); release(q); release(d);
+}
+
 void Engine::op_layer_norm(const float* x, const float* gamma, const float* beta, int rows, int c, float eps, float* out) {
     if (rows <= 0 || c <= 0) throw Error(SDMI_ERR_INVALID, "layer_norm: bad shape");
     if (bf16_ && c % 8 == 0) {
@@ -1660,6 +1797,25 @@ void Engine::op_conv2d(const float* x, const float* wt, const float* bias, int n
     if (!(k == 1 || k == 3) || pad != (k == 3 ? 1 : 0) || !(stride == 1 || stride == 2))
         throw Error(SDMI_ERR_UNSUPPORTED, "conv2d: only 3x3 pad 1 / 1x1 pad 0, stride 1|2 are on the hot path");
     if (!(cin % 32 == 0 || (cin < 32 && cin % 4 == 0))) throw Error(SDMI_ERR_UNSUPPORTED, "conv2d: Cin must be a multiple of 32, or < 32 and a multiple of 4");
+    if (fp8_ && opt_fp8_convs_ && k == 3 && stride == 1 && !ups && cin % 32 == 0 && cout % 8 == 0) {
+        // precision = 2 mirrors the model's ResBlock convs: MXFP8 input (quantised here from the fp32 argument; the model
+        // gets it from the fused GroupNorm), MXFP8 weight, bf16 output
+        const int cp = (cin + 127) / 128 * 128;
+        ConvW w; w.cin = cin; w.cout = cout; w.k = 3; w.dt = 1; w.bias = const_cast<float*>(bias);
+        Buf bt8(this, (size_t)cout * cp * 9), bs8(this, (size_t)cout * cp * 9 / 32);
+        SDMI_HIP(launch_pack_conv_weight_fp8(wt, bt8.p, bs8.p, cout, cin, 3, 3, stream_));
+        w.bt8 = bt8.f(); w.bs8 = bs8.f();
+        Act a32 = new_act(n, h, wd, cin, 0);
+        SDMI_HIP(launch_nchw_to_nhwc(x, a32.p, n, cin, h, wd, 1.0f, stream_));
+        ActQ q = new_actq(n, h, wd, cin);
+        SDMI_HIP(launch_quantize_fp8(a32.p, q.q, q.s, a32.rows(), cin, stream_));
+        release(a32);
+        Act y = new_act(n, h, wd, cout, 1);
+        conv_fp8(w, q, y, nullptr, nullptr);
+        SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(y.p, out, n, cout, h, wd, stream_));
+        release(q); release(y);
+        return;
+    }
     ConvW w; w.cin = cin; w.cout = cout; w.k = k;
     // precision = 1 mirrors the model: Cin % 64 == 0 -> bf16 kernel, Cin < 32 -> fp32 kernel emitting bf16,
     // <= 4 output channels (eps / RGB heads) -> fp32 output

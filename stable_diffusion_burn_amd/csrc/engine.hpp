@@ -77,7 +77,14 @@ struct Act {
     size_t bytes() const { return (size_t)rows() * c * (dt ? 2 : 4); }
 };
 
-struct ConvW { float* bt = nullptr; float* bias = nullptr; int cin = 0, cout = 0, k = 1; int dt = 0; };
+// bt8 / bs8 (precision = 2 only): the same weight as MXFP8 -- e4m3 [cout][Kp] + E8M0 scales [cout][Kp / 32] (k_fp8.hip)
+struct ConvW { float* bt = nullptr; float* bias = nullptr; int cin = 0, cout = 0, k = 1; int dt = 0; float* bt8 = nullptr; float* bs8 = nullptr; };
+// an MXFP8 activation: e4m3 [n][h][w][cp] + E8M0 scales [n][h][w][cp / 32], cp = c rounded up to 128 (zero padded)
+struct ActQ {
+    void* q = nullptr; void* s = nullptr;
+    int n = 0, h = 0, w = 0, c = 0, cp = 0;
+    long long rows() const { return (long long)n * h * w; }
+};
 struct LinW { float* bt = nullptr; float* bias = nullptr; int cin = 0, cout = 0; int dt = 0; };
 struct NormW { float* gamma = nullptr; float* beta = nullptr; int c = 0; float eps = 1e-5f; };  // eps: Q3 default, overridden by the dump's eps file
 
@@ -108,6 +115,8 @@ struct WeightEntry {
     float** dst;  // where the device pointer lives (null for alphas)
     int wdt = 0;  // storage type of the packed weight: 0 fp32, 1 bf16
     int group = 0;  // 0: hot path (required); 1: CLIP text encoder, 2: VAE encoder (each optional as a whole)
+    float** dst8 = nullptr;   // precision = 2: where the MXFP8 copy of a conv weight and its scales go (null: none)
+    float** dsts = nullptr;
     bool set = false;
 };
 
@@ -149,6 +158,8 @@ public:
     // operator-level (device pointers, reference layouts)
     void op_group_norm(const float* x, const float* gamma, const float* beta, int n, int c, int h, int w, int groups,
                        float eps, bool silu, float* out);
+    void op_group_norm_fp8(const float* x, const float* gamma, const float* beta, int n, int c, int h, int w, int groups, float eps,
+                           bool silu, float* out);
     void op_layer_norm(const float* x, const float* gamma, const float* beta, int rows, int c, float eps, float* out);
     void op_conv2d(const float* x, const float* w, const float* bias, int n, int cin, int h, int wd, int cout, int k,
                    int stride, int pad, int ups, float* out);
@@ -235,6 +246,12 @@ private:
     static float* adv(const float* p, long long elems, int dt) { return (float*)((char*)const_cast<float*>(p) + elems * (dt ? 2 : 4)); }
     TileChoice choose_tile(int M, int N, int kt_total, bool allow_x = false) const;   // cfg >= 100: k_gemm2x.hip tile cfg - 100
     void group_norm(const NormW& w, const Act& x, Act& y, bool silu);
+    // precision = 2: GroupNorm(+SiLU) writing MXFP8, and the 3x3 convolution that consumes it (k_fp8.hip)
+    ActQ new_actq(int n, int h, int w, int c);
+    void release(ActQ& a);
+    void group_norm_fp8(const NormW& w, const Act& x, ActQ& y, bool silu);
+    void conv_fp8(const ConvW& w, const ActQ& x, Act& y, const float* rowvec, const Act* resid);
+    bool use_fp8(const ConvW& w, const Act& x) const;
     void layer_norm(const NormW& w, const float* x, long long rows, float* y, int dt = -1);
     // GEGLU::forward (unet/mod.rs:579-591): out[rows, hidden] = (x W + b)[:, :hidden] * gelu((x W + b)[:, hidden:]); bt is the
     // packed [2 hidden][cin] weight.  Fused into a large-tile GEMM when possible, else GEMM into `proj_scratch` + gate kernel.
@@ -263,7 +280,7 @@ private:
 public:
     // per-kernel-class timing (option "profile=1"): HIP events around every launch on the
     // engine's stream, accumulated per class.  Used by bench.py for the roofline line.
-    enum ProfClass { PC_CONV_GEMM, PC_SPLITK_REDUCE, PC_ATTENTION, PC_GROUP_NORM, PC_LAYER_NORM, PC_OTHER, PC_COUNT };
+    enum ProfClass { PC_CONV_GEMM, PC_SPLITK_REDUCE, PC_ATTENTION, PC_GROUP_NORM, PC_LAYER_NORM, PC_CONV_FP8, PC_OTHER, PC_COUNT };
     struct ProfStat { double ms = 0; long long launches = 0; double flops = 0; double bytes = 0; };
     ProfStat prof_[PC_COUNT];
     void prof_flush();
@@ -282,7 +299,11 @@ private:
     std::vector<ProfPending> prof_pending_;
 
     sdmi_config cfg_;
-    bool bf16_ = false;  // precision = 1: bf16 activations / weights, fp32 accumulate
+    bool bf16_ = false;  // precision >= 1: bf16 activations / weights, fp32 accumulate
+    bool fp8_ = false;   // precision = 2: additionally the ResBlock / ResnetBlock 3x3 convs in MXFP8 (k_fp8.hip)
+    int opt_fp8_convs_ = 1;          // 0: run the fp8-capable convs on the bf16 kernels (A/B, accuracy comparison)
+    int opt_fp8_min_rows_ = 1024;    // GEMMs with fewer output rows stay bf16 (256-row tiles need rows to fill the chip)
+    int opt_fp8_tile_ = -1;
     hipStream_t stream_ = nullptr;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev_user_ = nullptr;
     hipStream_t user_stream_ = nullptr;

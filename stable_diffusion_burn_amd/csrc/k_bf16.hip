@@ -165,17 +165,23 @@ __global__ void gn_apply_bf16_kernel(const unsigned short* __restrict__ x, unsig
     }
 }
 
-hipError_t launch_group_norm_bf16(const void* x, void* y, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
-                                  int n_group, float eps, bool silu, void* partials, hipStream_t stream) {
+hipError_t launch_group_norm_bf16_stats(const void* x, int n, int hw, int c, int ldx, int n_group, void* partials, hipStream_t stream) {
     if ((c & 7) || (ldx & 7) || ldx < c || n_group > 64 || c % n_group || c / 8 > 1024) return hipErrorInvalidValue;
     const GnGeomH g = gn_geom_h(hw, c);
-    double* part = reinterpret_cast<double*>(partials);
     const size_t lds = (size_t)(2 * g.R + 1) * c * sizeof(float) + (size_t)2 * c * sizeof(double);
+    hipLaunchKernelGGL(gn_stats_bf16_kernel, dim3(g.chunks, n), dim3(g.threads), lds, stream, reinterpret_cast<const unsigned short*>(x), hw, c,
+                       ldx, n_group, g.rows_per_chunk, reinterpret_cast<double*>(partials));
+    return hipGetLastError();
+}
+
+hipError_t launch_group_norm_bf16(const void* x, void* y, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
+                                  int n_group, float eps, bool silu, void* partials, hipStream_t stream) {
+    hipError_t e = launch_group_norm_bf16_stats(x, n, hw, c, ldx, n_group, partials, stream);
+    if (e != hipSuccess) return e;
+    const GnGeomH g = gn_geom_h(hw, c);
+    double* part = reinterpret_cast<double*>(partials);
     auto xs = reinterpret_cast<const unsigned short*>(x);
     auto ys = reinterpret_cast<unsigned short*>(y);
-    hipLaunchKernelGGL(gn_stats_bf16_kernel, dim3(g.chunks, n), dim3(g.threads), lds, stream, xs, hw, c, ldx, n_group, g.rows_per_chunk, part);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
     if (silu)
         hipLaunchKernelGGL(gn_apply_bf16_kernel<true>, dim3(g.chunks, n), dim3(g.threads), 0, stream, xs, ys, gamma, beta, hw, c, ldx, n_group,
                            eps, g.chunks, g.rows_per_chunk, part, g.rows_per_chunk);

@@ -43,6 +43,8 @@ struct ConvGemm {
     unsigned a_bytes, b_bytes;  // extents of A / Bt for the buffer-load range check (v2 kernel)
     int out_mode;               // 0: output in the kernel's storage type; 1: force fp32 (bf16 kernel); 2: bf16 from the fp32 kernel
     const void* zero_page;      // >= 16 readable zero bytes (large-tile kernels: source of padded / out-of-range lanes)
+    const void* a_scale;        // fp8 kernel: E8M0 scales of A, [pixels][a_ld / 32] bytes (a_ld = padded channel count = bytes per pixel)
+    const void* b_scale;        // fp8 kernel: E8M0 scales of Bt, [N][b_ld / 32] bytes
     int geglu;                  // large-tile kernels: Bt holds 2 N rows (N value rows, then N gate rows; bias likewise) and the
                                 // epilogue writes value * gelu_erf(gate) -- GEGLU::forward (unet/mod.rs:579-591) without the [M, 2N] tensor
 };
@@ -62,6 +64,17 @@ const GemmTileInfo& gemm_tile_info_x(int cfg);
 hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 // the same structure for fp32 storage (k_gemm2x.hip; Cin % 32 == 0, fp32 output); same tile list
 hipError_t launch_conv_gemm2x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
+// MXFP8 (e4m3 + E8M0 block scales) 256-row LDS-DMA kernel on v_mfma_scale_f32_16x16x128_f8f6f4 (k_fp8.hip); its own tile list
+constexpr int kNumGemmTilesQ = 3;
+const GemmTileInfo& gemm_tile_info_q(int cfg);
+hipError_t launch_conv_gemm_fp8x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
+// fp32 OIHW -> e4m3 [Cout][Kp] + scales [Cout][Kp / 32], Kp = roundup(Cin, 128) * kh * kw, k = (slice * T + tap) * 128 + ci
+hipError_t launch_pack_conv_weight_fp8(const float* w_oihw, void* bt8, void* bs, int cout, int cin, int kh, int kw, hipStream_t s);
+// GroupNorm(+SiLU) of a bf16 tensor with MXFP8 output: y8 [n][hw][Cp] e4m3, y_scale [n][hw][Cp / 32], Cp = roundup(c, 128)
+hipError_t launch_group_norm_fp8(const void* x, void* y8, void* y_scale, const float* gamma, const float* beta, int n, int hw, int c,
+                                 int ldx, int n_group, float eps, bool silu, void* partials, hipStream_t stream);
+hipError_t launch_quantize_fp8(const float* x, void* q, void* s, long long rows, int c, hipStream_t stream);   // fp32 [rows][c] -> MXFP8
+hipError_t launch_dequant_fp8(const void* q, const void* s, float* out, long long rows, int c, hipStream_t stream);
 hipError_t launch_pack_conv_weight_bf16(const float* w_oihw, void* bt, int cout, int cin, int kh, int kw, hipStream_t s);
 hipError_t launch_pack_linear_weight_bf16(const float* w_in_out, void* bt, int cin, int cout, hipStream_t s);
 // sums split-K slabs in fixed order and applies the epilogue (the fallback when p.counters == null)
@@ -132,6 +145,8 @@ hipError_t launch_fill_normal(float* dst, long long n, uint64_t seed, hipStream_
 size_t gn_partials_bytes_bf16(int n, int hw, int c);
 hipError_t launch_group_norm_bf16(const void* x, void* y, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
                                   int n_group, float eps, bool silu, void* partials, hipStream_t stream);
+// the statistics half of launch_group_norm_bf16 alone (shared with the fp8-output apply of k_fp8.hip)
+hipError_t launch_group_norm_bf16_stats(const void* x, int n, int hw, int c, int ldx, int n_group, void* partials, hipStream_t stream);
 hipError_t launch_layer_norm_bf16(const void* x, void* y, const float* gamma, const float* beta, int rows, int c, float eps,
                                   hipStream_t stream);
 hipError_t launch_geglu_bf16(const void* proj, void* out, long long rows, int hidden, hipStream_t s);

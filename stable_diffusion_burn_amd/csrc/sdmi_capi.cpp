@@ -91,7 +91,7 @@ int sdmi_default_config(sdmi_config* cfg) {
     return SDMI_OK;
 }
 
-const char* sdmi_version(void) { return "sdmi 0.2 gfx950 fp32+bf16 (MI355X-native SD v1.4: CLIP, UNet DDIM/CFG loop, VAE)"; }
+const char* sdmi_version(void) { return "sdmi 0.3 gfx950 fp32+bf16+mxfp8 (MI355X-native SD v1.4: CLIP, UNet DDIM/CFG loop, VAE; multi-GPU sharding)"; }
 
 const char* sdmi_last_error(void) { return g_last_error.c_str(); }
 
@@ -409,6 +409,21 @@ int sdmi_op_group_norm(sdmi_ctx* ctx, const float* x, const float* gamma, const 
         DevIn dx(e, x, bytes), dg(e, gamma, c * sizeof(float)), db(e, beta, c * sizeof(float));
         DevOut dout(e, out, bytes);
         e.op_group_norm(dx.f(), dg.f(), db.f(), n, c, h, w, n_group, eps, fuse_silu != 0, dout.f());
+        call.finish();
+        dout.fetch();
+    });
+}
+
+int sdmi_op_group_norm_fp8(sdmi_ctx* ctx, const float* x, const float* gamma, const float* beta, int32_t n, int32_t c, int32_t h,
+                           int32_t w, int32_t n_group, float eps, int32_t fuse_silu, float* out) {
+    return guarded([&] {
+        Engine& e = eng(ctx);
+        if (n <= 0 || c <= 0 || h <= 0 || w <= 0) throw Error(SDMI_ERR_INVALID, "group_norm_fp8: bad shape");
+        const size_t bytes = (size_t)n * c * h * w * sizeof(float);
+        Engine::Call call(e);
+        DevIn dx(e, x, bytes), dg(e, gamma, c * sizeof(float)), db(e, beta, c * sizeof(float));
+        DevOut dout(e, out, bytes);
+        e.op_group_norm_fp8(dx.f(), dg.f(), db.f(), n, c, h, w, n_group, eps, fuse_silu != 0, dout.f());
         call.finish();
         dout.fetch();
     });

@@ -53,7 +53,7 @@ class ModelConfig:
     latent_h: int = 64
     latent_w: int = 64
     vae_ch: int = 128
-    precision: int = 0   # 0 = fp32 (BASELINE configs[0..1]); 1 = bf16 storage + fp32 accumulate (configs[2..3])
+    precision: int = 0   # 0 = fp32 (BASELINE configs[0..1]); 1 = bf16 storage + fp32 accumulate (configs[2..3]); 2 = 1 + MXFP8 ResBlock convs (configs[4])
     # CLIP text encoder, CLIPConfig::new(49408, 768, 12, 77, 12) (stablediffusion/mod.rs:29); width = ctx_dim.
     # 0 layers (the default here: the sampling path takes embeddings) builds the context without it.
     clip_layers: int = 0
@@ -313,7 +313,7 @@ class StableDiffusion:
         check(self._lib.sdmi_last_call_stats(self._ctx, C.byref(ms), C.byref(nk), C.byref(fl)))
         return {"gpu_ms": ms.value, "kernels": nk.value, "flops": fl.value}
 
-    PROFILE_CLASSES = ("conv_gemm", "splitk_reduce", "attention", "group_norm", "layer_norm")
+    PROFILE_CLASSES = ("conv_gemm", "splitk_reduce", "attention", "group_norm", "layer_norm", "conv_gemm_fp8")
 
     def profile_stats(self) -> dict:
         """Per-kernel-class HIP-event timings gathered while set_option("profile", 1)."""
@@ -342,6 +342,15 @@ class StableDiffusion:
         out = np.empty_like(x)
         check(self._lib.sdmi_op_group_norm(self._ctx, _fp(x), _fp(_f32(gamma, (c,))), _fp(_f32(beta, (c,))), n, c, h, w,
                                            n_group, eps, int(silu), _fp(out)))
+        return out
+
+    def op_group_norm_fp8(self, x, gamma, beta, n_group=32, eps=1e-5, silu=False):
+        """GroupNorm(+SiLU) with MXFP8 output (precision = 2), returned dequantised."""
+        x = _f32(x)
+        n, c, h, w = x.shape
+        out = np.empty_like(x)
+        check(self._lib.sdmi_op_group_norm_fp8(self._ctx, _fp(x), _fp(_f32(gamma, (c,))), _fp(_f32(beta, (c,))), n, c, h, w,
+                                               n_group, eps, int(silu), _fp(out)))
         return out
 
     def op_layer_norm(self, x, gamma, beta, eps=1e-5):
