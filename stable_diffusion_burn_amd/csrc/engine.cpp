@@ -3,6 +3,8 @@
 #include "engine.hpp"
 #include "mpk_reader.hpp"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -128,6 +130,36 @@ void Engine::prof_flush() {
     }
     prof_pending_.clear();
 }
+
+// =============================================================================
+// roctx ranges
+// =============================================================================
+namespace {
+struct Roctx {
+    void* lib = nullptr;
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    bool tried = false;
+} g_roctx;
+}  // namespace
+
+void Engine::roctx_enable(bool on) {
+    if (on && !g_roctx.tried) {
+        g_roctx.tried = true;
+        for (const char* name : {"libroctx64.so.4", "libroctx64.so", "librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/libroctx64.so"}) {
+            g_roctx.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (g_roctx.lib) break;
+        }
+        if (g_roctx.lib) {
+            g_roctx.push = reinterpret_cast<int (*)(const char*)>(dlsym(g_roctx.lib, "roctxRangePushA"));
+            g_roctx.pop = reinterpret_cast<int (*)()>(dlsym(g_roctx.lib, "roctxRangePop"));
+        }
+    }
+    if (on && (!g_roctx.push || !g_roctx.pop)) throw Error(SDMI_ERR_UNSUPPORTED, "roctx: libroctx64 (roctxRangePushA / roctxRangePop) not found");
+    roctx_on_ = on;
+}
+void Engine::roctx_push(const char* name) { if (g_roctx.push) (void)g_roctx.push(name); }
+void Engine::roctx_pop() { if (g_roctx.pop) (void)g_roctx.pop(); }
 
 // =============================================================================
 // construction / model definition
@@ -866,6 +898,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     if (key == "gemm_tile") opt_force_tile_ = (value == "auto") ? -1 : std::stoi(value);
     else if (key == "splitk") opt_force_splits_ = std::stoi(value);
     else if (key == "splitk_fused") opt_splitk_fused_ = std::stoi(value);
+    else if (key == "roctx") roctx_enable(std::stoi(value) != 0);
     else if (key == "fp8_convs") opt_fp8_convs_ = std::stoi(value);
     else if (key == "fp8_min_rows") opt_fp8_min_rows_ = std::stoi(value);
     else if (key == "fp8_tile") opt_fp8_tile_ = (value == "auto") ? -1 : std::stoi(value);
@@ -1207,6 +1240,7 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
 // =============================================================================
 // ResBlock::forward (unet/mod.rs:713-733) / ResnetBlock::forward (autoencoder/mod.rs:514-527)
 void Engine::res_block(const ResW& w, const Act& x, Act& y, int step) {
+    Range rng(this, "ResBlock");
     Act h2 = new_act(x.n, x.h, x.w, w.cout);
     const float* rowvec = nullptr;
     if (w.has_embed) rowvec = us_.temb.at(w.temb_index) + (size_t)step * w.cout;  // shared by the batch (one timestep)
@@ -1323,6 +1357,7 @@ void Engine::conv_fp8(const ConvW& w, const ActQ& x, Act& y, const float* rowvec
 // MultiHeadAttention (:642-652) + MLP/GEGLU (:552-591).  NHWC makes the reference's
 // two NCHW<->token transposes disappear.
 void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
+    Range rng(this, "SpatialTransformer");
     const int C = w.c, nb = x.n, hw = x.h * x.w;
     const long long M = x.rows();
     const int heads = cfg_.n_head, d = C / heads;
@@ -1365,6 +1400,7 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
 
 // ConvSelfAttentionBlock::forward (autoencoder/mod.rs:563-607)
 void Engine::vae_attn(const VaeAttnW& w, const Act& x, Act& y) {
+    Range rng(this, "ConvSelfAttentionBlock");
     const int C = w.c, hw = x.h * x.w;
     Act g = new_act(x.n, x.h, x.w, C);
     group_norm(w.norm, x, g, false);
@@ -1446,6 +1482,7 @@ void Engine::unet_prepare(const float* ctx_packed, int nb, int t_max, const int*
 // 11 - i writes its result straight into the skip slice (the GEMM epilogue's row stride), output block i - 1 (or
 // the middle block) writes the x slice, and output block i reads the whole buffer.
 void Engine::unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc) {
+    Range rng(this, "UNet::forward step " + std::to_string(step));
     const int H = cfg_.latent_h, W = cfg_.latent_w;
     Act x; x.p = const_cast<float*>(x_nhwc); x.n = nb; x.h = H; x.w = W; x.c = 4; x.dt = 0;  // latents stay fp32
 
@@ -1476,6 +1513,7 @@ void Engine::unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc) {
     std::vector<Act> cats(nblk);
     for (int j = 0; j < nblk; ++j) {
         const UBlock& b = in_blocks_[j];
+        Range rb(this, "input_block " + std::to_string(j));
         const int i = nblk - 1 - j;   // the output block that pops this skip (saved_inputs is a stack, unet/mod.rs:126,134)
         const int ctot = out_blocks_[i].cin, cskip = b.cout, cx = ctot - cskip;
         if (cx <= 0) throw Error(SDMI_ERR_STATE, "unet: block table inconsistent");
@@ -1495,6 +1533,7 @@ void Engine::unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc) {
     Act last{};
     for (int i = 0; i < nblk; ++i) {
         const UBlock& b = out_blocks_[i];
+        Range rb(this, "output_block " + std::to_string(i));
         const bool up = b.kind == BK_RES_UP || b.kind == BK_RES_ST_UP;
         Act y;
         if (i + 1 < nblk) {
@@ -1612,6 +1651,7 @@ void Engine::sample_latent_dev(const float* context, int n, int T, const float* 
 
 // Autoencoder::decode_latent (autoencoder/mod.rs:68-71) -> Decoder::forward (:205-217)
 void Engine::decode_one(const float* z_nhwc, int n, Act& img) {
+    Range rng(this, "Decoder::forward");
     const int H = cfg_.latent_h, W = cfg_.latent_w, vc = cfg_.vae_ch;
     Act z; z.p = const_cast<float*>(z_nhwc); z.n = n; z.h = H; z.w = W; z.c = 4; z.dt = 0;
     Act pq = new_act(n, H, W, 4, /*dt=*/0);  // the two Cin = 4 layers run on the fp32 kernel in both precisions
@@ -1890,6 +1930,37 @@ double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int str
     const int pad = k == 3 ? 1 : 0;
     const int hin = h << ups, win = w << ups;
     const int ho = (hin + 2 * pad - k) / stride + 1, wo = (win + 2 * pad - k) / stride + 1;
+    if (fp8_ && opt_fp8_convs_ && k == 3 && stride == 1 && !ups && cin % 32 == 0 && cout % 8 == 0) {
+        // precision = 2: time the MXFP8 kernel on a pre-quantised activation (what the fused GroupNorm hands it)
+        const int cp = (cin + 127) / 128 * 128;
+        Act x32 = new_act(n, h, w, cin, 0), y = new_act(n, h, w, cout, 1);
+        Buf w32(this, (size_t)cout * cin * 9 * 4), bt8(this, (size_t)cout * cp * 9), bs8(this, (size_t)cout * cp * 9 / 32), bias(this, (size_t)cout * 4);
+        SDMI_HIP(launch_fill_normal(x32.p, (long long)x32.rows() * cin, 11, stream_));
+        SDMI_HIP(launch_fill_normal(w32.f(), (long long)cout * cin * 9, 12, stream_));
+        SDMI_HIP(launch_fill_normal(bias.f(), cout, 13, stream_));
+        ActQ q = new_actq(n, h, w, cin);
+        SDMI_HIP(launch_quantize_fp8(x32.p, q.q, q.s, x32.rows(), cin, stream_));
+        SDMI_HIP(launch_pack_conv_weight_fp8(w32.f(), bt8.p, bs8.p, cout, cin, 3, 3, stream_));
+        ConvW cw; cw.cin = cin; cw.cout = cout; cw.k = 3; cw.dt = 1; cw.bias = bias.f(); cw.bt8 = bt8.f(); cw.bs8 = bs8.f();
+        const int save_t = opt_fp8_tile_, save_s = opt_force_splits_;
+        opt_fp8_tile_ = tile_cfg; opt_force_splits_ = splitk;
+        float ms = 0;
+        try {
+            conv_fp8(cw, q, y, nullptr, nullptr);
+            SDMI_HIP(hipEventRecord(ev0_, stream_));
+            for (int i = 0; i < iters; ++i) conv_fp8(cw, q, y, nullptr, nullptr);
+            SDMI_HIP(hipEventRecord(ev1_, stream_));
+            SDMI_HIP(hipEventSynchronize(ev1_));
+            SDMI_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
+        } catch (...) {
+            opt_fp8_tile_ = save_t; opt_force_splits_ = save_s;
+            release(x32); release(y); release(q);
+            throw;
+        }
+        opt_fp8_tile_ = save_t; opt_force_splits_ = save_s;
+        release(x32); release(y); release(q);
+        return (double)ms / std::max(1, iters);
+    }
     const int wdt = (bf16_ && cin % 64 == 0) ? 1 : 0;
     Act a = new_act(n, h, w, cin, wdt), y = new_act(n, ho, wo, cout, (bf16_ && cout > 4) ? 1 : 0);
     Buf bt(this, (size_t)cout * cin * k * k * 4), bias(this, (size_t)cout * 4);

@@ -19,14 +19,10 @@
 #include <vector>
 
 #include "../../include/sdmi.h"
+#include "error.hpp"
 #include "kernels.hpp"
 
 namespace sdmi {
-
-struct Error : std::runtime_error {
-    int status;
-    Error(int st, const std::string& m) : std::runtime_error(m), status(st) {}
-};
 
 #define SDMI_HIP(expr)                                                                                   \
     do {                                                                                                 \
@@ -272,6 +268,20 @@ private:
     void decode_one(const float* z_nhwc, int n, Act& img);
 
     void count_kernel(double flops = 0) { ++n_kernels_; flops_ += flops; }
+    // roctx ranges (option "roctx=1"; rocprofv3 --marker-trace shows them): one per DDIM step, UNet block, ResBlock,
+    // SpatialTransformer and VAE stage.  libroctx64 is opened lazily, like RCCL.
+    struct Range {
+        Engine* e;
+        Range(Engine* e_, const char* name) : e(e_->roctx_on_ ? e_ : nullptr) { if (e) e->roctx_push(name); }
+        Range(Engine* e_, const std::string& name) : Range(e_, name.c_str()) {}
+        ~Range() { if (e) e->roctx_pop(); }
+        Range(const Range&) = delete;
+        Range& operator=(const Range&) = delete;
+    };
+    bool roctx_on_ = false;
+    void roctx_enable(bool on);
+    void roctx_push(const char* name);
+    void roctx_pop();
     void check_batch(int n) const {
         if (cfg_.max_batch > 0 && n > cfg_.max_batch)
             throw Error(SDMI_ERR_INVALID, "batch of " + std::to_string(n) + " exceeds sdmi_config.max_batch = " + std::to_string(cfg_.max_batch));

@@ -102,16 +102,18 @@ __global__ void gn_stats_bf16_kernel(const unsigned short* __restrict__ x, int h
     }
     __syncthreads();
     const double n_rows = (double)(row_end - row_begin);
+    const double inv_rows = 1.0 / n_rows;   // one fp64 division per thread: the per-channel / per-group ones below are multiplies
     for (int ch = tid; ch < C; ch += blockDim.x) {
         double ds = 0.0, dq = 0.0;
         for (int r = 0; r < R; ++r) { ds += (double)shs[r * C + ch]; dq += (double)shq[r * C + ch]; }
-        const double m2 = dq - ds * ds / n_rows;
-        chm[ch] = (double)shp[ch] + ds / n_rows;
+        const double m2 = dq - ds * ds * inv_rows;
+        chm[ch] = (double)shp[ch] + ds * inv_rows;
         chq[ch] = m2 > 0.0 ? m2 : 0.0;
     }
     __syncthreads();
     for (int gi = tid; gi < G; gi += blockDim.x) {
         const int cpg = C / G;
+        const double inv_cpg = 1.0 / cpg;
         const double ref = chm[gi * cpg];
         double a = 0.0, b = 0.0, m2 = 0.0;
         for (int ch = gi * cpg; ch < (gi + 1) * cpg; ++ch) {
@@ -119,8 +121,8 @@ __global__ void gn_stats_bf16_kernel(const unsigned short* __restrict__ x, int h
             a += d; b += d * d; m2 += chq[ch];
         }
         double* o = part + ((long long)(smp * chunks + chunk) * G + gi) * 2;
-        o[0] = ref + a / cpg;
-        o[1] = m2 + n_rows * (b - a * a / cpg);
+        o[0] = ref + a * inv_cpg;
+        o[1] = m2 + n_rows * (b - a * a * inv_cpg);
     }
 }
 

@@ -34,9 +34,9 @@ __device__ __forceinline__ void gn_finalize(const double* __restrict__ part, int
     for (int gi = tid; gi < G; gi += blockDim.x) {
         double a = 0.0, b = 0.0, m2 = 0.0;
         for (int j = 0; j < 8; ++j) { a += s_red[0][gi][j]; b += s_red[1][gi][j]; m2 += s_red[2][gi][j]; }
-        const double cnt = (double)hw * cpg;
-        const double mean = part[((long long)smp * stat_chunks * G + gi) * 2] + a / cnt;
-        double var = (m2 + b - a * a / cnt) / cnt;
+        const double inv_cnt = 1.0 / ((double)hw * cpg);
+        const double mean = part[((long long)smp * stat_chunks * G + gi) * 2] + a * inv_cnt;
+        double var = (m2 + b - a * a * inv_cnt) * inv_cnt;
         if (var < 0.0) var = 0.0;
         const float hi = (float)mean;
         s_mean_hi[gi] = hi;

@@ -61,6 +61,53 @@ __device__ __forceinline__ unsigned cvt4_e4m3(float a, float b, float c, float d
 // =====================================================================================================================
 // GEMM
 // =====================================================================================================================
+// One k tile of a wave: output column fragments [NB0, NB0 + CNT) of its tile against all MI row fragments.
+// Register budget (256 per wave at two waves per SIMD): 4 MI NI accumulators + 8 per resident fragment.  With NI = 5 all
+// five weight fragments + a double-buffered activation fragment do not fit next to 160 accumulators (the compiler then
+// single-buffers and every 5 MFMAs wait for an LDS round trip: measured 27 % of the fp8 rate), so a 320-wide wave tile is
+// walked in two column halves (3 + 2 fragments resident), re-reading the activation fragments once more -- LDS has the
+// headroom (42 instead of 26 reads per 40 MFMAs).
+template <int MI, int NI, int NB0, int CNT>
+__device__ __forceinline__ void mx_columns(const unsigned char* stage, f32x4 (&acc)[MI][NI], int a_base, int b_base, int as_base, int bs_base,
+                                           int fr_off0, int fr_off1) {
+    auto frag = [&](int base, int row16) -> i32x8 {
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(stage + base + row16 * 2048 + fr_off0);
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(stage + base + row16 * 2048 + fr_off1);
+        i32x8 f;
+        f[0] = (int)lo[0]; f[1] = (int)lo[1]; f[2] = (int)lo[2]; f[3] = (int)lo[3];
+        f[4] = (int)hi[0]; f[5] = (int)hi[1]; f[6] = (int)hi[2]; f[7] = (int)hi[3];
+        return f;
+    };
+    i32x8 fb[CNT];
+    int sb[CNT];
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) {
+        fb[j] = frag(b_base, NB0 + j);
+        sb[j] = (int)stage[bs_base + (NB0 + j) * 64];
+    }
+    i32x8 fa[2];
+    int sa[2];
+    fa[0] = frag(a_base, 0);
+    sa[0] = (int)stage[as_base];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        if (mi + 1 < MI) {   // the next row group's fragment is requested before this group's MFMAs issue
+            fa[(mi + 1) & 1] = frag(a_base, mi + 1);
+            sa[(mi + 1) & 1] = (int)stage[as_base + (mi + 1) * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < CNT; ++j)
+            acc[mi][NB0 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa[mi & 1], acc[mi][NB0 + j], 0, 0, 0, sb[j], 0, sa[mi & 1]);
+    }
+    // pin the issue order spelled out above (3 DS reads per fragment: two b128 + the scale byte)
+    __builtin_amdgcn_sched_group_barrier(0x100, 3 * CNT + 3, 0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        if (mi + 1 < MI) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, CNT, 0);
+    }
+}
+
 template <int MI, int NI, int WM, int WN>
 __global__ __launch_bounds__(512) void conv_gemm_fp8x_kernel(const ConvGemm p) {
     constexpr int BM = 16 * MI * WM;
@@ -220,44 +267,16 @@ __global__ __launch_bounds__(512) void conv_gemm_fp8x_kernel(const ConvGemm p) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto frag = [&](const unsigned char* stage, int base, int row16) -> i32x8 {
-        const u32x4 lo = *reinterpret_cast<const u32x4*>(stage + base + row16 * 2048 + fr_off0);
-        const u32x4 hi = *reinterpret_cast<const u32x4*>(stage + base + row16 * 2048 + fr_off1);
-        i32x8 f;
-        f[0] = (int)lo[0]; f[1] = (int)lo[1]; f[2] = (int)lo[2]; f[3] = (int)lo[3];
-        f[4] = (int)hi[0]; f[5] = (int)hi[1]; f[6] = (int)hi[2]; f[7] = (int)hi[3];
-        return f;
-    };
-
     issue(0);
     for (int t = 0; t < n_t; ++t) {
         const int cur = t & 1;
         __syncthreads();                    // k tile t (operands and scales) is in LDS; every wave is done with stage cur ^ 1
         if (t + 1 < n_t) issue(cur ^ 1);
         const unsigned char* stage = smem_q + cur * STAGE;
-        i32x8 fb[NI];
-        int sb[NI];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            fb[ni] = frag(stage, b_base, ni);
-            sb[ni] = (int)stage[bs_base + ni * 64];
-        }
-        i32x8 fa = frag(stage, a_base, 0);
-        int sa = (int)stage[as_base];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            i32x8 fa_next = fa;
-            int sa_next = sa;
-            if (mi + 1 < MI) {   // one row group ahead of the MFMAs that use it
-                fa_next = frag(stage, a_base, mi + 1);
-                sa_next = (int)stage[as_base + (mi + 1) * 64];
-            }
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[ni], fa, acc[mi][ni], 0, 0, 0, sb[ni], 0, sa);
-            fa = fa_next;
-            sa = sa_next;
-        }
+        constexpr int NH = (NI > 4) ? 2 : 1;
+        constexpr int NI0 = (NI + NH - 1) / NH;
+        mx_columns<MI, NI, 0, NI0>(stage, acc, a_base, b_base, as_base, bs_base, fr_off0, fr_off1);
+        if constexpr (NH == 2) mx_columns<MI, NI, NI0, NI - NI0>(stage, acc, a_base, b_base, as_base, bs_base, fr_off0, fr_off1);
     }
 
     // ---- epilogue: fp32 bias + time-embedding row + (bf16) residual -> bf16 (or fp32 slab / fp32 output) -----------------

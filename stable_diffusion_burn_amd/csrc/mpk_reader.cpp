@@ -9,7 +9,7 @@
 
 #include <cstring>
 
-#include "engine.hpp"
+#include "error.hpp"
 
 namespace sdmi {
 
@@ -117,6 +117,7 @@ struct MpkParser {
 
     std::vector<Entry> entries(Cur& c, uint64_t n) {
         std::vector<Entry> es;
+        if (n > (uint64_t)(c.end - c.p)) bad(c, "map longer than the file");   // every entry takes at least two bytes
         es.reserve((size_t)n);
         for (uint64_t i = 0; i < n; ++i) {
             Cur k = c;

@@ -6,7 +6,7 @@
 #include <string>
 #include <vector>
 
-#include "engine.hpp"   // sdmi::Error, status codes
+#include "error.hpp"   // sdmi::Error, status codes
 
 namespace sdmi {
 

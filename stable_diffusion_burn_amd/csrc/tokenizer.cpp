@@ -7,7 +7,7 @@
 #include <fstream>
 #include <sstream>
 
-#include "engine.hpp"   // sdmi::Error, status codes
+#include "error.hpp"   // sdmi::Error, status codes
 
 namespace sdmi {
 
