@@ -1313,22 +1313,32 @@ void Engine::conv_fp8(const ConvW& w, const ActQ& x, Act& y, const float* rowvec
     p.zero_page = zero_page_;
     p.kt_total = p.K / 128;
     if ((unsigned long long)p.M * x.cp >= 0xFFFFFFE0ull || (unsigned long long)p.N * p.K >= 0xFFFFFFE0ull) throw Error(SDMI_ERR_UNSUPPORTED, "conv_fp8: operand larger than 4 GiB");
-    // tile: the widest one that divides N without waste, else the widest; split K only when the tiles leave most of the chip idle
-    int cfg = opt_fp8_tile_;
+    // tile + split-K: rounds of workgroups on 256 CUs x the time of one tile at the rate each tile shape sustains when the
+    // chip is full (tools/bench_gemm_fp8.py on MI355X: 256x320 2.4, 256x256 2.1, 256x128 1.7 PFLOP/s); K is split only when
+    // the tiles would leave more than half of the chip idle
+    static const double kRate[kNumGemmTilesQ] = {2400.0, 2100.0, 1700.0};
+    int cfg = opt_fp8_tile_, splits = 1;
+    auto plan = [&](int c, int* sp) {
+        const int bm = gemm_tile_info_q(c).bm, bn = gemm_tile_info_q(c).bn;
+        const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+        int s_ = 1;
+        if (tiles < 128) s_ = (int)std::max<long long>(1, std::min<long long>(p.kt_total / 4, (256 + tiles - 1) / tiles));
+        *sp = s_;
+        const double rounds = (double)((tiles * s_ + 255) / 256);
+        return rounds * (double)bm * bn / kRate[c] / s_ + (s_ > 1 ? 0.15 * (double)bm * bn / kRate[c] : 0.0);
+    };
     if (cfg < 0) {
         double best = 1e300;
         for (int c = 0; c < kNumGemmTilesQ; ++c) {
-            const int bm = gemm_tile_info_q(c).bm, bn = gemm_tile_info_q(c).bn;
-            const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-            const double t = (double)((tiles + 255) / 256) * bm * bn + 0.01 * bn;   // rounds of workgroups x tile area
-            if (t < best) { best = t; cfg = c; }
+            int sp;
+            const double t = plan(c, &sp);
+            if (t < best) { best = t; cfg = c; splits = sp; }
         }
+    } else {
+        if (cfg >= kNumGemmTilesQ) throw Error(SDMI_ERR_INVALID, "fp8_tile out of range");
+        (void)plan(cfg, &splits);
     }
-    if (cfg >= kNumGemmTilesQ) throw Error(SDMI_ERR_INVALID, "fp8_tile out of range");
-    const int bm = gemm_tile_info_q(cfg).bm, bn = gemm_tile_info_q(cfg).bn;
-    const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-    int splits = opt_force_splits_ > 0 ? opt_force_splits_ : 1;
-    if (opt_force_splits_ <= 0 && tiles < 128) splits = (int)std::min<long long>(p.kt_total / 4, (256 + tiles - 1) / tiles);
+    if (opt_force_splits_ > 0) splits = opt_force_splits_;
     splits = std::max(1, std::min(splits, p.kt_total));
     p.kt_per_split = (p.kt_total + splits - 1) / splits;
     splits = (p.kt_total + p.kt_per_split - 1) / p.kt_per_split;

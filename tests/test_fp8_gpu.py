@@ -10,7 +10,7 @@ The quantising GroupNorm is compared element by element with the oracle quantise
 Model level states what the FORMAT costs: e4m3 has 3 mantissa bits, i.e. ~2^-4/sqrt(3) = 3.6 % relative error per
 element and ~5 % per dot product of two quantised operands, whatever the scales are; a UNet forward with its 44 ResBlock
 convolutions in MXFP8 lands at ~1e-1 relative RMS on the synthetic weights (bf16: 1e-2) -- measured and asserted below,
-and the implementation itself is checked against the oracle with the SAME quantisation (bf16-level agreement).
+-- and the GPU must pay what the format costs according to the oracle with the same quantisation, not more.
 """
 import math
 
@@ -60,8 +60,7 @@ CONV8 = [
 ]
 
 
-@pytest.mark.parametrize("tile", ["auto", 0, 1, 2])
-@pytest.mark.parametrize("case", CONV8)
+@pytest.mark.parametrize("case,tile", [(c, "auto") for c in CONV8] + [(c, t) for c in (CONV8[0], CONV8[4], CONV8[5]) for t in (0, 1, 2)])
 def test_conv3x3_mxfp8(ops8, case, tile):
     n, cin, h, w, cout = case
     g = np.random.default_rng(hash(case) % (2 ** 31))
