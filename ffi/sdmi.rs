@@ -39,7 +39,13 @@ extern "C" {
     fn sdmi_last_error() -> *const c_char;
     fn sdmi_set_weight(ctx: *mut c_void, name: *const c_char, data: *const c_float, ndim: i32, dims: *const i64) -> c_int;
     fn sdmi_load_weights_dir(ctx: *mut c_void, dump_dir: *const c_char) -> c_int;
+    fn sdmi_load_weights_mpk(ctx: *mut c_void, mpk_path: *const c_char) -> c_int;
     fn sdmi_finalize_weights(ctx: *mut c_void) -> c_int;
+    fn sdmi_create_multi(out: *mut *mut c_void, cfg: *const SdmiConfig, devices: *const i32, n_devices: i32) -> c_int;
+    fn sdmi_destroy_multi(m: *mut c_void);
+    fn sdmi_multi_load_weights(m: *mut c_void, kind: *const c_char, path: *const c_char) -> c_int;
+    fn sdmi_sample_image_sharded(m: *mut c_void, context: *const c_float, t_len: i32, uncond: *const c_float, tu: i32, scale: c_double,
+                                 n_steps: usize, n_images: i32, init_latents: *const c_float, seed: u64, rgb_out: *mut u8) -> c_int;
     fn sdmi_unet_forward(ctx: *mut c_void, x: *const c_float, t: i32, context: *const c_float, n: i32, t_len: i32, out: *mut c_float) -> c_int;
     fn sdmi_sample_latent(ctx: *mut c_void, context: *const c_float, n: i32, t_len: i32, uncond: *const c_float, tu: i32,
                           scale: c_double, n_steps: usize, init_latent: *const c_float, seed: u64, latent_out: *mut c_float) -> c_int;
@@ -118,6 +124,31 @@ impl StableDiffusionMi355 {
             }
             let dir = CString::new(dump_dir)?;
             if sdmi_load_weights_dir(ctx, dir.as_ptr()) != 0 || sdmi_finalize_weights(ctx) != 0 {
+                let e = last_error();
+                sdmi_destroy(ctx);
+                return Err(e.into());
+            }
+            Ok(Self { ctx, ctx_dim: cfg.ctx_dim as usize, clip_ctx: cfg.clip_ctx as usize,
+                      latent: 4 * (cfg.latent_h * cfg.latent_w) as usize })
+        }
+    }
+
+    /// `load_stable_diffusion_model_file(filename, device)` (src/bin/sample/main.rs:27-34): the Burn
+    /// `NamedMpkFileRecorder<FullPrecisionSettings>` record, read natively by the library (the recorder appends ".mpk").
+    /// `precision`: 0 fp32 (the reference's arithmetic), 1 bf16, 2 bf16 + MXFP8 ResBlock convolutions.
+    pub fn load_record(model_name: &str, device: i32, precision: i32) -> Result<Self, Box<dyn Error>> {
+        unsafe {
+            let mut cfg: SdmiConfig = std::mem::zeroed();
+            sdmi_default_config(&mut cfg);
+            cfg.device = device;
+            cfg.precision = precision;
+            let mut ctx: *mut c_void = std::ptr::null_mut();
+            if sdmi_create(&mut ctx, &cfg) != 0 {
+                return Err(last_error().into());
+            }
+            let file = if model_name.ends_with(".mpk") { model_name.to_string() } else { format!("{}.mpk", model_name) };
+            let path = CString::new(file)?;
+            if sdmi_load_weights_mpk(ctx, path.as_ptr()) != 0 || sdmi_finalize_weights(ctx) != 0 {
                 let e = last_error();
                 sdmi_destroy(ctx);
                 return Err(e.into());
@@ -230,5 +261,59 @@ impl StableDiffusionMi355 {
 impl Drop for StableDiffusionMi355 {
     fn drop(&mut self) {
         unsafe { sdmi_destroy(self.ctx) }
+    }
+}
+
+/// `sd.sample_image(context, unconditional_context, scale, n_steps)` for `n_images` images of ONE prompt, sharded over the
+/// GPUs of a node inside the library (sdmi_create_multi): one weights replica, stream and host thread per device, ONE RCCL
+/// broadcast of the packed prompt embedding per call, contiguous image ranges, noise keyed by the global image index
+/// (seed + i) -- the result does not depend on the device count.  What `main.rs:104-109` calls when more than one image
+/// is wanted.
+pub struct StableDiffusionMi355Node {
+    m: *mut c_void,
+    ctx_dim: usize,
+    image_bytes: usize,
+}
+
+impl StableDiffusionMi355Node {
+    /// kind = "dump" (npy tree, load_stable_diffusion) | "burn" (.mpk record, load_stable_diffusion_model_file)
+    pub fn load(kind: &str, path: &str, devices: &[i32], precision: i32) -> Result<Self, Box<dyn Error>> {
+        unsafe {
+            let mut cfg: SdmiConfig = std::mem::zeroed();
+            sdmi_default_config(&mut cfg);
+            cfg.precision = precision;
+            let mut m: *mut c_void = std::ptr::null_mut();
+            if sdmi_create_multi(&mut m, &cfg, devices.as_ptr(), devices.len() as i32) != 0 {
+                return Err(last_error().into());
+            }
+            let (k, p) = (CString::new(kind)?, CString::new(path)?);
+            if sdmi_multi_load_weights(m, k.as_ptr(), p.as_ptr()) != 0 {
+                let e = last_error();
+                sdmi_destroy_multi(m);
+                return Err(e.into());
+            }
+            Ok(Self { m, ctx_dim: cfg.ctx_dim as usize, image_bytes: 3 * 64 * (cfg.latent_h * cfg.latent_w) as usize })
+        }
+    }
+
+    pub fn sample_image(&self, context: &[f32], unconditional_context: &[f32], unconditional_guidance_scale: f64, n_steps: usize,
+                        n_images: usize, seed: u64) -> Vec<Vec<u8>> {
+        assert!(context.len() % self.ctx_dim == 0 && unconditional_context.len() % self.ctx_dim == 0, "embedding width");
+        let mut rgb = vec![0u8; n_images * self.image_bytes];
+        let st = unsafe {
+            sdmi_sample_image_sharded(self.m, context.as_ptr(), (context.len() / self.ctx_dim) as i32, unconditional_context.as_ptr(),
+                                      (unconditional_context.len() / self.ctx_dim) as i32, unconditional_guidance_scale, n_steps,
+                                      n_images as i32, std::ptr::null(), seed, rgb.as_mut_ptr())
+        };
+        if st != 0 {
+            panic!("sdmi_sample_image_sharded: {}", last_error());
+        }
+        rgb.chunks(self.image_bytes).map(|c| c.to_vec()).collect()
+    }
+}
+
+impl Drop for StableDiffusionMi355Node {
+    fn drop(&mut self) {
+        unsafe { sdmi_destroy_multi(self.m) }
     }
 }

@@ -240,6 +240,9 @@ int sdmi_multi_load_weights(sdmi_multi* m, const char* kind, const char* path);
 int sdmi_sample_image_sharded(sdmi_multi* m, const float* context, int32_t T, const float* uncond, int32_t Tu,
                               double scale, size_t n_steps, int32_t n_images, const float* init_latents, uint64_t seed,
                               uint8_t* rgb_out);
+/* the contiguous global image range [begin, end) device `rank` of `n_ranks` samples (host only): the partition rule of
+ * sdmi_sample_image_sharded, and of the one-process-per-GPU launcher (bench.py / sharding.py use the same rule) */
+int sdmi_shard_range(int32_t n_images, int32_t rank, int32_t n_ranks, int32_t* begin, int32_t* end);
 /* number of RCCL broadcasts issued so far (one per sdmi_sample_image_sharded call) */
 int64_t sdmi_multi_broadcast_count(sdmi_multi* m);
 

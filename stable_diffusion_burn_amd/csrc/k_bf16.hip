@@ -111,19 +111,7 @@ __global__ void gn_stats_bf16_kernel(const unsigned short* __restrict__ x, int h
         chq[ch] = m2 > 0.0 ? m2 : 0.0;
     }
     __syncthreads();
-    for (int gi = tid; gi < G; gi += blockDim.x) {
-        const int cpg = C / G;
-        const double inv_cpg = 1.0 / cpg;
-        const double ref = chm[gi * cpg];
-        double a = 0.0, b = 0.0, m2 = 0.0;
-        for (int ch = gi * cpg; ch < (gi + 1) * cpg; ++ch) {
-            const double d = chm[ch] - ref;
-            a += d; b += d * d; m2 += chq[ch];
-        }
-        double* o = part + ((long long)(smp * chunks + chunk) * G + gi) * 2;
-        o[0] = ref + a * inv_cpg;
-        o[1] = m2 + n_rows * (b - a * a * inv_cpg);
-    }
+    gn_merge_group_channels(chm, chq, C, G, n_rows, part + (long long)(smp * chunks + chunk) * G * 2);
 }
 
 template <bool SILU>

@@ -10,6 +10,48 @@ namespace sdmi {
 // Partial statistics of one (sample, chunk, group) are (mean, M2 = sum (x - mean)^2) over the chunk's rows x (C/G)
 // channels: part[((smp*chunks + chunk)*G + g)*2 + {0, 1}].  Producers: gn_stats_kernel / gn_stats_bf16_kernel and the
 // GEMM epilogues that emit them for their own output tile.
+// Tail of the statistics kernels: per-channel (mean_c, M2_c) of one chunk (equal counts n_rows) -> per-group (mean, M2), shifted
+// by the group's first channel mean.  Four threads per group walk every fourth channel and are combined with two xor-shuffles
+// in a fixed order (a 3-sum fp64 dependency chain over up to 80 channels in ONE thread cost 1 us per launch).
+__device__ __forceinline__ double kc_shfl_xor_f64(double v, int m) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, m);
+    hi = __shfl_xor(hi, m);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void gn_merge_group_channels(const double* chm, const double* chq, int C, int G, double n_rows, double* out) {
+    const int cpg = C / G;
+    const double inv_cpg = 1.0 / cpg;
+    if ((blockDim.x & 3) == 0) {
+        for (int idx = threadIdx.x; idx < G * 4; idx += blockDim.x) {
+            const int gi = idx >> 2, j = idx & 3;
+            const double ref = chm[gi * cpg];
+            double a = 0.0, b = 0.0, m2 = 0.0;
+            for (int ch = gi * cpg + j; ch < (gi + 1) * cpg; ch += 4) {
+                const double d = chm[ch] - ref;
+                a += d; b += d * d; m2 += chq[ch];
+            }
+            a += kc_shfl_xor_f64(a, 1); b += kc_shfl_xor_f64(b, 1); m2 += kc_shfl_xor_f64(m2, 1);
+            a += kc_shfl_xor_f64(a, 2); b += kc_shfl_xor_f64(b, 2); m2 += kc_shfl_xor_f64(m2, 2);
+            if (j == 0) {
+                out[gi * 2] = ref + a * inv_cpg;
+                out[gi * 2 + 1] = m2 + n_rows * (b - a * a * inv_cpg);
+            }
+        }
+    } else {
+        for (int gi = threadIdx.x; gi < G; gi += blockDim.x) {
+            const double ref = chm[gi * cpg];
+            double a = 0.0, b = 0.0, m2 = 0.0;
+            for (int ch = gi * cpg; ch < (gi + 1) * cpg; ++ch) {
+                const double d = chm[ch] - ref;
+                a += d; b += d * d; m2 += chq[ch];
+            }
+            out[gi * 2] = ref + a * inv_cpg;
+            out[gi * 2 + 1] = m2 + n_rows * (b - a * a * inv_cpg);
+        }
+    }
+}
+
 // Merges the chunk partials of every group (8 threads per group, fixed order, one shifted pass in fp64) into
 // mean (as a float-float pair) and 1/sqrt(var + eps).  stat_rows = rows per partial chunk (the last may be short).
 __device__ __forceinline__ void gn_finalize(const double* __restrict__ part, int smp, int G, int cpg, int hw, int stat_chunks,

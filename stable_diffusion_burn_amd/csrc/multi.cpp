@@ -247,4 +247,12 @@ int sdmi_sample_image_sharded(sdmi_multi* m, const float* context, int32_t T, co
 
 int64_t sdmi_multi_broadcast_count(sdmi_multi* m) { return m ? m->m->broadcasts() : SDMI_ERR_INVALID; }
 
+int sdmi_shard_range(int32_t n_images, int32_t rank, int32_t n_ranks, int32_t* begin, int32_t* end) {
+    if (!begin || !end || n_images < 0 || n_ranks <= 0 || rank < 0 || rank >= n_ranks) { sdmi_set_last_error("sdmi_shard_range: bad argument"); return SDMI_ERR_INVALID; }
+    int b = 0, e = 0;
+    sdmi::shard_range(n_images, rank, n_ranks, &b, &e);
+    *begin = b; *end = e;
+    return SDMI_OK;
+}
+
 }  // extern "C"

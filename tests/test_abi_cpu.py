@@ -110,7 +110,8 @@ def test_rust_shim_matches_header():
     rs = (ROOT / "ffi" / "sdmi.rs").read_text()
     for s in ("sdmi_create", "sdmi_destroy", "sdmi_set_weight", "sdmi_finalize_weights", "sdmi_load_weights_dir",
               "sdmi_sample_image", "sdmi_sample_latent", "sdmi_latent_to_image", "sdmi_unet_forward",
-              "sdmi_decode_latent", "sdmi_qkv_attention", "sdmi_last_error"):
+              "sdmi_decode_latent", "sdmi_qkv_attention", "sdmi_last_error", "sdmi_load_weights_mpk", "sdmi_create_multi",
+              "sdmi_sample_image_sharded", "sdmi_multi_load_weights", "sdmi_destroy_multi"):
         assert re.search(r"\bfn\s+%s\b" % s, rs), s
 
 

@@ -282,7 +282,7 @@ def test_sample_image_bf16(sd16):
     assert u8.shape == (1, 64, 64, 3) and u8.dtype == np.uint8
     # the u8 image against the fp64 oracle's own image (truncating cast, stablediffusion/mod.rs:96): bf16 moves a pixel by a
     # few LSB, never by a visible amount
-    ref_u8, _ = o64.latent_to_image(torch.from_numpy(ref))
+    ref_u8 = np.clip((np.transpose(ref_img, (0, 2, 3, 1)) + 1.0) / 2.0 * 255.0, 0.0, 255.0).astype(np.uint8)   # stablediffusion/mod.rs:79-99, truncating
     du8 = np.abs(u8.astype(np.int16) - ref_u8.astype(np.int16))
     print(f"bf16 u8 image vs fp64 oracle: mean |d| = {du8.mean():.2f} LSB, max = {du8.max()} LSB")
     assert du8.mean() < 4.0 and du8.max() <= 40

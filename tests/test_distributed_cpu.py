@@ -67,3 +67,23 @@ def test_single_process_broadcast_is_noop():
     assert sharding.broadcast_prompt(p) is p
     c, u = sharding.unpack_prompt(p, 2, 1, 2)
     assert c.shape == (2, 2) and u.shape == (1, 2)
+
+
+def test_c_abi_partition_rule_matches_the_launcher():
+    """sdmi_sample_image_sharded (one process, one thread per device) and bench.py / sharding.py (one process per device)
+    must hand the same global image indices to the same device: sdmi_shard_range == sharding.shard_range."""
+    import ctypes as C
+
+    from stable_diffusion_burn_amd import _capi, sharding
+    lib = _capi.load_library()
+    for n in (0, 1, 3, 7, 8, 16, 64, 65, 128):
+        for world in (1, 2, 3, 4, 8):
+            covered = []
+            for r in range(world):
+                b, e = C.c_int32(), C.c_int32()
+                assert lib.sdmi_shard_range(n, r, world, C.byref(b), C.byref(e)) == 0
+                assert list(range(b.value, e.value)) == list(sharding.shard_range(n, r, world))
+                covered += list(range(b.value, e.value))
+            assert covered == list(range(n))
+    b, e = C.c_int32(), C.c_int32()
+    assert lib.sdmi_shard_range(4, 4, 4, C.byref(b), C.byref(e)) != 0

@@ -194,11 +194,11 @@ def test_sample_image_mxfp8_runs_and_repeats(sd8):
     lat = syn.initial_latent(0, 8, 8)[None]
     ctx = syn.cond_context(0, 77, 768)[None]
     unc = syn.uncond_context(77, 768)
-    a = sd8.sample_image(ctx, unc, 7.5, 3, init_latent=lat)
-    b = sd8.sample_image(ctx, unc, 7.5, 3, init_latent=lat)
+    a = sd8.sample_image(ctx, unc, 7.5, 2, init_latent=lat)
+    b = sd8.sample_image(ctx, unc, 7.5, 2, init_latent=lat)
     assert a.shape == (1, 64, 64, 3) and np.array_equal(a, b)
-    o64 = O.StableDiffusionOracle(syn.SyntheticWeights(), syn.alphas_cumprod(), DIMS8, torch.float64)
-    ref = o64.sample_image(torch.from_numpy(ctx), torch.from_numpy(unc), 7.5, 3, torch.from_numpy(lat))
+    o64 = O.StableDiffusionOracle(syn.SyntheticWeights(), syn.alphas_cumprod(), DIMS8, torch.float32)
+    ref = o64.sample_image(torch.from_numpy(ctx), torch.from_numpy(unc), 7.5, 2, torch.from_numpy(lat))
     d = np.abs(a.astype(np.int16) - ref.astype(np.int16))
-    print(f"precision 2 u8 image vs fp64 oracle: mean |d| = {d.mean():.2f} LSB, max {d.max()} LSB")
+    print(f"precision 2 u8 image vs the fp32 oracle: mean |d| = {d.mean():.2f} LSB, max {d.max()} LSB")
     assert d.mean() < 25
