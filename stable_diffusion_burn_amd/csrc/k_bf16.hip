@@ -181,45 +181,53 @@ hipError_t launch_group_norm_bf16(const void* x, void* y, const float* gamma, co
     return hipGetLastError();
 }
 
-// ---- LayerNorm: one wave per row, 8-channel vectors ---------------------------------------------------------
-constexpr int kLnMaxVecH = 4;  // C <= 2048
+// ---- LayerNorm: L lanes per row, 8-channel vectors (structure and reasons: k_norm.hip) ---------------------------------
+constexpr int kLnMaxVecH = 4;  // 16-byte vectors per lane
 
+template <int L>
 __global__ __launch_bounds__(256) void layer_norm_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int rows,
                                                               int C, float eps) {
+    constexpr int RPW = 64 / L;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int sub = lane / L, l = lane % L;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + sub;
+    const bool row_ok = row < rows;
     const int cq = C >> 3;
-    const unsigned short* xr = x + (long long)row * C;
+    const unsigned short* xr = x + (long long)(row_ok ? row : 0) * C;
     F8 v[kLnMaxVecH];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < kLnMaxVecH; ++i) {
-        const int f = lane + i * 64;
-        if (f < cq) {
+        const int f = l + i * L;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i].v[j] = 0.f;
+        if (f < cq && row_ok) {
             v[i] = unpack8(*reinterpret_cast<const u32x4*>(xr + f * 8));
 #pragma unroll
             for (int j = 0; j < 8; ++j) sum += v[i].v[j];
         }
     }
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
     const float mean = sum / (float)C;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < kLnMaxVecH; ++i) {
-        const int f = lane + i * 64;
+        const int f = l + i * L;
         if (f < cq) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float d = v[i].v[j] - mean; sq += d * d; }
         }
     }
-    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
     const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+    if (!row_ok) return;
     unsigned short* yr = y + (long long)row * C;
 #pragma unroll
     for (int i = 0; i < kLnMaxVecH; ++i) {
-        const int f = lane + i * 64;
+        const int f = l + i * L;
         if (f < cq) {
             F8 o;
 #pragma unroll
@@ -232,8 +240,15 @@ __global__ __launch_bounds__(256) void layer_norm_bf16_kernel(const unsigned sho
 hipError_t launch_layer_norm_bf16(const void* x, void* y, const float* gamma, const float* beta, int rows, int c, float eps,
                                   hipStream_t stream) {
     if ((c & 7) || c > kLnMaxVecH * 512) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(layer_norm_bf16_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, reinterpret_cast<const unsigned short*>(x),
-                       reinterpret_cast<unsigned short*>(y), gamma, beta, rows, c, eps);
+    const int cq = c >> 3;
+    auto xs = reinterpret_cast<const unsigned short*>(x);
+    auto ys = reinterpret_cast<unsigned short*>(y);
+    if (cq <= 16 * kLnMaxVecH)
+        hipLaunchKernelGGL(layer_norm_bf16_kernel<16>, dim3((rows + 15) / 16), dim3(256), 0, stream, xs, ys, gamma, beta, rows, c, eps);
+    else if (cq <= 32 * kLnMaxVecH)
+        hipLaunchKernelGGL(layer_norm_bf16_kernel<32>, dim3((rows + 7) / 8), dim3(256), 0, stream, xs, ys, gamma, beta, rows, c, eps);
+    else
+        hipLaunchKernelGGL(layer_norm_bf16_kernel<64>, dim3((rows + 3) / 4), dim3(256), 0, stream, xs, ys, gamma, beta, rows, c, eps);
     return hipGetLastError();
 }
 

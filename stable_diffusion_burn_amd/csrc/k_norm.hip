@@ -23,7 +23,7 @@
 //    a float-float pair (hi + lo), so  x - mean  is as exact as the reference's fp64-free u = x - mean can be.
 //    Algorithmic traffic: 2 reads + 1 write of the tensor; the second read of
 //    UNet-sized tensors (<= 21 MB) is served from L2 / Infinity Cache.
-//  * LayerNorm: one wave per token row, the row (<= 2048 channels) is held in
+//  * LayerNorm: 16 / 32 / 64 lanes per token row (4 / 2 / 1 rows per wave), the row (<= 2048 channels) is held in
 //    registers, exact two-pass mean / variance with xor-shuffle reductions.
 #include "kernels.hpp"
 #include "k_common.hpp"
@@ -179,45 +179,54 @@ hipError_t launch_group_norm(const float* x, float* y, const float* gamma, const
     return hipGetLastError();
 }
 
-// ---- LayerNorm: one wave per row ---------------------------------------------------------
-constexpr int kLnMaxVec = 8;  // float4 per lane -> C <= 2048
+// ---- LayerNorm: L lanes per row ---------------------------------------------------------------
+// A wave handles 64 / L rows at once, L = 16 / 32 / 64 chosen so that a lane holds <= 8 float4 of its row: at C = 320 a
+// one-wave-per-row kernel issues two loads of which the second keeps 16 lanes busy; with L = 16 every lane has 5 independent
+// 16-byte loads in flight and the wave covers 4 rows (exact two-pass mean / variance as before, xor-shuffles inside the L lanes).
+constexpr int kLnMaxVec = 8;  // float4 per lane
 
+template <int L>
 __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int rows, int C, float eps) {
+    constexpr int RPW = 64 / L;                       // rows per wave
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int sub = lane / L, l = lane % L;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + sub;
+    const bool row_ok = row < rows;
     const int cq = C >> 2;
-    const float* xr = x + (long long)row * C;
+    const float* xr = x + (long long)(row_ok ? row : 0) * C;
     f32x4 v[kLnMaxVec];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < kLnMaxVec; ++i) {
-        const int f = lane + i * 64;
+        const int f = l + i * L;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (f < cq) {
+        if (f < cq && row_ok) {
             v[i] = *reinterpret_cast<const f32x4*>(xr + f * 4);
             sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
     const float mean = sum / (float)C;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < kLnMaxVec; ++i) {
-        const int f = lane + i * 64;
+        const int f = l + i * L;
         if (f < cq) {
             const f32x4 d = v[i] - mean;
             sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
         }
     }
-    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
     const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+    if (!row_ok) return;
     float* yr = y + (long long)row * C;
 #pragma unroll
     for (int i = 0; i < kLnMaxVec; ++i) {
-        const int f = lane + i * 64;
+        const int f = l + i * L;
         if (f < cq) {
             const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + f * 4);
             const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + f * 4);
@@ -229,7 +238,13 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
 hipError_t launch_layer_norm(const float* x, float* y, const float* gamma, const float* beta, int rows, int c,
                              float eps, hipStream_t stream) {
     if ((c & 3) || c > kLnMaxVec * 256) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(layer_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, y, gamma, beta, rows, c, eps);
+    const int cq = c >> 2;
+    if (cq <= 16 * kLnMaxVec)
+        hipLaunchKernelGGL(layer_norm_kernel<16>, dim3((rows + 15) / 16), dim3(256), 0, stream, x, y, gamma, beta, rows, c, eps);
+    else if (cq <= 32 * kLnMaxVec)
+        hipLaunchKernelGGL(layer_norm_kernel<32>, dim3((rows + 7) / 8), dim3(256), 0, stream, x, y, gamma, beta, rows, c, eps);
+    else
+        hipLaunchKernelGGL(layer_norm_kernel<64>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, y, gamma, beta, rows, c, eps);
     return hipGetLastError();
 }
 
