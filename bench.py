@@ -42,6 +42,7 @@ sys.path.insert(0, str(ROOT))
 FP8_MFMA_PEAK_TFLOPS = 5000.0   # same table, "Peak FP8 MFMA" (dense; the MX-scaled K = 128 instruction)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA" (dense)
+SPLIT_PRODUCTS = 6              # k_gemm3x.hip: bf16 MFMAs issued per fp32 16x16x32 block (csrc/k_gemm3x.hip header)
 F_UNET = 0.8033e12              # FLOP per UNet forward per sample, T = 77
 F_VAE = 2.5145e12               # FLOP per decoded image
 T_CTX = 77
@@ -149,20 +150,26 @@ class Runner:
         self.torch.cuda.synchronize()
         sd.set_option("profile", 0)
         prof = sd.profile_stats()
-        g = prof["conv_gemm_fp8"] if self.fp8 else prof["conv_gemm"]
+        # precision = 0: the dominant kernel is the split kernel (fp32 operands as three bf16 terms, six bf16 MFMAs per fp32
+        # 16x16x32 block) unless it is switched off (--opt gemm_f32s=0), then the fp32-MFMA kernels
+        split = (not self.bf16) and prof["conv_gemm_split"]["ms"] > prof["conv_gemm"]["ms"]
+        g = prof["conv_gemm_fp8"] if self.fp8 else prof["conv_gemm_split"] if split else prof["conv_gemm"]
         if g["launches"] <= 0 or g["ms"] <= 0:
             return None, prof
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
-        peak = FP8_MFMA_PEAK_TFLOPS if self.fp8 else BF16_MFMA_PEAK_TFLOPS if self.bf16 else FP32_MFMA_PEAK_TFLOPS
+        peak = (FP8_MFMA_PEAK_TFLOPS if self.fp8 else BF16_MFMA_PEAK_TFLOPS if self.bf16 else
+                BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if split else FP32_MFMA_PEAK_TFLOPS)
         kname = ("conv_gemm_fp8x_kernel (implicit-GEMM 3x3 conv of the ResBlocks, v_mfma_scale_f32_16x16x128_f8f6f4, MXFP8)" if self.fp8 else
                  "conv_gemm_bf16x_kernel + conv_gemm_bf16_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x32_bf16)" if self.bf16 else
+                 "conv_gemm3x_kernel (implicit-GEMM conv/linear in fp32: operands split exactly into 3 bf16 terms, 6 partial products "
+                 "per multiply on v_mfma_f32_16x16x32_bf16, fp32 accumulation)" if split else
                  "conv_gemm2_kernel + conv_gemm2x_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x4_f32)")
         traffic, source = None, None
         pmc = ROOT / "profiles" / "pmc_summary.json"
         if pmc.exists() and not self.bf16 and self.B == 1:
             try:
                 j = json.loads(pmc.read_text())
-                traffic = j.get("conv_gemm_hbm_bytes_per_launch")
+                traffic = j.get("conv_gemm_split_hbm_bytes_per_launch" if split else "conv_gemm_hbm_bytes_per_launch")
                 source = f"profiles/pmc_summary.json ({j.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command')}); NOT measured in this run"
             except Exception:  # noqa: BLE001
                 traffic = None
@@ -171,6 +178,15 @@ class Runner:
                 "launches_per_image": g["launches"] / self.B, "avg_launch_us": g["ms"] * 1e3 / g["launches"],
                 "flop_per_launch": g["flops"] / g["launches"],
                 "share_of_gpu_time": g["ms"] / max(1e-9, sum(v["ms"] for v in prof.values()))}
+        if split:
+            o = prof["conv_gemm"]
+            roof["peak_note"] = (f"dense bf16 MFMA peak {BF16_MFMA_PEAK_TFLOPS:g} TFLOP/s / {SPLIT_PRODUCTS} matrix instructions per fp32 block; "
+                                 f"achieved counts ALGORITHMIC fp32 flops (2 M N K), not the 6x issued bf16 flops")
+            roof["achieved_vs_fp32_mfma_peak"] = achieved / FP32_MFMA_PEAK_TFLOPS   # > 1 is possible: the fp32 matrix instruction is not used
+            roof["issued_bf16_tflops"] = achieved * SPLIT_PRODUCTS
+            if o["launches"] > 0 and o["ms"] > 0:
+                roof["launches_left_on_fp32_mfma"] = {"launches_per_image": o["launches"] / self.B, "ms_per_image": o["ms"] / self.B,
+                                                      "achieved": o["flops"] / (o["ms"] * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS}
         return roof, prof
 
     def class_summary(self, prof):
@@ -185,6 +201,16 @@ class Runner:
 
     def close(self):
         self.sd.close()
+
+
+ARITHMETIC = {
+    "fp32": "fp32 storage, fp32 accumulation; conv/linear multiplications: each fp32 operand is the exact sum of three bf16 terms and "
+            "the six partial products >= 2^-24 of the product are accumulated in fp32 on the bf16 matrix pipe (csrc/k_gemm3x.hip; per-product "
+            "error <= 2^-25, measured against the fp64 oracle: not larger than the fp32 matrix instruction's -- tests/test_ops_gpu.py); "
+            "attention, norms and the remaining GEMMs in plain fp32",
+    "bf16": "bf16 storage, fp32 accumulation and statistics",
+    "fp8": "bf16 storage, fp32 accumulation; ResBlock 3x3 convolutions on MXFP8 operands",
+}
 
 
 def workload_name(precision, B, ddim_steps, scale):
@@ -265,19 +291,24 @@ def main():
     # ---- secondary: the reduced-precision configurations BASELINE.json names, witnessed by the same run ----------
     secondary = []
     if rank == 0 and world == 1 and not args.no_secondary and not bf16 and B == 1 and args.ddim_steps == 20:
-        for (prec2, b2, s2, k2) in (("bf16", 16, 50, 2), ("bf16", 8, 20, 3), ("fp8", 16, 20, 2)):
+        for (prec2, b2, s2, k2) in (("fp32", 1, 20, 3), ("bf16", 16, 50, 2), ("bf16", 8, 20, 3), ("fp8", 16, 20, 2)):
             idx = list(range(b2))
-            r2 = Runner(torch, np, dev, local_rank, prec2, b2, s2, args.scale, cond, uncond, idx, flat, [], None)
+            # the headline configuration once more with every GEMM on the fp32 matrix instruction (the split kernel off)
+            opts2, tune2 = (["gemm_f32s=0"], args.tune_file) if prec2 == "fp32" else ([], None)
+            r2 = Runner(torch, np, dev, local_rank, prec2, b2, s2, args.scale, cond, uncond, idx, flat, opts2, tune2)
             e2 = r2.timed(k2, 1, barrier)
             roof2, prof2 = r2.roofline()
             fpi = 2 * s2 * F_UNET + F_VAE
             v2 = k2 * b2 / e2
             entry = {"config": {"workload": workload_name(prec2, b2, s2, args.scale), "global_batch": b2, "ddim_steps": s2,
                                 "cfg_scale": args.scale, "context_len": T_CTX},
-                     "dtype": "bf16" if prec2 == "bf16" else "fp8(e4m3, MX)+bf16", "value": v2, "unit": "images/sec", "steps": k2, "warmup": 1, "ms_per_step": e2 / k2 * 1e3,
+                     "dtype": "f32" if prec2 == "fp32" else "bf16" if prec2 == "bf16" else "fp8(e4m3, MX)+bf16", "value": v2, "unit": "images/sec", "steps": k2, "warmup": 1, "ms_per_step": e2 / k2 * 1e3,
                      "algorithmic_tflop_per_image": fpi / 1e12, "whole_path_tflops_per_gpu": v2 * fpi / 1e12,
                      "whole_path_frac_of_bf16_mfma_peak": v2 * fpi / 1e12 / BF16_MFMA_PEAK_TFLOPS, "roofline": roof2,
                      "weights_load_s": r2.t_load}
+            if prec2 == "fp32":
+                entry["config"]["workload"] += "; GEMMs on v_mfma_f32_16x16x4_f32 only (option gemm_f32s=0)"
+                entry["whole_path_frac_of_fp32_mfma_peak"] = entry.pop("whole_path_frac_of_bf16_mfma_peak") * BF16_MFMA_PEAK_TFLOPS / FP32_MFMA_PEAK_TFLOPS
             entry.update(r2.class_summary(prof2))
             secondary.append(entry)
             r2.close()
@@ -296,6 +327,7 @@ def main():
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp8(e4m3, MX)+bf16" if args.precision == "fp8" else "bf16" if bf16 else "f32", "data": "synthetic",
+            "arithmetic": ARITHMETIC[args.precision],
             "config": {"workload": workload_name(args.precision, B, args.ddim_steps, args.scale),
                        "global_batch": B * world, "ddim_steps": args.ddim_steps, "cfg_scale": args.scale,
                        "context_len": T_CTX, "parallelism": f"image-sharded x{world}, 1 RCCL broadcast of the text embedding",

@@ -291,7 +291,9 @@ int sdmi_set_option(sdmi_ctx* ctx, const char* key, const char* value);
 int sdmi_last_call_stats(sdmi_ctx* ctx, double* gpu_ms, int64_t* n_kernels, double* flops);
 /* Per-kernel-class timing collected while option "profile" = "1": HIP events around every
  * launch on the context stream.  cls: 0 conv_gemm (implicit-GEMM conv/linear), 1 splitk_reduce,
- * 2 attention, 3 group_norm(+silu), 4 layer_norm, 5 conv_gemm_fp8 (the MXFP8 convs of precision = 2).  flops / bytes are the ALGORITHMIC work of
+ * 2 attention, 3 group_norm(+silu), 4 layer_norm, 5 conv_gemm_fp8 (the MXFP8 convs of precision = 2),
+ * 6 conv_gemm_split (precision = 0: the conv/linear launches that run on the bf16 matrix pipe with three-way split fp32
+ * operands, k_gemm3x.hip; class 0 then holds the launches left on the fp32 matrix instruction).  flops / bytes are the ALGORITHMIC work of
  * those launches (2*M*N*K; one read + one write of the tensor).  "profile_reset" clears. */
 int sdmi_profile_stats(sdmi_ctx* ctx, int32_t cls, double* ms, int64_t* launches, double* flops, double* bytes);
 /* micro-benchmark one implicit-GEMM conv shape on device-resident synthetic

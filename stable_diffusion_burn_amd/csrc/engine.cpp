@@ -555,6 +555,12 @@ void Engine::ensure_arena(int group) {
         char* base = nullptr;
         SDMI_HIP(hipMalloc((void**)&base, total));
         weight_allocs_.push_back(base);
+        arena_base_[group] = base;
+        arena_bytes_[group] = total;
+        if (!bf16_) {
+            SDMI_HIP(hipMalloc((void**)&split_base_[group], total / 2 * 3));
+            weight_allocs_.push_back(split_base_[group]);
+        }
         size_t off = 0;
         for (auto& e : entries_) {
             if (e.group != group || e.kind == 3 || *e.dst) continue;
@@ -566,6 +572,29 @@ void Engine::ensure_arena(int group) {
         }
     }
     arena_done_[group] = true;
+}
+
+Engine::TempSplit::TempSplit(Engine* e_, const float* bt_, long long rows, long long K) : e(e_), bt(bt_) {
+    if (e->bf16_ || K % 32 || rows <= 0) return;
+    planes = e->pool_.alloc((size_t)rows * K * 6);
+    hipError_t err = launch_pack_split3(bt, planes, rows, (int)K, e->stream_);
+    if (err != hipSuccess) { e->pool_.free(planes); planes = nullptr; SDMI_HIP(err); }
+    e->temp_split_bt_ = bt;
+    e->temp_split_planes_ = planes;
+}
+Engine::TempSplit::~TempSplit() {
+    if (!planes) return;
+    e->temp_split_bt_ = nullptr;
+    e->temp_split_planes_ = nullptr;
+    e->pool_.free(planes);
+}
+
+const void* Engine::split_planes(const float* bt) const {
+    if (bt && bt == temp_split_bt_) return temp_split_planes_;
+    const char* b = reinterpret_cast<const char*>(bt);
+    for (int g = 0; g < 3; ++g)
+        if (split_base_[g] && b >= arena_base_[g] && b < arena_base_[g] + arena_bytes_[g]) return split_base_[g] + (size_t)(b - arena_base_[g]) / 2 * 3;
+    return nullptr;
 }
 
 static size_t entry_count(const WeightEntry& e) {
@@ -617,6 +646,12 @@ void Engine::stage_commit(WeightEntry& e, size_t offset, int half) {
                         : launch_pack_linear_weight(stage, *e.dst, (int)e.dims[0], (int)e.dims[1], stream_);
         }
         SDMI_HIP(err);
+        if (!e.wdt) {   // the bf16 planes of the packed fp32 rows (k_gemm3x.hip)
+            const long long rows = e.kind == 0 ? e.dims[0] : e.dims[1];
+            const long long K = e.kind == 0 ? (e.dims[1] == 3 ? 4 : e.dims[1]) * e.dims[2] * e.dims[3] : e.dims[0];
+            void* planes = const_cast<void*>(split_planes(*e.dst));
+            if (planes && K % 32 == 0) SDMI_HIP(launch_pack_split3(*e.dst, planes, rows, (int)K, stream_));
+        }
     }
     e.set = true;
     finalized_ = false;
@@ -905,6 +940,8 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "attn_bf16") opt_attn_bf16_ = std::stoi(value);
     else if (key == "gemm_bf16x") opt_gemm_bf16x_ = std::stoi(value);
     else if (key == "gemm_x32") opt_gemm_x32_ = std::stoi(value);
+    else if (key == "gemm_f32s") opt_gemm_f32s_ = std::stoi(value);
+    else if (key == "gemm3x_variant") opt_gemm3x_variant_ = std::stoi(value);
     else if (key == "geglu_fuse") opt_geglu_fuse_ = std::stoi(value);
     else if (key == "record_shapes") { record_shapes_ = std::stoi(value) != 0; if (record_shapes_) shape_counts_.clear(); }
     else if (key == "dump_shapes") {
@@ -921,7 +958,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
         const bool b16 = key == "tune_bf16";
         TileChoice tc{0, 1};
         if (std::sscanf(value.c_str() + eq + 1, "%d,%d", &tc.cfg, &tc.splits) != 2 || tc.cfg < 0 || tc.splits < 1 ||
-            !(tc.cfg < kNumGemmTiles || (tc.cfg >= 100 && tc.cfg < 100 + kNumGemmTilesX)))
+            !(tc.cfg < kNumGemmTiles || (tc.cfg >= 100 && tc.cfg < 100 + kNumGemmTilesX) || (!b16 && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS)))
             throw Error(SDMI_ERR_INVALID, "tune: bad value");
         (b16 ? tuned_bf16_ : tuned_)[value.substr(0, eq)] = tc;
     } else if (key == "tune_clear") { tuned_.clear(); tuned_bf16_.clear(); }
@@ -933,7 +970,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
 // measured entries ("tune" option, see tools/autotune.py).  The K-reduction order
 // depends only on (M,N,K), so a sample's result is independent of where it sits
 // in the batch only for equal M; see DESIGN.md "Determinism".
-TileChoice Engine::choose_tile(int M, int N, int kt_total, bool allow_x) const {
+TileChoice Engine::choose_tile(int M, int N, int kt_total, bool allow_x, bool allow_s) const {
     static const double eff[kNumGemmTiles] = {0.85, 0.75, 0.60, 0.90, 0.75, 0.85, 0.75, 0.85, 0.65, 0.75};
     static const int split_opts[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
     const int n_cu = 256;
@@ -969,6 +1006,24 @@ TileChoice Engine::choose_tile(int M, int N, int kt_total, bool allow_x) const {
                 double t = per_cu * ((double)bm * bn * kt_per * 64.0 / 256.0 / eff_x[c] + 8000.0 + bm * bn * 4.0 / 10.0);
                 if (s > 1) t += 8000.0 + (double)M * N * 4.0 * (s + 1) / (5.0e12 / 2.4e9);
                 if (t < best) { best = t; bc = {100 + c, s}; }
+            }
+        }
+    }
+    if (allow_s && opt_gemm_f32s_) {
+        // k_gemm3x.hip: six bf16 MFMAs per 16x16x32 block = 96 cycles/SIMD against 256 on the fp32 pipe; the efficiencies
+        // are measured ones (tools/autotune.py), the per-workgroup constant covers the DMA prologue and the epilogue
+        static const double eff_s[kNumGemmTilesS] = {0.55, 0.55, 0.52, 0.52, 0.42, 0.40};
+        for (int c = 0; c < kNumGemmTilesS; ++c) {
+            const int bm = gemm_tile_info_s(c).bm, bn = gemm_tile_info_s(c).bn;
+            const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+            for (int s : split_opts) {
+                if (s > 1 && kt_total / s < 4) break;
+                const int kt_per = (kt_total + s - 1) / s;
+                const long long wgs = tiles * ((kt_total + kt_per - 1) / kt_per);
+                const double per_cu = (double)((wgs + n_cu - 1) / n_cu);
+                double t = per_cu * ((double)bm * bn * kt_per * 384.0 / 4096.0 / eff_s[c] + 8000.0 + bm * bn * 4.0 / 10.0);
+                if (s > 1) t += 8000.0 + (double)M * N * 4.0 * (s + 1) / (5.0e12 / 2.4e9);
+                if (t < best) { best = t; bc = {200 + c, s}; }
             }
         }
     }
@@ -1022,9 +1077,15 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     const auto& table = in_dt ? tuned_bf16_ : tuned_;  // measured per storage type (tuning/gfx950_{fp32,bf16}.txt)
     auto it = table.find(key);
     const bool x32_ok = !in_dt && p.CS == 32 && p.Cin % 32 == 0 && p.out_mode == 0;   // what k_gemm2x.hip handles
-    if (it != table.end() && (it->second.cfg < 100 || (in_dt ? opt_gemm_bf16x_ != 0 : (opt_gemm_x32_ != 0 && x32_ok)))) tc = it->second;
-    else tc = in_dt ? choose_tile_bf16(p.M, p.N, p.kt_total) : choose_tile(p.M, p.N, p.kt_total, x32_ok);
-    if (opt_force_tile_ >= 0 && (opt_force_tile_ < 100 || in_dt || x32_ok)) tc.cfg = opt_force_tile_;  // 100+: large-tile kernels, where applicable
+    p.Bt3 = in_dt ? nullptr : split_planes(p.Bt);
+    p.variant = opt_gemm3x_variant_;
+    // k_gemm3x.hip: the same layers, when the weight has its bf16 planes (weights in the arenas; not e.g. the K / V operands of
+    // the unfused VAE attention) and the 32-bit piece offsets reach
+    const bool s_ok = x32_ok && p.Bt3 && (unsigned long long)p.N * (p.geglu ? 2 : 1) * (unsigned long long)p.kt_total * 192ull < 0xFFFFFF00ull;
+    auto usable = [&](int cfg) { return cfg < 100 || (in_dt ? opt_gemm_bf16x_ != 0 : (cfg >= 200 ? (opt_gemm_f32s_ != 0 && s_ok) : (opt_gemm_x32_ != 0 && x32_ok))); };
+    if (it != table.end() && usable(it->second.cfg)) tc = it->second;
+    else tc = in_dt ? choose_tile_bf16(p.M, p.N, p.kt_total) : choose_tile(p.M, p.N, p.kt_total, x32_ok, s_ok);
+    if (opt_force_tile_ >= 0 && (opt_force_tile_ < 100 || in_dt || (opt_force_tile_ >= 200 ? s_ok : x32_ok))) tc.cfg = opt_force_tile_;  // 100+ / 200+: large-tile kernels, where applicable
     if (opt_force_splits_ > 0) tc.splits = opt_force_splits_;
     if (force_cfg >= 0) tc.cfg = force_cfg;
     if (force_splits > 0) tc.splits = force_splits;
@@ -1039,12 +1100,14 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     const unsigned long long a_ext = ((unsigned long long)p.NB * p.Hs * p.Ws - 1) * (unsigned long long)p.a_ld * es + (unsigned long long)p.Cin * es;
     const unsigned long long b_ext = ((unsigned long long)p.N * (p.geglu ? 2 : 1) - 1) * (unsigned long long)p.b_ld * es + (unsigned long long)p.K * es;
     p.zero_page = zero_page_;
-    if (tc.cfg >= 100 && (tc.cfg - 100 >= kNumGemmTilesX || (!in_dt && !x32_ok))) throw Error(SDMI_ERR_INVALID, "gemm: large-tile kernel index out of range or not applicable to this layer");
+    if (tc.cfg >= 200 ? (tc.cfg - 200 >= kNumGemmTilesS || !s_ok) : (tc.cfg >= 100 && (tc.cfg - 100 >= kNumGemmTilesX || (!in_dt && !x32_ok))))
+        throw Error(SDMI_ERR_INVALID, "gemm: large-tile kernel index out of range or not applicable to this layer");
     if (a_ext >= 0xFFFFFFE0ull || b_ext >= 0xFFFFFFE0ull) throw Error(SDMI_ERR_UNSUPPORTED, "GEMM: operand larger than 4 GiB (the buffer-load range check needs 32-bit extents)");
     p.a_bytes = (unsigned)a_ext;
     p.b_bytes = (unsigned)b_ext;
     auto launch = [&](const ConvGemm& q) {
         if (in_dt && tc.cfg >= 100) return launch_conv_gemm_bf16x(q, tc.cfg - 100, stream_);
+        if (tc.cfg >= 200) return launch_conv_gemm3x(q, tc.cfg - 200, stream_);
         if (tc.cfg >= 100) return launch_conv_gemm2x(q, tc.cfg - 100, stream_);
         if (in_dt) return launch_conv_gemm_bf16(q, tc.cfg, stream_);
         return launch_conv_gemm2(q, tc.cfg, stream_);
@@ -1052,9 +1115,10 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     p.slabs = nullptr;
     p.counters = nullptr;
     p.slab_wt = 0;
+    const int pc = tc.cfg >= 200 ? PC_CONV_SPLIT : PC_CONV_GEMM;   // k_gemm3x.hip launches are timed as their own class
     if (splits == 1) {
         p.slab_stride = 0;
-        ProfScope ps(this, PC_CONV_GEMM, flops);
+        ProfScope ps(this, pc, flops);
         SDMI_HIP(launch(p));
         count_kernel(flops);
     } else {
@@ -1062,8 +1126,8 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         Buf slab(this, (size_t)splits * p.slab_stride * sizeof(float));
         p.slabs = slab.f();
         // combine inside the launch (k_common.hpp) when the 16-byte epilogue applies and the tile count fits the counter array
-        const int bm = tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100).bm : gemm_tile_info(tc.cfg).bm;
-        const int bn = tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100).bn : gemm_tile_info(tc.cfg).bn;
+        const GemmTileInfo& ti = tc.cfg >= 200 ? gemm_tile_info_s(tc.cfg - 200) : (tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100) : gemm_tile_info(tc.cfg));
+        const int bm = ti.bm, bn = ti.bn;
         const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
         const bool vec = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (!p.resid || p.ldr % 4 == 0);
         const bool slab_ok = (unsigned long long)p.slab_stride * 4ull < 0xFFFFFFE0ull;   // write-through stores go through a 32-bit buffer descriptor
@@ -1072,7 +1136,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
             p.slab_wt = opt_splitk_fused_ == 2 ? 1 : 0;
         }
         {
-            ProfScope ps(this, PC_CONV_GEMM, flops);
+            ProfScope ps(this, pc, flops);
             SDMI_HIP(launch(p));
         }
         count_kernel(flops);
@@ -1874,6 +1938,7 @@ void Engine::op_conv2d(const float* x, const float* wt, const float* bias, int n
     Buf bt(this, (size_t)cout * cin * k * k * 4);
     if (w.dt) SDMI_HIP(launch_pack_conv_weight_bf16(wt, bt.p, cout, cin, k, k, stream_));
     else SDMI_HIP(launch_pack_conv_weight(wt, bt.f(), cout, cin, k, k, stream_));
+    TempSplit planes(this, bt.f(), w.dt ? 0 : cout, (long long)cin * k * k);
     w.bt = bt.f(); w.bias = const_cast<float*>(bias);
     Act a = new_act(n, h, wd, cin, w.dt);
     if (w.dt) SDMI_HIP(launch_nchw_f32_to_nhwc_bf16(x, a.p, n, cin, h, wd, 1.0f, stream_));
@@ -1898,6 +1963,7 @@ void Engine::op_linear(const float* x, const float* wt, const float* bias, int r
         return;
     }
     SDMI_HIP(launch_pack_linear_weight(wt, bt.f(), cin, cout, stream_));
+    TempSplit planes(this, bt.f(), cout, cin);
     gemm(x, rows, bt.f(), bias, cin, cout, out, cout, nullptr, 0, 0);
 }
 
@@ -1912,6 +1978,7 @@ void Engine::op_geglu_forward(const float* x, const float* wt, const float* bias
         return;
     }
     SDMI_HIP(launch_pack_linear_weight(wt, bt.f(), cin, 2 * hidden, stream_));
+    TempSplit planes(this, bt.f(), 2 * hidden, cin);
     gemm_geglu(x, rows, bt.f(), bias, cin, hidden, out, 0);
 }
 
@@ -1983,6 +2050,7 @@ double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int str
         SDMI_HIP(hipStreamSynchronize(stream_));
     }
     SDMI_HIP(launch_fill_normal(bias.f(), cout, 13, stream_));
+    TempSplit planes(this, bt.f(), wdt ? 0 : cout, (long long)cin * k * k);
     ConvW cw; cw.cin = cin; cw.cout = cout; cw.k = k; cw.bt = bt.f(); cw.bias = bias.f(); cw.dt = wdt;
     const int save_t = opt_force_tile_, save_s = opt_force_splits_;
     opt_force_tile_ = tile_cfg; opt_force_splits_ = splitk;

@@ -212,6 +212,24 @@ private:
     struct Stager;
     std::unique_ptr<Stager> stager_;
     bool arena_done_[3] = {false, false, false};
+    // precision = 0: every packed fp32 weight also exists as three bf16 planes (k_gemm3x.hip) in a parallel arena; the planes of
+    // the weight at byte offset o of arena g start at offset 3 o / 2 of split arena g (6 bytes per weight instead of 4), so
+    // weights that are adjacent rows of one GEMM (q | k | v) stay adjacent
+    char* arena_base_[3] = {nullptr, nullptr, nullptr};
+    size_t arena_bytes_[3] = {0, 0, 0};
+    char* split_base_[3] = {nullptr, nullptr, nullptr};
+    const void* split_planes(const float* bt) const;
+    // operator-level calls (op_conv2d, op_linear, bench_conv ...) pack their weight into a pool buffer: this gives it planes for
+    // the duration of the call, so that those calls run the kernels the model runs
+    struct TempSplit {
+        Engine* e; const float* bt; void* planes = nullptr;
+        TempSplit(Engine* e_, const float* bt_, long long rows, long long K);
+        ~TempSplit();
+        TempSplit(const TempSplit&) = delete;
+        TempSplit& operator=(const TempSplit&) = delete;
+    };
+    const float* temp_split_bt_ = nullptr;
+    const void* temp_split_planes_ = nullptr;
     char* stage_reserve(size_t bytes, size_t* offset, int* half);
     void stage_commit(WeightEntry& e, size_t offset, int half);
     void upload_weight(WeightEntry& e, const float* data);
@@ -240,7 +258,7 @@ private:
     size_t esz() const { return bf16_ ? 2 : 4; }
     // element-wise pointer advance on an activation of type dt
     static float* adv(const float* p, long long elems, int dt) { return (float*)((char*)const_cast<float*>(p) + elems * (dt ? 2 : 4)); }
-    TileChoice choose_tile(int M, int N, int kt_total, bool allow_x = false) const;   // cfg >= 100: k_gemm2x.hip tile cfg - 100
+    TileChoice choose_tile(int M, int N, int kt_total, bool allow_x = false, bool allow_s = false) const;   // cfg >= 100: k_gemm2x.hip tile cfg - 100, >= 200: k_gemm3x.hip tile cfg - 200
     void group_norm(const NormW& w, const Act& x, Act& y, bool silu);
     // precision = 2: GroupNorm(+SiLU) writing MXFP8, and the 3x3 convolution that consumes it (k_fp8.hip)
     ActQ new_actq(int n, int h, int w, int c);
@@ -290,7 +308,7 @@ private:
 public:
     // per-kernel-class timing (option "profile=1"): HIP events around every launch on the
     // engine's stream, accumulated per class.  Used by bench.py for the roofline line.
-    enum ProfClass { PC_CONV_GEMM, PC_SPLITK_REDUCE, PC_ATTENTION, PC_GROUP_NORM, PC_LAYER_NORM, PC_CONV_FP8, PC_OTHER, PC_COUNT };
+    enum ProfClass { PC_CONV_GEMM, PC_SPLITK_REDUCE, PC_ATTENTION, PC_GROUP_NORM, PC_LAYER_NORM, PC_CONV_FP8, PC_CONV_SPLIT, PC_OTHER, PC_COUNT };
     struct ProfStat { double ms = 0; long long launches = 0; double flops = 0; double bytes = 0; };
     ProfStat prof_[PC_COUNT];
     void prof_flush();
@@ -372,6 +390,8 @@ private:
     int opt_force_splits_ = 0;
     int opt_attn_bf16_ = 1;
     int opt_geglu_fuse_ = 1;    // GEGLU gate in the projection GEMM's epilogue: 0 never, 1 where there are >= 4 rounds of tiles, 2 / 3 always (256x128 / 256x256 tiles; tests)
+    int opt_gemm_f32s_ = 1;     // precision = 0: 1 = fp32 GEMMs on the bf16 matrix pipe (three-way operand split, k_gemm3x.hip) where faster
+    int opt_gemm3x_variant_ = 0;
     int opt_gemm_x32_ = 1;      // precision = 0: 1 = large-tile LDS-DMA fp32 GEMM (k_gemm2x.hip) where measured / modelled faster
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
     void* zero_page_ = nullptr;

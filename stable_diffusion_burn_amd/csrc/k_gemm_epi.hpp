@@ -1,0 +1,145 @@
+// k_gemm_epi.hpp -- the fp32 output epilogue shared by the 8-wave large-tile kernels whose accumulators have the
+// 16x16 MFMA D layout (lane (c = lane & 15, g = lane >> 4) holds D[4g .. 4g+3][c], D rows = output channels, D columns =
+// pixels): k_gemm2x.hip (v_mfma_f32_16x16x4_f32) and k_gemm3x.hip (v_mfma_f32_16x16x32_bf16 on split operands).
+//   * bias + time-embedding row + residual, or the GEGLU product, or a raw split-K slab
+//   * every wave transposes one 16-row fragment group at a time through its own LDS scratch (the stages are free by then)
+//     and writes whole row segments with 16-byte lanes; the residual is read the same way
+//   * split-K with p.counters: the last-arriving slice combines the slabs in the launch (k_common.hpp)
+#pragma once
+#include "kernels.hpp"
+#include "k_common.hpp"
+
+namespace sdmi {
+
+typedef float epi_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MI, int NI, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_f32(const ConvGemm& p, epi_f32x4 (&acc)[MI][NI], unsigned char* smem_x32, const int m0,
+                                                  const int n0, const int z, const int lid, const int wave, const int lane,
+                                                  const int HoWo) {
+    typedef epi_f32x4 f32x4;
+    constexpr int BM = 16 * MI * WM;
+    constexpr int BN = 16 * NI * WN;
+    constexpr int WNC = 16 * NI;        // columns of a wave tile
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
+    const int c15 = lane & 15, g4 = lane >> 4;
+    const bool geglu = p.geglu != 0;
+    // ---- epilogue: bias + time-embedding row + residual, fp32 -------------------------------------------
+    // Each wave transposes one 16-row fragment group at a time through its own LDS scratch (the stages are free
+    // now) and writes whole 320-byte row segments with 16-byte lanes; the residual is read the same way.
+    const bool split = p.splits > 1;
+    float* Cf = split ? (p.slabs + (long long)z * p.slab_stride) : p.C;
+    const int ldc = split ? p.N : p.ldc;
+    const bool has_resid = !split && p.resid;
+    const bool vec_ok = ((p.N & 3) == 0) && ((ldc & 3) == 0) && ((p.ldr & 3) == 0 || !has_resid);
+    constexpr int LDSW = WNC + 4;       // scratch row stride in floats
+    if (geglu) {   // launch-side guarantees: NI even, no split-K, N % 8 == 0, ldc % 8 == 0, no rowvec / residual
+        if constexpr (NI % 2 == 0) {
+            constexpr int WNO = WNC / 2;     // output columns of a wave tile
+            constexpr int LDSW2 = WNO + 4;
+            __syncthreads();
+            float* scr = reinterpret_cast<float*>(smem_x32 + wave * (16 * LDSW2 * 4));
+            const int nw0 = n0 + wn * WNO;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int mrow0 = m0 + (wm * MI + mi) * 16;
+#pragma unroll
+                for (int j = 0; j < NI / 2; ++j) {
+                    const int n = nw0 + j * 16 + g4 * 4;
+                    f32x4 v = acc[mi][2 * j], g = acc[mi][2 * j + 1];
+                    if (p.bias && n < p.N) {
+                        v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                        g += *reinterpret_cast<const f32x4*>(p.bias + p.N + n);
+                    }
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = v[e] * (0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752440f)));
+                    *reinterpret_cast<f32x4*>(scr + c15 * LDSW2 + j * 16 + g4 * 4) = o;
+                }
+                __builtin_amdgcn_wave_barrier();
+                constexpr int CH = WNO / 4;
+#pragma unroll
+                for (int q0 = 0; q0 < 16 * CH; q0 += 64) {
+                    const int q = q0 + lane;
+                    const int row = q / CH, c4 = q - row * CH;
+                    const int m = mrow0 + row, n = nw0 + c4 * 4;
+                    if (q < 16 * CH && m < p.M && n < p.N)
+                        *reinterpret_cast<f32x4*>(p.C + (long long)m * p.ldc + n) = *reinterpret_cast<const f32x4*>(scr + row * LDSW2 + c4 * 4);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    }
+    const SlabStore slab(Cf, split ? p.slab_stride : 0, split && p.counters && p.slab_wt);
+    if (vec_ok) {
+        __syncthreads();                // every wave is done with the last k tile
+        float* scr = reinterpret_cast<float*>(smem_x32 + wave * (16 * LDSW * 4));
+        const int nw0 = n0 + wn * WNC;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int mrow0 = m0 + (wm * MI + mi) * 16;
+            {
+                const int m = mrow0 + c15;
+                const int smp = (m < p.M ? m : 0) / HoWo;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int n = nw0 + ni * 16 + g4 * 4;
+                    f32x4 v = acc[mi][ni];
+                    if (!split && n < p.N) {
+                        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                        if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)smp * p.rowvec_stride + n);
+                    }
+                    *reinterpret_cast<f32x4*>(scr + c15 * LDSW + ni * 16 + g4 * 4) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            constexpr int CH = WNC / 4;   // 16-byte chunks per row
+#pragma unroll
+            for (int q0 = 0; q0 < 16 * CH; q0 += 64) {
+                const int q = q0 + lane;
+                const int row = q / CH, c4 = q - row * CH;
+                const int m = mrow0 + row, n = nw0 + c4 * 4;
+                if (q < 16 * CH && m < p.M && n < p.N) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * LDSW + c4 * 4);
+                    if (has_resid) v += *reinterpret_cast<const f32x4*>(p.resid + (long long)m * p.ldr + n);
+                    if (split) slab.store((long long)m * ldc + n, v);
+                    else *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+    // odd strides / N not a multiple of 4: element-wise stores straight from the accumulators
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + (wm * MI + mi) * 16 + c15;
+        if (m >= p.M) continue;
+        const int smp = m / HoWo;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + (wn * NI + ni) * 16 + g4 * 4;
+            if (n >= p.N) continue;
+            const f32x4 v = acc[mi][ni];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (n + r < p.N) {
+                    float sv = v[r];
+                    if (!split) {
+                        if (p.bias) sv += p.bias[n + r];
+                        if (p.rowvec) sv += p.rowvec[(long long)smp * p.rowvec_stride + n + r];
+                        if (p.resid) sv += p.resid[(long long)m * p.ldr + n + r];
+                    }
+                    Cf[(long long)m * ldc + n + r] = sv;
+                }
+            }
+        }
+    }
+    }
+    if (split && p.counters) {
+        if (splitk_arrive(p.counters, lid, p.splits, reinterpret_cast<unsigned*>(smem_x32), p.slab_wt != 0)) splitk_reduce_tile<false>(p, m0, n0, BM, BN);
+    }
+}
+
+}  // namespace sdmi

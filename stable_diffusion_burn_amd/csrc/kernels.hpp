@@ -19,6 +19,7 @@ namespace sdmi {
 struct ConvGemm {
     const float* A;       // source activations [NB][Hs][Ws][Cin]
     const float* Bt;      // packed weights [N][K]
+    const void* Bt3;      // split kernel (k_gemm3x.hip): the same weights as three bf16 planes, [N][K / 32][3][32]
     float* C;             // output [M][ldc]
     float* slabs;         // splits > 1: fp32 partial sums [splits][M][N]
     int slab_wt;          // with counters: slab tiles are stored write-through (sc1) and published without a release fence
@@ -45,6 +46,7 @@ struct ConvGemm {
     const void* zero_page;      // >= 16 readable zero bytes (large-tile kernels: source of padded / out-of-range lanes)
     const void* a_scale;        // fp8 kernel: E8M0 scales of A, [pixels][a_ld / 32] bytes (a_ld = padded channel count = bytes per pixel)
     const void* b_scale;        // fp8 kernel: E8M0 scales of Bt, [N][b_ld / 32] bytes
+    int variant;                // k_gemm3x.hip: bit 0 = DMA issued in one block per k tile (A/B switch, option gemm3x_variant)
     int geglu;                  // large-tile kernels: Bt holds 2 N rows (N value rows, then N gate rows; bias likewise) and the
                                 // epilogue writes value * gelu_erf(gate) -- GEGLU::forward (unet/mod.rs:579-591) without the [M, 2N] tensor
 };
@@ -64,6 +66,12 @@ const GemmTileInfo& gemm_tile_info_x(int cfg);
 hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 // the same structure for fp32 storage (k_gemm2x.hip; Cin % 32 == 0, fp32 output); same tile list
 hipError_t launch_conv_gemm2x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
+// fp32 on the bf16 matrix pipe: operands as exact sums of three bf16 terms, six partial products (k_gemm3x.hip); its own tile
+// list; needs p.Bt3 (launch_pack_split3 of the packed fp32 rows, once at load)
+constexpr int kNumGemmTilesS = 6;
+const GemmTileInfo& gemm_tile_info_s(int cfg);
+hipError_t launch_conv_gemm3x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
+hipError_t launch_pack_split3(const float* bt, void* w3, long long rows, int K, hipStream_t s);
 // MXFP8 (e4m3 + E8M0 block scales) 256-row LDS-DMA kernel on v_mfma_scale_f32_16x16x128_f8f6f4 (k_fp8.hip); its own tile list
 constexpr int kNumGemmTilesQ = 3;
 const GemmTileInfo& gemm_tile_info_q(int cfg);

@@ -202,6 +202,78 @@ def test_conv2d_large_tiles(sd_ops, tile, splitk, case):
     _check(got, ref.numpy(), f"conv large tile={tile} splitk={splitk} {case}")
 
 
+STILES = [200, 201, 202, 203, 204, 205]
+
+
+@pytest.mark.parametrize("variant", [0, 1])      # next k tile's DMA between the MFMAs / in one block behind the barrier
+@pytest.mark.parametrize("tile", STILES)
+@pytest.mark.parametrize("splitk", [1, 3])
+@pytest.mark.parametrize("case", XCASES)
+def test_conv2d_split_bf16_tiles(sd_ops, tile, splitk, case, variant):
+    """k_gemm3x.hip: fp32 operands as exact sums of three bf16 terms, six partial products on the bf16 matrix pipe
+    (tile 200 + x) -- held to the same bar as the fp32-MFMA kernels."""
+    n, cin, h, w, cout, k, stride, ups = case
+    g = _rng(5000 + tile + 7 * splitk + cin + cout)
+    x = g.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (g.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k)).astype(np.float32)
+    b = g.standard_normal(cout).astype(np.float32)
+    try:
+        sd_ops.set_option("gemm3x_variant", variant)
+        sd_ops.set_option("gemm_tile", tile)
+        sd_ops.set_option("splitk", splitk)
+        got = sd_ops.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
+    finally:
+        sd_ops.set_option("gemm3x_variant", 0)
+        sd_ops.set_option("gemm_tile", "auto")
+        sd_ops.set_option("splitk", 0)
+    xin = O.upsample2x(_t(x)) if ups else _t(x)
+    ref = O.conv2d(xin, (_t(wt), _t(b)), stride=stride, padding=1 if k == 3 else 0)
+    _check(got, ref.numpy(), f"conv split-bf16 tile={tile} splitk={splitk} variant={variant} {case}")
+
+
+def test_conv2d_split_bf16_is_fp32_accurate(sd_ops):
+    """What the three-way split costs, measured: on a K = 11520 convolution whose inputs span ten binary orders of
+    magnitude per channel, the split kernel's error against the fp64 oracle is of the size of the fp32-MFMA kernel's own
+    (both are fp32 accumulations of essentially exact products; measured 2.8e-6 against 4.6e-6 of max|ref|), inside the
+    2e-5 bar -- no bf16-sized (4e-3) or two-term-sized (1.5e-5 per product) error appears."""
+    n, cin, h, w, cout = 1, 1280, 16, 16, 320
+    g = _rng(777)
+    x = (g.standard_normal((n, cin, h, w)) * np.exp2(g.integers(-5, 6, (1, cin, 1, 1)))).astype(np.float32)
+    wt = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9) * np.exp2(g.integers(-3, 4, (cout, 1, 1, 1)))).astype(np.float32)
+    ref = O.conv2d(_t(x), (_t(wt), None), padding=1).numpy()
+    scale = np.abs(ref).max()
+    errs = {}
+    try:
+        for name, tile in (("fp32 mfma 128x320x", 103), ("split 128x320s", 201), ("split 256x128s", 202)):
+            sd_ops.set_option("gemm_tile", tile)
+            sd_ops.set_option("splitk", 1)
+            got = sd_ops.op_conv2d(x, wt, None)
+            errs[name] = float(np.abs(got - ref).max() / scale)
+    finally:
+        sd_ops.set_option("gemm_tile", "auto")
+        sd_ops.set_option("splitk", 0)
+    print("max |gpu - fp64| / max|ref|, K = 11520: " + ", ".join(f"{k}: {v:.2e}" for k, v in errs.items()))
+    assert errs["split 128x320s"] < 3.0 * errs["fp32 mfma 128x320x"] + 1e-7
+    assert errs["split 256x128s"] < 3.0 * errs["fp32 mfma 128x320x"] + 1e-7
+    assert max(errs.values()) < 1e-5
+
+
+def test_conv2d_split_bf16_exact_on_small_integers(sd_ops):
+    """Integers up to 2^16 need the low planes (bf16 alone keeps 8 bits): products and sums below 2^24 are exact in the split
+    kernel, bit for bit."""
+    g = _rng(31337)
+    x = g.integers(-300, 301, (1, 64, 9, 9)).astype(np.float32)
+    wt = g.integers(-40, 41, (64, 64, 3, 3)).astype(np.float32)
+    try:
+        sd_ops.set_option("gemm_tile", 205)
+        got = sd_ops.op_conv2d(x, wt, None)
+    finally:
+        sd_ops.set_option("gemm_tile", "auto")
+    ref = O.conv2d(_t(x), (_t(wt), None), padding=1).numpy()
+    assert np.abs(ref).max() < 2 ** 24
+    assert np.array_equal(got.astype(np.float64), ref)
+
+
 def test_conv2d_asymmetric_weights_not_transposed(sd_ops):
     """A = identity-like check with an asymmetric kernel: catches tap (ky,kx) swaps."""
     x = np.zeros((1, 32, 6, 6), np.float32)

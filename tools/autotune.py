@@ -64,10 +64,14 @@ def main():
     ap.add_argument("--only", default="", help="n,cin,h,w,cout,k,stride,ups : time just this shape (for rocprofv3 --pmc runs)")
     ap.add_argument("--cfg", type=int, default=-1)
     ap.add_argument("--splits", type=int, default=0)
-    ap.add_argument("--variant", type=int, default=1, help="gemm kernel generation: 1 = k_gemm2.hip, 0 = k_gemm.hip")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32", help="bf16: k_gemm_bf16.hip tiles 0..9 + k_gemm_bf16x.hip tiles 100..103")
     ap.add_argument("--batch", type=int, default=1, help="images per GPU: scales the n of every shape (the lists are for 1 image)")
     ap.add_argument("--append", action="store_true", help="append to --emit instead of overwriting")
+    ap.add_argument("--families", default="old,x,s", help="fp32 candidates: old = k_gemm2.hip tiles 0..9, x = k_gemm2x.hip 100..103, "
+                    "s = k_gemm3x.hip 200..205 (fp32 on the bf16 matrix pipe)")
+    ap.add_argument("--merge", default="", help="existing 'M,N,K=cfg,splits' table: its entry is timed as one more candidate for "
+                    "its shape, and --emit writes the whole table with the winners replaced")
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
     args = ap.parse_args()
     bf16 = args.precision == "bf16"
     shapes = QUICK if args.quick else (UNET_SHAPES + (VAE_SHAPES if args.vae else []))
@@ -86,15 +90,27 @@ def main():
     if bf16:
         shapes = [sh for sh in shapes if sh[1] % 64 == 0]     # Cin = 4 layers run on the fp32 kernel
     sd = StableDiffusion(ModelConfig(64, 1, 64, 8, 8, 64, precision=1) if bf16 else ModelConfig(32, 1, 32, 8, 8, 32))
-    sd.set_option("gemm_variant", args.variant)
     sd.set_option("tune_clear", 1)
-    tiles_all = dict(enumerate(TILES))
-    tiles_all.update({100: "256x320", 101: "256x256", 102: "256x128", 103: "128x320"})   # k_gemm_bf16x.hip / k_gemm2x.hip
+    for kv in args.opt:
+        k, v = kv.split("=", 1)
+        sd.set_option(k, v)
+    fams = set(args.families.split(","))
+    tiles_all = dict(enumerate(TILES)) if (bf16 or "old" in fams) else {}
+    if bf16 or "x" in fams:
+        tiles_all.update({100: "256x320", 101: "256x256", 102: "256x128", 103: "128x320"})   # k_gemm_bf16x.hip / k_gemm2x.hip
+    if not bf16 and "s" in fams:
+        tiles_all.update({200: "256x160", 201: "128x320", 202: "256x128", 203: "128x256", 204: "128x160", 205: "128x128"})   # k_gemm3x.hip
+    merged = {}
+    if args.merge:
+        for ln in Path(args.merge).read_text().splitlines():
+            if "=" in ln and not ln.startswith("#"):
+                key, val = ln.strip().split("=")
+                merged[key] = tuple(int(v) for v in val.split(","))
     if args.only:
         s = tuple(int(v) for v in args.only.split(","))
         M, N, K = mnk(s)
         ms = sd.bench_conv(*s[:5], k=s[5], stride=s[6], upsample2x=s[7], tile_cfg=args.cfg, splitk=args.splits, iters=args.iters)
-        print(f"{s} cfg={args.cfg} splits={args.splits} variant={args.variant}: {ms:.4f} ms {2.0 * M * N * K / ms / 1e9:.1f} TF")
+        print(f"{s} cfg={args.cfg} splits={args.splits}: {ms:.4f} ms {2.0 * M * N * K / ms / 1e9:.1f} TF")
         return
     results = []
     t_start = time.time()
@@ -108,7 +124,7 @@ def main():
             if bf16 and cfg < 100 and M * N > (1 << 24) and cfg in (2, 8):
                 continue   # 64-row tiles on very large GEMMs: never competitive, skip the launches
             if cfg >= 100 and not bf16 and s[1] % 32:
-                continue   # the large-tile fp32 kernel needs Cin % 32 == 0
+                continue   # the large-tile fp32 kernels need Cin % 32 == 0
             tiles = -(-M // bm) * -(-N // bn)
             split_opts = [1]
             for sp in (2, 3, 4, 6, 8, 12, 16, 24, 32):
@@ -123,7 +139,14 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     print(f"  {s} cfg={cfg} sp={sp}: {e}")
                     continue
-                cands.append({"cfg": cfg, "tile": tiles_all[cfg] + ("x" if cfg >= 100 else ""), "splits": sp, "ms": ms, "tflops": flops / ms / 1e9})
+                cands.append({"cfg": cfg, "tile": tiles_all[cfg] + ("s" if cfg >= 200 else "x" if cfg >= 100 else ""), "splits": sp, "ms": ms, "tflops": flops / ms / 1e9})
+        prev = merged.get(f"{M},{N},{K}")
+        if prev:
+            try:
+                ms = sd.bench_conv(*s[:5], k=s[5], stride=s[6], upsample2x=s[7], tile_cfg=prev[0], splitk=prev[1], iters=args.iters if flops < 5e11 else 2)
+                cands.append({"cfg": prev[0], "tile": f"table:{prev[0]}", "splits": prev[1], "ms": ms, "tflops": flops / ms / 1e9})
+            except Exception as e:  # noqa: BLE001
+                print(f"  {s} table entry {prev}: {e}")
         if not cands:
             continue
         best = min(cands, key=lambda c: c["ms"])
@@ -136,9 +159,15 @@ def main():
     Path(args.out).parent.mkdir(parents=True, exist_ok=True)
     Path(args.out).write_text(json.dumps(results, indent=1))
     if args.emit:
+        for r in results:
+            merged[f"{r['M']},{r['N']},{r['K']}"] = (r["best"]["cfg"], r["best"]["splits"])
         with open(args.emit, "a" if args.append else "w") as f:
-            for r in results:
-                f.write(f"{r['M']},{r['N']},{r['K']}={r['best']['cfg']},{r['best']['splits']}\n")
+            if args.merge:
+                for key, (cfg, sp) in merged.items():
+                    f.write(f"{key}={cfg},{sp}\n")
+            else:
+                for r in results:
+                    f.write(f"{r['M']},{r['N']},{r['K']}={r['best']['cfg']},{r['best']['splits']}\n")
     tot = sum(2.0 * r["M"] * r["N"] * r["K"] * r["count"] for r in results)
     tb = sum(r["best"]["ms"] * r["count"] for r in results)
     th = sum(r["heuristic_ms"] * r["count"] for r in results)
