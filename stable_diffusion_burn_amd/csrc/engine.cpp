@@ -938,6 +938,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "fp8_min_rows") opt_fp8_min_rows_ = std::stoi(value);
     else if (key == "fp8_tile") opt_fp8_tile_ = (value == "auto") ? -1 : std::stoi(value);
     else if (key == "attn_bf16") opt_attn_bf16_ = std::stoi(value);
+    else if (key == "attn_split") opt_attn_split_ = std::stoi(value);
     else if (key == "gemm_bf16x") opt_gemm_bf16x_ = std::stoi(value);
     else if (key == "gemm_x32") opt_gemm_x32_ = std::stoi(value);
     else if (key == "gemm_f32s") opt_gemm_f32s_ = std::stoi(value);
@@ -1260,6 +1261,7 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
         const double fl = 4.0 * n * n_head * (double)nq * nk * d_head;
         ProfScope ps(this, PC_ATTENTION, fl);
         if (dt && opt_attn_bf16_ && (d_head == 40 || d_head == 80 || d_head == 160)) SDMI_HIP(launch_attention_bf16(p, stream_));
+        else if (!dt && opt_attn_split_ && attn_split_supported(p)) SDMI_HIP(launch_attention_split(p, stream_));
         else SDMI_HIP(launch_attention(p, stream_));
         count_kernel(fl);
         return;

@@ -1,0 +1,359 @@
+// k_attn_split.hip -- fp32 qkv_attention (attention.rs:5-45) on the bf16 matrix pipe, precision = 0, head dims 40 / 80.
+//
+// The same idea as k_gemm3x.hip: an fp32 number is exactly the sum of three bf16 numbers (x = h + m + l, round-to-nearest
+// splits), a bf16 x bf16 product is exact in fp32, and the MFMA accumulates in fp32 -- so S = Q K^T and O = P V are computed
+// with fp32 q / k / v / probabilities as six bf16 MFMAs per block (the partial products >= 2^-24 of the product; per-product
+// error <= 2^-25).  Scores, running max, exponentials, row sums and the output stay fp32; q/k/v/o are fp32 in HBM.
+// v_mfma_f32_16x16x4_f32 retires 256 flop/clk/CU, six v_mfma_f32_32x32x16_bf16 per fp32 block 683: the fp32 flash kernel
+// (k_attn.hip, 87 TFLOP/s at d = 40) is bound by the former.
+//
+// Structure and operand layouts are those of k_attn_bf16.hip (a wave owns 32 query rows, S^T = K Q^T so the softmax is
+// lane-local, the packed probabilities ARE the B operand of O^T = V^T P^T, V^T fragments by the LDS transpose read), with
+//   * K / V tiles of 64 keys staged through registers: a thread splits the 8 floats it loaded and writes three 16-byte chunks,
+//     one per plane -- the LDS images are [buffer][plane][key][row stride] bf16, same strides as the bf16 kernel;
+//   * Q fragments split once per workgroup into registers; the probabilities split right after the exponentials, 32 keys at a time.
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+namespace sdmi {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <int D, int NW>
+struct AttnSpCfg {
+    static constexpr int NT = NW * 64;
+    static constexpr int BKV = 64;                           // keys per tile
+    static constexpr int KT = BKV / 32;                      // 32-key score tiles per K/V tile
+    static constexpr int DK = (D + 15) / 16 * 16;            // contraction width of K Q^T (48 / 80)
+    static constexpr int KS = DK / 16;
+    static constexpr int NDT = (D + 31) / 32;                // 32-row tiles of O^T (2 / 3)
+    static constexpr int KCH = DK / 8;                       // 16-byte bf16 chunks per K row holding data or zeros
+    static constexpr int RSK = (KCH | 1) * 16;               // K row stride, odd chunk count (112 / 176 B)
+    static constexpr int RSV = 192;                          // V row stride = 64 (mod 256) bytes; NDT * 64 <= 192
+    static constexpr int K_BYTES = BKV * RSK;                // one plane of one buffer
+    static constexpr int V_BYTES = BKV * RSV;
+    static constexpr int CHUNKS = BKV * (D / 8);             // 8-element chunks of one K (or V) tile
+    static constexpr int NLD = (CHUNKS + NT - 1) / NT;
+    static constexpr size_t LDS_BYTES = 2 * 3 * (size_t)(K_BYTES + V_BYTES);
+    static_assert(NDT * 64 <= RSV, "V rows must hold every d tile");
+    static_assert(D % 8 == 0, "8-element chunks");
+};
+
+__device__ __forceinline__ float sp_partner_max(float v) {  // max with lane l ^ 32
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float sp_partner_sum(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ unsigned sp_pack(float lo, float hi) {   // v_cvt_pk_bf16_f32 (RNE)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+// (a, b) -> packed bf16 pairs h, m, l with a = h.lo + m.lo + l.lo and b = h.hi + m.hi + l.hi exactly
+__device__ __forceinline__ void sp_split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = sp_pack(a, b);
+    const f32x2 r = f32x2{a, b} - f32x2{__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
+    m = sp_pack(r[0], r[1]);
+    const f32x2 r2 = r - f32x2{__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xffff0000u)};
+    l = sp_pack(r2[0], r2[1]);
+}
+__device__ __forceinline__ void sp_split8(const f32x4 x0, const f32x4 x1, u32x4& h, u32x4& m, u32x4& l) {
+    unsigned a[4], b[4], c[4];
+    sp_split2(x0[0], x0[1], a[0], b[0], c[0]);
+    sp_split2(x0[2], x0[3], a[1], b[1], c[1]);
+    sp_split2(x1[0], x1[1], a[2], b[2], c[2]);
+    sp_split2(x1[2], x1[3], a[3], b[3], c[3]);
+    h = u32x4{a[0], a[1], a[2], a[3]};
+    m = u32x4{b[0], b[1], b[2], b[3]};
+    l = u32x4{c[0], c[1], c[2], c[3]};
+}
+__device__ __forceinline__ bf16x8 sp_bf(const u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p) {
+    using Cfg = AttnSpCfg<D, NW>;
+    constexpr int NT = Cfg::NT, BKV = Cfg::BKV, KS = Cfg::KS, NDT = Cfg::NDT, RSK = Cfg::RSK, RSV = Cfg::RSV, NLD = Cfg::NLD;
+    constexpr int KT = Cfg::KT;
+    constexpr int CPR = D / 8;  // chunks per row
+    constexpr float kLog2e = 1.4426950408889634f;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_sp[];
+    unsigned char* Ks = smem_sp;                            // [buffer][plane][key][RSK]
+    unsigned char* Vs = smem_sp + 6 * Cfg::K_BYTES;         // [buffer][plane][key][RSV]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int hi = lane >> 5;
+    const int c = lane & 31;
+
+    const int b = blockIdx.y / p.n_head;
+    const int hh = blockIdx.y - b * p.n_head;
+    const int qrow = blockIdx.x * (32 * NW) + wave * 32 + c;
+    const bool q_ok = qrow < p.nq;
+
+    const float* Qf = p.q + (long long)b * p.q_bs + hh * D;
+    const float* Kf = p.k + (long long)b * p.k_bs + hh * D;
+    const float* Vf = p.v + (long long)b * p.v_bs + hh * D;
+    float* Of = p.o + (long long)b * p.o_bs + hh * D;
+
+    const int nk = p.kv_len ? p.kv_len[b] : p.nk;
+    const int n_tiles = (nk + BKV - 1) / BKV;
+    const int n_full = nk / BKV;
+    const float cs = p.scale * p.scale * kLog2e;  // scores -> log2 units
+
+    if constexpr (Cfg::DK > D) {  // zero the K columns D..DK-1 of every plane once (the staging never touches them)
+        for (int i = tid; i < 6 * BKV; i += NT)
+            *reinterpret_cast<u32x4*>(Ks + (i / BKV) * Cfg::K_BYTES + (i % BKV) * RSK + CPR * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    // Q^T fragments, split: B[k = 16 s + 8 hi + j][n = query]
+    u32x4 qh[KS], qm[KS], ql[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+        const int col = 16 * s + 8 * hi;
+        if (q_ok && col < D) {
+            x0 = *reinterpret_cast<const f32x4*>(Qf + (long long)qrow * p.ldq + col);
+            x1 = *reinterpret_cast<const f32x4*>(Qf + (long long)qrow * p.ldq + col + 4);
+        }
+        sp_split8(x0, x1, qh[s], qm[s], ql[s]);
+    }
+
+    f32x4 rk[NLD][2], rv[NLD][2];
+    auto gload = [&](int tile) {
+        const int kv0 = tile * BKV;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * NT;
+            const int row = idx / CPR;
+            const int c8 = idx - row * CPR;
+            const int key = kv0 + row;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            rk[i][0] = z; rk[i][1] = z; rv[i][0] = z; rv[i][1] = z;
+            if (idx < Cfg::CHUNKS && key < nk) {
+                const float* ks = Kf + (long long)key * p.ldk + c8 * 8;
+                const float* vs = Vf + (long long)key * p.ldv + c8 * 8;
+                rk[i][0] = *reinterpret_cast<const f32x4*>(ks);
+                rk[i][1] = *reinterpret_cast<const f32x4*>(ks + 4);
+                rv[i][0] = *reinterpret_cast<const f32x4*>(vs);
+                rv[i][1] = *reinterpret_cast<const f32x4*>(vs + 4);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * NT;
+            if (idx < Cfg::CHUNKS) {
+                const int row = idx / CPR;
+                const int c8 = idx - row * CPR;
+                u32x4 h, m, l;
+                sp_split8(rk[i][0], rk[i][1], h, m, l);
+                unsigned char* kd = Ks + buf * 3 * Cfg::K_BYTES + row * RSK + c8 * 16;
+                *reinterpret_cast<u32x4*>(kd) = h;
+                *reinterpret_cast<u32x4*>(kd + Cfg::K_BYTES) = m;
+                *reinterpret_cast<u32x4*>(kd + 2 * Cfg::K_BYTES) = l;
+                sp_split8(rv[i][0], rv[i][1], h, m, l);
+                unsigned char* vd = Vs + buf * 3 * Cfg::V_BYTES + row * RSV + c8 * 16;
+                *reinterpret_cast<u32x4*>(vd) = h;
+                *reinterpret_cast<u32x4*>(vd + Cfg::V_BYTES) = m;
+                *reinterpret_cast<u32x4*>(vd + 2 * Cfg::V_BYTES) = l;
+            }
+        }
+    };
+
+    f32x16 o[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY;  // running row max, raw score units
+    float l_run = 0.f;        // this lane's share of the row sum
+
+    // per-lane LDS offsets: K fragment row c, chunk hi; V transpose-read row 4 hi + (i >> 2), columns 16 (G & 1) + 4 (i & 3)
+    const int k_off = c * RSK + hi * 16;
+    const int i16 = lane & 15;
+    const int v_off = (4 * hi + (i16 >> 2)) * RSV + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int cur = tile & 1;
+        const bool more = (tile + 1) < n_tiles;
+        if (more) gload(tile + 1);
+
+        const unsigned char* Kt = Ks + cur * 3 * Cfg::K_BYTES + k_off;
+        const unsigned char* Vt = Vs + cur * 3 * Cfg::V_BYTES + v_off;
+        const int kv0 = tile * BKV;
+
+        // ---- S^T = K Q^T: six partial products, smallest first; the two 32-key tiles alternate (independent accumulators)
+        f32x16 s[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 kf[KT][3];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) kf[kt][pl] = *reinterpret_cast<const u32x4*>(Kt + pl * Cfg::K_BYTES + kt * 32 * RSK + ks * 32);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(kf[kt][2]), sp_bf(qh[ks]), s[kt], 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(kf[kt][0]), sp_bf(ql[ks]), s[kt], 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(kf[kt][1]), sp_bf(qm[ks]), s[kt], 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(kf[kt][1]), sp_bf(qh[ks]), s[kt], 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(kf[kt][0]), sp_bf(qm[ks]), s[kt], 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(kf[kt][0]), sp_bf(qh[ks]), s[kt], 0, 0, 0);
+        }
+
+        if (tile >= n_full) {  // ragged last tile (uniform)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= nk) s[kt][r] = -INFINITY;
+                }
+        }
+
+        float mt = s[0][0];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kt][r]);
+        mt = sp_partner_max(mt);
+        const float m_new = fmaxf(m_run, mt);
+        const float mc = m_new * cs;
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
+        m_run = m_new;
+        if (__any(alpha != 1.0f)) {  // the running max moved somewhere in the wave
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
+        }
+
+        // ---- per 32-key tile: probabilities (fp32), their three-way split, and O^T += V^T P^T for its two 16-key steps
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            unsigned pa[2][4], pb[2][4], pc[2][4];     // [16-key step of this tile][4 dwords = 8 bf16] x (h, m, l)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], cs, -mc));
+                const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r + 1], cs, -mc));
+                psum += e0 + e1;
+                sp_split2(e0, e1, pa[r >> 3][(r & 7) >> 1], pb[r >> 3][(r & 7) >> 1], pc[r >> 3][(r & 7) >> 1]);
+            }
+            u32x4 ph[2], pm[2], pl[2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                ph[h2] = u32x4{pa[h2][0], pa[h2][1], pa[h2][2], pa[h2][3]};
+                pm[h2] = u32x4{pb[h2][0], pb[h2][1], pb[h2][2], pb[h2][3]};
+                pl[h2] = u32x4{pc[h2][0], pc[h2][1], pc[h2][2], pc[h2][3]};
+            }
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int st = kt * 2 + h2;
+                u32x4 vf[NDT][3];
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                    for (int pn = 0; pn < 3; ++pn) {
+                        const unsigned char* vb = Vt + pn * Cfg::V_BYTES + st * 16 * RSV + dt * 64;
+                        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_s16x4*>((const lds_s16x4*)vb));
+                        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_s16x4*>((const lds_s16x4*)(vb + 8 * RSV)));
+                        vf[dt][pn] = __builtin_bit_cast(u32x4, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(vf[dt][2]), sp_bf(ph[h2]), o[dt], 0, 0, 0);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(vf[dt][0]), sp_bf(pl[h2]), o[dt], 0, 0, 0);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(vf[dt][1]), sp_bf(pm[h2]), o[dt], 0, 0, 0);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(vf[dt][1]), sp_bf(ph[h2]), o[dt], 0, 0, 0);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(vf[dt][0]), sp_bf(pm[h2]), o[dt], 0, 0, 0);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(vf[dt][0]), sp_bf(ph[h2]), o[dt], 0, 0, 0);
+            }
+        }
+        l_run = l_run * alpha + psum;
+
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    const float inv = 1.0f / sp_partner_sum(l_run);
+    if (q_ok) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int dcol = 32 * dt + 8 * rq + 4 * hi;
+                if (dcol < D) {
+                    const f32x4 w = {o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv, o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv};
+                    *reinterpret_cast<f32x4*>(Of + (long long)qrow * p.ldo + dcol) = w;
+                }
+            }
+        }
+    }
+}
+
+template <int D, int NW>
+static hipError_t launch_attn_split_d(const AttnParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    auto k = attn_split_kernel<D, NW>;
+    const size_t lds = AttnSpCfg<D, NW>::LDS_BYTES;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((p.nq + 32 * NW - 1) / (32 * NW), p.n * p.n_head);
+    hipLaunchKernelGGL(k, grid, dim3(NW * 64), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int D>
+static hipError_t launch_attn_split_any(const AttnParams& p, hipStream_t stream) {
+    // widest workgroup that still gives every CU a workgroup (256 CUs)
+    const long long bh = (long long)p.n * p.n_head;
+    if ((long long)((p.nq + 255) / 256) * bh >= 256) return launch_attn_split_d<D, 8>(p, stream);
+    return launch_attn_split_d<D, 4>(p, stream);
+}
+
+bool attn_split_supported(const AttnParams& p) {
+    return !p.bf16 && !p.mask && (p.d_head == 40 || p.d_head == 80) && !((p.ldq | p.ldk | p.ldv | p.ldo) & 3);
+}
+
+// fp32 q/k/v/o, no additive mask, d_head 40 or 80, 16-byte aligned rows (attn_split_supported)
+hipError_t launch_attention_split(const AttnParams& p, hipStream_t stream) {
+    if (!attn_split_supported(p)) return hipErrorInvalidValue;
+    if (p.d_head == 40) return launch_attn_split_any<40>(p, stream);
+    return launch_attn_split_any<80>(p, stream);
+}
+
+}  // namespace sdmi

@@ -105,6 +105,9 @@ struct AttnParams {
 };
 bool attn_supported_head_dim(int d);
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
+// fp32 q/k/v/o on the bf16 matrix pipe, three-way split operands (k_attn_split.hip): d_head 40 / 80, no additive mask
+bool attn_split_supported(const AttnParams& p);
+hipError_t launch_attention_split(const AttnParams& p, hipStream_t stream);
 // bf16 matrix-core kernel (k_attn_bf16.hip): p.bf16 set, no additive mask
 hipError_t launch_attention_bf16(const AttnParams& p, hipStream_t stream);
 // row softmax (in place) for the unfused single-head VAE attention: x[rows][cols] *= scale first

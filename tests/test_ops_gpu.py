@@ -350,6 +350,29 @@ def test_qkv_attention(sd_ops, case):
     _check(got, ref.numpy(), f"qkv_attention{case}")
 
 
+@pytest.mark.parametrize("case", [(2, 1024, 1024, 320, 8), (1, 300, 77, 640, 8), (1, 200, 333, 160, 4)])
+def test_qkv_attention_split_is_fp32_accurate(sd_ops, case):
+    """k_attn_split.hip (fp32 q/k/v as three bf16 terms each, six partial products on the bf16 matrix pipe, fp32 softmax)
+    against k_attn.hip (fp32 matrix instruction): same bar, and an error of the same size against the fp64 oracle."""
+    n, nq, nk, c, heads = case
+    g = _rng(4321 + nq)
+    q = (g.standard_normal((n, nq, c)) * 1.5).astype(np.float32)
+    k = (g.standard_normal((n, nk, c)) * 1.5).astype(np.float32)
+    v = (g.standard_normal((n, nk, c)) * np.exp2(g.integers(-4, 5, (1, 1, c)))).astype(np.float32)
+    ref = O.qkv_attention(_t(q), _t(k), _t(v), None, heads).numpy()
+    errs = {}
+    try:
+        for mode in (1, 0):
+            sd_ops.set_option("attn_split", mode)
+            got = sd_ops.qkv_attention(q, k, v, None, heads)
+            _check(got, ref, f"qkv_attention{case} attn_split={mode}")
+            errs[mode] = float(np.abs(got - ref).max() / np.abs(ref).max())
+    finally:
+        sd_ops.set_option("attn_split", 1)
+    print(f"attention {case}: max |gpu - fp64| / max|ref|: split {errs[1]:.2e}, fp32 mfma {errs[0]:.2e}")
+    assert errs[1] < 3.0 * errs[0] + 2e-7
+
+
 def test_qkv_attention_causal_mask(sd_ops):
     """attn_decoder_mask (attention.rs:47-56) as the additive mask."""
     n, s, c, heads = 1, 77, 320, 8
