@@ -294,7 +294,8 @@ def main():
         for (prec2, b2, s2, k2) in (("fp32", 1, 20, 3), ("bf16", 16, 50, 2), ("bf16", 8, 20, 3), ("fp8", 16, 20, 2)):
             idx = list(range(b2))
             # the headline configuration once more with every GEMM on the fp32 matrix instruction (the split kernel off)
-            opts2, tune2 = (["gemm_f32s=0"], args.tune_file) if prec2 == "fp32" else ([], None)
+            # (with the tile table that was tuned for those kernels: tuning/gfx950_fp32_mfma.txt)
+            opts2, tune2 = (["gemm_f32s=0", "attn_split=0"], str(ROOT / "stable_diffusion_burn_amd" / "tuning" / "gfx950_fp32_mfma.txt")) if prec2 == "fp32" else ([], None)
             r2 = Runner(torch, np, dev, local_rank, prec2, b2, s2, args.scale, cond, uncond, idx, flat, opts2, tune2)
             e2 = r2.timed(k2, 1, barrier)
             roof2, prof2 = r2.roofline()
@@ -307,7 +308,7 @@ def main():
                      "whole_path_frac_of_bf16_mfma_peak": v2 * fpi / 1e12 / BF16_MFMA_PEAK_TFLOPS, "roofline": roof2,
                      "weights_load_s": r2.t_load}
             if prec2 == "fp32":
-                entry["config"]["workload"] += "; GEMMs on v_mfma_f32_16x16x4_f32 only (option gemm_f32s=0)"
+                entry["config"]["workload"] += "; every GEMM and attention on v_mfma_f32_16x16x4_f32 (options gemm_f32s=0, attn_split=0)"
                 entry["whole_path_frac_of_fp32_mfma_peak"] = entry.pop("whole_path_frac_of_bf16_mfma_peak") * BF16_MFMA_PEAK_TFLOPS / FP32_MFMA_PEAK_TFLOPS
             entry.update(r2.class_summary(prof2))
             secondary.append(entry)

@@ -203,6 +203,10 @@ Engine::Engine(const sdmi_config& cfg) : cfg_(cfg) {
 #include "tuning_table.inc"
             {nullptr, 0, 0}};
         for (const Row* r = rows; r->key; ++r) tuned_[r->key] = TileChoice{r->cfg, r->splits};
+        static const Row rows_mfma[] = {
+#include "tuning_table_mfma.inc"
+            {nullptr, 0, 0}};
+        for (const Row* r = rows_mfma; r->key; ++r) tuned_mfma_[r->key] = TileChoice{r->cfg, r->splits};
         static const Row rows16[] = {
 #include "tuning_table_bf16.inc"
             {nullptr, 0, 0}};
@@ -962,7 +966,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
             !(tc.cfg < kNumGemmTiles || (tc.cfg >= 100 && tc.cfg < 100 + kNumGemmTilesX) || (!b16 && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS)))
             throw Error(SDMI_ERR_INVALID, "tune: bad value");
         (b16 ? tuned_bf16_ : tuned_)[value.substr(0, eq)] = tc;
-    } else if (key == "tune_clear") { tuned_.clear(); tuned_bf16_.clear(); }
+    } else if (key == "tune_clear") { tuned_.clear(); tuned_bf16_.clear(); tuned_mfma_.clear(); }
     else throw Error(SDMI_ERR_INVALID, "unknown option '" + key + "'");
 }
 
@@ -1084,7 +1088,9 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     // the unfused VAE attention) and the 32-bit piece offsets reach
     const bool s_ok = x32_ok && p.Bt3 && (unsigned long long)p.N * (p.geglu ? 2 : 1) * (unsigned long long)p.kt_total * 192ull < 0xFFFFFF00ull;
     auto usable = [&](int cfg) { return cfg < 100 || (in_dt ? opt_gemm_bf16x_ != 0 : (cfg >= 200 ? (opt_gemm_f32s_ != 0 && s_ok) : (opt_gemm_x32_ != 0 && x32_ok))); };
+    const auto it2 = in_dt ? tuned_mfma_.end() : tuned_mfma_.find(key);   // the table measured without the split kernels
     if (it != table.end() && usable(it->second.cfg)) tc = it->second;
+    else if (it2 != tuned_mfma_.end() && usable(it2->second.cfg)) tc = it2->second;
     else tc = in_dt ? choose_tile_bf16(p.M, p.N, p.kt_total) : choose_tile(p.M, p.N, p.kt_total, x32_ok, s_ok);
     if (opt_force_tile_ >= 0 && (opt_force_tile_ < 100 || in_dt || (opt_force_tile_ >= 200 ? s_ok : x32_ok))) tc.cfg = opt_force_tile_;  // 100+ / 200+: large-tile kernels, where applicable
     if (opt_force_splits_ > 0) tc.splits = opt_force_splits_;

@@ -12,6 +12,10 @@
 //   * K / V tiles of 64 keys staged through registers: a thread splits the 8 floats it loaded and writes three 16-byte chunks,
 //     one per plane -- the LDS images are [buffer][plane][key][row stride] bf16, same strides as the bf16 kernel;
 //   * Q fragments split once per workgroup into registers; the probabilities split right after the exponentials, 32 keys at a time.
+// Measured (rocprofv3 --pmc, 2 x 8 heads x 4096^2, d = 40): matrix pipe 56 % busy, 138 TFLOP/s against 95 for k_attn.hip; 8.4 bf16
+// flops are issued per fp32 flop (6 products x 1.4 for padding d = 40 to 48 in K Q^T and to 64 in V^T P^T).  A software-pipelined
+// variant (S(t+1) issued between the exponentials of tile t, staging between the MFMAs of V^T P^T) measured 3 % SLOWER and was
+// removed: the loop is bound by total issue slots of the two waves per SIMD, not by the order inside one wave.
 #include "kernels.hpp"
 
 #include <hip/hip_runtime.h>

@@ -45,39 +45,64 @@ __device__ __forceinline__ unsigned s3_cvt_pk(float a, float b) {   // v_cvt_pk_
 // x (8 floats of one lane's fragment) -> three packed-bf16 operands, x = h + m + l exactly.  The 36 instructions are exposed
 // one at a time (step s: pair s & 3, phase s >> 2) so that the kernel can place them between matrix instructions itself:
 // consecutive steps belong to different pairs, so a dependent instruction is four issue slots behind its producer.
-struct S3Split {
+// SCALAR = true: the two residual subtractions of a pair are two v_sub_f32 (inline asm, so that hipcc does not re-pack them)
+// instead of one v_pk_add_f32 -- packed fp32 VALU beside MFMAs costs more than its issue slot (MI355X_MICROARCH.md,
+// "price of one filler beside MFMAs").
+template <bool SCALAR>
+struct S3SplitT {
+    static constexpr int kSteps = SCALAR ? 44 : 36;
     f32x2 x[4], hf[4], r[4];
     unsigned hp[4], mp[4];
     u32x4 h, m, l;
     __device__ __forceinline__ void load(const f32x4 x0, const f32x4 x1) {
         x[0] = f32x2{x0[0], x0[1]}; x[1] = f32x2{x0[2], x0[3]}; x[2] = f32x2{x1[0], x1[1]}; x[3] = f32x2{x1[2], x1[3]};
     }
+    static __device__ __forceinline__ float sub(float a, float b) {
+        float d;
+        asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+        return d;
+    }
     template <int S>
     __device__ __forceinline__ void step() {
         constexpr int i = S & 3, ph = S >> 2;
-        if constexpr (ph == 0) { hp[i] = s3_cvt_pk(x[i][0], x[i][1]); h[i] = hp[i]; }
-        else if constexpr (ph == 1) hf[i][0] = __builtin_bit_cast(float, hp[i] << 16);
-        else if constexpr (ph == 2) hf[i][1] = __builtin_bit_cast(float, hp[i] & 0xffff0000u);
-        else if constexpr (ph == 3) r[i] = x[i] - hf[i];
-        else if constexpr (ph == 4) { mp[i] = s3_cvt_pk(r[i][0], r[i][1]); m[i] = mp[i]; }
-        else if constexpr (ph == 5) hf[i][0] = __builtin_bit_cast(float, mp[i] << 16);
-        else if constexpr (ph == 6) hf[i][1] = __builtin_bit_cast(float, mp[i] & 0xffff0000u);
-        else if constexpr (ph == 7) r[i] = r[i] - hf[i];
-        else l[i] = s3_cvt_pk(r[i][0], r[i][1]);
+        if constexpr (!SCALAR) {
+            if constexpr (ph == 0) { hp[i] = s3_cvt_pk(x[i][0], x[i][1]); h[i] = hp[i]; }
+            else if constexpr (ph == 1) hf[i][0] = __builtin_bit_cast(float, hp[i] << 16);
+            else if constexpr (ph == 2) hf[i][1] = __builtin_bit_cast(float, hp[i] & 0xffff0000u);
+            else if constexpr (ph == 3) r[i] = x[i] - hf[i];
+            else if constexpr (ph == 4) { mp[i] = s3_cvt_pk(r[i][0], r[i][1]); m[i] = mp[i]; }
+            else if constexpr (ph == 5) hf[i][0] = __builtin_bit_cast(float, mp[i] << 16);
+            else if constexpr (ph == 6) hf[i][1] = __builtin_bit_cast(float, mp[i] & 0xffff0000u);
+            else if constexpr (ph == 7) r[i] = r[i] - hf[i];
+            else l[i] = s3_cvt_pk(r[i][0], r[i][1]);
+        } else {
+            if constexpr (ph == 0) { hp[i] = s3_cvt_pk(x[i][0], x[i][1]); h[i] = hp[i]; }
+            else if constexpr (ph == 1) hf[i][0] = __builtin_bit_cast(float, hp[i] << 16);
+            else if constexpr (ph == 2) hf[i][1] = __builtin_bit_cast(float, hp[i] & 0xffff0000u);
+            else if constexpr (ph == 3) r[i][0] = sub(x[i][0], hf[i][0]);
+            else if constexpr (ph == 4) r[i][1] = sub(x[i][1], hf[i][1]);
+            else if constexpr (ph == 5) { mp[i] = s3_cvt_pk(r[i][0], r[i][1]); m[i] = mp[i]; }
+            else if constexpr (ph == 6) hf[i][0] = __builtin_bit_cast(float, mp[i] << 16);
+            else if constexpr (ph == 7) hf[i][1] = __builtin_bit_cast(float, mp[i] & 0xffff0000u);
+            else if constexpr (ph == 8) r[i][0] = sub(r[i][0], hf[i][0]);
+            else if constexpr (ph == 9) r[i][1] = sub(r[i][1], hf[i][1]);
+            else l[i] = s3_cvt_pk(r[i][0], r[i][1]);
+        }
     }
     template <int S0, int S1>
     __device__ __forceinline__ void steps() {
         if constexpr (S0 < S1) { step<S0>(); steps<S0 + 1, S1>(); }
     }
 };
-constexpr int kS3Steps = 36;
 
 // Per-wave state of the k loop.  Everything is indexed with compile-time constants (member templates), so the arrays live in
 // registers; the issue order of one k tile is spelled out instruction group by instruction group and fenced with
 // sched_barrier(0), because (a) hipcc otherwise hoists all the splits in front of the MFMAs and (b) with LDS-DMA in flight its
 // own waits are all lgkmcnt(0), so a fragment read must be issued well before, and never right in front of, a first use.
-template <int MI, int NI, int NA, int NBW, int PW, int A_BYTES, bool SPREAD>
+template <int MI, int NI, int NA, int NBW, int PW, int A_BYTES, bool SPREAD, bool SCALAR>
 struct S3Wave {
+    using S3Split = S3SplitT<SCALAR>;
+    static constexpr int kS3Steps = S3Split::kSteps;
     static constexpr int NMF = 6 * NI;        // MFMAs of one fragment row
     static constexpr int NP = NA + NBW;       // DMA pieces of one k tile, issued between the MFMAs of row 0 (and 1)
     static constexpr int DMA_ROWS = (MI > 1) ? 2 : 1;
@@ -194,7 +219,7 @@ struct S3Wave {
     }
 };
 
-template <int MI, int NI, int WM, int WN, bool SPREAD>
+template <int MI, int NI, int WM, int WN, bool SPREAD, bool SCALAR>
 __global__ __launch_bounds__(512) void conv_gemm3x_kernel(const ConvGemm p) {
     constexpr int BM = 16 * MI * WM;
     constexpr int BN = 16 * NI * WN;
@@ -236,7 +261,7 @@ __global__ __launch_bounds__(512) void conv_gemm3x_kernel(const ConvGemm p) {
     const int T = p.KH * p.KW;
     const int HoWo = p.Ho * p.Wo;
 
-    S3Wave<MI, NI, NA, NBW, PW, A_BYTES, SPREAD> w;
+    S3Wave<MI, NI, NA, NBW, PW, A_BYTES, SPREAD, SCALAR> w;
     w.Hin = p.Hs << p.ups;
     w.Win = p.Ws << p.ups;
     w.ups = p.ups;
@@ -325,10 +350,10 @@ __global__ __launch_bounds__(512) void conv_gemm3x_kernel(const ConvGemm p) {
     gemm_epilogue_f32<MI, NI, WM, WN>(p, w.acc, smem_x32, m0, n0, z, lid, wave, lane, HoWo);
 }
 
-template <int MI, int NI, int WM, int WN, bool SPREAD>
+template <int MI, int NI, int WM, int WN, bool SPREAD, bool SCALAR>
 static hipError_t launch_cfg_3x(const ConvGemm& p, dim3 grid, hipStream_t stream) {
     static bool attr_set = false;
-    auto k = conv_gemm3x_kernel<MI, NI, WM, WN, SPREAD>;
+    auto k = conv_gemm3x_kernel<MI, NI, WM, WN, SPREAD, SCALAR>;
     constexpr size_t lds = 2 * ((size_t)(16 * MI * WM) * 128 + (size_t)((NI * WN * 3 + 7) / 8) * 8192);
     static_assert(lds <= 160 * 1024, "two stages must fit the CU's LDS");
     if (!attr_set) {
@@ -352,8 +377,11 @@ hipError_t launch_conv_gemm3x(const ConvGemm& p, int cfg, hipStream_t stream) {
     const int tiles = MT * NT;
     dim3 grid(((tiles + 7) / 8) * 8, 1, p.splits);
     // p.variant bit 0: issue the next k tile's DMA in one block behind the barrier instead of between the MFMAs of rows 0 / 1
-    const bool spread = !(p.variant & 1);
-#define SDMI_3X(MI, NI, WM, WN) (spread ? launch_cfg_3x<MI, NI, WM, WN, true>(p, grid, stream) : launch_cfg_3x<MI, NI, WM, WN, false>(p, grid, stream))
+    // bit 1: the split's residual subtractions as scalar v_sub_f32 pairs instead of v_pk_add_f32
+    const bool spread = !(p.variant & 1), scalar = (p.variant & 2) != 0;
+#define SDMI_3X(MI, NI, WM, WN)                                                                                       \
+    (spread ? (scalar ? launch_cfg_3x<MI, NI, WM, WN, true, true>(p, grid, stream) : launch_cfg_3x<MI, NI, WM, WN, true, false>(p, grid, stream)) \
+            : (scalar ? launch_cfg_3x<MI, NI, WM, WN, false, true>(p, grid, stream) : launch_cfg_3x<MI, NI, WM, WN, false, false>(p, grid, stream)))
     switch (cfg) {
         case 0: return SDMI_3X(4, 5, 4, 2);
         case 1: return SDMI_3X(4, 5, 2, 4);

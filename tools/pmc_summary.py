@@ -15,6 +15,8 @@ from collections import defaultdict
 
 
 def classify(name: str) -> str:
+    if "conv_gemm3x" in name:
+        return "conv_gemm_split"
     if "conv_gemm" in name:
         return "conv_gemm"
     if "splitk_reduce" in name:
@@ -53,10 +55,11 @@ def main():
         classes[c] = {"launches_per_image": launches[c] / images, "fetch_kb": fetch[c], "write_kb": write[c],
                       "hbm_bytes_per_launch": b / launches[c], "hbm_gb_per_image": b / images / 1e9}
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 "
-                     "--no-cpu-baseline --no-roofline ; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md; "
+                     "--no-cpu-baseline --no-roofline --no-secondary ; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md; "
                      "Infinity-Cache hits are counted, so this is an upper bound on DRAM bytes)",
            "images_in_trace": images, "classes": classes,
-           "conv_gemm_hbm_bytes_per_launch": classes.get("conv_gemm", {}).get("hbm_bytes_per_launch")}
+           "conv_gemm_hbm_bytes_per_launch": classes.get("conv_gemm", {}).get("hbm_bytes_per_launch"),
+           "conv_gemm_split_hbm_bytes_per_launch": classes.get("conv_gemm_split", {}).get("hbm_bytes_per_launch")}
     with open(out, "w") as f:
         json.dump(doc, f, indent=1)
     for c, v in classes.items():
