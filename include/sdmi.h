@@ -284,7 +284,11 @@ int sdmi_op_geglu_forward(sdmi_ctx* ctx, const float* x, const float* weight, co
 int sdmi_op_timestep_embedding(sdmi_ctx* ctx, int32_t t, int32_t dim, float* out);
 
 /* ---- tuning / introspection ---------------------------------------------------- */
-/* "key=value" knobs for tests and tuning, e.g. "gemm_tile=auto", "splitk=0", "profile=1" (Engine::set_option). */
+/* "key=value" knobs for tests and tuning, e.g. "gemm_tile=auto", "splitk=0", "profile=1" (Engine::set_option).
+ * Arithmetic selectors of precision = 0 (both default 1): "gemm_f32s" = conv / linear GEMMs with Cin % 32 == 0 multiply on the bf16
+ * matrix pipe with fp32 operands split exactly into three bf16 terms, six partial products, fp32 accumulation (k_gemm3x.hip);
+ * "attn_split" = the same for qkv_attention at head dims 40 / 80 (k_attn_split.hip).  0 = the fp32 matrix instruction
+ * (v_mfma_f32_16x16x4_f32) everywhere.  Same parity bars either way. */
 int sdmi_set_option(sdmi_ctx* ctx, const char* key, const char* value);
 /* time (ms, HIP events on the context stream) and kernel count of the last
  * hot-path call; flops = algorithmic FLOPs it executed (2*MAC of conv/GEMM/attention). */

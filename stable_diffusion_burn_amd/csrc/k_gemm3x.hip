@@ -219,8 +219,9 @@ struct S3Wave {
     }
 };
 
-template <int MI, int NI, int WM, int WN, bool SPREAD, bool SCALAR>
+template <int MI, int NI, int WM, int WN, bool SPREAD, bool SCALAR, int NSTG>
 __global__ __launch_bounds__(512) void conv_gemm3x_kernel(const ConvGemm p) {
+    static_assert(NSTG == 2 || NSTG == 3, "LDS stages");
     constexpr int BM = 16 * MI * WM;
     constexpr int BN = 16 * NI * WN;
     static_assert(WM * WN == 8, "8 waves per workgroup");
@@ -336,13 +337,34 @@ __global__ __launch_bounds__(512) void conv_gemm3x_kernel(const ConvGemm p) {
 
     w.next_stage = smem_x32;
     w.template pieces<0, NA + NBW>();      // k tile 0
-    for (int t = 0; t < n_t; ++t) {
-        const int cur = t & 1;
-        __syncthreads();                    // k tile t is in LDS; every wave is done with stage cur ^ 1
-        w.next_stage = smem_x32 + (cur ^ 1) * STAGE;
-        w.a_tile = smem_x32 + cur * STAGE + a_base;
-        w.w_tile = smem_x32 + cur * STAGE + w_fr;
-        w.tile();
+    if constexpr (NSTG == 2) {
+        for (int t = 0; t < n_t; ++t) {
+            const int cur = t & 1;
+            __syncthreads();                    // k tile t is in LDS; every wave is done with stage cur ^ 1
+            w.next_stage = smem_x32 + (cur ^ 1) * STAGE;
+            w.a_tile = smem_x32 + cur * STAGE + a_base;
+            w.w_tile = smem_x32 + cur * STAGE + w_fr;
+            w.tile();
+        }
+    } else {
+        // Three stages: the DMA of k tile t + 2 is issued during tile t, so a tile's data has two tile times to arrive -- a k tile
+        // of a 32-row wave tile (0.7 us) is shorter than the latency of the DMA it would otherwise wait for.  Every wave issues
+        // exactly NA + NBW DMA instructions per tile (piece() has no branches) and they complete in order, so "tile t has
+        // landed" is vmcnt(NA + NBW): hand-written, because __syncthreads() would drain the tile behind it as well.
+        w.next_stage = smem_x32 + STAGE;
+        w.template pieces<0, NA + NBW>();      // k tile 1 (or tile 0 again when there is none: dead stage)
+        int cur = 0;
+        for (int t = 0; t < n_t; ++t) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NBW) : "memory");
+            __builtin_amdgcn_s_barrier();       // k tile t is in LDS; every wave is done with tile t - 1, whose stage tile t + 2 takes
+            asm volatile("" ::: "memory");
+            const int nxt = cur == 0 ? 2 : cur - 1;      // (cur + 2) % 3
+            w.next_stage = smem_x32 + nxt * STAGE;
+            w.a_tile = smem_x32 + cur * STAGE + a_base;
+            w.w_tile = smem_x32 + cur * STAGE + w_fr;
+            w.tile();
+            cur = cur == 2 ? 0 : cur + 1;
+        }
     }
     // the last k tile was fetched twice (piece()); that copy must have landed before the epilogue reuses the stages
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -350,12 +372,12 @@ __global__ __launch_bounds__(512) void conv_gemm3x_kernel(const ConvGemm p) {
     gemm_epilogue_f32<MI, NI, WM, WN>(p, w.acc, smem_x32, m0, n0, z, lid, wave, lane, HoWo);
 }
 
-template <int MI, int NI, int WM, int WN, bool SPREAD, bool SCALAR>
+template <int MI, int NI, int WM, int WN, bool SPREAD, bool SCALAR, int NSTG = 2>
 static hipError_t launch_cfg_3x(const ConvGemm& p, dim3 grid, hipStream_t stream) {
     static bool attr_set = false;
-    auto k = conv_gemm3x_kernel<MI, NI, WM, WN, SPREAD, SCALAR>;
-    constexpr size_t lds = 2 * ((size_t)(16 * MI * WM) * 128 + (size_t)((NI * WN * 3 + 7) / 8) * 8192);
-    static_assert(lds <= 160 * 1024, "two stages must fit the CU's LDS");
+    auto k = conv_gemm3x_kernel<MI, NI, WM, WN, SPREAD, SCALAR, NSTG>;
+    constexpr size_t lds = NSTG * ((size_t)(16 * MI * WM) * 128 + (size_t)((NI * WN * 3 + 7) / 8) * 8192);
+    static_assert(lds <= 160 * 1024, "the stages must fit the CU's LDS");
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -387,8 +409,9 @@ hipError_t launch_conv_gemm3x(const ConvGemm& p, int cfg, hipStream_t stream) {
         case 1: return SDMI_3X(4, 5, 2, 4);
         case 2: return SDMI_3X(4, 4, 4, 2);
         case 3: return SDMI_3X(4, 4, 2, 4);
-        case 4: return SDMI_3X(2, 5, 4, 2);
-        case 5: return SDMI_3X(2, 4, 4, 2);
+        // the 32-row wave tiles: three LDS stages unless variant bit 2 is set (DMA of tile t + 2 in flight during tile t)
+        case 4: return (p.variant & 4) ? SDMI_3X(2, 5, 4, 2) : (scalar ? launch_cfg_3x<2, 5, 4, 2, true, true, 3>(p, grid, stream) : launch_cfg_3x<2, 5, 4, 2, true, false, 3>(p, grid, stream));
+        case 5: return (p.variant & 4) ? SDMI_3X(2, 4, 4, 2) : (scalar ? launch_cfg_3x<2, 4, 4, 2, true, true, 3>(p, grid, stream) : launch_cfg_3x<2, 4, 4, 2, true, false, 3>(p, grid, stream));
     }
 #undef SDMI_3X
     return hipErrorInvalidValue;
