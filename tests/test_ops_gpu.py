@@ -205,7 +205,7 @@ def test_conv2d_large_tiles(sd_ops, tile, splitk, case):
 STILES = [200, 201, 202, 203, 204, 205]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])   # bit 0: next k tile's DMA in one block behind the barrier; bit 1: scalar residual subtractions
+@pytest.mark.parametrize("variant", [0, 1, 2, 6])   # bit 0: next k tile's DMA in one block behind the barrier; bit 1: scalar residual subtractions; bit 2: two LDS stages on the 128-row tiles too (default: three)
 @pytest.mark.parametrize("tile", STILES)
 @pytest.mark.parametrize("splitk", [1, 3])
 @pytest.mark.parametrize("case", XCASES)

@@ -1,10 +1,10 @@
 #!/bin/bash
 # round-2 evidence run: full GPU suite, the driver's bench line, split-K A/B, kernel trace, HBM-traffic counters
 set -x
-R=$PWD; out=gpurun_out/r02n; mkdir -p $out
+R=$PWD; out=gpurun_out/r02p; mkdir -p $out
 timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $out/pytest_gpu.log
 timeout 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench rc=$?"
-for f in 1 2; do timeout 200 python bench.py --no-secondary --no-cpu-baseline --no-roofline --opt splitk_fused=$f > $out/bench_fused$f.json 2>/dev/null; done
+timeout 200 python bench.py --no-secondary --no-cpu-baseline --opt gemm3x_variant=6 > $out/bench_2stage.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof_f32 -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary > $R/$out/prof_f32.log 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$out/pmc_fetch -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-secondary > $R/$out/pmc_fetch.log 2>&1
@@ -16,7 +16,7 @@ python -c "
 import json
 j=json.load(open('$out/bench_default.json')); print(j['value'], j['kernel_classes_ms_per_image']); print(j['roofline']); print(j['cpu_baseline'])
 for s in j.get('secondary', []): print(s['config']['workload'][:90], s['value'])
-for f in (1,2):
+for f in ():
     b=json.load(open('$out/bench_fused%d.json' % f)); print('splitk_fused', f, b['value'])
 "
 du -sh $out
