@@ -1017,7 +1017,7 @@ TileChoice Engine::choose_tile(int M, int N, int kt_total, bool allow_x, bool al
     if (allow_s && opt_gemm_f32s_) {
         // k_gemm3x.hip: six bf16 MFMAs per 16x16x32 block = 96 cycles/SIMD against 256 on the fp32 pipe; the efficiencies
         // are measured ones (tools/autotune.py), the per-workgroup constant covers the DMA prologue and the epilogue
-        static const double eff_s[kNumGemmTilesS] = {0.55, 0.55, 0.52, 0.52, 0.42, 0.40};
+        static const double eff_s[kNumGemmTilesS] = {0.55, 0.55, 0.52, 0.52, 0.46, 0.44};
         for (int c = 0; c < kNumGemmTilesS; ++c) {
             const int bm = gemm_tile_info_s(c).bm, bn = gemm_tile_info_s(c).bn;
             const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);

@@ -57,9 +57,10 @@ def test_unet_forward(sd_tiny, synth, tiny_dims, t):
     print(f"unet t={t}: |gpu-f64|={e64:.2e} |f32-f64|={e32:.2e}")
 
 
-@pytest.mark.parametrize("tile", [100, 103])
+@pytest.mark.parametrize("tile", [100, 103, 200, 203, 204, 205])
 def test_unet_forward_large_tiles_forced(sd_tiny, synth, tiny_dims, tile):
-    """every eligible GEMM of the UNet on a k_gemm2x.hip tile: its residual / time-embedding / split-K epilogues at model level."""
+    """every eligible GEMM of the UNet on one k_gemm2x.hip (100+) / k_gemm3x.hip (200+) tile: its residual / time-embedding /
+    split-K epilogues at model level."""
     d = tiny_dims
     lat, ctx, _ = _inputs(d, 2, 7, 2)
     o32, o64 = _oracles(synth, d)
@@ -71,6 +72,29 @@ def test_unet_forward_large_tiles_forced(sd_tiny, synth, tiny_dims, tile):
     r32 = o32.unet.forward(torch.from_numpy(lat), 500, torch.from_numpy(ctx)).numpy()
     r64 = o64.unet.forward(torch.from_numpy(lat), 500, torch.from_numpy(ctx)).numpy()
     _assert_close(got, r32, r64, f"unet_forward tile={tile}", atol=1e-4)
+
+
+def test_unet_forward_fp32_matrix_instruction_only(sd_tiny, synth, tiny_dims):
+    """gemm_f32s=0 / attn_split=0: every product on v_mfma_f32_16x16x4_f32 (round 1's arithmetic).  Same bar; and the default
+    path (fp32 operands as three bf16 terms, six partial products) agrees with it to fp32 rounding noise."""
+    d = tiny_dims
+    lat, ctx, _ = _inputs(d, 2, 7, 2)
+    o32, o64 = _oracles(synth, d)
+    split = sd_tiny.unet.forward(lat, [700], ctx)
+    try:
+        sd_tiny.set_option("gemm_f32s", 0)
+        sd_tiny.set_option("attn_split", 0)
+        plain = sd_tiny.unet.forward(lat, [700], ctx)
+    finally:
+        sd_tiny.set_option("gemm_f32s", 1)
+        sd_tiny.set_option("attn_split", 1)
+    r32 = o32.unet.forward(torch.from_numpy(lat), 700, torch.from_numpy(ctx)).numpy()
+    r64 = o64.unet.forward(torch.from_numpy(lat), 700, torch.from_numpy(ctx)).numpy()
+    e_plain, _ = _assert_close(plain, r32, r64, "unet_forward fp32 MFMA only", atol=1e-4)
+    e_split, e32 = _assert_close(split, r32, r64, "unet_forward split kernels", atol=1e-4)
+    print(f"|gpu-f64|: split kernels {e_split:.2e}, fp32 matrix instruction {e_plain:.2e}; the fp32 oracle itself {e32:.2e}")
+    assert e_split <= 2.0 * max(e_plain, e32)
+    assert np.abs(split - plain).max() <= 2e-5 * max(1.0, np.abs(r64).max())
 
 
 def test_unet_forward_batch_independent(sd_tiny, tiny_dims):
