@@ -174,23 +174,44 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) 
     for (int tile = 0; tile < n_tiles; ++tile) {
         const int cur = tile & 1;
         const bool more = (tile + 1) < n_tiles;
-        if (more) gload(tile + 1);
 
         const unsigned char* Kt = Ks + cur * Cfg::K_BYTES + k_off;
         const unsigned char* Vt = Vs + cur * Cfg::V_BYTES + v_off;
         const int kv0 = tile * BKV;
 
+        // S^T = K Q^T.  The K fragments of 32-key tile kt + 1 are read before the MFMAs of tile kt are issued (fenced: hipcc
+        // otherwise reads each fragment right in front of its MFMA and the wave sits out one LDS latency per MFMA).
+        // (d = 160: ten fragments per tile -- a second set does not fit the register file; read in place as before)
+        constexpr bool PF = KS <= 5;
         f32x16 s[KT];
+        bf16x8 kf[PF ? 2 : 1][KS];
+        if constexpr (PF) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kf[0][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Kt + ks * 32));
+        }
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
+            if constexpr (PF) {
+                if (kt + 1 < KT) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+                        kf[(kt + 1) & 1][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Kt + (kt + 1) * 32 * RSK + ks * 32));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kf[0][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Kt + kt * 32 * RSK + ks * 32));
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Kt + kt * 32 * RSK + ks * 32));
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
-            }
+            for (int ks = 0; ks < KS; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PF ? (kt & 1) : 0][ks], qf[ks], s[kt], 0, 0, 0);
+            if constexpr (PF) __builtin_amdgcn_sched_barrier(0);
         }
+
+        // the next tile's global loads go out here, not at the top of the iteration: hipcc puts a vmcnt(0) in front of the first
+        // MFMA of the loop body, which made every tile wait for the loads it had just issued; they are consumed by lstore() below
+        if (more) gload(tile + 1);
 
         if (tile >= n_full) {  // ragged last tile (uniform)
 #pragma unroll
@@ -231,17 +252,31 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) 
             for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
         }
 
+        // O^T += V^T P^T, 16 keys at a time; the V^T fragments of step st + 1 are read before the MFMAs of step st (fenced, as above)
+        auto read_vf = [&](bf16x8 (&vf)[NDT], int st) {
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-#pragma unroll
-            for (int st = 0; st < ST; ++st) {
-                const lds_s16x4* vp = (const lds_s16x4*)(Vt + st * 16 * RSV + dt * 64);
-                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_s16x4*>(vp));
-                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_s16x4*>((const lds_s16x4*)(Vt + (st * 16 + 8) * RSV + dt * 64)));
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
-                const u32x4 pw = {pb[st][0], pb[st][1], pb[st][2], pb[st][3]};
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pw), o[dt], 0, 0, 0);
+            for (int dt = 0; dt < NDT; ++dt) {
+                const unsigned char* vb = Vt + st * 16 * RSV + dt * 64;
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_s16x4*>((const lds_s16x4*)vb));
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_s16x4*>((const lds_s16x4*)(vb + 8 * RSV)));
+                vf[dt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
             }
+        };
+        bf16x8 vf[PF ? 2 : 1][NDT];
+        if constexpr (PF) read_vf(vf[0], 0);
+#pragma unroll
+        for (int st = 0; st < ST; ++st) {
+            if constexpr (PF) {
+                if (st + 1 < ST) read_vf(vf[(st + 1) & 1], st + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                read_vf(vf[0], st);
+            }
+            const u32x4 pw = {pb[st][0], pb[st][1], pb[st][2], pb[st][3]};
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PF ? (st & 1) : 0][dt], __builtin_bit_cast(bf16x8, pw), o[dt], 0, 0, 0);
+            if constexpr (PF) __builtin_amdgcn_sched_barrier(0);
         }
 
         if (more) lstore(cur ^ 1);

@@ -15,7 +15,9 @@
 // Measured (rocprofv3 --pmc, 2 x 8 heads x 4096^2, d = 40): matrix pipe 56 % busy, 138 TFLOP/s against 95 for k_attn.hip; 8.4 bf16
 // flops are issued per fp32 flop (6 products x 1.4 for padding d = 40 to 48 in K Q^T and to 64 in V^T P^T).  A software-pipelined
 // variant (S(t+1) issued between the exponentials of tile t, staging between the MFMAs of V^T P^T) measured 3 % SLOWER and was
-// removed: the loop is bound by total issue slots of the two waves per SIMD, not by the order inside one wave.
+// removed: the loop is bound by total issue slots of the two waves per SIMD, not by the order inside one wave.  Explicit, fenced
+// prefetch of the K / V^T fragments one step ahead (what helps k_attn_bf16.hip by 6-14 %) measured 6 % slower here: hipcc's own
+// schedule already overlaps these reads with the six-MFMA groups.
 #include "kernels.hpp"
 
 #include <hip/hip_runtime.h>

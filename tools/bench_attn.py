@@ -15,7 +15,7 @@ for s in SHAPES:
     fl = 4.0 * n * h * nq * nk * (c // h)
     row = []
     for variant in (0, 1):
-        sd.set_option("attn_bf16" if BF16 else "attn_variant", variant)
+        sd.set_option("attn_bf16" if BF16 else "attn_split", variant)   # fp32: 0 = k_attn.hip (fp32 MFMA), 1 = k_attn_split.hip
         ms = sd.bench_attention(*s, iters=10)
         row.append(f"v{variant}: {ms * 1e3:8.1f} us {fl / ms / 1e9:6.1f} TF")
     print(f"{str(s):34s} " + " | ".join(row), flush=True)
