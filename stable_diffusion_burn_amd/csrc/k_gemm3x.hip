@@ -7,13 +7,14 @@
 //      wl*ah, wh*al, wm*am, wm*ah, wh*am, wh*ah          (dropped: wm*al + wl*am + wl*al <= 2^-25 |a w|)
 // i.e. each product carries a relative error <= 2^-25, half of what rounding the exact product to fp32 costs, and the sum
 // is an fp32 sum as in the fp32 MFMA.  Six bf16 MFMAs per 16x16x32 block = 96 matrix-pipe cycles against 256 for the eight
-// 16x16x4 fp32 MFMAs of the same block: the matrix-pipe bound of an fp32 GEMM moves from 157 to 419 TFLOP/s.  Same parity
-// bars as k_gemm2x.hip (tests/test_ops_gpu.py); DESIGN.md "fp32 on the bf16 pipe" has the error analysis and measurements.
+// 16x16x4 fp32 MFMAs of the same block: the matrix-pipe bound of an fp32 GEMM moves from 157 to 417 TFLOP/s.  Same parity
+// bars as k_gemm2x.hip (tests/test_ops_gpu.py); DESIGN.md section 4a has the error analysis and the measurements.
 //
 // Structure: k_gemm2x.hip (8 waves, LDS-DMA staged, double-buffered 32-channel k tiles, XCD-aware tile map, deterministic
 // split-K slabs, shared epilogue) with
-//   * activations staged as fp32 exactly as there and split IN REGISTERS after the fragment read (v_cvt_pk_bf16_f32 +
-//     v_pk_add_f32: 36 VALU instructions per 16x32 fragment, issued between the 6 NI MFMAs of the previous fragment);
+//   * activations staged as fp32 exactly as there and split IN REGISTERS after the fragment read (v_cvt_pk_bf16_f32, shift / and,
+//     v_sub_f32: 44 VALU instructions per 16x32 fragment -- 36 with v_pk_add_f32, variant bit 1 --, issued one or two at a time
+//     between the 6 NI MFMAs of the previous fragment);
 //   * weights split once at load into three bf16 planes (launch_pack_split3): [N][kt][plane][32] bf16, 192 bytes per row per
 //     k tile, staged as 16-row x 64-byte pieces (one DMA instruction = one plane of one 16-row fragment group) and read as
 //     one ds_read_b128 per plane per fragment.
