@@ -326,6 +326,12 @@ void Engine::build_model() {
             SDMI_HIP(hipMalloc(&p, (size_t)3 * c * c * esz()));
             weight_allocs_.push_back(p);
             m.q.bt = reinterpret_cast<float*>(p);
+            if (!bf16_) {   // and its bf16 planes (k_gemm3x.hip), same 1.5x offset rule as the arenas
+                void* pl = nullptr;
+                SDMI_HIP(hipMalloc(&pl, (size_t)3 * c * c * 6));
+                weight_allocs_.push_back(pl);
+                split_regions_.push_back(SplitRegion{reinterpret_cast<char*>(p), (size_t)3 * c * c * 4, reinterpret_cast<char*>(pl)});
+            }
             m.k.bt = adv(m.q.bt, (long long)c * c, edt());
             m.v.bt = adv(m.q.bt, (long long)2 * c * c, edt());
         }
@@ -598,6 +604,8 @@ const void* Engine::split_planes(const float* bt) const {
     const char* b = reinterpret_cast<const char*>(bt);
     for (int g = 0; g < 3; ++g)
         if (split_base_[g] && b >= arena_base_[g] && b < arena_base_[g] + arena_bytes_[g]) return split_base_[g] + (size_t)(b - arena_base_[g]) / 2 * 3;
+    for (const SplitRegion& r : split_regions_)    // the packed q | k | v weights of the self-attentions (own allocations)
+        if (b >= r.base && b < r.base + r.bytes) return r.planes + (size_t)(b - r.base) / 2 * 3;
     return nullptr;
 }
 
@@ -948,11 +956,16 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "gemm_f32s") opt_gemm_f32s_ = std::stoi(value);
     else if (key == "gemm3x_variant") opt_gemm3x_variant_ = std::stoi(value);
     else if (key == "geglu_fuse") opt_geglu_fuse_ = std::stoi(value);
-    else if (key == "record_shapes") { record_shapes_ = std::stoi(value) != 0; if (record_shapes_) shape_counts_.clear(); }
+    else if (key == "record_shapes") { record_shapes_ = std::stoi(value) != 0; if (record_shapes_) { shape_counts_.clear(); choice_counts_.clear(); } }
     else if (key == "dump_shapes") {
         std::ofstream f(value);
         if (!f) throw Error(SDMI_ERR_IO, "dump_shapes: cannot write " + value);
         for (auto& kv : shape_counts_) f << kv.first << " " << kv.second << "\n";
+    }
+    else if (key == "dump_choices") {
+        std::ofstream f(value);
+        if (!f) throw Error(SDMI_ERR_IO, "dump_choices: cannot write " + value);
+        for (auto& kv : choice_counts_) f << kv.first << " x" << kv.second << "\n";
     }
     else if (key == "profile") { prof_flush(); profiling_ = std::stoi(value) != 0; }
     else if (key == "profile_reset") prof_reset();
@@ -1095,6 +1108,11 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     if (opt_force_tile_ >= 0 && (opt_force_tile_ < 100 || in_dt || (opt_force_tile_ >= 200 ? s_ok : x32_ok))) tc.cfg = opt_force_tile_;  // 100+ / 200+: large-tile kernels, where applicable
     if (opt_force_splits_ > 0) tc.splits = opt_force_splits_;
     if (force_cfg >= 0) tc.cfg = force_cfg;
+    if (record_shapes_) {   // which kernel / tile / split-K each (M, N, K) got: option dump_choices
+        char ck[96];
+        std::snprintf(ck, sizeof ck, "%d,%d,%d cfg=%d splits=%d%s", p.M, p.N, p.K, tc.cfg, tc.splits, p.Bt3 ? "" : " (no planes)");
+        ++choice_counts_[ck];
+    }
     if (force_splits > 0) tc.splits = force_splits;
     if (!in_dt && p.out_mode == 2) tc.splits = 1;  // fp32 kernel emitting bf16: no split-K path
     int splits = std::max(1, std::min(tc.splits, p.kt_total));

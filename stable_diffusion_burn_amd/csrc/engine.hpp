@@ -218,6 +218,8 @@ private:
     char* arena_base_[3] = {nullptr, nullptr, nullptr};
     size_t arena_bytes_[3] = {0, 0, 0};
     char* split_base_[3] = {nullptr, nullptr, nullptr};
+    struct SplitRegion { char* base; size_t bytes; char* planes; };
+    std::vector<SplitRegion> split_regions_;
     const void* split_planes(const float* bt) const;
     // operator-level calls (op_conv2d, op_linear, bench_conv ...) pack their weight into a pool buffer: this gives it planes for
     // the duration of the call, so that those calls run the kernels the model runs
@@ -407,6 +409,7 @@ private:
     std::map<std::string, TileChoice> tuned_mfma_;   // fp32 shapes measured with the fp32-MFMA kernels only (gemm_f32s=0)
     bool record_shapes_ = false;
     std::map<std::string, long long> shape_counts_;  // "n,cin,h,w,cout,k,stride,ups" -> launches
+    std::map<std::string, long long> choice_counts_;   // "M,N,K cfg=.. splits=.." -> launches (record_shapes)
 
     long long n_kernels_ = 0;
     double flops_ = 0;

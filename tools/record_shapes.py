@@ -16,5 +16,6 @@ sd.set_option("record_shapes", 1)
 sd.sample_image(syn.cond_context(0)[None], syn.uncond_context(), 7.5, 1, init_latent=syn.initial_latent(0)[None])
 Path(out).parent.mkdir(parents=True, exist_ok=True)
 sd.set_option("dump_shapes", out)
+sd.set_option("dump_choices", out + ".choices")
 sd.set_option("record_shapes", 0)
-print(Path(out).read_text())
+print(Path(out + ".choices").read_text())
