@@ -1225,6 +1225,13 @@ void Engine::gemm_geglu(const float* x, long long rows, const float* bt, const f
         // two rounds) and the fused form LOSES 2.6 % end to end in fp32; with >= 4 rounds it wins ~1 % (bf16, batch 8)
         if (t256 >= 1024 || opt_geglu_fuse_ == 3) cfg = 101;
         else if (t128 >= 1024 || opt_geglu_fuse_ == 2) cfg = 102;
+        // precision = 0 with the split kernels: their even-fragment tiles (128x256s / 256x128s / 128x128s = 128 / 64 / 64 output
+        // columns per tile); geglu_fuse = 4 / 5 / 6 force them
+        if (!dt && opt_gemm_f32s_ && split_planes(bt)) {
+            if (opt_geglu_fuse_ == 4) cfg = 203;
+            else if (opt_geglu_fuse_ == 5) cfg = 202;
+            else if (opt_geglu_fuse_ == 6) cfg = 205;      // (measured at batch 1: 3.56 / 3.58 / 3.54 img/s against 3.66 unfused)
+        }
     }
     if (cfg >= 0) {
         ConvGemm p{};

@@ -35,6 +35,11 @@ namespace sdmi {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- split-K reduction + epilogue ------------------------------------------------
+// G lanes share one 16-byte output: lane g sums slabs g, g + G, g + 2G, ... in that order, then the G partial sums are
+// combined by xor-shuffles (1, 2, 4) -- a fixed order, so results stay bit-reproducible.  G > 1 is for small outputs with
+// many slabs (M = 128 ... 512 rows x 16 ... 32 slices at batch 1): one thread per output would leave most of the chip idle
+// behind a serial chain of 32 dependent-latency loads.
+template <int G>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvGemm p) {
     const float* slabs = p.slabs;
     float* C = p.C;
@@ -42,18 +47,37 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvGemm p) {
     const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0);
     if (vec_ok) {
         const int n4 = p.N >> 2;
-        const long long total = (long long)p.M * n4;
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-             i += (long long)gridDim.x * blockDim.x) {
-            const int m = (int)(i / n4);
-            const int n = (int)(i - (long long)m * n4) * 4;
+        const long long total = (long long)p.M * n4;              // 16-byte outputs
+        const long long rounded = (total * G + 255) / 256 * 256;   // whole workgroups take part in the shuffles
+        for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < rounded; t += (long long)gridDim.x * blockDim.x) {
+            const long long i = t / G;
+            const int g = (int)(t - i * G);
+            const bool live = i < total;
+            const long long ii = live ? i : 0;
+            const int m = (int)(ii / n4);
+            const int n = (int)(ii - (long long)m * n4) * 4;
             const long long off = (long long)m * p.N + n;
-            f32x4 v = *reinterpret_cast<const f32x4*>(slabs + off);
-            for (int s = 1; s < p.splits; ++s) v += *reinterpret_cast<const f32x4*>(slabs + s * p.slab_stride + off);
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)(m / HoWo) * p.rowvec_stride + n);
-            if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (long long)m * p.ldr + n);
-            *reinterpret_cast<f32x4*>(C + (long long)m * p.ldc + n) = v;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            int s = g;
+            for (; s + 3 * G < p.splits; s += 4 * G) {      // four loads in flight, summed in slice order
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(slabs + (long long)s * p.slab_stride + off);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(slabs + (long long)(s + G) * p.slab_stride + off);
+                const f32x4 a2 = *reinterpret_cast<const f32x4*>(slabs + (long long)(s + 2 * G) * p.slab_stride + off);
+                const f32x4 a3 = *reinterpret_cast<const f32x4*>(slabs + (long long)(s + 3 * G) * p.slab_stride + off);
+                v += a0; v += a1; v += a2; v += a3;
+            }
+            for (; s < p.splits; s += G) v += *reinterpret_cast<const f32x4*>(slabs + (long long)s * p.slab_stride + off);
+#pragma unroll
+            for (int o = 1; o < G; o <<= 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], o, 64);
+            }
+            if (live && g == 0) {
+                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)(m / HoWo) * p.rowvec_stride + n);
+                if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (long long)m * p.ldr + n);
+                *reinterpret_cast<f32x4*>(C + (long long)m * p.ldc + n) = v;
+            }
         }
     } else {
         const long long total = (long long)p.M * p.N;
@@ -124,11 +148,21 @@ static const GemmTileInfo kTiles[kNumGemmTiles] = {
 const GemmTileInfo& gemm_tile_info(int cfg) { return kTiles[cfg]; }
 
 hipError_t launch_splitk_reduce(const ConvGemm& p, hipStream_t stream) {
+    const bool vec = ((p.N & 3) == 0) && ((p.ldc & 3) == 0);
     const long long work = ((long long)p.M * p.N + 3) / 4;
-    int blocks = (int)((work + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    // lanes per output: enough threads to cover the chip (>= 256 K) while every lane still has two slabs to sum
+    int g = 1;
+    if (vec)
+        while (g < 8 && work * g < 262144 && 4 * g <= p.splits) g *= 2;
+    long long blocks = (work * g + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    switch (g) {
+        case 1: hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, p); break;
+        case 4: hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, p); break;
+        default: hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, stream, p); break;
+    }
     return hipGetLastError();
 }
 

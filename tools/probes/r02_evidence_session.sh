@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-2 evidence run: full GPU suite, the driver's bench line, split-K A/B, kernel trace, HBM-traffic counters
 set -x
-R=$PWD; out=gpurun_out/r02p; mkdir -p $out
+R=$PWD; out=gpurun_out/r02t; mkdir -p $out
 timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $out/pytest_gpu.log
 timeout 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench rc=$?"
 timeout 200 python bench.py --no-secondary --no-cpu-baseline --opt gemm3x_variant=6 > $out/bench_2stage.json 2>/dev/null
