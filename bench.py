@@ -206,7 +206,7 @@ class Runner:
 ARITHMETIC = {
     "fp32": "fp32 storage, fp32 accumulation; conv/linear multiplications: each fp32 operand is the exact sum of three bf16 terms and "
             "the six partial products >= 2^-24 of the product are accumulated in fp32 on the bf16 matrix pipe (csrc/k_gemm3x.hip; per-product "
-            "error <= 2^-25, measured against the fp64 oracle: not larger than the fp32 matrix instruction's -- tests/test_ops_gpu.py); "
+            "error <= 2^-23 worst case / 2^-28 on average (tests/test_split_oracle_cpu.py), measured against the fp64 oracle: not larger than the fp32 matrix instruction's -- tests/test_ops_gpu.py); "
             "attention, norms and the remaining GEMMs in plain fp32",
     "bf16": "bf16 storage, fp32 accumulation and statistics",
     "fp8": "bf16 storage, fp32 accumulation; ResBlock 3x3 convolutions on MXFP8 operands",

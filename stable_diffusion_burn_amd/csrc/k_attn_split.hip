@@ -3,7 +3,7 @@
 // The same idea as k_gemm3x.hip: an fp32 number is exactly the sum of three bf16 numbers (x = h + m + l, round-to-nearest
 // splits), a bf16 x bf16 product is exact in fp32, and the MFMA accumulates in fp32 -- so S = Q K^T and O = P V are computed
 // with fp32 q / k / v / probabilities as six bf16 MFMAs per block (the partial products >= 2^-24 of the product; per-product
-// error <= 2^-25).  Scores, running max, exponentials, row sums and the output stay fp32; q/k/v/o are fp32 in HBM.
+// error <= 2^-23 worst case, 2^-28 on average).  Scores, running max, exponentials, row sums and the output stay fp32; q/k/v/o are fp32 in HBM.
 // v_mfma_f32_16x16x4_f32 retires 256 flop/clk/CU, six v_mfma_f32_32x32x16_bf16 per fp32 block 683: the fp32 flash kernel
 // (k_attn.hip, 87 TFLOP/s at d = 40) is bound by the former.
 //

@@ -4,9 +4,10 @@
 // three bf16 numbers (round-to-nearest splits: x = h + m + l, |m| <= 2^-9 |x|, |l| <= 2^-17 |x|; 8 + 8 + 8 significand
 // bits, same exponent range as fp32), the product of two bf16 numbers is exact in fp32, and the MFMA accumulates in fp32.
 // So a*w = (ah + am + al)(wh + wm + wl) is accumulated as the six partial products that are not below 2^-24 |a w|:
-//      wl*ah, wh*al, wm*am, wm*ah, wh*am, wh*ah          (dropped: wm*al + wl*am + wl*al <= 2^-25 |a w|)
-// i.e. each product carries a relative error <= 2^-25, half of what rounding the exact product to fp32 costs, and the sum
-// is an fp32 sum as in the fp32 MFMA.  Six bf16 MFMAs per 16x16x32 block = 96 matrix-pipe cycles against 256 for the eight
+//      wl*ah, wh*al, wm*am, wm*ah, wh*am, wh*ah          (dropped: wm*al + wl*am + wl*al)
+// The dropped terms are at most 2^-23 |a w| (both operands just above a power of two: about one fp32 ulp of the product), 2^-28 |a w|
+// on average -- tests/test_split_oracle_cpu.py proves this on the numpy restatement oracle/split_oracle.py -- and the sum is an fp32
+// sum as in the fp32 MFMA, whose every accumulation step rounds away up to 2^-24.  Six bf16 MFMAs per 16x16x32 block = 96 matrix-pipe cycles against 256 for the eight
 // 16x16x4 fp32 MFMAs of the same block: the matrix-pipe bound of an fp32 GEMM moves from 157 to 417 TFLOP/s.  Same parity
 // bars as k_gemm2x.hip (tests/test_ops_gpu.py); DESIGN.md section 4a has the error analysis and the measurements.
 //
