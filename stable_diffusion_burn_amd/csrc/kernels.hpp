@@ -46,7 +46,8 @@ struct ConvGemm {
     const void* zero_page;      // >= 16 readable zero bytes (large-tile kernels: source of padded / out-of-range lanes)
     const void* a_scale;        // fp8 kernel: E8M0 scales of A, [pixels][a_ld / 32] bytes (a_ld = padded channel count = bytes per pixel)
     const void* b_scale;        // fp8 kernel: E8M0 scales of Bt, [N][b_ld / 32] bytes
-    int variant;                // k_gemm3x.hip: bit 0 = DMA issued in one block per k tile (A/B switch, option gemm3x_variant)
+    int variant;                // k_gemm3x.hip A/B switches (option gemm3x_variant): bit 0 DMA issued in one block per k tile, 1 scalar residual subtractions,
+                                // 2 two LDS stages on the 128-row tiles, 3 hoisted k-tile head, 5 (with 3) weight-plane prefetch, 4 s_setprio 1 for waves 4-7
     int geglu;                  // large-tile kernels: Bt holds 2 N rows (N value rows, then N gate rows; bias likewise) and the
                                 // epilogue writes value * gelu_erf(gate) -- GEGLU::forward (unet/mod.rs:579-591) without the [M, 2N] tensor
 };

@@ -74,6 +74,20 @@ def test_unet_forward_large_tiles_forced(sd_tiny, synth, tiny_dims, tile):
     _assert_close(got, r32, r64, f"unet_forward tile={tile}", atol=1e-4)
 
 
+@pytest.mark.parametrize("variant", [10, 42, 58])
+def test_unet_forward_hoisted_split_gemm(sd_tiny, synth, tiny_dims, variant):
+    """the hoisted k loops of k_gemm3x.hip (gemm3x_variant bits 3 / 5 / 4) under the whole UNet: bit-identical to the default loop."""
+    d = tiny_dims
+    lat, ctx, _ = _inputs(d, 2, 7, 2)
+    base = sd_tiny.unet.forward(lat, [300], ctx)
+    try:
+        sd_tiny.set_option("gemm3x_variant", variant)
+        got = sd_tiny.unet.forward(lat, [300], ctx)
+    finally:
+        sd_tiny.set_option("gemm3x_variant", 2)
+    assert np.array_equal(got, base)
+
+
 def test_unet_forward_fp32_matrix_instruction_only(sd_tiny, synth, tiny_dims):
     """gemm_f32s=0 / attn_split=0: every product on v_mfma_f32_16x16x4_f32 (round 1's arithmetic).  Same bar; and the default
     path (fp32 operands as three bf16 terms, six partial products) agrees with it to fp32 rounding noise."""

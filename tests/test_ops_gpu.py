@@ -209,7 +209,14 @@ def test_conv2d_large_tiles(sd_ops, tile, splitk, case):
 STILES = [200, 201, 202, 203, 204, 205]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 6])   # bit 0: next k tile's DMA in one block behind the barrier; bit 1: scalar residual subtractions; bit 2: two LDS stages on the 128-row tiles too (default: three)
+# gemm3x_variant bits -- 0: next k tile's DMA in one block behind the barrier; 1: scalar residual subtractions; 2: two LDS stages on the
+# 128-row tiles too (default: three); 3: the head of a k tile (first fragment reads + split) hoisted into the last fragment row of the tile
+# before it, barrier in front of that row; 5 (with 3): the next tile's weight planes prefetched into the registers the last row no longer
+# needs; 4: s_setprio 1 for waves 4-7
+SPLIT_VARIANTS = [0, 1, 2, 6, 10, 42, 46, 58]
+
+
+@pytest.mark.parametrize("variant", SPLIT_VARIANTS)
 @pytest.mark.parametrize("tile", STILES)
 @pytest.mark.parametrize("splitk", [1, 3])
 @pytest.mark.parametrize("case", XCASES)
@@ -233,6 +240,62 @@ def test_conv2d_split_bf16_tiles(sd_ops, tile, splitk, case, variant):
     xin = O.upsample2x(_t(x)) if ups else _t(x)
     ref = O.conv2d(xin, (_t(wt), _t(b)), stride=stride, padding=1 if k == 3 else 0)
     _check(got, ref.numpy(), f"conv split-bf16 tile={tile} splitk={splitk} variant={variant} {case}")
+
+
+SHORT_K_CASES = [
+    # (n, cin, h, w, cout, k, splitk): one to four k tiles per slice -- the hoisted variants run their prologue and the dead-stage
+    # re-fetch of the last tile right next to each other here
+    (1, 32, 16, 16, 64, 1, 1), (1, 64, 16, 16, 320, 1, 1), (1, 64, 16, 16, 320, 1, 2), (1, 96, 12, 12, 160, 1, 1), (1, 96, 12, 12, 160, 1, 3),
+    (2, 32, 8, 8, 128, 3, 1), (2, 32, 8, 8, 128, 3, 3), (2, 32, 8, 8, 128, 3, 9), (1, 128, 20, 20, 100, 1, 1), (1, 128, 20, 20, 100, 1, 2),
+]
+
+
+@pytest.mark.parametrize("variant", [2, 10, 42, 46])
+@pytest.mark.parametrize("tile", STILES)
+@pytest.mark.parametrize("case", SHORT_K_CASES)
+def test_conv2d_split_bf16_short_k(sd_ops, tile, case, variant):
+    """k_gemm3x.hip with 1 ... 4 k tiles per split-K slice, every tile shape, plain and hoisted k loops."""
+    n, cin, h, w, cout, k, splitk = case
+    g = _rng(6000 + tile + 7 * splitk + cin + cout)
+    x = g.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (g.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k)).astype(np.float32)
+    b = g.standard_normal(cout).astype(np.float32)
+    try:
+        sd_ops.set_option("gemm3x_variant", variant)
+        sd_ops.set_option("gemm_tile", tile)
+        sd_ops.set_option("splitk", splitk)
+        got = sd_ops.op_conv2d(x, wt, b)
+    finally:
+        sd_ops.set_option("gemm3x_variant", 0)
+        sd_ops.set_option("gemm_tile", "auto")
+        sd_ops.set_option("splitk", 0)
+    ref = O.conv2d(_t(x), (_t(wt), _t(b)), padding=1 if k == 3 else 0)
+    _check(got, ref.numpy(), f"conv split-bf16 short K tile={tile} variant={variant} {case}")
+
+
+def test_conv2d_split_bf16_hoisted_variants_bit_identical(sd_ops):
+    """The hoisted k loops (variant bits 3 / 5 / 4) change WHEN operands are read and split, not the arithmetic: every tile
+    shape gives bit-identical results with and without them (same products, same accumulation order)."""
+    n, cin, h, w, cout = 2, 320, 24, 24, 320
+    g = _rng(8118)
+    x = g.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+    b = g.standard_normal(cout).astype(np.float32)
+    try:
+        for tile in STILES:
+            for splitk in (1, 4):
+                sd_ops.set_option("gemm_tile", tile)
+                sd_ops.set_option("splitk", splitk)
+                outs = {}
+                for variant in (2, 10, 42, 58, 6, 14, 46):
+                    sd_ops.set_option("gemm3x_variant", variant)
+                    outs[variant] = sd_ops.op_conv2d(x, wt, b)
+                for variant, o in outs.items():
+                    assert np.array_equal(o, outs[2]), f"tile {tile} splitk {splitk}: variant {variant} differs from variant 2"
+    finally:
+        sd_ops.set_option("gemm3x_variant", 0)
+        sd_ops.set_option("gemm_tile", "auto")
+        sd_ops.set_option("splitk", 0)
 
 
 def test_conv2d_split_bf16_is_fp32_accurate(sd_ops):

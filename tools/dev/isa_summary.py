@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Static look at a cross-compiled kernel file (no GPU needed): registers / scratch / LDS per kernel from
+-Rpass-analysis=kernel-resource-usage, and the instruction stream of one kernel's k loop in compressed form.
+
+    python tools/dev/isa_summary.py stable_diffusion_burn_amd/csrc/k_gemm3x.hip [--kernel SUBSTR] [--loop]
+"""
+import argparse, re, subprocess, tempfile, os, sys
+
+ap = argparse.ArgumentParser()
+ap.add_argument("src")
+ap.add_argument("--kernel", default=None, help="substring of the mangled name: dump that kernel's stream")
+ap.add_argument("--full", action="store_true", help="dump every instruction, not only the compressed stream")
+args = ap.parse_args()
+d = tempfile.mkdtemp(prefix="isa_")
+src = os.path.abspath(args.src)
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-c", src, "-o", "x.o",
+       "--save-temps", "-Rpass-analysis=kernel-resource-usage"]
+r = subprocess.run(cmd, cwd=d, capture_output=True, text=True)
+if r.returncode:
+    sys.exit(r.stderr)
+for b in re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]:
+    name = b.split()[0]
+    g = lambda k: re.search(k + r": (\S+)", b).group(1)
+    scr, occ = g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]")
+    print(f"{name[:110]:110s} VGPR {g('VGPRs'):>3s} AGPR {g('AGPRs'):>3s} SGPR {g('SGPRs'):>3s} scratch {scr} occ {occ}")
+if args.kernel:
+    asm = [f for f in os.listdir(d) if f.endswith("gfx950.s")][0]
+    s = open(os.path.join(d, asm)).read()
+    names = [m for m in re.findall(r"^(\w+):\s*; @", s, re.M) if args.kernel in m]
+    for name in names:
+        i = s.index(name + ":")
+        j = s.index(".Lfunc_end", i)
+        print("\n==== " + name)
+        row = []
+        for l in s[i:j].split("\n"):
+            l = l.strip()
+            if not l or l.startswith(";"):
+                continue
+            if l.startswith("."):
+                if l.startswith(".LBB"):
+                    print(" | ".join(row)); row = []; print(l)
+                continue
+            m = l.split()[0]
+            keep = args.full or m.startswith(("s_waitcnt", "s_barrier", "s_cbranch", "s_branch", "global_load_lds", "ds_read", "ds_write", "s_setprio", "s_nop", "global_load", "global_store", "buffer_"))
+            row.append(l.split(";")[0].strip() if keep else m)
+            if len(row) == 8:
+                print(" | ".join(row)); row = []
+        print(" | ".join(row))
