@@ -952,6 +952,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "attn_bf16") opt_attn_bf16_ = std::stoi(value);
     else if (key == "attn_split") opt_attn_split_ = std::stoi(value);
     else if (key == "gemm_bf16x") opt_gemm_bf16x_ = std::stoi(value);
+    else if (key == "gemm_bf16x_variant") opt_gemm_bf16x_variant_ = std::stoi(value);
     else if (key == "gemm_x32") opt_gemm_x32_ = std::stoi(value);
     else if (key == "gemm_f32s") opt_gemm_f32s_ = std::stoi(value);
     else if (key == "gemm3x_variant") opt_gemm3x_variant_ = std::stoi(value);
@@ -1096,7 +1097,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     auto it = table.find(key);
     const bool x32_ok = !in_dt && p.CS == 32 && p.Cin % 32 == 0 && p.out_mode == 0;   // what k_gemm2x.hip handles
     p.Bt3 = in_dt ? nullptr : split_planes(p.Bt);
-    p.variant = opt_gemm3x_variant_;
+    p.variant = in_dt ? opt_gemm_bf16x_variant_ : opt_gemm3x_variant_;
     // k_gemm3x.hip: the same layers, when the weight has its bf16 planes (weights in the arenas; not e.g. the K / V operands of
     // the unfused VAE attention) and the 32-bit piece offsets reach
     const bool s_ok = x32_ok && p.Bt3 && (unsigned long long)p.N * (p.geglu ? 2 : 1) * (unsigned long long)p.kt_total * 192ull < 0xFFFFFF00ull;

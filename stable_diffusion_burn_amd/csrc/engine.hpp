@@ -398,6 +398,7 @@ private:
                                      // bit 3: k-tile head hoisted into the previous tile's last fragment row; bit 5 (with 3): weight planes prefetched into dead registers; bit 4: s_setprio 1 for waves 4-7 (k_gemm3x.hip)
     int opt_gemm_x32_ = 1;      // precision = 0: 1 = large-tile LDS-DMA fp32 GEMM (k_gemm2x.hip) where measured / modelled faster
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
+    int opt_gemm_bf16x_variant_ = 0;   // k_gemm_bf16x.hip: bit 0 = pipelined k loop (DMA pieces and fragment reads behind the matrix instructions, barrier near the end of a tile)
     void* zero_page_ = nullptr;
     TileChoice choose_tile_bf16(int M, int N, int kt_total) const;   // cfg >= 100: k_gemm_bf16x.hip tile cfg - 100     // precision = 1: 1 = bf16 matrix-core attention, 0 = bf16 storage widened onto the fp32 kernel  // 1: attn2_kernel, 0: attn_f32_kernel
     // split-K combine: 0 = separate reduce kernel (the measured best, profiles/README.md); 1 = inside the GEMM launch by the

@@ -44,7 +44,125 @@ static const GemmTileInfo kTilesX[kNumGemmTilesX] = {
     {256, 320, "256x320x"}, {256, 256, "256x256x"}, {256, 128, "256x128x"}, {128, 320, "128x320x"}};
 const GemmTileInfo& gemm_tile_info_x(int cfg) { return kTilesX[cfg]; }
 
-template <int MI, int NI, int WM, int WN>
+// ---- PIPE (option gemm_bf16x_variant bit 0): the k loop as one gap-free matrix-instruction stream -------------------------------
+// The loop below the barrier of the plain form opens every k tile with the DMA of the next tile in one block (address arithmetic
+// with exec-mask branches for the padding taps: ~150 instructions for 9 pieces) and the reads of the first fragments -- more than
+// a thousand cycles in which neither wave of a SIMD issues a matrix instruction, against 2 560 cycles of matrix work per tile.
+// Here a k tile is a straight line of 2 MI fragment rows (two 32-deep k steps x MI rows) of NI matrix instructions, and everything
+// else sits in the issue slots behind them, pinned with sched_barrier(0) as in k_gemm3x.hip:
+//   * the next tile's DMA pieces, branch-free (zero page by select, 32-bit offsets), one every other slot of the first rows;
+//   * activation fragments through a ring of R registers: the fragment of row r + R is read behind the last instruction of row r;
+//   * weight fragments WITHOUT a second buffer: in the last row of a k step fragment ni is dead as soon as its matrix instruction
+//     has issued, and the next k step's fragment ni is read into it right there, NI instructions ahead of its use;
+//   * the barrier "the next tile has landed" therefore moves from the top of the tile to the end of row 2 MI - R, the last point
+//     before a read of the next tile; by then this wave has issued -- and waited for -- every read of the current stage, so the barrier
+//     still doubles as "this stage may be overwritten", and all DMA pieces were issued rows ago: vmcnt(0) finds them landed.
+template <int MI, int NI, int NA, int NB, int A_BYTES>
+struct BxWave {
+    static constexpr int ROWS = 2 * MI;
+    static constexpr int R = (MI >= 8) ? 4 : 2;
+    static constexpr int BAR_ROW = ROWS - R;
+    static constexpr int NP = NA + NB;
+    static constexpr int DMA_ROWS = (BAR_ROW < 4) ? BAR_ROW : 4;
+    static_assert(R >= 2 && R <= MI && DMA_ROWS <= BAR_ROW && DMA_ROWS * NI >= NP, "ring / barrier / DMA placement");
+
+    f32x4 acc[MI][NI];
+    u32x4 fb[NI];
+    u32x4 fa[R];
+    int a_iy0[NA], a_ix0[NA];
+    unsigned a_off[NA];               // byte offset of the sample + this lane's chunk (operands are < 4 GiB: launch_gemm checks)
+    unsigned b_off[NB];
+    const char *Abase, *Bbase, *zero;
+    unsigned pix_bytes;
+    int Hin, Win, ups, Ws, KH, KW, wave;
+    int cs, ky, kx, kt_next, kt_end;
+    const unsigned char *a_tile, *b_tile;     // current stage + this wave's activation / weight rows
+    const unsigned char *a_next, *b_next;     // the next k tile's
+    unsigned char* next_stage;                // where the DMA of k tile kt_next goes
+    int fr_off0, fr_off1;
+
+    // DMA piece J of k tile kt_next -> next_stage: straight-line code as in k_gemm3x.hip (S3Wave::piece); after the last piece the
+    // source moves on to the next k tile, unless there is none: then the same tile is fetched once more into the stage nobody reads
+    template <int J>
+    __device__ __forceinline__ void piece() {
+        if constexpr (J < NA) {
+            const int iy = a_iy0[J] + ky;
+            const int ix = a_ix0[J] + kx;
+            const bool ok = ((unsigned)iy < (unsigned)Hin) & ((unsigned)ix < (unsigned)Win);
+            const unsigned off = a_off[J] + (unsigned)((iy >> ups) * Ws + (ix >> ups)) * pix_bytes + (unsigned)cs * 128u;
+            const char* src = (ok ? Abase : zero) + (ok ? off : 0u);
+            __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(next_stage + (wave + 8 * J) * 1024), 16, 0, 0);
+        } else {
+            constexpr int j = J - NA;
+            const char* src = Bbase + (b_off[j] + (unsigned)kt_next * 128u);
+            __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(next_stage + A_BYTES + (wave + 8 * j) * 1024), 16, 0, 0);
+        }
+        if constexpr (J == NP - 1) {
+            const bool adv = kt_next + 1 < kt_end;
+            const bool wrap_x = (kx + 1 == KW);
+            const bool wrap_y = wrap_x && (ky + 1 == KH);
+            const int kx1 = wrap_x ? 0 : kx + 1;
+            const int ky1 = wrap_x ? (wrap_y ? 0 : ky + 1) : ky;
+            const int cs1 = wrap_y ? cs + 1 : cs;
+            kx = adv ? kx1 : kx;
+            ky = adv ? ky1 : ky;
+            cs = adv ? cs1 : cs;
+            kt_next = adv ? kt_next + 1 : kt_next;
+        }
+    }
+    template <int J0, int J1>
+    __device__ __forceinline__ void pieces() {
+        if constexpr (J0 < J1) { piece<J0>(); pieces<J0 + 1, J1>(); }
+    }
+
+    static __device__ __forceinline__ u32x4 rd(const unsigned char* q) { return *reinterpret_cast<const u32x4*>(q); }
+
+    // slot (row RW, column fragment NIX): one matrix instruction and what rides behind it
+    template <int RW, int NIX>
+    __device__ __forceinline__ void slots() {
+        if constexpr (RW < ROWS) {
+            constexpr int kk = RW / MI, mi = RW % MI;
+            acc[mi][NIX] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[NIX]), __builtin_bit_cast(bf16x8, fa[RW % R]),
+                                                                  acc[mi][NIX], 0, 0, 0);
+            if constexpr (RW < DMA_ROWS) {
+                constexpr int sl = RW * NI + NIX, SL = DMA_ROWS * NI;
+                pieces<sl * NP / SL, (sl + 1) * NP / SL>();
+            }
+            if constexpr (mi == MI - 1) {     // last row of a k step: weight fragment NIX of the next k step into the register just used
+                if constexpr (kk == 0) fb[NIX] = rd(b_tile + NIX * 2048 + fr_off1);
+                else fb[NIX] = rd(b_next + NIX * 2048 + fr_off0);
+            }
+            if constexpr (NIX == NI - 1) {
+                if constexpr (RW == BAR_ROW) {
+                    // every read of the current stage has been issued (the last ones a row ago) and every DMA piece of the next tile rows ago
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                constexpr int nr = RW + R;     // the activation fragment this ring slot holds next
+                if constexpr (nr < ROWS) fa[RW % R] = rd(a_tile + (nr % MI) * 2048 + ((nr / MI) ? fr_off1 : fr_off0));
+                else fa[RW % R] = rd(a_next + (nr - ROWS) * 2048 + fr_off0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NIX + 1 < NI) slots<RW, NIX + 1>();
+            else slots<RW + 1, 0>();
+        }
+    }
+    __device__ __forceinline__ void tile() {
+        __builtin_amdgcn_sched_barrier(0);
+        slots<0, 0>();
+    }
+    // the first k tile of the launch: what the tail of a tile does for its successor
+    __device__ __forceinline__ void head() {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) fb[ni] = rd(b_tile + ni * 2048 + fr_off0);
+#pragma unroll
+        for (int i = 0; i < R; ++i) fa[i] = rd(a_tile + i * 2048 + fr_off0);
+    }
+};
+
+template <int MI, int NI, int WM, int WN, bool PIPE>
 __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) {
     constexpr int BM = 16 * MI * WM;
     constexpr int BN = 16 * NI * WN;
@@ -84,6 +202,84 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
 
     const int T = p.KH * p.KW;
     const int HoWo = p.Ho * p.Wo;
+    BxWave<MI, NI, NA, NB, BM * 128> w;       // the accumulators live here in both forms; the plain loop uses nothing else of it
+    auto& acc = w.acc;
+    const int c15 = lane & 15, g4 = lane >> 4;
+    if constexpr (PIPE) {
+        w.Hin = p.Hs << p.ups;
+        w.Win = p.Ws << p.ups;
+        w.ups = p.ups;
+        w.Ws = p.Ws;
+        w.KH = p.KH;
+        w.KW = p.KW;
+        w.wave = wave;
+        w.pix_bytes = (unsigned)p.a_ld * 2u;
+        w.Abase = reinterpret_cast<const char*>(p.A);
+        w.Bbase = reinterpret_cast<const char*>(p.Bt);
+        w.zero = reinterpret_cast<const char*>(p.zero_page);
+        const int sub = lane >> 3;
+        const int chunk = (lane & 7) ^ sub;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int m = m0 + (wave + 8 * j) * 8 + sub;
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0;
+            const int nb = mm / HoWo;
+            const int rem = mm - nb * HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            w.a_off[j] = (unsigned)nb * (unsigned)(p.Hs * p.Ws) * w.pix_bytes + chunk * 16;
+            w.a_iy0[j] = ok ? oy * p.stride - p.pad : -(1 << 28);   // rows past M: never in range -> zero page
+            w.a_ix0[j] = ox * p.stride - p.pad;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int r0 = (wave + 8 * j) * 8 + sub;   // tile row of operand B
+            int n = n0 + r0;
+            long long wrow = n;
+            if (geglu) {
+                const int f = r0 >> 4, fw = f / NI, ni = f - fw * NI;
+                n = n0 + fw * (WNC / 2) + (ni >> 1) * 16 + (r0 & 15);
+                wrow = (long long)n + ((ni & 1) ? p.N : 0);
+            }
+            // rows past N (ragged last tile) fetch the last valid row instead: real memory, and the accumulator columns they feed are never stored
+            if (n >= p.N) wrow -= (n - (p.N - 1));
+            w.b_off[j] = (unsigned)wrow * (unsigned)p.b_ld * 2u + chunk * 16;
+        }
+        w.cs = kt_begin / T;
+        const int tap0 = kt_begin - w.cs * T;
+        w.ky = tap0 / p.KW;
+        w.kx = tap0 - w.ky * p.KW;
+        w.kt_next = kt_begin;
+        w.kt_end = kt_end;
+        w.fr_off0 = c15 * 128 + (((0 + g4) ^ (c15 & 7)) << 4);
+        w.fr_off1 = c15 * 128 + (((4 + g4) ^ (c15 & 7)) << 4);
+        const int a_base = wm * 16 * MI * 128;
+        const int b_base = BM * 128 + wn * 16 * NI * 128;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        w.next_stage = smem_x;
+        w.template pieces<0, NA + NB>();      // k tile 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        w.a_tile = smem_x + a_base;
+        w.b_tile = smem_x + b_base;
+        w.head();
+        for (int t = 0; t < n_t; ++t) {
+            const int cur = t & 1;
+            w.next_stage = smem_x + (cur ^ 1) * STAGE;
+            w.a_tile = smem_x + cur * STAGE + a_base;
+            w.b_tile = smem_x + cur * STAGE + b_base;
+            w.a_next = smem_x + (cur ^ 1) * STAGE + a_base;
+            w.b_next = smem_x + (cur ^ 1) * STAGE + b_base;
+            w.tile();
+        }
+        // the last k tile was fetched twice (piece()); that copy must have landed before the epilogue reuses the stages
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
     const int Hin = p.Hs << p.ups;
     const int Win = p.Ws << p.ups;
     const long long pix_bytes = (long long)p.a_ld * 2;
@@ -158,13 +354,11 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     };
 
     // fragment reads: lane (c = lane & 15, g = lane >> 4) reads row base + c, chunk (4 kk + g) ^ (c & 7)
-    const int c15 = lane & 15, g4 = lane >> 4;
     const int fr_off0 = c15 * 128 + (((0 + g4) ^ (c15 & 7)) << 4);
     const int fr_off1 = c15 * 128 + (((4 + g4) ^ (c15 & 7)) << 4);
     const int a_base = wm * 16 * MI * 128;
     const int b_base = BM * 128 + wn * 16 * NI * 128;
 
-    f32x4 acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -217,6 +411,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
                 }
         }
     }
+    }   // plain k loop
 
     // ---- epilogue: fp32 bias + time-embedding row + (bf16) residual, then bf16 or fp32 store ----------
     // A lane holds 4 consecutive channels of 16 different rows, so storing straight from the accumulators issues
@@ -374,10 +569,10 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     }
 }
 
-template <int MI, int NI, int WM, int WN>
+template <int MI, int NI, int WM, int WN, bool PIPE>
 static hipError_t launch_cfg_bf16x(const ConvGemm& p, dim3 grid, hipStream_t stream) {
     static bool attr_set = false;
-    auto k = conv_gemm_bf16x_kernel<MI, NI, WM, WN>;
+    auto k = conv_gemm_bf16x_kernel<MI, NI, WM, WN, PIPE>;
     constexpr size_t lds = 2 * (size_t)(16 * MI * WM + 16 * NI * WN) * 128;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -397,11 +592,20 @@ hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int cfg, hipStream_t stream
     const int MT = (p.M + bm - 1) / bm, NT = (p.N + bno - 1) / bno;
     const int tiles = MT * NT;
     dim3 grid(((tiles + 7) / 8) * 8, 1, p.splits);
+    // p.variant bit 0 (option gemm_bf16x_variant): the pipelined k loop (BxWave)
+    if (p.variant & 1) {
+        switch (cfg) {
+            case 0: return launch_cfg_bf16x<8, 5, 2, 4, true>(p, grid, stream);
+            case 1: return launch_cfg_bf16x<8, 4, 2, 4, true>(p, grid, stream);
+            case 2: return launch_cfg_bf16x<4, 4, 4, 2, true>(p, grid, stream);
+            case 3: return launch_cfg_bf16x<4, 5, 2, 4, true>(p, grid, stream);
+        }
+    }
     switch (cfg) {
-        case 0: return launch_cfg_bf16x<8, 5, 2, 4>(p, grid, stream);
-        case 1: return launch_cfg_bf16x<8, 4, 2, 4>(p, grid, stream);
-        case 2: return launch_cfg_bf16x<4, 4, 4, 2>(p, grid, stream);
-        case 3: return launch_cfg_bf16x<4, 5, 2, 4>(p, grid, stream);
+        case 0: return launch_cfg_bf16x<8, 5, 2, 4, false>(p, grid, stream);
+        case 1: return launch_cfg_bf16x<8, 4, 2, 4, false>(p, grid, stream);
+        case 2: return launch_cfg_bf16x<4, 4, 4, 2, false>(p, grid, stream);
+        case 3: return launch_cfg_bf16x<4, 5, 2, 4, false>(p, grid, stream);
     }
     return hipErrorInvalidValue;
 }

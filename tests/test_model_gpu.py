@@ -74,6 +74,7 @@ def test_unet_forward_large_tiles_forced(sd_tiny, synth, tiny_dims, tile):
     _assert_close(got, r32, r64, f"unet_forward tile={tile}", atol=1e-4)
 
 
+@pytest.mark.unverified
 @pytest.mark.parametrize("variant", [10, 42, 58])
 def test_unet_forward_hoisted_split_gemm(sd_tiny, synth, tiny_dims, variant):
     """the hoisted k loops of k_gemm3x.hip (gemm3x_variant bits 3 / 5 / 4) under the whole UNet: bit-identical to the default loop."""

@@ -213,7 +213,8 @@ STILES = [200, 201, 202, 203, 204, 205]
 # 128-row tiles too (default: three); 3: the head of a k tile (first fragment reads + split) hoisted into the last fragment row of the tile
 # before it, barrier in front of that row; 5 (with 3): the next tile's weight planes prefetched into the registers the last row no longer
 # needs; 4: s_setprio 1 for waves 4-7
-SPLIT_VARIANTS = [0, 1, 2, 6, 10, 42, 46, 58]
+UNVERIFIED = pytest.mark.unverified
+SPLIT_VARIANTS = [0, 1, 2, 6] + [pytest.param(v, marks=UNVERIFIED) for v in (10, 42, 46, 58)]
 
 
 @pytest.mark.parametrize("variant", SPLIT_VARIANTS)
@@ -250,7 +251,7 @@ SHORT_K_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [2, 10, 42, 46])
+@pytest.mark.parametrize("variant", [2] + [pytest.param(v, marks=UNVERIFIED) for v in (10, 42, 46)])
 @pytest.mark.parametrize("tile", STILES)
 @pytest.mark.parametrize("case", SHORT_K_CASES)
 def test_conv2d_split_bf16_short_k(sd_ops, tile, case, variant):
@@ -273,6 +274,7 @@ def test_conv2d_split_bf16_short_k(sd_ops, tile, case, variant):
     _check(got, ref.numpy(), f"conv split-bf16 short K tile={tile} variant={variant} {case}")
 
 
+@UNVERIFIED
 def test_conv2d_split_bf16_hoisted_variants_bit_identical(sd_ops):
     """The hoisted k loops (variant bits 3 / 5 / 4) change WHEN operands are read and split, not the arithmetic: every tile
     shape gives bit-identical results with and without them (same products, same accumulation order)."""
