@@ -243,6 +243,11 @@ int sdmi_sample_image_sharded(sdmi_multi* m, const float* context, int32_t T, co
 /* the contiguous global image range [begin, end) device `rank` of `n_ranks` samples (host only): the partition rule of
  * sdmi_sample_image_sharded, and of the one-process-per-GPU launcher (bench.py / sharding.py use the same rule) */
 int sdmi_shard_range(int32_t n_images, int32_t rank, int32_t n_ranks, int32_t* begin, int32_t* end);
+/* how one GEMM launch of mt x nt output tiles and `splits` split-K slices is cut over the 8 XCDs of an MI355X (option "xcd_map"; host only,
+ * no device needed): out = {cuts along M tiles, cuts along N tiles, M tiles / N tiles / slices per XCD}; the cut along the slices is
+ * 8 / (out[0] out[1]).  a_bytes / w_bytes: the activation / weight bytes the launch reads; flops: its 2 M N K; cu_flops: what one
+ * CU sustains in the kernel (FLOP/s).  What the CPU tests check the map with. */
+int sdmi_plan_xcd_map(int32_t mt, int32_t nt, int32_t splits, double a_bytes, double w_bytes, double flops, double cu_flops, int32_t out[5]);
 /* number of RCCL broadcasts issued so far (one per sdmi_sample_image_sharded call) */
 int64_t sdmi_multi_broadcast_count(sdmi_multi* m);
 

@@ -953,6 +953,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "attn_split") opt_attn_split_ = std::stoi(value);
     else if (key == "gemm_bf16x") opt_gemm_bf16x_ = std::stoi(value);
     else if (key == "gemm_bf16x_variant") opt_gemm_bf16x_variant_ = std::stoi(value);
+    else if (key == "xcd_map") opt_xcd_map_ = std::stoi(value);
     else if (key == "gemm_x32") opt_gemm_x32_ = std::stoi(value);
     else if (key == "gemm_f32s") opt_gemm_f32s_ = std::stoi(value);
     else if (key == "gemm3x_variant") opt_gemm3x_variant_ = std::stoi(value);
@@ -1081,6 +1082,21 @@ TileChoice Engine::choose_tile_bf16(int M, int N, int kt_total) const {
     return bc;
 }
 
+// How the 8 XCDs share one GEMM launch (ConvGemm::xcd_*; kernels.hpp).  Every XCD has its own L2, so an operand byte crosses the
+// fabric once per XCD that touches it: with the box of work items (MT x NT x splits) cut xm x xn x xz ways (xm xn xz = 8) the launch
+// moves xn * (activation bytes) + xm * (weight bytes) into the L2s.  The legacy map is xm = 8 (bands of M tiles; or of N tiles when
+// there is one M tile), xz = 1: every XCD streams ALL the weights -- at batch 1 the weights are the big operand (88 MB of planes for
+// a 1280 -> 1280 3x3 convolution against 2.6 MB of activations) and most launches are split-K, whose slices are a third axis to cut
+// along: a slice reads 1 / splits of BOTH operands.  Chosen here (xcd_map_choose, kernels.hpp): the cut with the smallest modelled time,
+// rounds of work items on the busiest XCD x the time of one item + bytes / fabric bandwidth.  Option xcd_map = 1: on; 0: legacy map.
+void Engine::choose_xcd_map(ConvGemm& p, int MT, int NT, double a_bytes, double w_bytes, double flops, double cu_flops) const {
+    p.xcd_m = 0;
+    if (opt_xcd_map_ <= 0) return;
+    int o[5];
+    xcd_map_choose(MT, NT, p.splits, a_bytes, w_bytes, flops, cu_flops, o);
+    p.xcd_m = o[0]; p.xcd_n = o[1]; p.xcd_ml = o[2]; p.xcd_nl = o[3]; p.xcd_zl = o[4];
+}
+
 void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits) {
     const int kt_elems = in_dt ? 64 : 32;  // a k tile is 128 bytes of K per row in both storage types
     p.kt_total = (p.K + kt_elems - 1) / kt_elems;
@@ -1131,6 +1147,16 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     if (a_ext >= 0xFFFFFFE0ull || b_ext >= 0xFFFFFFE0ull) throw Error(SDMI_ERR_UNSUPPORTED, "GEMM: operand larger than 4 GiB (the buffer-load range check needs 32-bit extents)");
     p.a_bytes = (unsigned)a_ext;
     p.b_bytes = (unsigned)b_ext;
+    {
+        const GemmTileInfo& ti = in_dt ? (tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100) : gemm_tile_info(tc.cfg))
+                                       : (tc.cfg >= 200 ? gemm_tile_info_s(tc.cfg - 200) : (tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100) : gemm_tile_info(tc.cfg)));
+        const int bno = p.geglu ? ti.bn / 2 : ti.bn;
+        const double wes = in_dt ? 2.0 : (tc.cfg >= 200 ? 6.0 : 4.0);     // bytes per weight as this kernel reads them (three bf16 planes: 6)
+        // what a CU sustains in the kernel's k loop (chip rate / 256; measured per family: profiles/README.md)
+        const double cu_flops = (in_dt ? 1.2e15 : (tc.cfg >= 200 ? 2.3e14 : 1.3e14)) / 256.0;
+        choose_xcd_map(p, (p.M + ti.bm - 1) / ti.bm, (p.N + bno - 1) / bno, (double)p.NB * p.Hs * p.Ws * p.Cin * (double)es,
+                       (double)p.N * (p.geglu ? 2.0 : 1.0) * (double)p.K * wes, flops, cu_flops);
+    }
     auto launch = [&](const ConvGemm& q) {
         if (in_dt && tc.cfg >= 100) return launch_conv_gemm_bf16x(q, tc.cfg - 100, stream_);
         if (tc.cfg >= 200) return launch_conv_gemm3x(q, tc.cfg - 200, stream_);

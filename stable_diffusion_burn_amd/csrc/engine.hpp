@@ -255,6 +255,7 @@ private:
     static Act slice(const Act& parent, int c_off, int c);   // channel-slice view
     void gemm(const float* A, int a_rows, const float* bt, const float* bias, int cin, int cout, float* C, int ldc,
               const float* resid, int ldr, int dt = -1, int out_mode = 0);
+    void choose_xcd_map(ConvGemm& p, int MT, int NT, double a_bytes, double w_bytes, double flops, double cu_flops) const;
     void launch_gemm(ConvGemm& p, int in_dt, int force_cfg = -1, int force_splits = 0);
     int edt() const { return bf16_ ? 1 : 0; }
     size_t esz() const { return bf16_ ? 2 : 4; }
@@ -399,6 +400,7 @@ private:
     int opt_gemm_x32_ = 1;      // precision = 0: 1 = large-tile LDS-DMA fp32 GEMM (k_gemm2x.hip) where measured / modelled faster
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
     int opt_gemm_bf16x_variant_ = 0;   // k_gemm_bf16x.hip: bit 0 = pipelined k loop (DMA pieces and fragment reads behind the matrix instructions, barrier near the end of a tile)
+    int opt_xcd_map_ = 0;              // 1: cut every GEMM launch over the 8 XCDs so that the fewest operand bytes cross the fabric (choose_xcd_map); 0: bands of tiles, every XCD reads all weights
     void* zero_page_ = nullptr;
     TileChoice choose_tile_bf16(int M, int N, int kt_total) const;   // cfg >= 100: k_gemm_bf16x.hip tile cfg - 100     // precision = 1: 1 = bf16 matrix-core attention, 0 = bf16 storage widened onto the fp32 kernel  // 1: attn2_kernel, 0: attn_f32_kernel
     // split-K combine: 0 = separate reduce kernel (the measured best, profiles/README.md); 1 = inside the GEMM launch by the

@@ -129,15 +129,15 @@ __global__ __launch_bounds__(512) void conv_gemm_fp8x_kernel(const ConvGemm p) {
 
     const int MT = (p.M + BM - 1) / BM;
     const int NT = (p.N + BN - 1) / BN;
-    const int tpx = gridDim.x >> 3;
-    const int lid = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3);
-    if (lid >= MT * NT) return;
-    const int tm = lid / NT;
-    const int tn = lid - tm * NT;
+    const GemmWork gw = gemm_work_of_block(p, MT, NT);
+    if (!gw.live) return;
+    const int lid = gw.lid;
+    const int tm = gw.tm;
+    const int tn = gw.tn;
     const int m0 = tm * BM;
     const int n0 = tn * BN;
 
-    const int z = blockIdx.z;
+    const int z = gw.z;
     const int kt_begin = z * p.kt_per_split;
     const int kt_end = min(kt_begin + p.kt_per_split, p.kt_total);
     const int n_t = kt_end - kt_begin;
@@ -374,7 +374,7 @@ hipError_t launch_conv_gemm_fp8x(const ConvGemm& p, int cfg, hipStream_t stream)
     if ((p.N & 7) || (p.ldc & 7) || (p.resid && (p.ldr & 7))) return hipErrorInvalidValue;   // 16-byte epilogue only
     const int bm = kTilesQ[cfg].bm, bn = kTilesQ[cfg].bn;
     const int MT = (p.M + bm - 1) / bm, NT = (p.N + bn - 1) / bn;
-    dim3 grid(((MT * NT + 7) / 8) * 8, 1, p.splits);
+    const dim3 grid = gemm_grid(p, MT * NT);
     switch (cfg) {
         case 0: return launch_cfg_fp8x<8, 5, 2, 4>(p, grid, stream);
         case 1: return launch_cfg_fp8x<8, 4, 2, 4>(p, grid, stream);

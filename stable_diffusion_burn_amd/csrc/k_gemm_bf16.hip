@@ -57,15 +57,15 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const ConvGemm p) {
 
     const int MT = (p.M + BM - 1) / BM;
     const int NT = (p.N + BN - 1) / BN;
-    const int tpx = gridDim.x >> 3;
-    const int lid = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3);
-    if (lid >= MT * NT) return;
-    const int tm = lid / NT;
-    const int tn = lid - tm * NT;
+    const GemmWork gw = gemm_work_of_block(p, MT, NT);
+    if (!gw.live) return;
+    const int lid = gw.lid;
+    const int tm = gw.tm;
+    const int tn = gw.tn;
     const int m0 = tm * BM;
     const int n0 = tn * BN;
 
-    const int z = blockIdx.z;
+    const int z = gw.z;
     const int kt_begin = z * p.kt_per_split;
     const int kt_end = min(kt_begin + p.kt_per_split, p.kt_total);
     const int n_t = kt_end - kt_begin;
@@ -369,7 +369,7 @@ hipError_t launch_conv_gemm_bf16(const ConvGemm& p, int cfg, hipStream_t stream)
     const int bm = gemm_tile_info(cfg).bm, bn = gemm_tile_info(cfg).bn;
     const int MT = (p.M + bm - 1) / bm, NT = (p.N + bn - 1) / bn;
     const int tiles = MT * NT;
-    dim3 grid(((tiles + 7) / 8) * 8, 1, p.splits);
+    const dim3 grid = gemm_grid(p, tiles);
     const size_t lds = gemm2_tile_lds_bytes(cfg);
     switch (cfg) {
         case 0: return launch_cfg_bf16<4, 4, 2, 2>(p, lds, grid, stream);

@@ -187,15 +187,15 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     const int BNO = geglu ? BN / 2 : BN;   // output columns per tile
     const int MT = (p.M + BM - 1) / BM;
     const int NT = (p.N + BNO - 1) / BNO;
-    const int tpx = gridDim.x >> 3;
-    const int lid = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3);
-    if (lid >= MT * NT) return;
-    const int tm = lid / NT;
-    const int tn = lid - tm * NT;
+    const GemmWork gw = gemm_work_of_block(p, MT, NT);
+    if (!gw.live) return;
+    const int lid = gw.lid;
+    const int tm = gw.tm;
+    const int tn = gw.tn;
     const int m0 = tm * BM;
     const int n0 = tn * BNO;
 
-    const int z = blockIdx.z;
+    const int z = gw.z;
     const int kt_begin = z * p.kt_per_split;
     const int kt_end = min(kt_begin + p.kt_per_split, p.kt_total);
     const int n_t = kt_end - kt_begin;
@@ -591,7 +591,7 @@ hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int cfg, hipStream_t stream
     const int bno = p.geglu ? bn / 2 : bn;
     const int MT = (p.M + bm - 1) / bm, NT = (p.N + bno - 1) / bno;
     const int tiles = MT * NT;
-    dim3 grid(((tiles + 7) / 8) * 8, 1, p.splits);
+    const dim3 grid = gemm_grid(p, tiles);
     // p.variant bit 0 (option gemm_bf16x_variant): the pipelined k loop (BxWave)
     if (p.variant & 1) {
         switch (cfg) {

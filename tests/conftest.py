@@ -19,15 +19,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: takes more than ~30 s")
     config.addinivalue_line("markers", "unverified: GPU test of a kernel variant that has not run on an MI355X yet (an option that is off by "
                                        "default); skipped unless SDMI_UNVERIFIED=1 -- the mark is removed once a GPU run has confirmed it")
+    config.addinivalue_line("markers", "variants: the extended parity matrix of kernel variants that are OFF by default (verified on an MI355X, "
+                                       "gpurun_out r02y: 479 passed); skipped unless SDMI_VARIANTS=1 to keep the default GPU suite short -- "
+                                       "one bit-identity test per variant family always runs")
 
 
 def pytest_collection_modifyitems(config, items):
-    if os.environ.get("SDMI_UNVERIFIED") == "1":
-        return
-    skip = pytest.mark.skip(reason="kernel variant not yet verified on an MI355X (off by default); set SDMI_UNVERIFIED=1 to run")
-    for item in items:
-        if "unverified" in item.keywords:
-            item.add_marker(skip)
+    for env, mark, why in (("SDMI_UNVERIFIED", "unverified", "kernel variant not yet verified on an MI355X (off by default); set SDMI_UNVERIFIED=1 to run"),
+                           ("SDMI_VARIANTS", "variants", "extended matrix of an off-by-default kernel variant; set SDMI_VARIANTS=1 to run")):
+        if os.environ.get(env) == "1":
+            continue
+        skip = pytest.mark.skip(reason=why)
+        for item in items:
+            if mark in item.keywords:
+                item.add_marker(skip)
 
 
 def gpu_available() -> bool:

@@ -125,7 +125,6 @@ XCASES_SHORT_K = [
 ]
 
 
-@pytest.mark.unverified
 @pytest.mark.parametrize("tile", [100, 101, 102, 103])
 def test_conv2d_bf16_large_tiles_pipelined_loop(ops16, tile):
     """gemm_bf16x_variant = 1: the pipelined k loop of k_gemm_bf16x.hip (DMA pieces and fragment reads behind the matrix
@@ -298,7 +297,6 @@ def test_unet_forward_bf16_large_tiles_forced(sd16, tile):
     assert np.isfinite(got).all() and r < BAR_UNET
 
 
-@pytest.mark.unverified
 @pytest.mark.parametrize("tile", ["auto", 100, 103])
 def test_unet_forward_bf16_pipelined_loop(sd16, tile):
     """the whole UNet with gemm_bf16x_variant = 1: bit-identical to the plain k loop (auto tiles and forced large tiles)."""
@@ -311,6 +309,23 @@ def test_unet_forward_bf16_pipelined_loop(sd16, tile):
         got = sd16.unet.forward(lat, [500], ctx)
     finally:
         sd16.set_option("gemm_bf16x_variant", 0)
+        sd16.set_option("gemm_tile", "auto")
+    assert np.isfinite(got).all() and np.array_equal(got, base)
+
+
+@pytest.mark.unverified
+@pytest.mark.parametrize("tile", ["auto", 2, 100, 103])
+def test_unet_forward_bf16_xcd_map(sd16, tile):
+    """option xcd_map = 1 with the bf16 GEMM kernels: bit-identical to the legacy block -> tile map."""
+    lat = np.stack([syn.initial_latent(i, 8, 8) for i in range(2)])
+    ctx = np.stack([syn.cond_context(i, 77, 768) for i in range(2)])
+    try:
+        sd16.set_option("gemm_tile", tile)
+        base = sd16.unet.forward(lat, [500], ctx)
+        sd16.set_option("xcd_map", 1)
+        got = sd16.unet.forward(lat, [500], ctx)
+    finally:
+        sd16.set_option("xcd_map", 0)
         sd16.set_option("gemm_tile", "auto")
     assert np.isfinite(got).all() and np.array_equal(got, base)
 

@@ -214,7 +214,8 @@ STILES = [200, 201, 202, 203, 204, 205]
 # before it, barrier in front of that row; 5 (with 3): the next tile's weight planes prefetched into the registers the last row no longer
 # needs; 4: s_setprio 1 for waves 4-7
 UNVERIFIED = pytest.mark.unverified
-SPLIT_VARIANTS = [0, 1, 2, 6] + [pytest.param(v, marks=UNVERIFIED) for v in (10, 42, 46, 58)]
+VARIANTS = pytest.mark.variants
+SPLIT_VARIANTS = [0, 1, 2, 6] + [pytest.param(v, marks=VARIANTS) for v in (10, 42, 46, 58)]
 
 
 @pytest.mark.parametrize("variant", SPLIT_VARIANTS)
@@ -251,7 +252,7 @@ SHORT_K_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [2] + [pytest.param(v, marks=UNVERIFIED) for v in (10, 42, 46)])
+@pytest.mark.parametrize("variant", [pytest.param(v, marks=VARIANTS) for v in (2, 10, 42, 46)])
 @pytest.mark.parametrize("tile", STILES)
 @pytest.mark.parametrize("case", SHORT_K_CASES)
 def test_conv2d_split_bf16_short_k(sd_ops, tile, case, variant):
@@ -274,7 +275,6 @@ def test_conv2d_split_bf16_short_k(sd_ops, tile, case, variant):
     _check(got, ref.numpy(), f"conv split-bf16 short K tile={tile} variant={variant} {case}")
 
 
-@UNVERIFIED
 def test_conv2d_split_bf16_hoisted_variants_bit_identical(sd_ops):
     """The hoisted k loops (variant bits 3 / 5 / 4) change WHEN operands are read and split, not the arithmetic: every tile
     shape gives bit-identical results with and without them (same products, same accumulation order)."""
@@ -298,6 +298,36 @@ def test_conv2d_split_bf16_hoisted_variants_bit_identical(sd_ops):
         sd_ops.set_option("gemm3x_variant", 0)
         sd_ops.set_option("gemm_tile", "auto")
         sd_ops.set_option("splitk", 0)
+
+
+@UNVERIFIED
+@pytest.mark.parametrize("tile", ["auto", 0, 2, 4, 8, 9, 100, 103, 200, 201, 202, 203, 204, 205])
+def test_conv2d_xcd_map_bit_identical(sd_ops, tile):
+    """option xcd_map = 1 (the GEMM launch cut over the 8 XCDs along M tiles x N tiles x split-K slices, kernels.hpp
+    xcd_map_choose) changes WHICH block computes a work item, nothing else: bit-identical outputs for every kernel family, ragged
+    M / N tiles, 1x1 / 3x3 / strided / upsampling convolutions, with and without split-K."""
+    for case in XCASES + [(1, 320, 16, 16, 1280, 3, 1, 0), (2, 64, 8, 8, 2560, 1, 1, 0)]:
+        n, cin, h, w, cout, k, stride, ups = case
+        g = _rng(9000 + cin + cout)
+        x = g.standard_normal((n, cin, h, w)).astype(np.float32)
+        wt = (g.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k)).astype(np.float32)
+        b = g.standard_normal(cout).astype(np.float32)
+        for splitk in (1, 3, 8):
+            try:
+                sd_ops.set_option("gemm_tile", tile)
+                sd_ops.set_option("splitk", splitk if tile != "auto" else 0)
+                base = sd_ops.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
+                sd_ops.set_option("xcd_map", 1)
+                got = sd_ops.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
+            finally:
+                sd_ops.set_option("xcd_map", 0)
+                sd_ops.set_option("gemm_tile", "auto")
+                sd_ops.set_option("splitk", 0)
+            assert np.array_equal(got, base), f"xcd_map changes the result: tile={tile} splitk={splitk} {case}"
+            if tile == "auto":
+                break
+    xin = O.upsample2x(_t(x)) if ups else _t(x)
+    _check(got, O.conv2d(xin, (_t(wt), _t(b)), stride=stride, padding=1 if k == 3 else 0).numpy(), f"conv xcd_map tile={tile}")
 
 
 def test_conv2d_split_bf16_is_fp32_accurate(sd_ops):
