@@ -57,7 +57,15 @@ const GemmTileInfo& gemm_tile_info_x(int cfg) { return kTilesX[cfg]; }
 //   * the barrier "the next tile has landed" therefore moves from the top of the tile to the end of row 2 MI - R, the last point
 //     before a read of the next tile; by then this wave has issued -- and waited for -- every read of the current stage, so the barrier
 //     still doubles as "this stage may be overwritten", and all DMA pieces were issued rows ago: vmcnt(0) finds them landed.
-template <int MI, int NI, int NA, int NB, int A_BYTES>
+// ASMW (variant bit 1): hipcc's own LDS waits in a kernel with LDS-DMA in flight are all `s_waitcnt lgkmcnt(0)`, so the wait in front of the
+// first use of a fragment also waits for the fragment read that was issued one slot ago -- a full LDS round trip (several hundred cycles
+// with sixteen waves and the DMA sharing the LDS) at every row of the rolling schedule above, which is why that schedule alone measured
+// no faster than the plain loop (profiles/r02y_*).  Here the fragment reads are inline asm (invisible to the waitcnt pass) and the waits are
+// COUNTED by hand: LDS reads of a wave complete in issue order, so `lgkmcnt(n)` in front of a matrix instruction is exactly "everything but
+// the n reads issued after my operands has landed".  n is computed at compile time from the schedule itself (reads_in / wait_n below);
+// tools/dev/check_lgkm.py re-derives the guarantee from the COMPILED instruction stream (every use of a fragment register is behind a
+// wait that covers its read), and the parity tests hold the loop bit-identical to the plain one.
+template <int MI, int NI, int NA, int NB, int A_BYTES, bool ASMW = false>
 struct BxWave {
     static constexpr int ROWS = 2 * MI;
     static constexpr int R = (MI >= 8) ? 4 : 2;
@@ -80,6 +88,31 @@ struct BxWave {
     const unsigned char *a_next, *b_next;     // the next k tile's
     unsigned char* next_stage;                // where the DMA of k tile kt_next goes
     int fr_off0, fr_off1;
+
+    // ---- ASMW: the schedule's own arithmetic (slots are numbered r * NI + ni and continue across tiles, periodically) -------------
+    static constexpr int TILE = ROWS * NI;
+    static constexpr int fmod(int a, int m) { return ((a % m) + m) % m; }
+    static constexpr bool roll_row(int r) { return fmod(r, MI) == MI - 1; }            // its slots re-load the weight fragments
+    static constexpr int cnt(int s) { return (roll_row(fmod(s, TILE) / NI) ? 1 : 0) + (fmod(s, NI) == NI - 1 ? 1 : 0); }   // reads issued behind slot s's matrix instruction
+    static constexpr int reads_in(int a, int b) { int n = 0; for (int u = a; u < b; ++u) n += cnt(u); return n; }
+    // reads issued after the operands of matrix instruction (r, ni) and before it: the count its wait may leave outstanding
+    static constexpr int newer_than_a(int r, int ni) { return reads_in((r - R) * NI + NI, r * NI + ni); }     // fa[r % R]: last read of slot (r - R, NI - 1)
+    static constexpr int newer_than_b(int r, int ni) {                                                            // fb[ni]: first read of slot (rho, ni), rho = the roll row before r
+        const int rho = (r >= MI) ? MI - 1 : -1;
+        return (ni == NI - 1 ? 1 : 0) + reads_in(rho * NI + ni + 1, r * NI + ni);
+    }
+    static constexpr int wait_n(int r, int ni) {     // -1: an earlier wait of the row covers this instruction's operands
+        const int a = newer_than_a(r, ni), b = newer_than_b(r, ni);
+        int n = -1;
+        if (ni == 0) n = a < b ? a : b;
+        else if (r == 0 || r == MI) n = b;
+        return n > 15 ? 15 : n;                      // lgkmcnt is a 4-bit field
+    }
+    unsigned a_lds[2], b_lds[2], an_lds, bn_lds;     // LDS byte addresses (+ this lane's chunk) of the wave's rows: current tile k step 0 / 1, next tile k step 0
+    template <int OFF>
+    static __device__ __forceinline__ void rd_asm(u32x4& dst, unsigned addr) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+    }
 
     // DMA piece J of k tile kt_next -> next_stage: straight-line code as in k_gemm3x.hip (S3Wave::piece); after the last piece the
     // source moves on to the next k tile, unless there is none: then the same tile is fetched once more into the stage nobody reads
@@ -122,6 +155,10 @@ struct BxWave {
     __device__ __forceinline__ void slots() {
         if constexpr (RW < ROWS) {
             constexpr int kk = RW / MI, mi = RW % MI;
+            if constexpr (ASMW) {
+                constexpr int WN_ = wait_n(RW, NIX);
+                if constexpr (WN_ >= 0) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fb[NIX]), "+v"(fa[RW % R]) : "n"(WN_));
+            }
             acc[mi][NIX] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[NIX]), __builtin_bit_cast(bf16x8, fa[RW % R]),
                                                                   acc[mi][NIX], 0, 0, 0);
             if constexpr (RW < DMA_ROWS) {
@@ -129,20 +166,32 @@ struct BxWave {
                 pieces<sl * NP / SL, (sl + 1) * NP / SL>();
             }
             if constexpr (mi == MI - 1) {     // last row of a k step: weight fragment NIX of the next k step into the register just used
-                if constexpr (kk == 0) fb[NIX] = rd(b_tile + NIX * 2048 + fr_off1);
-                else fb[NIX] = rd(b_next + NIX * 2048 + fr_off0);
+                if constexpr (ASMW) {
+                    if constexpr (kk == 0) rd_asm<NIX * 2048>(fb[NIX], b_lds[1]);
+                    else rd_asm<NIX * 2048>(fb[NIX], bn_lds);
+                } else {
+                    if constexpr (kk == 0) fb[NIX] = rd(b_tile + NIX * 2048 + fr_off1);
+                    else fb[NIX] = rd(b_next + NIX * 2048 + fr_off0);
+                }
             }
             if constexpr (NIX == NI - 1) {
                 if constexpr (RW == BAR_ROW) {
                     // every read of the current stage has been issued (the last ones a row ago) and every DMA piece of the next tile rows ago
                     __builtin_amdgcn_sched_barrier(0);
+                    // (ASMW: the reads of the current stage were issued a row or more ago; waiting for them all here costs nothing and
+                    // keeps "every wave is done with this stage" literally true at the barrier)
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                 }
                 constexpr int nr = RW + R;     // the activation fragment this ring slot holds next
-                if constexpr (nr < ROWS) fa[RW % R] = rd(a_tile + (nr % MI) * 2048 + ((nr / MI) ? fr_off1 : fr_off0));
-                else fa[RW % R] = rd(a_next + (nr - ROWS) * 2048 + fr_off0);
+                if constexpr (ASMW) {
+                    if constexpr (nr < ROWS) rd_asm<(nr % MI) * 2048>(fa[RW % R], a_lds[nr / MI]);
+                    else rd_asm<(nr - ROWS) * 2048>(fa[RW % R], an_lds);
+                } else {
+                    if constexpr (nr < ROWS) fa[RW % R] = rd(a_tile + (nr % MI) * 2048 + ((nr / MI) ? fr_off1 : fr_off0));
+                    else fa[RW % R] = rd(a_next + (nr - ROWS) * 2048 + fr_off0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (NIX + 1 < NI) slots<RW, NIX + 1>();
@@ -159,10 +208,26 @@ struct BxWave {
         for (int ni = 0; ni < NI; ++ni) fb[ni] = rd(b_tile + ni * 2048 + fr_off0);
 #pragma unroll
         for (int i = 0; i < R; ++i) fa[i] = rd(a_tile + i * 2048 + fr_off0);
+        if constexpr (ASMW) {
+            // these reads are hipcc's (it waits for them itself at their first use, which the asm waits below do not know): make them land
+            // before the counted schedule starts, so that from here on the only LDS reads in flight are the loop's own
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(fb[ni]));
+#pragma unroll
+            for (int i = 0; i < R; ++i) asm volatile("" : "+v"(fa[i]));
+        }
+    }
+    __device__ __forceinline__ void set_lds(unsigned cur_stage, unsigned nxt_stage, unsigned a_base, unsigned b_base) {   // LDS byte addresses of the stages
+        a_lds[0] = cur_stage + a_base + (unsigned)fr_off0;
+        a_lds[1] = cur_stage + a_base + (unsigned)fr_off1;
+        b_lds[0] = cur_stage + b_base + (unsigned)fr_off0;
+        b_lds[1] = cur_stage + b_base + (unsigned)fr_off1;
+        an_lds = nxt_stage + a_base + (unsigned)fr_off0;
+        bn_lds = nxt_stage + b_base + (unsigned)fr_off0;
     }
 };
 
-template <int MI, int NI, int WM, int WN, bool PIPE>
+template <int MI, int NI, int WM, int WN, int PIPE>
 __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) {
     constexpr int BM = 16 * MI * WM;
     constexpr int BN = 16 * NI * WN;
@@ -202,7 +267,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
 
     const int T = p.KH * p.KW;
     const int HoWo = p.Ho * p.Wo;
-    BxWave<MI, NI, NA, NB, BM * 128> w;       // the accumulators live here in both forms; the plain loop uses nothing else of it
+    BxWave<MI, NI, NA, NB, BM * 128, PIPE == 2> w;       // the accumulators live here in both forms; the plain loop uses nothing else of it
     auto& acc = w.acc;
     const int c15 = lane & 15, g4 = lane >> 4;
     if constexpr (PIPE) {
@@ -267,6 +332,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
         asm volatile("" ::: "memory");
         w.a_tile = smem_x + a_base;
         w.b_tile = smem_x + b_base;
+        const unsigned lds0 = (unsigned)(unsigned long long)(lds_void*)smem_x;     // LDS byte address of the stages
         w.head();
         for (int t = 0; t < n_t; ++t) {
             const int cur = t & 1;
@@ -275,8 +341,10 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
             w.b_tile = smem_x + cur * STAGE + b_base;
             w.a_next = smem_x + (cur ^ 1) * STAGE + a_base;
             w.b_next = smem_x + (cur ^ 1) * STAGE + b_base;
+            if constexpr (PIPE == 2) w.set_lds(lds0 + cur * STAGE, lds0 + (cur ^ 1) * STAGE, a_base, b_base);
             w.tile();
         }
+        if constexpr (PIPE == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads past the last tile (never used) have landed
         // the last k tile was fetched twice (piece()); that copy must have landed before the epilogue reuses the stages
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
@@ -569,7 +637,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     }
 }
 
-template <int MI, int NI, int WM, int WN, bool PIPE>
+template <int MI, int NI, int WM, int WN, int PIPE>
 static hipError_t launch_cfg_bf16x(const ConvGemm& p, dim3 grid, hipStream_t stream) {
     static bool attr_set = false;
     auto k = conv_gemm_bf16x_kernel<MI, NI, WM, WN, PIPE>;
@@ -592,20 +660,28 @@ hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int cfg, hipStream_t stream
     const int MT = (p.M + bm - 1) / bm, NT = (p.N + bno - 1) / bno;
     const int tiles = MT * NT;
     const dim3 grid = gemm_grid(p, tiles);
-    // p.variant bit 0 (option gemm_bf16x_variant): the pipelined k loop (BxWave)
+    // p.variant (option gemm_bf16x_variant) bit 0: the pipelined k loop (BxWave); bit 1 (with 0): its fragment reads as inline asm with hand-counted waits
+    if ((p.variant & 3) == 3) {
+        switch (cfg) {
+            case 0: return launch_cfg_bf16x<8, 5, 2, 4, 2>(p, grid, stream);
+            case 1: return launch_cfg_bf16x<8, 4, 2, 4, 2>(p, grid, stream);
+            case 2: return launch_cfg_bf16x<4, 4, 4, 2, 2>(p, grid, stream);
+            case 3: return launch_cfg_bf16x<4, 5, 2, 4, 2>(p, grid, stream);
+        }
+    }
     if (p.variant & 1) {
         switch (cfg) {
-            case 0: return launch_cfg_bf16x<8, 5, 2, 4, true>(p, grid, stream);
-            case 1: return launch_cfg_bf16x<8, 4, 2, 4, true>(p, grid, stream);
-            case 2: return launch_cfg_bf16x<4, 4, 4, 2, true>(p, grid, stream);
-            case 3: return launch_cfg_bf16x<4, 5, 2, 4, true>(p, grid, stream);
+            case 0: return launch_cfg_bf16x<8, 5, 2, 4, 1>(p, grid, stream);
+            case 1: return launch_cfg_bf16x<8, 4, 2, 4, 1>(p, grid, stream);
+            case 2: return launch_cfg_bf16x<4, 4, 4, 2, 1>(p, grid, stream);
+            case 3: return launch_cfg_bf16x<4, 5, 2, 4, 1>(p, grid, stream);
         }
     }
     switch (cfg) {
-        case 0: return launch_cfg_bf16x<8, 5, 2, 4, false>(p, grid, stream);
-        case 1: return launch_cfg_bf16x<8, 4, 2, 4, false>(p, grid, stream);
-        case 2: return launch_cfg_bf16x<4, 4, 4, 2, false>(p, grid, stream);
-        case 3: return launch_cfg_bf16x<4, 5, 2, 4, false>(p, grid, stream);
+        case 0: return launch_cfg_bf16x<8, 5, 2, 4, 0>(p, grid, stream);
+        case 1: return launch_cfg_bf16x<8, 4, 2, 4, 0>(p, grid, stream);
+        case 2: return launch_cfg_bf16x<4, 4, 4, 2, 0>(p, grid, stream);
+        case 3: return launch_cfg_bf16x<4, 5, 2, 4, 0>(p, grid, stream);
     }
     return hipErrorInvalidValue;
 }

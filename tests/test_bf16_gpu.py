@@ -125,10 +125,11 @@ XCASES_SHORT_K = [
 ]
 
 
+@pytest.mark.parametrize("variant", [1, pytest.param(3, marks=pytest.mark.unverified)])
 @pytest.mark.parametrize("tile", [100, 101, 102, 103])
-def test_conv2d_bf16_large_tiles_pipelined_loop(ops16, tile):
+def test_conv2d_bf16_large_tiles_pipelined_loop(ops16, tile, variant):
     """gemm_bf16x_variant = 1: the pipelined k loop of k_gemm_bf16x.hip (DMA pieces and fragment reads behind the matrix
-    instructions, barrier near the end of a tile).  Same products in the same order as the plain loop: bit-identical results,
+    instructions, barrier near the end of a tile); = 3: the same with the fragment reads as inline asm and hand-counted waits.  Same products in the same order as the plain loop: bit-identical results,
     on every conv flavour, with ragged M / N tiles, split-K, and 1 ... 3 k tiles per slice; and the plain loop's parity bar."""
     for case in [c + (s,) for c in XCASES for s in (1, 3)] + [c[:6] + (1, 0, c[6]) for c in XCASES_SHORT_K]:
         n, cin, h, w, cout, k, stride, ups, splitk = case
@@ -140,7 +141,7 @@ def test_conv2d_bf16_large_tiles_pipelined_loop(ops16, tile):
             ops16.set_option("gemm_tile", tile)
             ops16.set_option("splitk", splitk)
             plain = ops16.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
-            ops16.set_option("gemm_bf16x_variant", 1)
+            ops16.set_option("gemm_bf16x_variant", variant)
             got = ops16.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
             again = ops16.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
         finally:
@@ -297,15 +298,16 @@ def test_unet_forward_bf16_large_tiles_forced(sd16, tile):
     assert np.isfinite(got).all() and r < BAR_UNET
 
 
+@pytest.mark.parametrize("variant", [1, pytest.param(3, marks=pytest.mark.unverified)])
 @pytest.mark.parametrize("tile", ["auto", 100, 103])
-def test_unet_forward_bf16_pipelined_loop(sd16, tile):
+def test_unet_forward_bf16_pipelined_loop(sd16, tile, variant):
     """the whole UNet with gemm_bf16x_variant = 1: bit-identical to the plain k loop (auto tiles and forced large tiles)."""
     lat = np.stack([syn.initial_latent(i, 8, 8) for i in range(2)])
     ctx = np.stack([syn.cond_context(i, 77, 768) for i in range(2)])
     try:
         sd16.set_option("gemm_tile", tile)
         base = sd16.unet.forward(lat, [500], ctx)
-        sd16.set_option("gemm_bf16x_variant", 1)
+        sd16.set_option("gemm_bf16x_variant", variant)
         got = sd16.unet.forward(lat, [500], ctx)
     finally:
         sd16.set_option("gemm_bf16x_variant", 0)

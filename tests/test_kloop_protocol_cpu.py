@@ -36,6 +36,21 @@ def wave_program(form, nstg, n_t, mi):
             dma(t + nstg - 1)
             ev.append(("read", t, stage(t), "rows"))
         return ev
+    if form == "hoist3":           # k_gemm3x.hip HOIST = 3: two stages, tiles 0 and 1 before the loop, tile t + 2 issued behind tile t's barrier
+        assert nstg == 2
+        dma(0)
+        dma(1)
+        ev.append(("wait", 1))
+        ev.append(("bar",))
+        ev.append(("read", 0, stage(0), "head: fragments 0, 1, l and m planes"))
+        for t in range(n_t):
+            ev.append(("read", t, stage(t), "row 0: h planes, fragments 2, 3"))
+            ev.append(("wait", 0))                                # row BR: every read of this stage has landed (lgkmcnt(0)), the next tile's pieces too
+            ev.append(("bar",))
+            ev.append(("read", t + 1, stage(t + 1), "row BR: next tile's fragments 0, 1"))
+            dma(t + 2)                                            # rows BR .. MI - 1, into the stage this tile has just given up
+            ev.append(("read", t + 1, stage(t + 1), "last row: next tile's l and m planes"))
+        return ev
     # hoisted forms
     dma(0)
     if nstg == 3:
@@ -108,7 +123,7 @@ def simulate(form, nstg, n_t, mi, n_waves, rng, program=None):
     return True
 
 
-@pytest.mark.parametrize("form,nstg,mi", [("plain", 2, 4), ("plain", 3, 2), ("hoist", 2, 4), ("hoist", 2, 2), ("hoist", 3, 2), ("hoist", 3, 4)])
+@pytest.mark.parametrize("form,nstg,mi", [("plain", 2, 4), ("plain", 3, 2), ("hoist", 2, 4), ("hoist", 2, 2), ("hoist", 3, 2), ("hoist", 3, 4), ("hoist3", 2, 4), ("hoist3", 2, 2)])
 def test_stage_protocol_has_no_race(form, nstg, mi):
     rng = random.Random(1234 + nstg * 10 + mi)
     for n_t in range(1, 8):

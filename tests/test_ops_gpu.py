@@ -212,10 +212,11 @@ STILES = [200, 201, 202, 203, 204, 205]
 # gemm3x_variant bits -- 0: next k tile's DMA in one block behind the barrier; 1: scalar residual subtractions; 2: two LDS stages on the
 # 128-row tiles too (default: three); 3: the head of a k tile (first fragment reads + split) hoisted into the last fragment row of the tile
 # before it, barrier in front of that row; 5 (with 3): the next tile's weight planes prefetched into the registers the last row no longer
-# needs; 4: s_setprio 1 for waves 4-7
+# needs; 4: s_setprio 1 for waves 4-7; 6 (with 3): HOIST = 3 -- asm fragment reads with hand-counted waits, barrier two rows early, products in
+# the order l, m, m, h, h, h (not bit-identical to the other variants: a different summation order)
 UNVERIFIED = pytest.mark.unverified
 VARIANTS = pytest.mark.variants
-SPLIT_VARIANTS = [0, 1, 2, 6] + [pytest.param(v, marks=VARIANTS) for v in (10, 42, 46, 58)]
+SPLIT_VARIANTS = [0, 1, 2, 6] + [pytest.param(v, marks=VARIANTS) for v in (10, 42, 46, 58)] + [pytest.param(74, marks=UNVERIFIED)]
 
 
 @pytest.mark.parametrize("variant", SPLIT_VARIANTS)
@@ -252,7 +253,7 @@ SHORT_K_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [pytest.param(v, marks=VARIANTS) for v in (2, 10, 42, 46)])
+@pytest.mark.parametrize("variant", [pytest.param(v, marks=VARIANTS) for v in (2, 10, 42, 46)] + [pytest.param(74, marks=UNVERIFIED)])
 @pytest.mark.parametrize("tile", STILES)
 @pytest.mark.parametrize("case", SHORT_K_CASES)
 def test_conv2d_split_bf16_short_k(sd_ops, tile, case, variant):
@@ -328,6 +329,36 @@ def test_conv2d_xcd_map_bit_identical(sd_ops, tile):
                 break
     xin = O.upsample2x(_t(x)) if ups else _t(x)
     _check(got, O.conv2d(xin, (_t(wt), _t(b)), stride=stride, padding=1 if k == 3 else 0).numpy(), f"conv xcd_map tile={tile}")
+
+
+@UNVERIFIED
+def test_conv2d_split_bf16_counted_waits_variant(sd_ops):
+    """gemm3x_variant = 74 (HOIST = 3): repeatable bit for bit, equal to the default loop up to fp32 summation order, and -- on a
+    long-K convolution with inputs spanning ten binary orders of magnitude -- as close to the fp64 oracle as the default."""
+    n, cin, h, w, cout = 1, 1280, 16, 16, 320
+    g = _rng(777)
+    x = (g.standard_normal((n, cin, h, w)) * np.exp2(g.integers(-5, 6, (1, cin, 1, 1)))).astype(np.float32)
+    wt = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9) * np.exp2(g.integers(-3, 4, (cout, 1, 1, 1)))).astype(np.float32)
+    ref = O.conv2d(_t(x), (_t(wt), None), padding=1).numpy()
+    scale = np.abs(ref).max()
+    try:
+        for tile in STILES:
+            for splitk in (1, 5):
+                sd_ops.set_option("gemm_tile", tile)
+                sd_ops.set_option("splitk", splitk)
+                sd_ops.set_option("gemm3x_variant", 2)
+                base = sd_ops.op_conv2d(x, wt, None)
+                sd_ops.set_option("gemm3x_variant", 74)
+                got = sd_ops.op_conv2d(x, wt, None)
+                again = sd_ops.op_conv2d(x, wt, None)
+                assert np.array_equal(got, again), f"tile {tile} splitk {splitk}: not repeatable"
+                e74, e2 = float(np.abs(got - ref).max() / scale), float(np.abs(base - ref).max() / scale)
+                assert e74 < 1e-5 and e74 < 3.0 * e2 + 1e-7, f"tile {tile} splitk {splitk}: {e74:.2e} vs {e2:.2e}"
+                assert np.abs(got - base).max() <= 4e-6 * scale
+    finally:
+        sd_ops.set_option("gemm3x_variant", 0)
+        sd_ops.set_option("gemm_tile", "auto")
+        sd_ops.set_option("splitk", 0)
 
 
 def test_conv2d_split_bf16_is_fp32_accurate(sd_ops):
