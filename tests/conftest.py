@@ -20,7 +20,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "unverified: GPU test of a kernel variant that has not run on an MI355X yet (an option that is off by "
                                        "default); skipped unless SDMI_UNVERIFIED=1 -- the mark is removed once a GPU run has confirmed it")
     config.addinivalue_line("markers", "variants: the extended parity matrix of kernel variants that are OFF by default (verified on an MI355X, "
-                                       "gpurun_out r02y: 479 passed); skipped unless SDMI_VARIANTS=1 to keep the default GPU suite short -- "
+                                       "gpurun_out r02y / r02z / r02zz: 479 + 20 + 161 passed); skipped unless SDMI_VARIANTS=1 to keep the default GPU suite short -- "
                                        "one bit-identity test per variant family always runs")
 
 

@@ -125,7 +125,7 @@ XCASES_SHORT_K = [
 ]
 
 
-@pytest.mark.parametrize("variant", [1, pytest.param(3, marks=pytest.mark.unverified)])
+@pytest.mark.parametrize("variant", [1, 3])
 @pytest.mark.parametrize("tile", [100, 101, 102, 103])
 def test_conv2d_bf16_large_tiles_pipelined_loop(ops16, tile, variant):
     """gemm_bf16x_variant = 1: the pipelined k loop of k_gemm_bf16x.hip (DMA pieces and fragment reads behind the matrix
@@ -298,7 +298,7 @@ def test_unet_forward_bf16_large_tiles_forced(sd16, tile):
     assert np.isfinite(got).all() and r < BAR_UNET
 
 
-@pytest.mark.parametrize("variant", [1, pytest.param(3, marks=pytest.mark.unverified)])
+@pytest.mark.parametrize("variant", [1, 3])
 @pytest.mark.parametrize("tile", ["auto", 100, 103])
 def test_unet_forward_bf16_pipelined_loop(sd16, tile, variant):
     """the whole UNet with gemm_bf16x_variant = 1: bit-identical to the plain k loop (auto tiles and forced large tiles)."""
@@ -315,7 +315,6 @@ def test_unet_forward_bf16_pipelined_loop(sd16, tile, variant):
     assert np.isfinite(got).all() and np.array_equal(got, base)
 
 
-@pytest.mark.unverified
 @pytest.mark.parametrize("tile", ["auto", 2, 100, 103])
 def test_unet_forward_bf16_xcd_map(sd16, tile):
     """option xcd_map = 1 with the bf16 GEMM kernels: bit-identical to the legacy block -> tile map."""

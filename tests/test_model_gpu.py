@@ -88,7 +88,6 @@ def test_unet_forward_hoisted_split_gemm(sd_tiny, synth, tiny_dims, variant):
     assert np.array_equal(got, base)
 
 
-@pytest.mark.unverified
 @pytest.mark.parametrize("f32s", [1, 0])
 def test_unet_forward_xcd_map(sd_tiny, synth, tiny_dims, f32s):
     """option xcd_map = 1 under the whole UNet (split kernels on / off): bit-identical to the legacy block -> tile map."""
@@ -105,7 +104,6 @@ def test_unet_forward_xcd_map(sd_tiny, synth, tiny_dims, f32s):
     assert np.array_equal(got, base)
 
 
-@pytest.mark.unverified
 def test_unet_forward_counted_waits_split_gemm(sd_tiny, synth, tiny_dims):
     """gemm3x_variant = 74 (k_gemm3x.hip HOIST = 3) under the whole UNet: the model-level bar, and the default loop's result up to
     fp32 summation order."""

@@ -216,7 +216,7 @@ STILES = [200, 201, 202, 203, 204, 205]
 # the order l, m, m, h, h, h (not bit-identical to the other variants: a different summation order)
 UNVERIFIED = pytest.mark.unverified
 VARIANTS = pytest.mark.variants
-SPLIT_VARIANTS = [0, 1, 2, 6] + [pytest.param(v, marks=VARIANTS) for v in (10, 42, 46, 58)] + [pytest.param(74, marks=UNVERIFIED)]
+SPLIT_VARIANTS = [0, 1, 2, 6] + [pytest.param(v, marks=VARIANTS) for v in (10, 42, 46, 58, 74)]
 
 
 @pytest.mark.parametrize("variant", SPLIT_VARIANTS)
@@ -253,7 +253,7 @@ SHORT_K_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [pytest.param(v, marks=VARIANTS) for v in (2, 10, 42, 46)] + [pytest.param(74, marks=UNVERIFIED)])
+@pytest.mark.parametrize("variant", [pytest.param(v, marks=VARIANTS) for v in (2, 10, 42, 46, 74)])
 @pytest.mark.parametrize("tile", STILES)
 @pytest.mark.parametrize("case", SHORT_K_CASES)
 def test_conv2d_split_bf16_short_k(sd_ops, tile, case, variant):
@@ -301,7 +301,6 @@ def test_conv2d_split_bf16_hoisted_variants_bit_identical(sd_ops):
         sd_ops.set_option("splitk", 0)
 
 
-@UNVERIFIED
 @pytest.mark.parametrize("tile", ["auto", 0, 2, 4, 8, 9, 100, 103, 200, 201, 202, 203, 204, 205])
 def test_conv2d_xcd_map_bit_identical(sd_ops, tile):
     """option xcd_map = 1 (the GEMM launch cut over the 8 XCDs along M tiles x N tiles x split-K slices, kernels.hpp
@@ -331,7 +330,6 @@ def test_conv2d_xcd_map_bit_identical(sd_ops, tile):
     _check(got, O.conv2d(xin, (_t(wt), _t(b)), stride=stride, padding=1 if k == 3 else 0).numpy(), f"conv xcd_map tile={tile}")
 
 
-@UNVERIFIED
 def test_conv2d_split_bf16_counted_waits_variant(sd_ops):
     """gemm3x_variant = 74 (HOIST = 3): repeatable bit for bit, equal to the default loop up to fp32 summation order, and -- on a
     long-K convolution with inputs spanning ten binary orders of magnitude -- as close to the fp64 oracle as the default."""
