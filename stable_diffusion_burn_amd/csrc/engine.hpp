@@ -396,10 +396,10 @@ private:
     int opt_attn_split_ = 1;    // precision = 0: 1 = d_head 40 / 80 attention on the bf16 matrix pipe with three-way split operands (k_attn_split.hip)
     int opt_gemm_f32s_ = 1;     // precision = 0: 1 = fp32 GEMMs on the bf16 matrix pipe (three-way operand split, k_gemm3x.hip) where faster
     int opt_gemm3x_variant_ = 2;     // bit 0: DMA in one block per k tile; bit 1: scalar residual subtractions (+0.7 %); bit 2: two LDS stages on the 128-row tiles (default three: +5..10 % on long K);
-                                     // bit 3: k-tile head hoisted into the previous tile's last fragment row; bit 5 (with 3): weight planes prefetched into dead registers; bit 4: s_setprio 1 for waves 4-7 (k_gemm3x.hip)
+                                     // bit 4: s_setprio 1 for waves 4-7; bits 3 + 6 (74 with bit 1): the pipelined k loop with hand-counted LDS waits (k_gemm3x.hip HOIST = 3; measured: not faster)
     int opt_gemm_x32_ = 1;      // precision = 0: 1 = large-tile LDS-DMA fp32 GEMM (k_gemm2x.hip) where measured / modelled faster
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
-    int opt_gemm_bf16x_variant_ = 0;   // k_gemm_bf16x.hip: bit 0 = pipelined k loop (DMA pieces and fragment reads behind the matrix instructions, barrier near the end of a tile)
+    int opt_gemm_bf16x_variant_ = 0;   // k_gemm_bf16x.hip: 3 = pipelined k loop (DMA pieces and asm fragment reads with hand-counted waits behind the matrix instructions, barrier near the end of a tile; measured: not faster)
     int opt_xcd_map_ = 0;              // 1: cut every GEMM launch over the 8 XCDs so that the fewest operand bytes cross the fabric (choose_xcd_map); 0: bands of tiles, every XCD reads all weights
     void* zero_page_ = nullptr;
     TileChoice choose_tile_bf16(int M, int N, int kt_total) const;   // cfg >= 100: k_gemm_bf16x.hip tile cfg - 100     // precision = 1: 1 = bf16 matrix-core attention, 0 = bf16 storage widened onto the fp32 kernel  // 1: attn2_kernel, 0: attn_f32_kernel

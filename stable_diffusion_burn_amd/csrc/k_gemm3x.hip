@@ -103,29 +103,18 @@ struct S3SplitT {
 // registers; the issue order of one k tile is spelled out instruction group by instruction group and fenced with
 // sched_barrier(0), because (a) hipcc otherwise hoists all the splits in front of the MFMAs and (b) with LDS-DMA in flight its
 // own waits are all lgkmcnt(0), so a fragment read must be issued well before, and never right in front of, a first use.
-// HOIST (variant bit 3): the head of a k tile -- the reads of its first two activation fragments and the 44-step split of
-// the first one, ~450 cycles in which neither wave of a SIMD has a matrix instruction to issue, right behind the barrier that
-// released both -- moves into the LAST fragment row of the tile before it (that row carries no split work: there is no next row
-// to prepare).  The wait + barrier "the next tile has landed" therefore sits in front of the last row instead of in front of
-// the tile: by then a wave has consumed every LDS read of the current stage (the last row's fragment went into registers a row
-// earlier), so the barrier still doubles as "this stage may be overwritten", and all DMA pieces of the tile in flight were issued
-// in the rows before it (DMA_ROWS <= MI - 1), so the wait is a constant.  What is left at the head of a tile is the read of the weight planes.
-// HOIST = 2 (variant bits 3 + 5) removes that as well, without a register: the six partial products of a fragment row use the
-// weight planes in the order l, h, m, m, h, h, so in a tile's LAST row the l registers are dead after the first NI matrix
-// instructions and the m registers after 4 NI -- the next tile's l and m planes are read into them right there (behind the
-// barrier, so they have landed), and the h planes in the first slot of the next tile, NI matrix instructions ahead of their use.
-// The matrix stream then runs across k tiles without a gap; the barrier in front of the last row is the only rendezvous.
+// HOIST = 3 (variant bits 3 + 6) is the pipelined form of the loop, described at tile3() below; HOIST = 0 the plain one (tile()).
+// (Two intermediate forms -- the tile head hoisted into the previous tile's last row with hipcc's own waits, with and without the
+// weight planes prefetched into dead registers -- were built, verified bit-identical and measured no faster in round 2, then
+// removed: profiles/r02y_ab_fp32_b1_hoisted_loops.jsonl, profiles/README.md.)
 template <int MI, int NI, int NA, int NBW, int PW, int A_BYTES, bool SPREAD, bool SCALAR, int HOIST = 0, int NSTG = 2>
 struct S3Wave {
     using S3Split = S3SplitT<SCALAR>;
     static constexpr int kS3Steps = S3Split::kSteps;
     static constexpr int NMF = 6 * NI;        // MFMAs of one fragment row
     static constexpr int NP = NA + NBW;       // DMA pieces of one k tile, issued between the MFMAs of row 0 (and 1)
-    static constexpr int DMA_ROWS = HOIST ? ((MI > 2) ? 2 : 1) : ((MI > 1) ? 2 : 1);
-    // HOIST: MFMA slots of the last row in front of the first use of the hoisted reads (LDS latency).  With HOIST = 2 the next tile's
-    // l planes are read in slot NI - 1 and hipcc's wait in front of the first use waits for them too: three slots further down
-    static constexpr int HK0 = (HOIST == 2) ? NI + 2 : NMF / 6;
-    static_assert(!HOIST || (MI % 2 == 0 && MI >= 2), "HOIST: the next tile's first fragment is split into sp[0] while sp[1] feeds the last row");
+    static constexpr int DMA_ROWS = (MI > 1) ? 2 : 1;
+    static_assert(HOIST == 0 || HOIST == 3, "loop forms");
     static_assert(HOIST != 3 || (NSTG == 2 && (MI == 2 || MI == 4) && SPREAD), "HOIST = 3: two stages, two or four fragment rows");
 
     f32x4 acc[MI][NI];
@@ -143,8 +132,6 @@ struct S3Wave {
     // current k tile
     const unsigned char* a_tile;      // stage + this wave's activation rows
     const unsigned char* w_tile;      // stage + this wave's weight pieces + lane offset
-    const unsigned char* a_next;      // HOIST: the next k tile's stage + this wave's activation rows
-    const unsigned char* w_next;      // HOIST = 2: ... + this wave's weight pieces + lane offset
     unsigned char* next_stage;        // where the DMA of k tile kt_next goes
     int fr_off0, fr_off1;
 
@@ -190,18 +177,6 @@ struct S3Wave {
         raw[F & 1][1] = *reinterpret_cast<const f32x4*>(a_tile + F * 2048 + fr_off1);
     }
 
-    template <int F>
-    __device__ __forceinline__ void read_next() {         // HOIST: activation fragment F of the NEXT k tile -> raw[F & 1]
-        raw[F & 1][0] = *reinterpret_cast<const f32x4*>(a_next + F * 2048 + fr_off0);
-        raw[F & 1][1] = *reinterpret_cast<const f32x4*>(a_next + F * 2048 + fr_off1);
-    }
-
-    template <int PL>
-    __device__ __forceinline__ void read_planes(const unsigned char* wt) {   // plane PL (0 h, 1 m, 2 l) of the wave's NI weight fragments
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) wf[PL][ni] = *reinterpret_cast<const u32x4*>(wt + (ni * 3 + PL) * 1024);
-    }
-
     // MFMA K of fragment row MIDX: partial product K / NI (smallest first: wl*ah, wh*al, wm*am, wm*ah, wh*am, wh*ah) on column
     // fragment K % NI; behind it this slot's share of the next fragment's split, of the next k tile's DMA, and -- half a
     // row ahead of its first use -- the read of fragment MIDX + 2
@@ -214,20 +189,11 @@ struct S3Wave {
             acc[MIDX][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[WP[pr]][ni]), __builtin_bit_cast(bf16x8, a),
                                                                     acc[MIDX][ni], 0, 0, 0);
             if constexpr (MIDX + 1 < MI) sp[b ^ 1].template steps<K * kS3Steps / NMF, (K + 1) * kS3Steps / NMF>();
-            else if constexpr (HOIST && K >= HK0) {   // last row: the next tile's fragment 0 -> sp[0], in the slots behind the LDS latency
-                if constexpr (K == HK0) sp[b ^ 1].load(raw[0][0], raw[0][1]);
-                sp[b ^ 1].template steps<(K - HK0) * kS3Steps / (NMF - HK0), (K - HK0 + 1) * kS3Steps / (NMF - HK0)>();
-            }
             if constexpr (SPREAD && MIDX < DMA_ROWS) {
                 constexpr int slot = MIDX * NMF + K, slots = DMA_ROWS * NMF;
                 pieces<slot * NP / slots, (slot + 1) * NP / slots>();
             }
             if constexpr (MIDX + 2 < MI && K == NMF / 2) read_fragment<MIDX + 2>();
-            if constexpr (HOIST == 2) {
-                if constexpr (MIDX == 0 && K == 0) read_planes<0>(w_tile);                 // h: first use at K = NI
-                if constexpr (MIDX == MI - 1 && K == NI - 1) read_planes<2>(w_next);       // l of the next tile: the last wl*ah of this one has issued
-                if constexpr (MIDX == MI - 1 && K == 4 * NI - 1) read_planes<1>(w_next);   // m of the next tile: the last wm*a. of this one has issued
-            }
             __builtin_amdgcn_sched_barrier(0);
             mfmas<MIDX, K + 1>();
         }
@@ -236,16 +202,6 @@ struct S3Wave {
     __device__ __forceinline__ void rows() {
         if constexpr (MIDX < MI) {
             if constexpr (MIDX + 1 < MI) sp[(MIDX & 1) ^ 1].load(raw[(MIDX & 1) ^ 1][0], raw[(MIDX & 1) ^ 1][1]);
-            if constexpr (HOIST && MIDX == MI - 1) {
-                // every DMA piece of this iteration is issued (rows < DMA_ROWS <= MI - 1): with two stages they are the next tile's,
-                // with three the tile's after it -- and the next tile's are the NP older ones
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTG == 3 ? NP : 0) : "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                read_next<0>();
-                read_next<1>();
-            }
             __builtin_amdgcn_sched_barrier(0);
             mfmas<MIDX, 0>();
             rows<MIDX + 1>();
@@ -256,17 +212,6 @@ struct S3Wave {
     // outstanding), the weight planes (in flight during the rest of split 0), then the fragment rows
     __device__ __forceinline__ void tile() {
         if constexpr (!SPREAD) pieces<0, NP>();
-        if constexpr (HOIST) {      // fragments 0 / 1 and split 0 were done in the last row of the tile before (or by head())
-            if constexpr (HOIST == 1) {
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) wf[pl][ni] = *reinterpret_cast<const u32x4*>(w_tile + (ni * 3 + pl) * 1024);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            rows<0>();
-            return;
-        }
         read_fragment<0>();
         if constexpr (MI > 1) read_fragment<1>();
         __builtin_amdgcn_sched_barrier(0);
@@ -284,10 +229,13 @@ struct S3Wave {
     }
 
     // ================================================================================================================
-    // HOIST = 3 (variant bits 3 + 6): the schedule of HOIST = 2 with every LDS read issued a fragment row or more ahead of its
-    // wait, which needs waits that hipcc does not write.  Measured (profiles/r02y_*): HOIST = 1 / 2 are correct and not faster.
-    // Why: with LDS-DMA in flight every wait hipcc inserts is `s_waitcnt lgkmcnt(0)`, so a wait in front of the first use of one
-    // fragment also waits for whatever was read a slot ago -- and a hoisted schedule issues reads all the time.  Here
+    // HOIST = 3 (variant bits 3 + 6): the pipelined k loop.  The plain loop above opens every k tile behind a barrier with the reads of its
+    // first two fragments, the 44-step split of the first one and the reads of the weight planes -- a stretch without matrix
+    // instructions for both waves of a SIMD.  Here that head is done for tile t + 1 in the LAST fragment row of tile t (a row that has
+    // no split work of its own), the matrix stream runs across k tiles without a gap, and every LDS read is issued a fragment row or
+    // more ahead of its wait.  The last point needs waits hipcc does not write: with LDS-DMA in flight every wait it inserts is
+    // `s_waitcnt lgkmcnt(0)`, so a wait in front of the first use of one fragment also waits for whatever was read a slot ago (the
+    // first hoisted forms used its waits; measured no faster than the plain loop, profiles/r02y_*).  Here
     //   * the fragment / plane reads are inline asm (invisible to the waitcnt pass) and the waits are counted by hand: a wave's
     //     LDS reads complete in issue order, so `lgkmcnt(n)` = "everything but the n newest reads has landed"; the n of every
     //     wait is written next to the list of reads it may leave in flight, and tools/dev/check_lgkm.py re-derives the guarantee
@@ -413,20 +361,6 @@ struct S3Wave {
         an_l0 = nxt + a_base + (unsigned)fr_off0; an_l1 = nxt + a_base + (unsigned)fr_off1; wn_l = nxt + w_fr;
     }
 
-    // HOIST: what the last row of a tile does for its successor, for the first k tile of the launch
-    __device__ __forceinline__ void head() {
-        read_fragment<0>();
-        read_fragment<1>();
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (HOIST == 2) {
-            read_planes<2>(w_tile);
-            read_planes<1>(w_tile);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        sp[0].load(raw[0][0], raw[0][1]);
-        sp[0].template steps<0, kS3Steps>();
-        __builtin_amdgcn_sched_barrier(0);
-    }
 };
 
 template <int MI, int NI, int WM, int WN, bool SPREAD, bool SCALAR, int NSTG, int HOIST>
@@ -545,7 +479,7 @@ __global__ __launch_bounds__(512) void conv_gemm3x_kernel(const ConvGemm p) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) w.acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // variant bit 4: static priority for the second-dispatched half of the workgroup, the arbitration loser of every SIMD's pair
+    // variant bit 4: static priority for the second-dispatched half of the workgroup, the arbitration loser of every SIMD's pair (measured: no gain)
     if ((p.variant & 16) && wave >= 4) __builtin_amdgcn_s_setprio(1);
     w.next_stage = smem_x32;
     w.template pieces<0, NA + NBW>();      // k tile 0
@@ -566,30 +500,6 @@ __global__ __launch_bounds__(512) void conv_gemm3x_kernel(const ConvGemm p) {
             w.tile3();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads past the last tile (never used)
-    } else if constexpr (HOIST) {
-        // the barrier sits in front of a tile's last fragment row (S3Wave::rows); the loop body starts with the weight-plane reads
-        if constexpr (NSTG == 3) {
-            w.next_stage = smem_x32 + STAGE;
-            w.template pieces<0, NA + NBW>();      // k tile 1 (or tile 0 again: dead stage)
-        }
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTG == 3 ? NA + NBW : 0) : "memory");
-        __builtin_amdgcn_s_barrier();           // k tile 0 is in LDS
-        asm volatile("" ::: "memory");
-        w.a_tile = smem_x32 + a_base;
-        w.w_tile = smem_x32 + w_fr;
-        w.head();
-        int cur = 0;
-        for (int t = 0; t < n_t; ++t) {
-            const int nx1 = (NSTG == 3) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);            // stage of k tile t + 1
-            const int dma = (NSTG == 3) ? (cur == 0 ? 2 : cur - 1) : (cur ^ 1);            // stage the DMA of this iteration fills: tile t + 2 / t + 1
-            w.next_stage = smem_x32 + dma * STAGE;
-            w.a_tile = smem_x32 + cur * STAGE + a_base;
-            w.w_tile = smem_x32 + cur * STAGE + w_fr;
-            w.a_next = smem_x32 + nx1 * STAGE + a_base;
-            w.w_next = smem_x32 + nx1 * STAGE + w_fr;
-            w.tile();
-            cur = nx1;
-        }
     } else if constexpr (NSTG == 2) {
         for (int t = 0; t < n_t; ++t) {
             const int cur = t & 1;
@@ -654,33 +564,17 @@ hipError_t launch_conv_gemm3x(const ConvGemm& p, int cfg, hipStream_t stream) {
     const dim3 grid = gemm_grid(p, tiles);
     // p.variant bit 0: issue the next k tile's DMA in one block behind the barrier instead of between the MFMAs of rows 0 / 1
     // bit 1: the split's residual subtractions as scalar v_sub_f32 pairs instead of v_pk_add_f32
-    // bit 3: the head of a k tile hoisted into the last fragment row of the tile before it (S3Wave, HOIST; built for the default
-    //        placement spread + scalar only);  bit 5 (with bit 3): the weight planes of the next tile prefetched into the registers the
-    //        last row no longer needs (HOIST = 2);  bit 4: s_setprio 1 for waves 4-7 during the k loop
+    // bits 3 + 6 (with the default placement, bits 0 clear / 1 set): HOIST = 3, the pipelined loop with hand-counted LDS waits (two stages on every tile)
     const bool spread = !(p.variant & 1), scalar = (p.variant & 2) != 0;
-    if ((p.variant & 8) && spread && scalar) {
-        const bool two = (p.variant & 4) != 0;
-        if (p.variant & 64) {     // bit 6 (with 3): HOIST = 3 -- asm fragment reads with hand-counted waits, barrier two rows early, two stages everywhere
-            switch (cfg) {
-                case 0: return launch_cfg_3x<4, 5, 4, 2, true, true, 2, 3>(p, grid, stream);
-                case 1: return launch_cfg_3x<4, 5, 2, 4, true, true, 2, 3>(p, grid, stream);
-                case 2: return launch_cfg_3x<4, 4, 4, 2, true, true, 2, 3>(p, grid, stream);
-                case 3: return launch_cfg_3x<4, 4, 2, 4, true, true, 2, 3>(p, grid, stream);
-                case 4: return launch_cfg_3x<2, 5, 4, 2, true, true, 2, 3>(p, grid, stream);
-                case 5: return launch_cfg_3x<2, 4, 4, 2, true, true, 2, 3>(p, grid, stream);
-            }
-        }
-#define SDMI_3XH(MI, NI, WM, WN, NSTG) \
-    ((p.variant & 32) ? launch_cfg_3x<MI, NI, WM, WN, true, true, NSTG, 2>(p, grid, stream) : launch_cfg_3x<MI, NI, WM, WN, true, true, NSTG, 1>(p, grid, stream))
+    if ((p.variant & 72) == 72 && spread && scalar) {
         switch (cfg) {
-            case 0: return SDMI_3XH(4, 5, 4, 2, 2);
-            case 1: return SDMI_3XH(4, 5, 2, 4, 2);
-            case 2: return SDMI_3XH(4, 4, 4, 2, 2);
-            case 3: return SDMI_3XH(4, 4, 2, 4, 2);
-            case 4: return two ? SDMI_3XH(2, 5, 4, 2, 2) : SDMI_3XH(2, 5, 4, 2, 3);
-            case 5: return two ? SDMI_3XH(2, 4, 4, 2, 2) : SDMI_3XH(2, 4, 4, 2, 3);
+            case 0: return launch_cfg_3x<4, 5, 4, 2, true, true, 2, 3>(p, grid, stream);
+            case 1: return launch_cfg_3x<4, 5, 2, 4, true, true, 2, 3>(p, grid, stream);
+            case 2: return launch_cfg_3x<4, 4, 4, 2, true, true, 2, 3>(p, grid, stream);
+            case 3: return launch_cfg_3x<4, 4, 2, 4, true, true, 2, 3>(p, grid, stream);
+            case 4: return launch_cfg_3x<2, 5, 4, 2, true, true, 2, 3>(p, grid, stream);
+            case 5: return launch_cfg_3x<2, 4, 4, 2, true, true, 2, 3>(p, grid, stream);
         }
-#undef SDMI_3XH
     }
 #define SDMI_3X(MI, NI, WM, WN)                                                                                       \
     (spread ? (scalar ? launch_cfg_3x<MI, NI, WM, WN, true, true>(p, grid, stream) : launch_cfg_3x<MI, NI, WM, WN, true, false>(p, grid, stream)) \

@@ -44,7 +44,7 @@ static const GemmTileInfo kTilesX[kNumGemmTilesX] = {
     {256, 320, "256x320x"}, {256, 256, "256x256x"}, {256, 128, "256x128x"}, {128, 320, "128x320x"}};
 const GemmTileInfo& gemm_tile_info_x(int cfg) { return kTilesX[cfg]; }
 
-// ---- PIPE (option gemm_bf16x_variant bit 0): the k loop as one gap-free matrix-instruction stream -------------------------------
+// ---- PIPE = 2 (option gemm_bf16x_variant = 3): the k loop as one gap-free matrix-instruction stream ------------------------------
 // The loop below the barrier of the plain form opens every k tile with the DMA of the next tile in one block (address arithmetic
 // with exec-mask branches for the padding taps: ~150 instructions for 9 pieces) and the reads of the first fragments -- more than
 // a thousand cycles in which neither wave of a SIMD issues a matrix instruction, against 2 560 cycles of matrix work per tile.
@@ -57,15 +57,15 @@ const GemmTileInfo& gemm_tile_info_x(int cfg) { return kTilesX[cfg]; }
 //   * the barrier "the next tile has landed" therefore moves from the top of the tile to the end of row 2 MI - R, the last point
 //     before a read of the next tile; by then this wave has issued -- and waited for -- every read of the current stage, so the barrier
 //     still doubles as "this stage may be overwritten", and all DMA pieces were issued rows ago: vmcnt(0) finds them landed.
-// ASMW (variant bit 1): hipcc's own LDS waits in a kernel with LDS-DMA in flight are all `s_waitcnt lgkmcnt(0)`, so the wait in front of the
-// first use of a fragment also waits for the fragment read that was issued one slot ago -- a full LDS round trip (several hundred cycles
-// with sixteen waves and the DMA sharing the LDS) at every row of the rolling schedule above, which is why that schedule alone measured
-// no faster than the plain loop (profiles/r02y_*).  Here the fragment reads are inline asm (invisible to the waitcnt pass) and the waits are
+// The waits: hipcc's own LDS waits in a kernel with LDS-DMA in flight are all `s_waitcnt lgkmcnt(0)`, so the wait in front of the first use of
+// a fragment also waits for the fragment read that was issued one slot ago -- an LDS round trip at every row of the rolling schedule above
+// (a first form of this loop used hipcc's waits: bit-identical, not faster, removed; profiles/r02y_ab_bf16_b8_pipelined_loop.jsonl).  So the
+// fragment reads are inline asm (invisible to the waitcnt pass) and the waits are
 // COUNTED by hand: LDS reads of a wave complete in issue order, so `lgkmcnt(n)` in front of a matrix instruction is exactly "everything but
 // the n reads issued after my operands has landed".  n is computed at compile time from the schedule itself (reads_in / wait_n below);
 // tools/dev/check_lgkm.py re-derives the guarantee from the COMPILED instruction stream (every use of a fragment register is behind a
 // wait that covers its read), and the parity tests hold the loop bit-identical to the plain one.
-template <int MI, int NI, int NA, int NB, int A_BYTES, bool ASMW = false>
+template <int MI, int NI, int NA, int NB, int A_BYTES>
 struct BxWave {
     static constexpr int ROWS = 2 * MI;
     static constexpr int R = (MI >= 8) ? 4 : 2;
@@ -85,11 +85,10 @@ struct BxWave {
     int Hin, Win, ups, Ws, KH, KW, wave;
     int cs, ky, kx, kt_next, kt_end;
     const unsigned char *a_tile, *b_tile;     // current stage + this wave's activation / weight rows
-    const unsigned char *a_next, *b_next;     // the next k tile's
     unsigned char* next_stage;                // where the DMA of k tile kt_next goes
     int fr_off0, fr_off1;
 
-    // ---- ASMW: the schedule's own arithmetic (slots are numbered r * NI + ni and continue across tiles, periodically) -------------
+    // ---- the schedule's own arithmetic (slots are numbered r * NI + ni and continue across tiles, periodically) -------------
     static constexpr int TILE = ROWS * NI;
     static constexpr int fmod(int a, int m) { return ((a % m) + m) % m; }
     static constexpr bool roll_row(int r) { return fmod(r, MI) == MI - 1; }            // its slots re-load the weight fragments
@@ -155,10 +154,8 @@ struct BxWave {
     __device__ __forceinline__ void slots() {
         if constexpr (RW < ROWS) {
             constexpr int kk = RW / MI, mi = RW % MI;
-            if constexpr (ASMW) {
-                constexpr int WN_ = wait_n(RW, NIX);
-                if constexpr (WN_ >= 0) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fb[NIX]), "+v"(fa[RW % R]) : "n"(WN_));
-            }
+            constexpr int WN_ = wait_n(RW, NIX);
+            if constexpr (WN_ >= 0) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fb[NIX]), "+v"(fa[RW % R]) : "n"(WN_));
             acc[mi][NIX] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[NIX]), __builtin_bit_cast(bf16x8, fa[RW % R]),
                                                                   acc[mi][NIX], 0, 0, 0);
             if constexpr (RW < DMA_ROWS) {
@@ -166,32 +163,22 @@ struct BxWave {
                 pieces<sl * NP / SL, (sl + 1) * NP / SL>();
             }
             if constexpr (mi == MI - 1) {     // last row of a k step: weight fragment NIX of the next k step into the register just used
-                if constexpr (ASMW) {
-                    if constexpr (kk == 0) rd_asm<NIX * 2048>(fb[NIX], b_lds[1]);
-                    else rd_asm<NIX * 2048>(fb[NIX], bn_lds);
-                } else {
-                    if constexpr (kk == 0) fb[NIX] = rd(b_tile + NIX * 2048 + fr_off1);
-                    else fb[NIX] = rd(b_next + NIX * 2048 + fr_off0);
-                }
+                if constexpr (kk == 0) rd_asm<NIX * 2048>(fb[NIX], b_lds[1]);
+                else rd_asm<NIX * 2048>(fb[NIX], bn_lds);
             }
             if constexpr (NIX == NI - 1) {
                 if constexpr (RW == BAR_ROW) {
                     // every read of the current stage has been issued (the last ones a row ago) and every DMA piece of the next tile rows ago
                     __builtin_amdgcn_sched_barrier(0);
-                    // (ASMW: the reads of the current stage were issued a row or more ago; waiting for them all here costs nothing and
+                    // (the reads of the current stage were issued a row or more ago; waiting for them all here costs nothing and
                     // keeps "every wave is done with this stage" literally true at the barrier)
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                 }
                 constexpr int nr = RW + R;     // the activation fragment this ring slot holds next
-                if constexpr (ASMW) {
-                    if constexpr (nr < ROWS) rd_asm<(nr % MI) * 2048>(fa[RW % R], a_lds[nr / MI]);
-                    else rd_asm<(nr - ROWS) * 2048>(fa[RW % R], an_lds);
-                } else {
-                    if constexpr (nr < ROWS) fa[RW % R] = rd(a_tile + (nr % MI) * 2048 + ((nr / MI) ? fr_off1 : fr_off0));
-                    else fa[RW % R] = rd(a_next + (nr - ROWS) * 2048 + fr_off0);
-                }
+                if constexpr (nr < ROWS) rd_asm<(nr % MI) * 2048>(fa[RW % R], a_lds[nr / MI]);
+                else rd_asm<(nr - ROWS) * 2048>(fa[RW % R], an_lds);
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (NIX + 1 < NI) slots<RW, NIX + 1>();
@@ -208,7 +195,7 @@ struct BxWave {
         for (int ni = 0; ni < NI; ++ni) fb[ni] = rd(b_tile + ni * 2048 + fr_off0);
 #pragma unroll
         for (int i = 0; i < R; ++i) fa[i] = rd(a_tile + i * 2048 + fr_off0);
-        if constexpr (ASMW) {
+        {
             // these reads are hipcc's (it waits for them itself at their first use, which the asm waits below do not know): make them land
             // before the counted schedule starts, so that from here on the only LDS reads in flight are the loop's own
 #pragma unroll
@@ -267,7 +254,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
 
     const int T = p.KH * p.KW;
     const int HoWo = p.Ho * p.Wo;
-    BxWave<MI, NI, NA, NB, BM * 128, PIPE == 2> w;       // the accumulators live here in both forms; the plain loop uses nothing else of it
+    BxWave<MI, NI, NA, NB, BM * 128> w;       // the accumulators live here in both forms; the plain loop uses nothing else of it
     auto& acc = w.acc;
     const int c15 = lane & 15, g4 = lane >> 4;
     if constexpr (PIPE) {
@@ -339,12 +326,10 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
             w.next_stage = smem_x + (cur ^ 1) * STAGE;
             w.a_tile = smem_x + cur * STAGE + a_base;
             w.b_tile = smem_x + cur * STAGE + b_base;
-            w.a_next = smem_x + (cur ^ 1) * STAGE + a_base;
-            w.b_next = smem_x + (cur ^ 1) * STAGE + b_base;
-            if constexpr (PIPE == 2) w.set_lds(lds0 + cur * STAGE, lds0 + (cur ^ 1) * STAGE, a_base, b_base);
+            w.set_lds(lds0 + cur * STAGE, lds0 + (cur ^ 1) * STAGE, a_base, b_base);
             w.tile();
         }
-        if constexpr (PIPE == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads past the last tile (never used) have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads past the last tile (never used) have landed
         // the last k tile was fetched twice (piece()); that copy must have landed before the epilogue reuses the stages
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
@@ -660,21 +645,13 @@ hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int cfg, hipStream_t stream
     const int MT = (p.M + bm - 1) / bm, NT = (p.N + bno - 1) / bno;
     const int tiles = MT * NT;
     const dim3 grid = gemm_grid(p, tiles);
-    // p.variant (option gemm_bf16x_variant) bit 0: the pipelined k loop (BxWave); bit 1 (with 0): its fragment reads as inline asm with hand-counted waits
+    // p.variant (option gemm_bf16x_variant) = 3: the pipelined k loop (BxWave: fragment reads as inline asm with hand-counted waits)
     if ((p.variant & 3) == 3) {
         switch (cfg) {
             case 0: return launch_cfg_bf16x<8, 5, 2, 4, 2>(p, grid, stream);
             case 1: return launch_cfg_bf16x<8, 4, 2, 4, 2>(p, grid, stream);
             case 2: return launch_cfg_bf16x<4, 4, 4, 2, 2>(p, grid, stream);
             case 3: return launch_cfg_bf16x<4, 5, 2, 4, 2>(p, grid, stream);
-        }
-    }
-    if (p.variant & 1) {
-        switch (cfg) {
-            case 0: return launch_cfg_bf16x<8, 5, 2, 4, 1>(p, grid, stream);
-            case 1: return launch_cfg_bf16x<8, 4, 2, 4, 1>(p, grid, stream);
-            case 2: return launch_cfg_bf16x<4, 4, 4, 2, 1>(p, grid, stream);
-            case 3: return launch_cfg_bf16x<4, 5, 2, 4, 1>(p, grid, stream);
         }
     }
     switch (cfg) {

@@ -47,7 +47,8 @@ struct ConvGemm {
     const void* a_scale;        // fp8 kernel: E8M0 scales of A, [pixels][a_ld / 32] bytes (a_ld = padded channel count = bytes per pixel)
     const void* b_scale;        // fp8 kernel: E8M0 scales of Bt, [N][b_ld / 32] bytes
     int variant;                // k_gemm3x.hip A/B switches (option gemm3x_variant): bit 0 DMA issued in one block per k tile, 1 scalar residual subtractions,
-                                // 2 two LDS stages on the 128-row tiles, 3 hoisted k-tile head, 5 (with 3) weight-plane prefetch, 4 s_setprio 1 for waves 4-7
+                                // 2 two LDS stages on the 128-row tiles, 4 s_setprio 1 for waves 4-7, 3 + 6 the pipelined k loop (HOIST = 3);
+                                // k_gemm_bf16x.hip (option gemm_bf16x_variant): 3 = the pipelined k loop
     // XCD-aware work map (option xcd_map; host side: Engine::choose_xcd_map, device side: gemm_work_of_block in k_common.hpp).  The box of
     // work items (M tiles x N tiles x split-K slices) is cut xcd_m x xcd_n x (8 / (xcd_m xcd_n)) ways over the 8 XCDs; the blocks that land on
     // XCD b % 8 walk that XCD's sub-box of xcd_ml x xcd_nl x xcd_zl items (n fastest, then m, then slices).  What the cut decides is how often

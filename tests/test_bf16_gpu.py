@@ -125,11 +125,11 @@ XCASES_SHORT_K = [
 ]
 
 
-@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("variant", [3])
 @pytest.mark.parametrize("tile", [100, 101, 102, 103])
 def test_conv2d_bf16_large_tiles_pipelined_loop(ops16, tile, variant):
-    """gemm_bf16x_variant = 1: the pipelined k loop of k_gemm_bf16x.hip (DMA pieces and fragment reads behind the matrix
-    instructions, barrier near the end of a tile); = 3: the same with the fragment reads as inline asm and hand-counted waits.  Same products in the same order as the plain loop: bit-identical results,
+    """gemm_bf16x_variant = 3: the pipelined k loop of k_gemm_bf16x.hip (DMA pieces and fragment reads behind the matrix
+    instructions, barrier near the end of a tile, fragment reads as inline asm with hand-counted waits).  Same products in the same order as the plain loop: bit-identical results,
     on every conv flavour, with ragged M / N tiles, split-K, and 1 ... 3 k tiles per slice; and the plain loop's parity bar."""
     for case in [c + (s,) for c in XCASES for s in (1, 3)] + [c[:6] + (1, 0, c[6]) for c in XCASES_SHORT_K]:
         n, cin, h, w, cout, k, stride, ups, splitk = case
@@ -298,10 +298,10 @@ def test_unet_forward_bf16_large_tiles_forced(sd16, tile):
     assert np.isfinite(got).all() and r < BAR_UNET
 
 
-@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("variant", [3])
 @pytest.mark.parametrize("tile", ["auto", 100, 103])
 def test_unet_forward_bf16_pipelined_loop(sd16, tile, variant):
-    """the whole UNet with gemm_bf16x_variant = 1: bit-identical to the plain k loop (auto tiles and forced large tiles)."""
+    """the whole UNet with gemm_bf16x_variant = 3: bit-identical to the plain k loop (auto tiles and forced large tiles)."""
     lat = np.stack([syn.initial_latent(i, 8, 8) for i in range(2)])
     ctx = np.stack([syn.cond_context(i, 77, 768) for i in range(2)])
     try:

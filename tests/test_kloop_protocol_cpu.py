@@ -1,14 +1,16 @@
-"""The LDS-stage protocol of the pipelined k loops (k_gemm3x.hip HOIST variants, k_gemm_bf16x.hip PIPE), checked on the CPU.
+"""The LDS-stage protocol of the pipelined k loops (k_gemm3x.hip HOIST = 3, k_gemm_bf16x.hip PIPE = 2), checked on the CPU.
 
-These loops put the "next k tile has landed" barrier INSIDE a tile (in front of its last fragment row) instead of in front of
-it, read the next tile's first fragments behind that barrier, and let the DMA of a later tile overwrite a stage one barrier
-after its last read.  What can go wrong is a race, which a GPU parity test only catches when the timing happens to expose it.
-This file models the protocol -- every wave's sequence of {issue DMA piece, wait for own pieces, barrier, read stage} events,
-DMA pieces landing at ANY moment between their issue and the issuing wave's covering wait, waves interleaved at random -- and
-asserts that (1) every read of tile t finds every wave's piece of tile t in the stage, and (2) no piece of a later tile lands in
-a stage while some wave still has a read of the older tile ahead of it.  The event sequences below are transcribed from the
-kernels (S3Wave::tile / rows / mfmas; BxWave::slots has the shape of the two-stage hoisted form: reads of the current stage up
-to the row before the barrier, reads of the next stage behind it); tools/dev/isa_summary.py shows the same order in the compiled loops.
+These loops put the "next k tile has landed" barrier INSIDE a tile instead of in front of it, read the next tile's first fragments
+behind that barrier, and let the DMA of a later tile overwrite a stage one barrier after its last read.  What can go wrong is a
+race, which a GPU parity test only catches when the timing happens to expose it.  This file models the protocol -- every wave's
+sequence of {issue DMA pieces, wait for own pieces, barrier, read stage} events, DMA pieces landing at ANY moment between their
+issue and the issuing wave's covering wait, waves interleaved at random -- and asserts that (1) every read of tile t finds every
+wave's piece of tile t in the stage, and (2) no piece of a later tile lands in a stage while some wave still has a read of the
+older tile ahead of it.  Forms: "plain" = barrier in front of the tile (the default loops, two or three stages); "hoist" = barrier
+in front of the last fragment row(s), the next tile's DMA issued in the first rows (k_gemm_bf16x.hip PIPE = 2 with two stages; the
+round-2 HOIST = 1 / 2 loops of k_gemm3x.hip, since removed, were this form with two and three stages); "hoist3" = k_gemm3x.hip
+HOIST = 3: barrier two rows early, the DMA of tile t + 2 issued behind it.  The event sequences are transcribed from the kernels
+(S3Wave::tile3 / rows3 / mfmas3, BxWave::slots); tools/dev/isa_summary.py shows the same order in the compiled loops.
 """
 import random
 

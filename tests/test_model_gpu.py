@@ -74,36 +74,6 @@ def test_unet_forward_large_tiles_forced(sd_tiny, synth, tiny_dims, tile):
     _assert_close(got, r32, r64, f"unet_forward tile={tile}", atol=1e-4)
 
 
-@pytest.mark.parametrize("variant", [10, 42, 58])
-def test_unet_forward_hoisted_split_gemm(sd_tiny, synth, tiny_dims, variant):
-    """the hoisted k loops of k_gemm3x.hip (gemm3x_variant bits 3 / 5 / 4) under the whole UNet: bit-identical to the default loop."""
-    d = tiny_dims
-    lat, ctx, _ = _inputs(d, 2, 7, 2)
-    base = sd_tiny.unet.forward(lat, [300], ctx)
-    try:
-        sd_tiny.set_option("gemm3x_variant", variant)
-        got = sd_tiny.unet.forward(lat, [300], ctx)
-    finally:
-        sd_tiny.set_option("gemm3x_variant", 2)
-    assert np.array_equal(got, base)
-
-
-@pytest.mark.parametrize("f32s", [1, 0])
-def test_unet_forward_xcd_map(sd_tiny, synth, tiny_dims, f32s):
-    """option xcd_map = 1 under the whole UNet (split kernels on / off): bit-identical to the legacy block -> tile map."""
-    d = tiny_dims
-    lat, ctx, _ = _inputs(d, 2, 7, 2)
-    try:
-        sd_tiny.set_option("gemm_f32s", f32s)
-        base = sd_tiny.unet.forward(lat, [300], ctx)
-        sd_tiny.set_option("xcd_map", 1)
-        got = sd_tiny.unet.forward(lat, [300], ctx)
-    finally:
-        sd_tiny.set_option("xcd_map", 0)
-        sd_tiny.set_option("gemm_f32s", 1)
-    assert np.array_equal(got, base)
-
-
 def test_unet_forward_counted_waits_split_gemm(sd_tiny, synth, tiny_dims):
     """gemm3x_variant = 74 (k_gemm3x.hip HOIST = 3) under the whole UNet: the model-level bar, and the default loop's result up to
     fp32 summation order."""

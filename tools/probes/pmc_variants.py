@@ -9,10 +9,10 @@ bf16 = "--bf16" in sys.argv
 sd = StableDiffusion(ModelConfig(64, 1, 64, 8, 8, 64, precision=1 if bf16 else 0))
 if bf16:
     shapes = [((16, 320, 64, 64, 320, 3, 1, 0), 100, 1), ((16, 640, 32, 32, 640, 3, 1, 0), 100, 1)]
-    variants, key = (0, 1, 3), "gemm_bf16x_variant"
+    variants, key = (0, 3), "gemm_bf16x_variant"   # (round 2 also measured 1: the pipelined loop with hipcc's waits, since removed)
 else:
     shapes = [((2, 320, 64, 64, 320, 3, 1, 0), 201, 4), ((2, 1280, 16, 16, 1280, 3, 1, 0), 204, 8), ((2, 640, 32, 32, 640, 3, 1, 0), 200, 8)]
-    variants, key = (2, 42, 74), "gemm3x_variant"
+    variants, key = (2, 74), "gemm3x_variant"        # (round 2 also measured 42: hoisted head + plane prefetch with hipcc's waits, since removed)
 for v in variants:
     sd.set_option(key, v)
     for s, cfg, sp in shapes:
