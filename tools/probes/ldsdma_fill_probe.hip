@@ -1,4 +1,4 @@
-// ldsdma_fill_probe.hip -- how fast can ONE compute unit land bytes in its LDS?   (round-3 first measurement; written in round 2, not yet run)
+// ldsdma_fill_probe.hip -- how fast can ONE compute unit land bytes in its LDS?   (run once at the very end of round 2: profiles/r02_ldsdma_fill_probe.txt)
 //
 //   hipcc -O3 --offload-arch=gfx950 tools/probes/ldsdma_fill_probe.hip -o /tmp/ldsdma_fill_probe && /tmp/ldsdma_fill_probe
 //
@@ -74,7 +74,10 @@ __global__ __launch_bounds__(512) void fill_kernel(const Args a) {
                     off += step;
                 }
 #pragma unroll
-                for (int d = 0; d < DEPTH; ++d) *reinterpret_cast<u32x4*>(slot0 + ((i + d) & 15) * 1024 + lane * 16) = r[d];
+                for (int d = 0; d < DEPTH; ++d) {
+                    asm volatile("" : "+v"(r[d]));      // the load must happen (round 2's first run printed 790 B/clk here: hipcc had removed the dead loads and stores)
+                    *reinterpret_cast<volatile u32x4*>(slot0 + ((i + d) & 15) * 1024 + lane * 16) = r[d];
+                }
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
