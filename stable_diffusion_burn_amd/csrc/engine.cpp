@@ -978,7 +978,8 @@ void Engine::set_option(const std::string& key, const std::string& value) {
         const bool b16 = key == "tune_bf16";
         TileChoice tc{0, 1};
         if (std::sscanf(value.c_str() + eq + 1, "%d,%d", &tc.cfg, &tc.splits) != 2 || tc.cfg < 0 || tc.splits < 1 ||
-            !(tc.cfg < kNumGemmTiles || (tc.cfg >= 100 && tc.cfg < 100 + kNumGemmTilesX) || (!b16 && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS)))
+            !(tc.cfg < kNumGemmTiles || (tc.cfg >= 100 && tc.cfg < 100 + kNumGemmTilesX) || (!b16 && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS) ||
+              (!b16 && tc.cfg >= 300 && tc.cfg < 300 + kNumGemmTilesY)))
             throw Error(SDMI_ERR_INVALID, "tune: bad value");
         (b16 ? tuned_bf16_ : tuned_)[value.substr(0, eq)] = tc;
     } else if (key == "tune_clear") { tuned_.clear(); tuned_bf16_.clear(); tuned_mfma_.clear(); }
@@ -1117,7 +1118,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     // k_gemm3x.hip: the same layers, when the weight has its bf16 planes (weights in the arenas; not e.g. the K / V operands of
     // the unfused VAE attention) and the 32-bit piece offsets reach
     const bool s_ok = x32_ok && p.Bt3 && (unsigned long long)p.N * (p.geglu ? 2 : 1) * (unsigned long long)p.kt_total * 192ull < 0xFFFFFF00ull;
-    auto usable = [&](int cfg) { return cfg < 100 || (in_dt ? opt_gemm_bf16x_ != 0 : (cfg >= 200 ? (opt_gemm_f32s_ != 0 && s_ok) : (opt_gemm_x32_ != 0 && x32_ok))); };
+    auto usable = [&](int cfg) { return cfg < 100 || (in_dt ? opt_gemm_bf16x_ != 0 : (cfg >= 200 ? (opt_gemm_f32s_ != 0 && s_ok && (cfg < 300 || !p.geglu)) : (opt_gemm_x32_ != 0 && x32_ok))); };
     const auto it2 = in_dt ? tuned_mfma_.end() : tuned_mfma_.find(key);   // the table measured without the split kernels
     if (it != table.end() && usable(it->second.cfg)) tc = it->second;
     else if (it2 != tuned_mfma_.end() && usable(it2->second.cfg)) tc = it2->second;
@@ -1142,14 +1143,15 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     const unsigned long long a_ext = ((unsigned long long)p.NB * p.Hs * p.Ws - 1) * (unsigned long long)p.a_ld * es + (unsigned long long)p.Cin * es;
     const unsigned long long b_ext = ((unsigned long long)p.N * (p.geglu ? 2 : 1) - 1) * (unsigned long long)p.b_ld * es + (unsigned long long)p.K * es;
     p.zero_page = zero_page_;
-    if (tc.cfg >= 200 ? (tc.cfg - 200 >= kNumGemmTilesS || !s_ok) : (tc.cfg >= 100 && (tc.cfg - 100 >= kNumGemmTilesX || (!in_dt && !x32_ok))))
+    if (tc.cfg >= 300 ? (in_dt || tc.cfg - 300 >= kNumGemmTilesY || !s_ok || p.geglu)
+        : tc.cfg >= 200 ? (tc.cfg - 200 >= kNumGemmTilesS || !s_ok) : (tc.cfg >= 100 && (tc.cfg - 100 >= kNumGemmTilesX || (!in_dt && !x32_ok))))
         throw Error(SDMI_ERR_INVALID, "gemm: large-tile kernel index out of range or not applicable to this layer");
     if (a_ext >= 0xFFFFFFE0ull || b_ext >= 0xFFFFFFE0ull) throw Error(SDMI_ERR_UNSUPPORTED, "GEMM: operand larger than 4 GiB (the buffer-load range check needs 32-bit extents)");
     p.a_bytes = (unsigned)a_ext;
     p.b_bytes = (unsigned)b_ext;
     {
         const GemmTileInfo& ti = in_dt ? (tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100) : gemm_tile_info(tc.cfg))
-                                       : (tc.cfg >= 200 ? gemm_tile_info_s(tc.cfg - 200) : (tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100) : gemm_tile_info(tc.cfg)));
+                                       : (tc.cfg >= 300 ? gemm_tile_info_y(tc.cfg - 300) : tc.cfg >= 200 ? gemm_tile_info_s(tc.cfg - 200) : (tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100) : gemm_tile_info(tc.cfg)));
         const int bno = p.geglu ? ti.bn / 2 : ti.bn;
         const double wes = in_dt ? 2.0 : (tc.cfg >= 200 ? 6.0 : 4.0);     // bytes per weight as this kernel reads them (three bf16 planes: 6)
         // what a CU sustains in the kernel's k loop (chip rate / 256; measured per family: profiles/README.md)
@@ -1159,6 +1161,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     }
     auto launch = [&](const ConvGemm& q) {
         if (in_dt && tc.cfg >= 100) return launch_conv_gemm_bf16x(q, tc.cfg - 100, stream_);
+        if (tc.cfg >= 300) return launch_conv_gemm3y(q, tc.cfg - 300, stream_);
         if (tc.cfg >= 200) return launch_conv_gemm3x(q, tc.cfg - 200, stream_);
         if (tc.cfg >= 100) return launch_conv_gemm2x(q, tc.cfg - 100, stream_);
         if (in_dt) return launch_conv_gemm_bf16(q, tc.cfg, stream_);
@@ -1178,12 +1181,12 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         Buf slab(this, (size_t)splits * p.slab_stride * sizeof(float));
         p.slabs = slab.f();
         // combine inside the launch (k_common.hpp) when the 16-byte epilogue applies and the tile count fits the counter array
-        const GemmTileInfo& ti = tc.cfg >= 200 ? gemm_tile_info_s(tc.cfg - 200) : (tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100) : gemm_tile_info(tc.cfg));
+        const GemmTileInfo& ti = tc.cfg >= 300 ? gemm_tile_info_y(tc.cfg - 300) : tc.cfg >= 200 ? gemm_tile_info_s(tc.cfg - 200) : (tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100) : gemm_tile_info(tc.cfg));
         const int bm = ti.bm, bn = ti.bn;
         const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
         const bool vec = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (!p.resid || p.ldr % 4 == 0);
         const bool slab_ok = (unsigned long long)p.slab_stride * 4ull < 0xFFFFFFE0ull;   // write-through stores go through a 32-bit buffer descriptor
-        if (opt_splitk_fused_ && vec && tiles <= kSplitkCounters && (opt_splitk_fused_ != 2 || slab_ok)) {
+        if (opt_splitk_fused_ && vec && tiles <= kSplitkCounters && (opt_splitk_fused_ != 2 || slab_ok) && tc.cfg < 300) {   // (k_gemm3y.hip: separate reduce only)
             p.counters = splitk_counters_;
             p.slab_wt = opt_splitk_fused_ == 2 ? 1 : 0;
         }

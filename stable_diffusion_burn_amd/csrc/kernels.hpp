@@ -110,6 +110,10 @@ constexpr int kNumGemmTilesS = 6;
 const GemmTileInfo& gemm_tile_info_s(int cfg);
 hipError_t launch_conv_gemm3x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 hipError_t launch_pack_split3(const float* bt, void* w3, long long rows, int K, hipStream_t s);
+// the same arithmetic on v_mfma_f32_32x32x16_bf16 with 32 x 160 wave tiles (k_gemm3y.hip; EXPERIMENTAL, tile_cfg 300 + x, reads the same planes)
+constexpr int kNumGemmTilesY = 4;
+const GemmTileInfo& gemm_tile_info_y(int cfg);
+hipError_t launch_conv_gemm3y(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 // MXFP8 (e4m3 + E8M0 block scales) 256-row LDS-DMA kernel on v_mfma_scale_f32_16x16x128_f8f6f4 (k_fp8.hip); its own tile list
 constexpr int kNumGemmTilesQ = 3;
 const GemmTileInfo& gemm_tile_info_q(int cfg);

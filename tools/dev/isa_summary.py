@@ -2,7 +2,10 @@
 """Static look at a cross-compiled kernel file (no GPU needed): registers / scratch / LDS per kernel from
 -Rpass-analysis=kernel-resource-usage, and the instruction stream of one kernel's k loop in compressed form.
 
-    python tools/dev/isa_summary.py stable_diffusion_burn_amd/csrc/k_gemm3x.hip [--kernel SUBSTR] [--loop]
+    python tools/dev/isa_summary.py stable_diffusion_burn_amd/csrc/k_gemm3x.hip [--kernel SUBSTR] [--mix]
+
+--mix: the instruction mix of the k loop (the innermost loop with matrix instructions) of every kernel that matches --kernel:
+matrix / other VALU / SALU / LDS / VMEM / waits per trip -- the numbers DESIGN.md and profiles/README.md quote.
 """
 import argparse, re, subprocess, tempfile, os, sys
 
@@ -10,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("src")
 ap.add_argument("--kernel", default=None, help="substring of the mangled name: dump that kernel's stream")
 ap.add_argument("--full", action="store_true", help="dump every instruction, not only the compressed stream")
+ap.add_argument("--mix", action="store_true", help="instruction mix of the k loop instead of the stream")
 args = ap.parse_args()
 d = tempfile.mkdtemp(prefix="isa_")
 src = os.path.abspath(args.src)
@@ -23,6 +27,26 @@ for b in re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]:
     g = lambda k: re.search(k + r": (\S+)", b).group(1)
     scr, occ = g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]")
     print(f"{name[:110]:110s} VGPR {g('VGPRs'):>3s} AGPR {g('AGPRs'):>3s} SGPR {g('SGPRs'):>3s} scratch {scr} occ {occ}")
+if args.kernel and args.mix:
+    import collections
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import check_lgkm as ck
+    asm_text = open(os.path.join(d, [f for f in os.listdir(d) if f.endswith("gfx950.s")][0])).read()
+    for name in [m for m in re.findall(r"^(\w+):\s*; @", asm_text, re.M) if args.kernel in m]:
+        lines = ck.function_lines(asm_text, name)
+        try:
+            h, b = ck.innermost_loop(lines)
+        except SystemExit:
+            continue
+        c = collections.Counter()
+        for l in lines[h:b + 1]:
+            if l.startswith("."):
+                continue
+            op = l.split()[0]
+            c["matrix" if "v_mfma" in op else "valu" if op.startswith("v_") else "wait" if op.startswith(("s_waitcnt", "s_barrier", "s_nop")) else
+              "branch" if op.startswith(("s_cbranch", "s_branch")) else "salu" if op.startswith("s_") else "lds" if op.startswith("ds_") else "vmem"] += 1
+        print(f"{name[:100]:100s} k loop: " + ", ".join(f"{k} {v}" for k, v in sorted(c.items())) + f"; total {sum(c.values())}")
+    sys.exit(0)
 if args.kernel:
     asm = [f for f in os.listdir(d) if f.endswith("gfx950.s")][0]
     s = open(os.path.join(d, asm)).read()
