@@ -6,7 +6,9 @@ sample_image under each option setting, interleaved (A B C A B C ...) so that cl
     python tools/ab_variants.py --precision bf16 --batch 8 --arms "gemm_bf16x_variant=0" "gemm_bf16x_variant=1"
 
 An arm is a comma-separated list of key=value options; every key of every arm is set for every arm (a key an arm does not name
-keeps the value the FIRST arm gives it, so the first arm should be the baseline).  Prints one JSON line per arm.
+keeps the value the FIRST arm gives it, so the first arm should be the baseline).  The pseudo-option tunefile=PATH applies every
+"M,N,K=cfg,splits" line of a tuning table through the "tune" option (give every arm one, e.g. the built-in table
+stable_diffusion_burn_amd/tuning/gfx950_fp32.txt for the baseline).  Prints one JSON line per arm.
 """
 from __future__ import annotations
 
@@ -46,7 +48,7 @@ def main():
     uncond = torch.from_numpy(syn.uncond_context(bench.T_CTX, ctx_dim)).to(dev)
     run = bench.Runner(torch, np, dev, 0, args.precision, args.batch, args.ddim_steps, 7.5, cond, uncond, list(range(args.batch)), flat, [], None)
 
-    arms = [dict(kv.split("=") for kv in a.split(",")) for a in args.arms]
+    arms = [dict(kv.split("=", 1) for kv in a.split(",")) for a in args.arms]
     base = dict(arms[0])
     for a in arms:
         for k, v in base.items():
@@ -54,7 +56,12 @@ def main():
 
     def apply(a):
         for k, v in a.items():
-            run.sd.set_option(k, v)
+            if k == "tunefile":
+                for line in Path(v).read_text().split():
+                    if "=" in line and not line.startswith("#"):
+                        run.sd.set_option("tune", line.strip())
+            else:
+                run.sd.set_option(k, v)
 
     times = [[] for _ in arms]
     for i, a in enumerate(arms):   # warm-up: one image per arm (first-launch costs, function attributes)
