@@ -57,9 +57,10 @@ def main():
     def apply(a):
         for k, v in a.items():
             if k == "tunefile":
-                for line in Path(v).read_text().split():
+                for line in Path(v).read_text().splitlines():
+                    line = line.strip()
                     if "=" in line and not line.startswith("#"):
-                        run.sd.set_option("tune", line.strip())
+                        run.sd.set_option("tune", line)
             else:
                 run.sd.set_option(k, v)
 
