@@ -954,6 +954,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "gemm_bf16x") opt_gemm_bf16x_ = std::stoi(value);
     else if (key == "gemm_bf16x_variant") opt_gemm_bf16x_variant_ = std::stoi(value);
     else if (key == "xcd_map") opt_xcd_map_ = std::stoi(value);
+    else if (key == "gemm_y") opt_gemm_y_ = std::stoi(value);
     else if (key == "gemm_x32") opt_gemm_x32_ = std::stoi(value);
     else if (key == "gemm_f32s") opt_gemm_f32s_ = std::stoi(value);
     else if (key == "gemm3x_variant") opt_gemm3x_variant_ = std::stoi(value);
@@ -979,7 +980,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
         TileChoice tc{0, 1};
         if (std::sscanf(value.c_str() + eq + 1, "%d,%d", &tc.cfg, &tc.splits) != 2 || tc.cfg < 0 || tc.splits < 1 ||
             !(tc.cfg < kNumGemmTiles || (tc.cfg >= 100 && tc.cfg < 100 + kNumGemmTilesX) || (!b16 && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS) ||
-              (!b16 && tc.cfg >= 300 && tc.cfg < 300 + kNumGemmTilesY)))
+              (tc.cfg >= 300 && tc.cfg < 300 + (b16 ? kNumGemmTilesX : kNumGemmTilesY))))
             throw Error(SDMI_ERR_INVALID, "tune: bad value");
         (b16 ? tuned_bf16_ : tuned_)[value.substr(0, eq)] = tc;
     } else if (key == "tune_clear") { tuned_.clear(); tuned_bf16_.clear(); tuned_mfma_.clear(); }
@@ -1118,7 +1119,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     // k_gemm3x.hip: the same layers, when the weight has its bf16 planes (weights in the arenas; not e.g. the K / V operands of
     // the unfused VAE attention) and the 32-bit piece offsets reach
     const bool s_ok = x32_ok && p.Bt3 && (unsigned long long)p.N * (p.geglu ? 2 : 1) * (unsigned long long)p.kt_total * 192ull < 0xFFFFFF00ull;
-    auto usable = [&](int cfg) { return cfg < 100 || (in_dt ? opt_gemm_bf16x_ != 0 : (cfg >= 200 ? (opt_gemm_f32s_ != 0 && s_ok && (cfg < 300 || !p.geglu)) : (opt_gemm_x32_ != 0 && x32_ok))); };
+    auto usable = [&](int cfg) { return cfg < 100 || (in_dt ? (opt_gemm_bf16x_ != 0 && (cfg < 300 || !p.geglu)) : (cfg >= 200 ? (opt_gemm_f32s_ != 0 && s_ok && (cfg < 300 || !p.geglu)) : (opt_gemm_x32_ != 0 && x32_ok))); };
     const auto it2 = in_dt ? tuned_mfma_.end() : tuned_mfma_.find(key);   // the table measured without the split kernels
     if (it != table.end() && usable(it->second.cfg)) tc = it->second;
     else if (it2 != tuned_mfma_.end() && usable(it2->second.cfg)) tc = it2->second;
@@ -1126,6 +1127,13 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     if (opt_force_tile_ >= 0 && (opt_force_tile_ < 100 || in_dt || (opt_force_tile_ >= 200 ? s_ok : x32_ok))) tc.cfg = opt_force_tile_;  // 100+ / 200+: large-tile kernels, where applicable
     if (opt_force_splits_ > 0) tc.splits = opt_force_splits_;
     if (force_cfg >= 0) tc.cfg = force_cfg;
+    // option gemm_y = 1 (EXPERIMENTAL): every launch that chose a large tile of the 16x16x32 families runs on the tile of the same shape of the
+    // 32x32x16 families instead (k_gemm_bf16y.hip: 100 + x -> 300 + x; k_gemm3y.hip: 128x320 / 256x160 / 128x256 / 256x128 only) -- the switch for their first A/B
+    if (opt_gemm_y_ && !p.geglu) {
+        static const int kSplitToY[kNumGemmTilesS] = {301, 300, 303, 302, -1, -1};
+        if (in_dt && tc.cfg >= 100 && tc.cfg < 100 + kNumGemmTilesX) tc.cfg += 200;
+        else if (!in_dt && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS && kSplitToY[tc.cfg - 200] >= 0) tc.cfg = kSplitToY[tc.cfg - 200];
+    }
     if (record_shapes_) {   // which kernel / tile / split-K each (M, N, K) got: option dump_choices
         char ck[96];
         std::snprintf(ck, sizeof ck, "%d,%d,%d cfg=%d splits=%d%s", p.M, p.N, p.K, tc.cfg, tc.splits, p.Bt3 ? "" : " (no planes)");
@@ -1143,14 +1151,14 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     const unsigned long long a_ext = ((unsigned long long)p.NB * p.Hs * p.Ws - 1) * (unsigned long long)p.a_ld * es + (unsigned long long)p.Cin * es;
     const unsigned long long b_ext = ((unsigned long long)p.N * (p.geglu ? 2 : 1) - 1) * (unsigned long long)p.b_ld * es + (unsigned long long)p.K * es;
     p.zero_page = zero_page_;
-    if (tc.cfg >= 300 ? (in_dt || tc.cfg - 300 >= kNumGemmTilesY || !s_ok || p.geglu)
+    if (tc.cfg >= 300 ? (p.geglu || (in_dt ? tc.cfg - 300 >= kNumGemmTilesX : (tc.cfg - 300 >= kNumGemmTilesY || !s_ok)))
         : tc.cfg >= 200 ? (tc.cfg - 200 >= kNumGemmTilesS || !s_ok) : (tc.cfg >= 100 && (tc.cfg - 100 >= kNumGemmTilesX || (!in_dt && !x32_ok))))
         throw Error(SDMI_ERR_INVALID, "gemm: large-tile kernel index out of range or not applicable to this layer");
     if (a_ext >= 0xFFFFFFE0ull || b_ext >= 0xFFFFFFE0ull) throw Error(SDMI_ERR_UNSUPPORTED, "GEMM: operand larger than 4 GiB (the buffer-load range check needs 32-bit extents)");
     p.a_bytes = (unsigned)a_ext;
     p.b_bytes = (unsigned)b_ext;
     {
-        const GemmTileInfo& ti = in_dt ? (tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100) : gemm_tile_info(tc.cfg))
+        const GemmTileInfo& ti = in_dt ? (tc.cfg >= 300 ? gemm_tile_info_x(tc.cfg - 300) : tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100) : gemm_tile_info(tc.cfg))
                                        : (tc.cfg >= 300 ? gemm_tile_info_y(tc.cfg - 300) : tc.cfg >= 200 ? gemm_tile_info_s(tc.cfg - 200) : (tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100) : gemm_tile_info(tc.cfg)));
         const int bno = p.geglu ? ti.bn / 2 : ti.bn;
         const double wes = in_dt ? 2.0 : (tc.cfg >= 200 ? 6.0 : 4.0);     // bytes per weight as this kernel reads them (three bf16 planes: 6)
@@ -1160,6 +1168,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
                        (double)p.N * (p.geglu ? 2.0 : 1.0) * (double)p.K * wes, flops, cu_flops);
     }
     auto launch = [&](const ConvGemm& q) {
+        if (in_dt && tc.cfg >= 300) return launch_conv_gemm_bf16y(q, tc.cfg - 300, stream_);
         if (in_dt && tc.cfg >= 100) return launch_conv_gemm_bf16x(q, tc.cfg - 100, stream_);
         if (tc.cfg >= 300) return launch_conv_gemm3y(q, tc.cfg - 300, stream_);
         if (tc.cfg >= 200) return launch_conv_gemm3x(q, tc.cfg - 200, stream_);
@@ -1181,7 +1190,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         Buf slab(this, (size_t)splits * p.slab_stride * sizeof(float));
         p.slabs = slab.f();
         // combine inside the launch (k_common.hpp) when the 16-byte epilogue applies and the tile count fits the counter array
-        const GemmTileInfo& ti = tc.cfg >= 300 ? gemm_tile_info_y(tc.cfg - 300) : tc.cfg >= 200 ? gemm_tile_info_s(tc.cfg - 200) : (tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100) : gemm_tile_info(tc.cfg));
+        const GemmTileInfo& ti = tc.cfg >= 300 ? (in_dt ? gemm_tile_info_x(tc.cfg - 300) : gemm_tile_info_y(tc.cfg - 300)) : tc.cfg >= 200 ? gemm_tile_info_s(tc.cfg - 200) : (tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100) : gemm_tile_info(tc.cfg));
         const int bm = ti.bm, bn = ti.bn;
         const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
         const bool vec = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (!p.resid || p.ldr % 4 == 0);

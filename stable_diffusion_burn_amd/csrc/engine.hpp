@@ -401,6 +401,7 @@ private:
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
     int opt_gemm_bf16x_variant_ = 0;   // k_gemm_bf16x.hip: 3 = pipelined k loop (DMA pieces and asm fragment reads with hand-counted waits behind the matrix instructions, barrier near the end of a tile; measured: not faster)
     int opt_xcd_map_ = 0;              // 1: cut every GEMM launch over the 8 XCDs so that the fewest operand bytes cross the fabric (choose_xcd_map); 0: bands of tiles, every XCD reads all weights
+    int opt_gemm_y_ = 0;               // 1 (EXPERIMENTAL, not yet run on a GPU): large-tile GEMMs on the v_mfma_f32_32x32x16_bf16 families (k_gemm3y.hip, k_gemm_bf16y.hip) where a tile of the same shape exists
     void* zero_page_ = nullptr;
     TileChoice choose_tile_bf16(int M, int N, int kt_total) const;   // cfg >= 100: k_gemm_bf16x.hip tile cfg - 100     // precision = 1: 1 = bf16 matrix-core attention, 0 = bf16 storage widened onto the fp32 kernel  // 1: attn2_kernel, 0: attn_f32_kernel
     // split-K combine: 0 = separate reduce kernel (the measured best, profiles/README.md); 1 = inside the GEMM launch by the

@@ -102,6 +102,8 @@ hipError_t launch_splitk_reduce_bf16(const ConvGemm& p, hipStream_t stream);
 constexpr int kNumGemmTilesX = 4;
 const GemmTileInfo& gemm_tile_info_x(int cfg);
 hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
+// the same tile shapes on v_mfma_f32_32x32x16_bf16 (k_gemm_bf16y.hip; EXPERIMENTAL, tile_cfg 300 + x at precision = 1, tile list = gemm_tile_info_x)
+hipError_t launch_conv_gemm_bf16y(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 // the same structure for fp32 storage (k_gemm2x.hip; Cin % 32 == 0, fp32 output); same tile list
 hipError_t launch_conv_gemm2x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 // fp32 on the bf16 matrix pipe: operands as exact sums of three bf16 terms, six partial products (k_gemm3x.hip); its own tile

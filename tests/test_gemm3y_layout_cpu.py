@@ -1,4 +1,4 @@
-"""Index arithmetic of k_gemm3y.hip (the 32x32x16 split-GEMM family, not yet run on a GPU), emulated on the CPU.
+"""Index arithmetic of k_gemm3y.hip and k_gemm_bf16y.hip (the 32x32x16 GEMM families, not yet run on a GPU), emulated on the CPU.
 
 The kernel's correctness hangs on a chain of layouts that must agree with each other: the DMA's source-side swizzles, the LDS addresses
 of the fragment reads, which eight k-values a lane of v_mfma_f32_32x32x16_bf16 supplies on the weight and on the activation side, the
@@ -158,3 +158,89 @@ def test_gemm3y_tile_reproduces_a_times_w_transposed(ni, wm, wn):
 def test_every_k_of_a_tile_is_used_exactly_once():
     used = sorted(k for s in range(2) for hi in range(2) for k in plane_chunk_elems(2 * s + hi))
     assert used == list(range(32))
+
+
+# ---- k_gemm_bf16y.hip -----------------------------------------------------------------------------------------------------------------
+def emulate_bf16y(mi_n, ni, wm_n, wn_n, rng, out_f32):
+    bm, bn = 32 * mi_n * wm_n, 32 * ni * wn_n
+    na, nb = bm // 64, bn // 64
+    a_bytes = bm * 128
+    A = rng.standard_normal((bm, 64))                      # one k tile: 64 bf16 per row = 8 chunks of 8
+    W = rng.standard_normal((bn, 64))
+    lds = [None] * (((bm + bn) * 128) // 16)               # 16-byte cells
+    for wave in range(8):
+        for j in range(max(na, nb)):
+            for lane in range(64):
+                sub = lane >> 3
+                chunk = (lane & 7) ^ ((((wave & 1) << 2) + (sub >> 1)) & 7)
+                row = (wave + 8 * j) * 8 + sub
+                if j < na:
+                    lds[((wave + 8 * j) * 1024 + lane * 16) // 16] = ("a", row, chunk, A[row, chunk * 8: chunk * 8 + 8])
+                if j < nb:
+                    lds[(a_bytes + (wave + 8 * j) * 1024 + lane * 16) // 16] = ("w", row, chunk, W[row, chunk * 8: chunk * 8 + 8])
+    out = np.zeros((bm, bn))
+    conflicts = 0
+    for wave in range(8):
+        wm, wn = wave // wn_n, wave % wn_n
+        acc = np.zeros((mi_n, ni, 64, 16))
+        for s_ in range(4):
+            fa = [[None] * 64 for _ in range(mi_n)]
+            fb = [[None] * 64 for _ in range(ni)]
+            addr_a = [[0] * 64 for _ in range(mi_n)]
+            addr_b = [[0] * 64 for _ in range(ni)]
+            for lane in range(64):
+                c, hi = lane & 31, lane >> 5
+                sw = (c >> 1) & 7
+                g_off = ((2 * s_ + hi) ^ sw) << 4
+                a_lane = (wm * mi_n * 32 + c) * 128
+                b_lane = a_bytes + (wn * ni * 32 + c) * 128
+                for mi in range(mi_n):
+                    off = a_lane + g_off + mi * 4096
+                    cell = lds[off // 16]
+                    assert cell[0] == "a" and cell[1] == (wm * mi_n + mi) * 32 + c and cell[2] == 2 * s_ + hi
+                    fa[mi][lane] = cell[3]
+                    addr_a[mi][lane] = off
+                for n_ in range(ni):
+                    off = b_lane + g_off + n_ * 4096
+                    cell = lds[off // 16]
+                    assert cell[0] == "w" and cell[1] == (wn * ni + n_) * 32 + c and cell[2] == 2 * s_ + hi
+                    fb[n_][lane] = cell[3]
+                    addr_b[n_][lane] = off
+            for lst in addr_a + addr_b:
+                conflicts += bank_conflicts(lst)
+            for mi in range(mi_n):
+                for n_ in range(ni):
+                    for lb in range(64):                                     # B-operand lane = pixel column of D
+                        cb, hb = lb & 31, lb >> 5
+                        for r in range(16):
+                            row = (r & 3) + 8 * (r >> 2) + 4 * hb
+                            acc[mi, n_, lb, r] += sum(float(np.dot(fb[n_][row + 32 * hh], fa[mi][cb + 32 * hh])) for hh in range(2))
+        for mi in range(mi_n):
+            for n_ in range(ni):
+                scr = np.full((32, 36), np.nan)
+                for lane in range(64):
+                    c, hi = lane & 31, lane >> 5
+                    for q in range(4):
+                        scr[c, 8 * q + 4 * hi: 8 * q + 4 * hi + 4] = acc[mi, n_, lane, 4 * q: 4 * q + 4]
+                mrow0, nf0 = (wm * mi_n + mi) * 32, (wn * ni + n_) * 32
+                if not out_f32:
+                    for it in range(2):
+                        for lane in range(64):
+                            row, c8 = it * 16 + (lane >> 2), lane & 3
+                            out[mrow0 + row, nf0 + c8 * 8: nf0 + c8 * 8 + 8] = scr[row, c8 * 8: c8 * 8 + 8]
+                else:
+                    for it in range(4):
+                        for lane in range(64):
+                            row, c4 = it * 8 + (lane >> 3), lane & 7
+                            out[mrow0 + row, nf0 + c4 * 4: nf0 + c4 * 4 + 4] = scr[row, c4 * 4: c4 * 4 + 4]
+    return A, W, out, conflicts
+
+
+@pytest.mark.parametrize("out_f32", [False, True])
+@pytest.mark.parametrize("mi,ni,wm,wn", [(2, 5, 4, 2), (2, 4, 4, 2), (2, 2, 4, 2), (1, 5, 4, 2)])
+def test_gemm_bf16y_tile_reproduces_a_times_w_transposed(mi, ni, wm, wn, out_f32):
+    rng = np.random.default_rng(10 * mi + ni)
+    A, W, out, conflicts = emulate_bf16y(mi, ni, wm, wn, rng, out_f32)
+    ref = A @ W.T
+    assert np.allclose(out, ref, rtol=1e-12, atol=1e-12), f"max |diff| = {np.abs(out - ref).max()}"
+    assert conflicts == 0, f"{conflicts} extra LDS cycles from bank conflicts in the fragment reads"
