@@ -1179,7 +1179,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     p.slabs = nullptr;
     p.counters = nullptr;
     p.slab_wt = 0;
-    const int pc = tc.cfg >= 200 ? PC_CONV_SPLIT : PC_CONV_GEMM;   // k_gemm3x.hip launches are timed as their own class
+    const int pc = (!in_dt && tc.cfg >= 200) ? PC_CONV_SPLIT : PC_CONV_GEMM;   // k_gemm3x.hip / k_gemm3y.hip launches are timed as their own class
     if (splits == 1) {
         p.slab_stride = 0;
         ProfScope ps(this, pc, flops);
