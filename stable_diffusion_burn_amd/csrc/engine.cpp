@@ -893,12 +893,29 @@ Act Engine::new_act(int n, int h, int w, int c, int dt) {
     a.p = reinterpret_cast<float*>(pool_.alloc(a.bytes()));
     return a;
 }
-void Engine::release(Act& a) { if (a.p && !a.view) pool_.free(a.p); a.p = nullptr; }
+Act Engine::new_act3(int n, int h, int w, int c, int what) {
+    if ((what & 2) && (c % 32 || bf16_)) throw Error(SDMI_ERR_STATE, "new_act3: planes need fp32 storage and c % 32 == 0");
+    Act a; a.n = n; a.h = h; a.w = w; a.c = c; a.dt = 0;
+    if (what & 1) a.p = reinterpret_cast<float*>(pool_.alloc(a.bytes()));
+    if (what & 2) { a.p3 = pool_.alloc(a.bytes3()); a.ld3 = (c / 32) * 192; }
+    return a;
+}
+void Engine::release(Act& a) {
+    if (!a.view) {
+        if (a.p) pool_.free(a.p);
+        if (a.p3) pool_.free(a.p3);
+    }
+    a.p = nullptr; a.p3 = nullptr;
+}
 
 Act Engine::slice(const Act& parent, int c_off, int c) {
     if (c_off < 0 || c <= 0 || c_off + c > parent.c || parent.view) throw Error(SDMI_ERR_STATE, "slice: bad channel range");
     Act a = parent;
-    a.p = adv(parent.p, c_off, parent.dt);
+    a.p = parent.p ? adv(parent.p, c_off, parent.dt) : nullptr;
+    if (parent.p3) {
+        if (c_off % 32 || c % 32) throw Error(SDMI_ERR_STATE, "slice: plane tensors are cut at multiples of 32 channels");
+        a.p3 = (char*)parent.p3 + (size_t)(c_off / 32) * 192;
+    }
     a.c = c; a.ld = parent.stride(); a.view = true;
     return a;
 }
@@ -954,9 +971,9 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "gemm_bf16x") opt_gemm_bf16x_ = std::stoi(value);
     else if (key == "gemm_bf16x_variant") opt_gemm_bf16x_variant_ = std::stoi(value);
     else if (key == "xcd_map") opt_xcd_map_ = std::stoi(value);
-    else if (key == "gemm_y") opt_gemm_y_ = std::stoi(value);
     else if (key == "gemm_x32") opt_gemm_x32_ = std::stoi(value);
     else if (key == "gemm_f32s") opt_gemm_f32s_ = std::stoi(value);
+    else if (key == "gemm_planes") opt_gemm_planes_ = (value == "default") ? kGemmPlanesDefault : std::stoi(value);
     else if (key == "gemm3x_variant") opt_gemm3x_variant_ = std::stoi(value);
     else if (key == "geglu_fuse") opt_geglu_fuse_ = std::stoi(value);
     else if (key == "record_shapes") { record_shapes_ = std::stoi(value) != 0; if (record_shapes_) { shape_counts_.clear(); choice_counts_.clear(); } }
@@ -980,7 +997,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
         TileChoice tc{0, 1};
         if (std::sscanf(value.c_str() + eq + 1, "%d,%d", &tc.cfg, &tc.splits) != 2 || tc.cfg < 0 || tc.splits < 1 ||
             !(tc.cfg < kNumGemmTiles || (tc.cfg >= 100 && tc.cfg < 100 + kNumGemmTilesX) || (!b16 && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS) ||
-              (tc.cfg >= 300 && tc.cfg < 300 + (b16 ? kNumGemmTilesX : kNumGemmTilesY))))
+              (!b16 && tc.cfg >= 300 && tc.cfg < 300 + kNumGemmTilesP)))
             throw Error(SDMI_ERR_INVALID, "tune: bad value");
         (b16 ? tuned_bf16_ : tuned_)[value.substr(0, eq)] = tc;
     } else if (key == "tune_clear") { tuned_.clear(); tuned_bf16_.clear(); tuned_mfma_.clear(); }
@@ -1108,6 +1125,10 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         std::snprintf(sk, sizeof sk, "%d,%d,%d,%d,%d,%d,%d,%d", p.NB, p.Cin, p.Hs, p.Ws, p.N, p.KH, p.stride, p.ups);
         ++shape_counts_[sk];
     }
+    auto tile_info = [&](int cfg) -> const GemmTileInfo& {
+        if (in_dt) return cfg >= 100 ? gemm_tile_info_x(cfg - 100) : gemm_tile_info(cfg);
+        return cfg >= 300 ? gemm_tile_info_p(cfg - 300) : cfg >= 200 ? gemm_tile_info_s(cfg - 200) : cfg >= 100 ? gemm_tile_info_x(cfg - 100) : gemm_tile_info(cfg);
+    };
     TileChoice tc;
     char key[64];
     std::snprintf(key, sizeof key, "%d,%d,%d", p.M, p.N, p.K);
@@ -1119,20 +1140,23 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     // k_gemm3x.hip: the same layers, when the weight has its bf16 planes (weights in the arenas; not e.g. the K / V operands of
     // the unfused VAE attention) and the 32-bit piece offsets reach
     const bool s_ok = x32_ok && p.Bt3 && (unsigned long long)p.N * (p.geglu ? 2 : 1) * (unsigned long long)p.kt_total * 192ull < 0xFFFFFF00ull;
-    auto usable = [&](int cfg) { return cfg < 100 || (in_dt ? (opt_gemm_bf16x_ != 0 && (cfg < 300 || !p.geglu)) : (cfg >= 200 ? (opt_gemm_f32s_ != 0 && s_ok && (cfg < 300 || !p.geglu)) : (opt_gemm_x32_ != 0 && x32_ok))); };
+    // k_gemm3p.hip (300 + x): the same layers with the activations as planes too -- written by their producer (p.A3) or, for a tensor that
+    // arrives as fp32, by split3_rows_kernel right here
+    const bool p_ok = s_ok && opt_gemm_planes_ != 0 && (unsigned long long)p.NB * p.Hs * p.Ws * (unsigned long long)(p.A3 ? p.a3_ld : p.Cin * 6) < 0xFFFFFF00ull;
+    auto usable = [&](int cfg) { return cfg < 100 || (in_dt ? opt_gemm_bf16x_ != 0 : (cfg >= 300 ? p_ok : cfg >= 200 ? (opt_gemm_f32s_ != 0 && s_ok) : (opt_gemm_x32_ != 0 && x32_ok))); };
     const auto it2 = in_dt ? tuned_mfma_.end() : tuned_mfma_.find(key);   // the table measured without the split kernels
     if (it != table.end() && usable(it->second.cfg)) tc = it->second;
     else if (it2 != tuned_mfma_.end() && usable(it2->second.cfg)) tc = it2->second;
     else tc = in_dt ? choose_tile_bf16(p.M, p.N, p.kt_total) : choose_tile(p.M, p.N, p.kt_total, x32_ok, s_ok);
-    if (opt_force_tile_ >= 0 && (opt_force_tile_ < 100 || in_dt || (opt_force_tile_ >= 200 ? s_ok : x32_ok))) tc.cfg = opt_force_tile_;  // 100+ / 200+: large-tile kernels, where applicable
+    if (opt_force_tile_ >= 0 && (opt_force_tile_ < 100 || in_dt || (opt_force_tile_ >= 300 ? p_ok : opt_force_tile_ >= 200 ? s_ok : x32_ok))) tc.cfg = opt_force_tile_;  // 100+ / 200+: large-tile kernels, where applicable
     if (opt_force_splits_ > 0) tc.splits = opt_force_splits_;
     if (force_cfg >= 0) tc.cfg = force_cfg;
-    // option gemm_y = 1 (EXPERIMENTAL): every launch that chose a large tile of the 16x16x32 families runs on the tile of the same shape of the
-    // 32x32x16 families instead (k_gemm_bf16y.hip: 100 + x -> 300 + x; k_gemm3y.hip: 128x320 / 256x160 / 128x256 / 256x128 only) -- the switch for their first A/B
-    if (opt_gemm_y_ && !p.geglu) {
-        static const int kSplitToY[kNumGemmTilesS] = {301, 300, 303, 302, -1, -1};
-        if (in_dt && tc.cfg >= 100 && tc.cfg < 100 + kNumGemmTilesX) tc.cfg += 200;
-        else if (!in_dt && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS && kSplitToY[tc.cfg - 200] >= 0) tc.cfg = kSplitToY[tc.cfg - 200];
+    // gemm_planes = 1: every launch that chose a k_gemm3x.hip tile runs on the k_gemm3p.hip tile nearest in shape (A/B switch; a per-shape
+    // table entry 300 + x needs no mapping)
+    if (!in_dt && p_ok && opt_gemm_planes_ == 1 && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS) {
+        static const int kSplitToP[kNumGemmTilesS] = {300, 303, 301, 302, 303, 304};
+        const int c = kSplitToP[tc.cfg - 200];
+        if (!p.geglu || c == 301 || c == 302 || c == 304) tc.cfg = c;
     }
     if (record_shapes_) {   // which kernel / tile / split-K each (M, N, K) got: option dump_choices
         char ck[96];
@@ -1151,26 +1175,35 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     const unsigned long long a_ext = ((unsigned long long)p.NB * p.Hs * p.Ws - 1) * (unsigned long long)p.a_ld * es + (unsigned long long)p.Cin * es;
     const unsigned long long b_ext = ((unsigned long long)p.N * (p.geglu ? 2 : 1) - 1) * (unsigned long long)p.b_ld * es + (unsigned long long)p.K * es;
     p.zero_page = zero_page_;
-    if (tc.cfg >= 300 ? (p.geglu || (in_dt ? tc.cfg - 300 >= kNumGemmTilesX : (tc.cfg - 300 >= kNumGemmTilesY || !s_ok)))
-        : tc.cfg >= 200 ? (tc.cfg - 200 >= kNumGemmTilesS || !s_ok) : (tc.cfg >= 100 && (tc.cfg - 100 >= kNumGemmTilesX || (!in_dt && !x32_ok))))
+    if (tc.cfg >= 300 ? (in_dt || tc.cfg - 300 >= kNumGemmTilesP || !p_ok)
+        : tc.cfg >= 200 ? (in_dt || tc.cfg - 200 >= kNumGemmTilesS || !s_ok) : (tc.cfg >= 100 && (tc.cfg - 100 >= kNumGemmTilesX || (!in_dt && !x32_ok))))
         throw Error(SDMI_ERR_INVALID, "gemm: large-tile kernel index out of range or not applicable to this layer");
     if (a_ext >= 0xFFFFFFE0ull || b_ext >= 0xFFFFFFE0ull) throw Error(SDMI_ERR_UNSUPPORTED, "GEMM: operand larger than 4 GiB (the buffer-load range check needs 32-bit extents)");
     p.a_bytes = (unsigned)a_ext;
     p.b_bytes = (unsigned)b_ext;
     {
-        const GemmTileInfo& ti = in_dt ? (tc.cfg >= 300 ? gemm_tile_info_x(tc.cfg - 300) : tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100) : gemm_tile_info(tc.cfg))
-                                       : (tc.cfg >= 300 ? gemm_tile_info_y(tc.cfg - 300) : tc.cfg >= 200 ? gemm_tile_info_s(tc.cfg - 200) : (tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100) : gemm_tile_info(tc.cfg)));
+        const GemmTileInfo& ti = tile_info(tc.cfg);
         const int bno = p.geglu ? ti.bn / 2 : ti.bn;
         const double wes = in_dt ? 2.0 : (tc.cfg >= 200 ? 6.0 : 4.0);     // bytes per weight as this kernel reads them (three bf16 planes: 6)
+        const double aes = (!in_dt && tc.cfg >= 300) ? 6.0 : (double)es;
         // what a CU sustains in the kernel's k loop (chip rate / 256; measured per family: profiles/README.md)
         const double cu_flops = (in_dt ? 1.2e15 : (tc.cfg >= 200 ? 2.3e14 : 1.3e14)) / 256.0;
-        choose_xcd_map(p, (p.M + ti.bm - 1) / ti.bm, (p.N + bno - 1) / bno, (double)p.NB * p.Hs * p.Ws * p.Cin * (double)es,
+        choose_xcd_map(p, (p.M + ti.bm - 1) / ti.bm, (p.N + bno - 1) / bno, (double)p.NB * p.Hs * p.Ws * p.Cin * aes,
                        (double)p.N * (p.geglu ? 2.0 : 1.0) * (double)p.K * wes, flops, cu_flops);
     }
+    std::unique_ptr<Buf> a3_tmp;
+    if (tc.cfg >= 300 && !p.A3) {   // the source is fp32: split it once for this launch (a producer that writes planes itself saves this pass)
+        const long long rows = (long long)p.NB * p.Hs * p.Ws;
+        p.a3_ld = (p.Cin / 32) * 192;
+        a3_tmp.reset(new Buf(this, (size_t)rows * p.a3_ld));
+        ProfScope ps(this, PC_SPLIT_ROWS, 0, (double)rows * p.Cin * 10.0);
+        SDMI_HIP(launch_split3_rows(p.A, a3_tmp->p, rows, p.Cin, p.a_ld, p.a3_ld, stream_));
+        count_kernel();
+        p.A3 = a3_tmp->p;
+    }
     auto launch = [&](const ConvGemm& q) {
-        if (in_dt && tc.cfg >= 300) return launch_conv_gemm_bf16y(q, tc.cfg - 300, stream_);
+        if (tc.cfg >= 300) return launch_conv_gemm3p(q, tc.cfg - 300, stream_);
         if (in_dt && tc.cfg >= 100) return launch_conv_gemm_bf16x(q, tc.cfg - 100, stream_);
-        if (tc.cfg >= 300) return launch_conv_gemm3y(q, tc.cfg - 300, stream_);
         if (tc.cfg >= 200) return launch_conv_gemm3x(q, tc.cfg - 200, stream_);
         if (tc.cfg >= 100) return launch_conv_gemm2x(q, tc.cfg - 100, stream_);
         if (in_dt) return launch_conv_gemm_bf16(q, tc.cfg, stream_);
@@ -1179,7 +1212,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     p.slabs = nullptr;
     p.counters = nullptr;
     p.slab_wt = 0;
-    const int pc = (!in_dt && tc.cfg >= 200) ? PC_CONV_SPLIT : PC_CONV_GEMM;   // k_gemm3x.hip / k_gemm3y.hip launches are timed as their own class
+    const int pc = (!in_dt && tc.cfg >= 200) ? PC_CONV_SPLIT : PC_CONV_GEMM;   // k_gemm3x.hip launches are timed as their own class
     if (splits == 1) {
         p.slab_stride = 0;
         ProfScope ps(this, pc, flops);
@@ -1190,12 +1223,12 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         Buf slab(this, (size_t)splits * p.slab_stride * sizeof(float));
         p.slabs = slab.f();
         // combine inside the launch (k_common.hpp) when the 16-byte epilogue applies and the tile count fits the counter array
-        const GemmTileInfo& ti = tc.cfg >= 300 ? (in_dt ? gemm_tile_info_x(tc.cfg - 300) : gemm_tile_info_y(tc.cfg - 300)) : tc.cfg >= 200 ? gemm_tile_info_s(tc.cfg - 200) : (tc.cfg >= 100 ? gemm_tile_info_x(tc.cfg - 100) : gemm_tile_info(tc.cfg));
+        const GemmTileInfo& ti = tile_info(tc.cfg);
         const int bm = ti.bm, bn = ti.bn;
         const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
         const bool vec = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (!p.resid || p.ldr % 4 == 0);
         const bool slab_ok = (unsigned long long)p.slab_stride * 4ull < 0xFFFFFFE0ull;   // write-through stores go through a 32-bit buffer descriptor
-        if (opt_splitk_fused_ && vec && tiles <= kSplitkCounters && (opt_splitk_fused_ != 2 || slab_ok) && tc.cfg < 300) {   // (k_gemm3y.hip: separate reduce only)
+        if (opt_splitk_fused_ && vec && tiles <= kSplitkCounters && (opt_splitk_fused_ != 2 || slab_ok)) {
             p.counters = splitk_counters_;
             p.slab_wt = opt_splitk_fused_ == 2 ? 1 : 0;
         }
@@ -1226,6 +1259,7 @@ void Engine::conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, con
     ConvGemm p{};
     if (resid && (resid->rows() != y.rows() || resid->c != y.c || resid->dt != y.dt)) throw Error(SDMI_ERR_STATE, "conv: residual shape / type mismatch");
     p.A = x.p; p.Bt = w.bt; p.C = y.p; p.bias = w.bias; p.rowvec = rowvec; p.resid = resid ? resid->p : nullptr;
+    p.A3 = x.p3; p.a3_ld = x.ld3;
     p.M = x.n * ho * wo; p.N = w.cout; p.K = w.cin * w.k * w.k;
     p.NB = x.n; p.Hs = x.h; p.Ws = x.w; p.Cin = w.cin; p.Ho = ho; p.Wo = wo;
     p.KH = w.k; p.KW = w.k; p.stride = stride; p.pad = pad; p.ups = ups;
@@ -2123,9 +2157,14 @@ double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int str
     }
     SDMI_HIP(launch_fill_normal(bias.f(), cout, 13, stream_));
     TempSplit planes(this, bt.f(), wdt ? 0 : cout, (long long)cin * k * k);
+    if (!wdt && tile_cfg >= 300 && cin % 32 == 0) {   // plane tiles are timed on planes their producer would have written
+        a.p3 = pool_.alloc(a.bytes3()); a.ld3 = (cin / 32) * 192;
+        SDMI_HIP(launch_split3_rows(a.p, a.p3, a.rows(), cin, cin, a.ld3, stream_));
+    }
     ConvW cw; cw.cin = cin; cw.cout = cout; cw.k = k; cw.bt = bt.f(); cw.bias = bias.f(); cw.dt = wdt;
-    const int save_t = opt_force_tile_, save_s = opt_force_splits_;
+    const int save_t = opt_force_tile_, save_s = opt_force_splits_, save_p = opt_gemm_planes_;
     opt_force_tile_ = tile_cfg; opt_force_splits_ = splitk;
+    if (tile_cfg >= 300 && !opt_gemm_planes_) opt_gemm_planes_ = 2;
     float ms = 0;
     try {
         conv(cw, a, y, stride, ups, nullptr, 0, nullptr);  // warm-up
@@ -2135,11 +2174,11 @@ double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int str
         SDMI_HIP(hipEventSynchronize(ev1_));
         SDMI_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
     } catch (...) {
-        opt_force_tile_ = save_t; opt_force_splits_ = save_s;
+        opt_force_tile_ = save_t; opt_force_splits_ = save_s; opt_gemm_planes_ = save_p;
         release(a); release(y);
         throw;
     }
-    opt_force_tile_ = save_t; opt_force_splits_ = save_s;
+    opt_force_tile_ = save_t; opt_force_splits_ = save_s; opt_gemm_planes_ = save_p;
     release(a); release(y);
     return (double)ms / std::max(1, iters);
 }

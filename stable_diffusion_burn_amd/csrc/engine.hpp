@@ -62,12 +62,17 @@ private:
 // historical reasons; for dt == 1 it is an opaque pointer to 2-byte elements.
 // ld: elements between consecutive pixels (0 = dense, i.e. c).  A channel-slice VIEW of a wider buffer (view = true, never
 // freed) is how Tensor::cat (unet/mod.rs:134) is realised without a copy: producers write their slice, the consumer reads the whole.
+// p3 (precision = 0 only): the same tensor as three bf16 planes [pixel][ld3 / 192 slices][h, m, l][32] (k_split3.hpp), what k_gemm3p.hip
+// reads; written by the tensor's producer.  A tensor may exist as fp32 (p), as planes (p3), or as both.
 struct Act {
     float* p = nullptr;
     int n = 0, h = 0, w = 0, c = 0;
     int dt = 0;
     int ld = 0;
     bool view = false;
+    void* p3 = nullptr;
+    int ld3 = 0;       // bytes between pixels of p3
+    size_t bytes3() const { return (size_t)rows() * (size_t)(c / 32) * 192; }
     long long rows() const { return (long long)n * h * w; }
     int stride() const { return ld ? ld : c; }
     size_t bytes() const { return (size_t)rows() * c * (dt ? 2 : 4); }
@@ -248,6 +253,8 @@ private:
 
     // primitive ops on device activations (NHWC)
     Act new_act(int n, int h, int w, int c, int dt = -1);  // dt -1: the engine's activation type
+    // fp32 engines: what = 1 fp32 only, 2 planes only, 3 both (c % 32 == 0 for planes)
+    Act new_act3(int n, int h, int w, int c, int what);
     void release(Act& a);
     // pad_br: zero padding on the bottom / right only (PaddingCfg::new(0, 1, 0, 1), the VAE encoder's downsampler)
     void conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, const float* rowvec, int rowvec_stride,
@@ -311,7 +318,7 @@ private:
 public:
     // per-kernel-class timing (option "profile=1"): HIP events around every launch on the
     // engine's stream, accumulated per class.  Used by bench.py for the roofline line.
-    enum ProfClass { PC_CONV_GEMM, PC_SPLITK_REDUCE, PC_ATTENTION, PC_GROUP_NORM, PC_LAYER_NORM, PC_CONV_FP8, PC_CONV_SPLIT, PC_OTHER, PC_COUNT };
+    enum ProfClass { PC_CONV_GEMM, PC_SPLITK_REDUCE, PC_ATTENTION, PC_GROUP_NORM, PC_LAYER_NORM, PC_CONV_FP8, PC_CONV_SPLIT, PC_SPLIT_ROWS, PC_OTHER, PC_COUNT };
     struct ProfStat { double ms = 0; long long launches = 0; double flops = 0; double bytes = 0; };
     ProfStat prof_[PC_COUNT];
     void prof_flush();
@@ -397,11 +404,13 @@ private:
     int opt_gemm_f32s_ = 1;     // precision = 0: 1 = fp32 GEMMs on the bf16 matrix pipe (three-way operand split, k_gemm3x.hip) where faster
     int opt_gemm3x_variant_ = 2;     // bit 0: DMA in one block per k tile; bit 1: scalar residual subtractions (+0.7 %); bit 2: two LDS stages on the 128-row tiles (default three: +5..10 % on long K);
                                      // bit 4: s_setprio 1 for waves 4-7; bits 3 + 6 (74 with bit 1): the pipelined k loop with hand-counted LDS waits (k_gemm3x.hip HOIST = 3; measured: not faster)
+    static constexpr int kGemmPlanesDefault = 0;
+    int opt_gemm_planes_ = kGemmPlanesDefault;   // precision = 0: k_gemm3p.hip (activations as bf16 planes too, no split in the k loop): 0 never, 1 every launch that would take a k_gemm3x.hip tile,
+                                // 2 only where the per-shape table says 300 + x
     int opt_gemm_x32_ = 1;      // precision = 0: 1 = large-tile LDS-DMA fp32 GEMM (k_gemm2x.hip) where measured / modelled faster
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
     int opt_gemm_bf16x_variant_ = 0;   // k_gemm_bf16x.hip: 3 = pipelined k loop (DMA pieces and asm fragment reads with hand-counted waits behind the matrix instructions, barrier near the end of a tile; measured: not faster)
     int opt_xcd_map_ = 0;              // 1: cut every GEMM launch over the 8 XCDs so that the fewest operand bytes cross the fabric (choose_xcd_map); 0: bands of tiles, every XCD reads all weights
-    int opt_gemm_y_ = 0;               // 1 (EXPERIMENTAL, not yet run on a GPU): large-tile GEMMs on the v_mfma_f32_32x32x16_bf16 families (k_gemm3y.hip, k_gemm_bf16y.hip) where a tile of the same shape exists
     void* zero_page_ = nullptr;
     TileChoice choose_tile_bf16(int M, int N, int kt_total) const;   // cfg >= 100: k_gemm_bf16x.hip tile cfg - 100     // precision = 1: 1 = bf16 matrix-core attention, 0 = bf16 storage widened onto the fp32 kernel  // 1: attn2_kernel, 0: attn_f32_kernel
     // split-K combine: 0 = separate reduce kernel (the measured best, profiles/README.md); 1 = inside the GEMM launch by the

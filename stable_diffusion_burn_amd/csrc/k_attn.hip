@@ -340,14 +340,9 @@ bool attn_supported_head_dim(int d) { return d == 40 || d == 64 || d == 80 || d 
 
 template <int D, int NW, bool HAS_MASK, bool H16>
 static hipError_t launch_attn2_d(const AttnParams& p, hipStream_t stream) {
-    static bool attr_set = false;
     auto k = attn2_kernel<D, NW, HAS_MASK, H16>;
     const size_t lds = Attn2Cfg<D, NW, H16>::LDS_BYTES;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds); e != hipSuccess) return e;
     dim3 grid((p.nq + 16 * NW - 1) / (16 * NW), p.n * p.n_head);
     hipLaunchKernelGGL(k, grid, dim3(NW * 64), lds, stream, p);
     return hipGetLastError();

@@ -302,14 +302,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) 
 
 template <int D, int NW>
 static hipError_t launch_attn_bf16_d(const AttnParams& p, hipStream_t stream) {
-    static bool attr_set = false;
     auto k = attn_bf16_kernel<D, NW>;
     const size_t lds = AttnBfCfg<D, NW>::LDS_BYTES;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds); e != hipSuccess) return e;
     dim3 grid((p.nq + 32 * NW - 1) / (32 * NW), p.n * p.n_head);
     hipLaunchKernelGGL(k, grid, dim3(NW * 64), lds, stream, p);
     return hipGetLastError();

@@ -30,7 +30,26 @@
 //    the separate-kernel form of the same sum (option splitk_fused=0, odd strides).
 #include "kernels.hpp"
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 namespace sdmi {
+
+// Kernels that need more than 64 KiB of dynamic LDS must say so once per (kernel, device).  The engines of a multi-device context
+// launch from one host thread per device (multi.cpp), so the "already done" set is keyed by the current device and guarded.
+hipError_t set_max_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel, dev})) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({kernel, dev});
+    return e;
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -294,23 +294,14 @@ size_t gemm2_tile_lds_bytes(int cfg) {
 
 template <int MI, int NI, int WM, int WN>
 static hipError_t launch_cfg2(const ConvGemm& p, size_t lds, dim3 grid, hipStream_t stream) {
-    static bool attr_set[2] = {false, false};
     const bool generic = (p.Cin % 32) != 0;
     if (generic) {
         auto k = conv_gemm2_kernel<MI, NI, WM, WN, true>;
-        if (!attr_set[1]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_set[1] = true;
-        }
+        if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds); e != hipSuccess) return e;
         hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, p);
     } else {
         auto k = conv_gemm2_kernel<MI, NI, WM, WN, false>;
-        if (!attr_set[0]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_set[0] = true;
-        }
+        if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds); e != hipSuccess) return e;
         hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, p);
     }
     return hipGetLastError();

@@ -202,14 +202,9 @@ __global__ __launch_bounds__(512) void conv_gemm2x_kernel(const ConvGemm p) {
 
 template <int MI, int NI, int WM, int WN>
 static hipError_t launch_cfg_2x(const ConvGemm& p, dim3 grid, hipStream_t stream) {
-    static bool attr_set = false;
     auto k = conv_gemm2x_kernel<MI, NI, WM, WN>;
     constexpr size_t lds = 2 * (size_t)(16 * MI * WM + 16 * NI * WN) * 128;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, dim3(512), lds, stream, p);
     return hipGetLastError();
 }

@@ -482,15 +482,10 @@ __global__ __launch_bounds__(512) void conv_gemm3x_kernel(const ConvGemm p) {
 
 template <int MI, int NI, int WM, int WN, bool SPREAD, bool SCALAR, int NSTG = 2, int HOIST = 0>
 static hipError_t launch_cfg_3x(const ConvGemm& p, dim3 grid, hipStream_t stream) {
-    static bool attr_set = false;
     auto k = conv_gemm3x_kernel<MI, NI, WM, WN, SPREAD, SCALAR, NSTG, HOIST>;
     constexpr size_t lds = NSTG * ((size_t)(16 * MI * WM) * 128 + (size_t)((NI * WN * 3 + 7) / 8) * 8192);
     static_assert(lds <= 160 * 1024, "the stages must fit the CU's LDS");
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, dim3(512), lds, stream, p);
     return hipGetLastError();
 }
@@ -537,37 +532,11 @@ hipError_t launch_conv_gemm3x(const ConvGemm& p, int cfg, hipStream_t stream) {
 }
 
 // ---- weight planes ---------------------------------------------------------------------------------------------------
-// bt [rows][K] fp32 in the kernels' k order (K % 32 == 0) -> w3 [rows][K / 32][3][32] bf16; element j of chunk g of a plane is
-// k-tile element (j < 4 ? 4 g + j : 16 + 4 g + j - 4).  One thread per (row, k tile, chunk).
-__global__ void pack_split3_kernel(const float* __restrict__ bt, unsigned short* __restrict__ w3, long long rows, int kt_total) {
-    const long long total = rows * kt_total * 4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int g = (int)(i & 3);
-        const long long rk = i >> 2;                       // row * kt_total + kt
-        const float* src = bt + rk * 32;
-        unsigned short* dst = w3 + rk * 96 + g * 8;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float x = src[(j < 4) ? 4 * g + j : 16 + 4 * g + (j - 4)];
-            const unsigned hp = s3_cvt_pk(x, 0.f) & 0xffffu;
-            const float r = x - __builtin_bit_cast(float, hp << 16);
-            const unsigned mp = s3_cvt_pk(r, 0.f) & 0xffffu;
-            const float r2 = r - __builtin_bit_cast(float, mp << 16);
-            dst[j] = (unsigned short)hp;
-            dst[32 + j] = (unsigned short)mp;
-            dst[64 + j] = (unsigned short)(s3_cvt_pk(r2, 0.f) & 0xffffu);
-        }
-    }
-}
-
+// bt [rows][K] fp32 in the kernels' k order (K % 32 == 0) -> w3 [rows][K / 32][3][32] bf16: split3_rows_kernel (k_gemm3p.hip), the
+// split every plane producer uses (k_split3.hpp: chunk g of a plane row = k-tile elements 4g..4g+3, 16+4g..16+4g+3).
 hipError_t launch_pack_split3(const float* bt, void* w3, long long rows, int K, hipStream_t s) {
     if (K % 32) return hipErrorInvalidValue;
-    const long long total = rows * (K / 32) * 4;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 8192) blocks = 8192;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(pack_split3_kernel, dim3(blocks), dim3(256), 0, s, bt, reinterpret_cast<unsigned short*>(w3), rows, K / 32);
-    return hipGetLastError();
+    return launch_split3_rows(bt, w3, rows, K, K, (long long)(K / 32) * 192, s);
 }
 
 }  // namespace sdmi

@@ -352,13 +352,8 @@ __global__ void pack_linear_weight_bf16_kernel(const float* __restrict__ w, unsi
 
 template <int MI, int NI, int WM, int WN>
 static hipError_t launch_cfg_bf16(const ConvGemm& p, size_t lds, dim3 grid, hipStream_t stream) {
-    static bool attr_set = false;
     auto k = conv_gemm_bf16_kernel<MI, NI, WM, WN>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, p);
     return hipGetLastError();
 }

@@ -19,7 +19,9 @@ namespace sdmi {
 struct ConvGemm {
     const float* A;       // source activations [NB][Hs][Ws][Cin]
     const float* Bt;      // packed weights [N][K]
-    const void* Bt3;      // split kernel (k_gemm3x.hip): the same weights as three bf16 planes, [N][K / 32][3][32]
+    const void* Bt3;      // split kernels (k_gemm3x.hip, k_gemm3p.hip): the same weights as three bf16 planes, [N][K / 32][3][32]
+    const void* A3;       // plane kernel (k_gemm3p.hip): the source activations as three bf16 planes, [NB][Hs][Ws][a3_ld / 192 slices][3][32]
+    int a3_ld;            // bytes between source pixels in A3 (192 per 32 channels of the -- possibly wider -- buffer)
     float* C;             // output [M][ldc]
     float* slabs;         // splits > 1: fp32 partial sums [splits][M][N]
     int slab_wt;          // with counters: slab tiles are stored write-through (sc1) and published without a release fence
@@ -102,8 +104,6 @@ hipError_t launch_splitk_reduce_bf16(const ConvGemm& p, hipStream_t stream);
 constexpr int kNumGemmTilesX = 4;
 const GemmTileInfo& gemm_tile_info_x(int cfg);
 hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
-// the same tile shapes on v_mfma_f32_32x32x16_bf16 (k_gemm_bf16y.hip; EXPERIMENTAL, tile_cfg 300 + x at precision = 1, tile list = gemm_tile_info_x)
-hipError_t launch_conv_gemm_bf16y(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 // the same structure for fp32 storage (k_gemm2x.hip; Cin % 32 == 0, fp32 output); same tile list
 hipError_t launch_conv_gemm2x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 // fp32 on the bf16 matrix pipe: operands as exact sums of three bf16 terms, six partial products (k_gemm3x.hip); its own tile
@@ -112,10 +112,14 @@ constexpr int kNumGemmTilesS = 6;
 const GemmTileInfo& gemm_tile_info_s(int cfg);
 hipError_t launch_conv_gemm3x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 hipError_t launch_pack_split3(const float* bt, void* w3, long long rows, int K, hipStream_t s);
-// the same arithmetic on v_mfma_f32_32x32x16_bf16 with 32 x 160 wave tiles (k_gemm3y.hip; EXPERIMENTAL, tile_cfg 300 + x, reads the same planes)
-constexpr int kNumGemmTilesY = 4;
-const GemmTileInfo& gemm_tile_info_y(int cfg);
-hipError_t launch_conv_gemm3y(const ConvGemm& p, int tile_cfg, hipStream_t stream);
+// the same arithmetic with the ACTIVATIONS as planes too, written once by their producer (k_gemm3p.hip; tile_cfg 300 + x; needs p.A3)
+constexpr int kNumGemmTilesP = 5;
+const GemmTileInfo& gemm_tile_info_p(int cfg);
+hipError_t launch_conv_gemm3p(const ConvGemm& p, int tile_cfg, hipStream_t stream);
+// fp32 rows [rows][ld] (c channels, c % 32 == 0) -> planes [rows][ld3_bytes / 192 slices][3][32] bf16 (slices [0, c / 32) written)
+hipError_t launch_split3_rows(const float* x, void* y3, long long rows, int c, long long ld, long long ld3_bytes, hipStream_t s);
+// hipFuncAttributeMaxDynamicSharedMemorySize, once per (kernel, device); safe to call from several host threads (multi.cpp)
+hipError_t set_max_dynamic_lds(const void* kernel, int bytes);
 // MXFP8 (e4m3 + E8M0 block scales) 256-row LDS-DMA kernel on v_mfma_scale_f32_16x16x128_f8f6f4 (k_fp8.hip); its own tile list
 constexpr int kNumGemmTilesQ = 3;
 const GemmTileInfo& gemm_tile_info_q(int cfg);

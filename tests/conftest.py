@@ -17,16 +17,13 @@ if str(ROOT) not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: takes more than ~30 s")
-    config.addinivalue_line("markers", "unverified: GPU test of a kernel variant that has not run on an MI355X yet (an option that is off by "
-                                       "default); skipped unless SDMI_UNVERIFIED=1 -- the mark is removed once a GPU run has confirmed it")
     config.addinivalue_line("markers", "variants: the extended parity matrix of kernel variants that are OFF by default (verified on an MI355X, "
                                        "gpurun_out r02y / r02z / r02zz: 479 + 20 + 161 passed); skipped unless SDMI_VARIANTS=1 to keep the default GPU suite short -- "
                                        "one bit-identity test per variant family always runs")
 
 
 def pytest_collection_modifyitems(config, items):
-    for env, mark, why in (("SDMI_UNVERIFIED", "unverified", "kernel variant not yet verified on an MI355X (off by default); set SDMI_UNVERIFIED=1 to run"),
-                           ("SDMI_VARIANTS", "variants", "extended matrix of an off-by-default kernel variant; set SDMI_VARIANTS=1 to run")):
+    for env, mark, why in (("SDMI_VARIANTS", "variants", "extended matrix of an off-by-default kernel variant; set SDMI_VARIANTS=1 to run"),):
         if os.environ.get(env) == "1":
             continue
         skip = pytest.mark.skip(reason=why)

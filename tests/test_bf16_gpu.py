@@ -155,53 +155,6 @@ def test_conv2d_bf16_large_tiles_pipelined_loop(ops16, tile, variant):
         assert np.array_equal(got, plain), f"pipelined loop differs from the plain loop: tile={tile} {case}"
 
 
-@pytest.mark.unverified
-@pytest.mark.parametrize("tile", [300, 301, 302, 303])
-@pytest.mark.parametrize("splitk", [1, 3])
-def test_conv2d_bf16_32x32_tiles(ops16, tile, splitk):
-    """k_gemm_bf16y.hip (tile 300 + x at precision = 1): the large-tile bf16 GEMM on v_mfma_f32_32x32x16_bf16 -- every conv flavour, ragged
-    M / N tiles, split-K, one to many k tiles; the bf16 GEMM bar, repeatable bit for bit, and equal to the 16x16x32 kernel up to summation order."""
-    for case in XCASES + [c[:6] + (1, 0) for c in XCASES_SHORT_K if c[6] == 1]:
-        n, cin, h, w, cout, k, stride, ups = case
-        g = np.random.default_rng(3700 + tile + 7 * splitk + cin + cout)
-        x = bf16_round(g.standard_normal((n, cin, h, w)))
-        wt = bf16_round(g.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k))
-        b = g.standard_normal(cout).astype(np.float32)
-        try:
-            ops16.set_option("splitk", splitk)
-            ops16.set_option("gemm_tile", tile - 200)
-            base = ops16.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
-            ops16.set_option("gemm_tile", tile)
-            got = ops16.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
-            again = ops16.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
-        finally:
-            ops16.set_option("gemm_tile", "auto")
-            ops16.set_option("splitk", 0)
-        xin = O.upsample2x(_t(x)) if ups else _t(x)
-        ref = O.conv2d(xin, (_t(wt), _t(b)), stride=stride, padding=1 if k == 3 else 0).numpy()
-        _check(got, ref, f"conv bf16 32x32 tile={tile} splitk={splitk} {case}", 2 ** -8)
-        assert np.array_equal(got, again)
-        assert np.abs(got - base).max() <= 2 ** -7 * max(1.0, np.abs(ref).max())     # one bf16 ulp of the output apart at most
-
-
-@pytest.mark.unverified
-@pytest.mark.parametrize("tile", [300, 303])
-def test_unet_forward_bf16_32x32_tiles_forced(sd16, tile):
-    """every eligible bf16 GEMM of the UNet on a k_gemm_bf16y.hip tile: its residual / time-embedding / split-K epilogues at model level"""
-    lat = np.stack([syn.initial_latent(i, 8, 8) for i in range(2)])
-    ctx = np.stack([syn.cond_context(i, 77, 768) for i in range(2)])
-    try:
-        sd16.set_option("gemm_tile", tile)
-        got = sd16.unet.forward(lat, [500], ctx)
-    finally:
-        sd16.set_option("gemm_tile", "auto")
-    o64 = O.UNetOracle(syn.SyntheticWeights(), DIMS16, torch.float64)
-    ref = o64.forward(torch.from_numpy(lat), 500, torch.from_numpy(ctx)).numpy()
-    r = _rel_rms(got, ref)
-    print(f"bf16 UNet forward, tile {tile} forced: rel-RMS {r:.3e}")
-    assert np.isfinite(got).all() and r < BAR_UNET
-
-
 @pytest.mark.parametrize("tile", [100, 103])
 def test_linear_bf16_large_tiles(ops16, tile):
     g = np.random.default_rng(tile)

@@ -94,23 +94,6 @@ def test_unet_forward_counted_waits_split_gemm(sd_tiny, synth, tiny_dims):
     assert np.abs(got - base).max() <= 2e-5 * max(1.0, np.abs(r64).max())
 
 
-@pytest.mark.unverified
-@pytest.mark.parametrize("tile", [300, 301, 302, 303])
-def test_unet_forward_32x32_split_tiles_forced(sd_tiny, synth, tiny_dims, tile):
-    """every eligible GEMM of the UNet on one k_gemm3y.hip tile (300 + x): its bias / time-embedding / residual / split-K epilogues at model level"""
-    d = tiny_dims
-    lat, ctx, _ = _inputs(d, 2, 7, 2)
-    o32, o64 = _oracles(synth, d)
-    try:
-        sd_tiny.set_option("gemm_tile", tile)
-        got = sd_tiny.unet.forward(lat, [500], ctx)
-    finally:
-        sd_tiny.set_option("gemm_tile", "auto")
-    r32 = o32.unet.forward(torch.from_numpy(lat), 500, torch.from_numpy(ctx)).numpy()
-    r64 = o64.unet.forward(torch.from_numpy(lat), 500, torch.from_numpy(ctx)).numpy()
-    _assert_close(got, r32, r64, f"unet_forward tile={tile}", atol=1e-4)
-
-
 def test_unet_forward_fp32_matrix_instruction_only(sd_tiny, synth, tiny_dims):
     """gemm_f32s=0 / attn_split=0: every product on v_mfma_f32_16x16x4_f32 (round 1's arithmetic).  Same bar; and the default
     path (fp32 operands as three bf16 terms, six partial products) agrees with it to fp32 rounding noise."""

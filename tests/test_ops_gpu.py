@@ -213,7 +213,6 @@ STILES = [200, 201, 202, 203, 204, 205]
 # 128-row tiles too (default: three); 4: s_setprio 1 for waves 4-7; 3 + 6 (= 72, with bit 1: 74): the pipelined k loop (HOIST = 3) -- asm fragment
 # reads with hand-counted waits, barrier two rows early, products in the order l, m, m, h, h, h (not bit-identical to the plain loop: a
 # different summation order).  Two earlier pipelined forms (bits 3 / 5 with hipcc's waits) were verified on MI355X, measured no faster and removed.
-UNVERIFIED = pytest.mark.unverified
 VARIANTS = pytest.mark.variants
 SPLIT_VARIANTS = [0, 1, 2, 6] + [pytest.param(74, marks=VARIANTS)]
 
@@ -325,61 +324,6 @@ def test_conv2d_split_bf16_counted_waits_variant(sd_ops):
                 assert np.abs(got - base).max() <= 4e-6 * scale
     finally:
         sd_ops.set_option("gemm3x_variant", 0)
-        sd_ops.set_option("gemm_tile", "auto")
-        sd_ops.set_option("splitk", 0)
-
-
-YTILES = [300, 301, 302, 303]
-
-
-@UNVERIFIED
-@pytest.mark.parametrize("tile", YTILES)
-@pytest.mark.parametrize("splitk", [1, 3])
-@pytest.mark.parametrize("case", XCASES + [c[:6] + (1, 0) for c in SHORT_K_CASES[:6]])
-def test_conv2d_split_bf16_32x32_tiles(sd_ops, tile, splitk, case):
-    """k_gemm3y.hip (tile 300 + x): the split GEMM on v_mfma_f32_32x32x16_bf16 with 32 x 160 wave tiles -- same arithmetic, same planes,
-    same parity bar as k_gemm3x.hip; every conv flavour, ragged M / N tiles, split-K, one to many k tiles."""
-    n, cin, h, w, cout, k, stride, ups = case
-    g = _rng(7000 + tile + 7 * splitk + cin + cout)
-    x = g.standard_normal((n, cin, h, w)).astype(np.float32)
-    wt = (g.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k)).astype(np.float32)
-    b = g.standard_normal(cout).astype(np.float32)
-    try:
-        sd_ops.set_option("gemm_tile", tile)
-        sd_ops.set_option("splitk", splitk)
-        got = sd_ops.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
-        again = sd_ops.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
-    finally:
-        sd_ops.set_option("gemm_tile", "auto")
-        sd_ops.set_option("splitk", 0)
-    xin = O.upsample2x(_t(x)) if ups else _t(x)
-    ref = O.conv2d(xin, (_t(wt), _t(b)), stride=stride, padding=1 if k == 3 else 0)
-    _check(got, ref.numpy(), f"conv split-bf16 32x32 tile={tile} splitk={splitk} {case}")
-    assert np.array_equal(got, again)
-
-
-@UNVERIFIED
-def test_conv2d_split_bf16_32x32_tiles_are_fp32_accurate(sd_ops):
-    """the 32x32 family on the long-K, wide-dynamic-range convolution of test_conv2d_split_bf16_is_fp32_accurate, and exact on small integers"""
-    n, cin, h, w, cout = 1, 1280, 16, 16, 320
-    g = _rng(777)
-    x = (g.standard_normal((n, cin, h, w)) * np.exp2(g.integers(-5, 6, (1, cin, 1, 1)))).astype(np.float32)
-    wt = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9) * np.exp2(g.integers(-3, 4, (cout, 1, 1, 1)))).astype(np.float32)
-    ref = O.conv2d(_t(x), (_t(wt), None), padding=1).numpy()
-    scale = np.abs(ref).max()
-    xi = g.integers(-300, 301, (1, 64, 9, 9)).astype(np.float32)
-    wi = g.integers(-40, 41, (64, 64, 3, 3)).astype(np.float32)
-    refi = O.conv2d(_t(xi), (_t(wi), None), padding=1).numpy()
-    try:
-        sd_ops.set_option("splitk", 1)
-        sd_ops.set_option("gemm_tile", 201)
-        e3x = float(np.abs(sd_ops.op_conv2d(x, wt, None) - ref).max() / scale)
-        for tile in YTILES:
-            sd_ops.set_option("gemm_tile", tile)
-            e = float(np.abs(sd_ops.op_conv2d(x, wt, None) - ref).max() / scale)
-            assert e < 1e-5 and e < 3.0 * e3x + 1e-7, f"tile {tile}: {e:.2e} (k_gemm3x.hip: {e3x:.2e})"
-            assert np.array_equal(sd_ops.op_conv2d(xi, wi, None).astype(np.float64), refi), f"tile {tile}: small integers not exact"
-    finally:
         sd_ops.set_option("gemm_tile", "auto")
         sd_ops.set_option("splitk", 0)
 

@@ -1,0 +1,166 @@
+"""k_gemm3p.hip -- the fp32 GEMM / convolution on the bf16 matrix pipe with BOTH operands as three bf16 planes (tile 300 + x) -- against the
+fp64 oracle, at the bar every fp32 operator holds (tests/test_ops_gpu.py: 2e-5 max(1, |ref|)).  Reference arithmetic: Burn's Conv2d / Linear
+at unet/mod.rs:397,425,468,479,553,580,645-651,716,726,729 and autoencoder/mod.rs:516-523,568-604.  Also here: the behaviour of the
+producer-side split (k_split3.hpp, s3_split1) at the edges of the fp32 range, which include/sdmi.h documents."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sd_oracle as O  # noqa: E402
+
+PTILES = [300, 301, 302, 303, 304]
+XCASES = [
+    # (n, cin, h, w, cout, k, stride, ups): several M tiles with a ragged last one, N tails, every conv flavour
+    (2, 128, 23, 19, 320, 3, 1, 0), (1, 64, 40, 36, 200, 3, 1, 0), (2, 192, 16, 16, 640, 1, 1, 0), (1, 128, 33, 31, 128, 3, 2, 0),
+    (1, 64, 12, 20, 384, 3, 1, 1), (1, 96, 9, 7, 100, 3, 1, 0),
+]
+SHORT_K_CASES = [
+    # (n, cin, h, w, cout, k, splitk): one to four k tiles per slice (prologue and dead-stage re-fetch next to each other)
+    (1, 32, 16, 16, 64, 1, 1), (1, 64, 16, 16, 320, 1, 1), (1, 64, 16, 16, 320, 1, 2), (1, 96, 12, 12, 160, 1, 1), (1, 96, 12, 12, 160, 1, 3),
+    (2, 32, 8, 8, 128, 3, 1), (2, 32, 8, 8, 128, 3, 3), (2, 32, 8, 8, 128, 3, 9), (1, 128, 20, 20, 100, 1, 1), (1, 128, 20, 20, 100, 1, 2),
+]
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).double()
+
+
+def _check(got, ref, what, rel=2e-5):
+    assert np.isfinite(got).all(), f"{what}: non-finite output"
+    err = np.abs(got.astype(np.float64) - ref).max()
+    tol = rel * max(1.0, np.abs(ref).max())
+    assert err <= tol, f"{what}: max err {err:.3e} > {tol:.3e}"
+
+
+class _Forced:
+    """gemm_planes = 2 (plane tiles where asked for) + a forced tile / split-K, restored on exit"""
+
+    def __init__(self, sd, tile, splitk=0):
+        self.sd, self.tile, self.splitk = sd, tile, splitk
+
+    def __enter__(self):
+        self.sd.set_option("gemm_planes", 2)
+        self.sd.set_option("gemm_tile", self.tile)
+        self.sd.set_option("splitk", self.splitk)
+        return self.sd
+
+    def __exit__(self, *a):
+        self.sd.set_option("gemm_tile", "auto")
+        self.sd.set_option("splitk", 0)
+        self.sd.set_option("gemm_planes", "default")
+
+
+@pytest.mark.parametrize("tile", PTILES)
+@pytest.mark.parametrize("splitk", [1, 3])
+@pytest.mark.parametrize("case", XCASES)
+def test_conv2d_plane_tiles(sd_ops, tile, splitk, case):
+    n, cin, h, w, cout, k, stride, ups = case
+    g = np.random.default_rng(9000 + tile + 7 * splitk + cin + cout)
+    x = g.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (g.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k)).astype(np.float32)
+    b = g.standard_normal(cout).astype(np.float32)
+    with _Forced(sd_ops, tile, splitk):
+        got = sd_ops.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
+        again = sd_ops.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
+    xin = O.upsample2x(_t(x)) if ups else _t(x)
+    ref = O.conv2d(xin, (_t(wt), _t(b)), stride=stride, padding=1 if k == 3 else 0)
+    _check(got, ref.numpy(), f"conv planes tile={tile} splitk={splitk} {case}")
+    assert np.array_equal(got, again)
+
+
+@pytest.mark.parametrize("tile", PTILES)
+@pytest.mark.parametrize("case", SHORT_K_CASES)
+def test_conv2d_plane_tiles_short_k(sd_ops, tile, case):
+    n, cin, h, w, cout, k, splitk = case
+    g = np.random.default_rng(9500 + tile + 7 * splitk + cin + cout)
+    x = g.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (g.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k)).astype(np.float32)
+    b = g.standard_normal(cout).astype(np.float32)
+    with _Forced(sd_ops, tile, splitk):
+        got = sd_ops.op_conv2d(x, wt, b)
+    ref = O.conv2d(_t(x), (_t(wt), _t(b)), padding=1 if k == 3 else 0)
+    _check(got, ref.numpy(), f"conv planes short K tile={tile} {case}")
+
+
+def test_plane_kernel_is_fp32_accurate_and_exact_on_small_integers(sd_ops):
+    """The K = 11520, ten-binades-per-channel convolution of test_conv2d_split_bf16_is_fp32_accurate: the plane kernel's error against fp64 is
+    of the size of the fp32 matrix instruction's own; integers whose products and sums stay below 2^24 come out bit-exact (they need the
+    low planes: bf16 alone keeps 8 bits)."""
+    n, cin, h, w, cout = 1, 1280, 16, 16, 320
+    g = np.random.default_rng(777)
+    x = (g.standard_normal((n, cin, h, w)) * np.exp2(g.integers(-5, 6, (1, cin, 1, 1)))).astype(np.float32)
+    wt = (g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9) * np.exp2(g.integers(-3, 4, (cout, 1, 1, 1)))).astype(np.float32)
+    ref = O.conv2d(_t(x), (_t(wt), None), padding=1).numpy()
+    scale = np.abs(ref).max()
+    xi = g.integers(-300, 301, (1, 64, 9, 9)).astype(np.float32)
+    wi = g.integers(-40, 41, (64, 64, 3, 3)).astype(np.float32)
+    refi = O.conv2d(_t(xi), (_t(wi), None), padding=1).numpy()
+    assert np.abs(refi).max() < 2 ** 24
+    with _Forced(sd_ops, 103, 1):
+        e_mfma = float(np.abs(sd_ops.op_conv2d(x, wt, None) - ref).max() / scale)
+    errs = {}
+    for tile in PTILES:
+        with _Forced(sd_ops, tile, 1):
+            errs[tile] = float(np.abs(sd_ops.op_conv2d(x, wt, None) - ref).max() / scale)
+            assert np.array_equal(sd_ops.op_conv2d(xi, wi, None).astype(np.float64), refi), f"tile {tile}: small integers not exact"
+    print(f"max |gpu - fp64| / max|ref|, K = 11520: fp32 mfma {e_mfma:.2e}, planes " + ", ".join(f"{t}: {e:.2e}" for t, e in errs.items()))
+    for tile, e in errs.items():
+        assert e < 1e-5 and e < 3.0 * e_mfma + 1e-7, f"tile {tile}: {e:.2e} (fp32 matrix instruction: {e_mfma:.2e})"
+
+
+def test_plane_path_at_the_edges_of_the_fp32_range(sd_ops):
+    """NaN, +-inf, values that round-to-nearest would carry to inf in bf16 (3.4e38, -FLT_MAX) and tiny values through
+    the plane path (producer-side split s3_split1 + k_gemm3p.hip), next to the fp32 matrix instruction (tile 103).  What include/sdmi.h
+    ("fp32 semantics of precision 0") promises, and this test pins:
+      * outputs are finite exactly where the fp32 matrix instruction's are; NaN stays NaN;
+      * an INFINITE operand gives a non-finite result, but possibly NaN where fp32 gives +-inf: the low-order partial products contain
+        0 * inf.  (The split itself keeps inf: h = inf, m = l = 0 -- not the inf - inf = NaN of a naive residual.)
+      * finite values up to FLT_MAX are exact: where round-to-nearest of h would overflow to inf, h is truncated instead;
+      * below 2^-109 the low planes are flushed: correct to an absolute 2^-118 max|w| per term."""
+    cin, cout, hw = 64, 64, 8
+    x = np.zeros((1, cin, hw, hw), np.float32)
+    wt = np.zeros((cout, cin, 1, 1), np.float32)
+    wt[np.arange(cout), np.arange(cout) % cin, 0, 0] = 1.0                 # output channel c = input channel c
+    wt[1, 1] = 2.0 ** -100
+    wt[7, 7] = 3.0
+    x[0, 0, 0, 0] = np.inf
+    x[0, 0, 0, 1] = -np.inf
+    x[0, 2, 1, 1] = np.nan
+    x[0, 1, 2, 2] = np.float32(3.4e38)                                    # bf16 round-to-nearest of it is inf
+    x[0, 1, 2, 3] = np.float32(-3.4028235e38)                             # -FLT_MAX
+    x[0, 3, 3, 3] = np.float32(1e-38)
+    x[0, 4, 3, 4] = np.float32(1e-44)                                     # fp32 subnormal
+    x[0, 7, 4, 4] = np.float32(1.0000001)
+    with _Forced(sd_ops, 103, 1):
+        mfma = sd_ops.op_conv2d(x, wt, None)
+    assert mfma[0, 0, 0, 0] == np.inf and mfma[0, 0, 0, 1] == -np.inf and np.isnan(mfma[0, 2, 1, 1])
+    for tile in (300, 304):
+        with _Forced(sd_ops, tile, 1):
+            got = sd_ops.op_conv2d(x, wt, None)
+        fin = np.isfinite(mfma)
+        assert np.array_equal(np.isfinite(got), fin), "finite / non-finite pattern differs from the fp32 matrix instruction"
+        assert np.isnan(got[np.isnan(mfma)]).all(), "NaN must stay NaN"
+        assert not np.isfinite(got[0, 0, 0, 0]) and not np.isfinite(got[0, 0, 0, 1])
+        assert got[0, 1, 2, 2] == np.float32(3.4e38) * np.float32(2.0 ** -100)
+        assert got[0, 1, 2, 3] == np.float32(-3.4028235e38) * np.float32(2.0 ** -100)
+        assert got[0, 7, 4, 4] == np.float32(1.0000001) * np.float32(3.0)
+        assert abs(float(got[0, 3, 3, 3]) - 1e-38) <= 2.0 ** -118
+        assert abs(float(got[0, 4, 3, 4]) - 1e-44) <= 2.0 ** -118
+        assert np.abs(got[fin].astype(np.float64) - mfma[fin].astype(np.float64)).max() <= 2.0 ** -118
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(154, 768, 320), (20, 320, 1280), (512, 320, 2560), (1, 1280, 1280), (77, 64, 160)])
+def test_linear_on_plane_tiles(sd_ops, rows, cin, cout):
+    g = np.random.default_rng(9900 + rows + cin)
+    x = g.standard_normal((rows, cin)).astype(np.float32)
+    wt = (g.standard_normal((cin, cout)) / math.sqrt(cin)).astype(np.float32)
+    b = g.standard_normal(cout).astype(np.float32)
+    ref = (_t(x) @ _t(wt) + _t(b)).numpy()
+    for tile in (303, 304):
+        with _Forced(sd_ops, tile, 0):
+            got = sd_ops.op_linear(x, wt, b)
+        _check(got, ref, f"linear planes tile={tile} rows={rows} cin={cin} cout={cout}")
