@@ -51,3 +51,48 @@ def conv_res_mx(x_gn: torch.Tensor, w: torch.Tensor, b, padding: int = 1) -> tor
     xq = mx_quantize(x_gn, 1)
     wq = mx_quantize(w, 1)
     return torch.nn.functional.conv2d(xq, wq, b, padding=padding)
+
+
+# ---- the oracle network with the quantisation precision = 2 applies (tests/test_fp8_gpu.py, tests/golden/gen_golden_cfg5.py) ------------
+from oracle import sd_oracle as _O  # noqa: E402
+
+
+class MxResConvs:
+    """context manager: the oracle's ResBlock / ResnetBlock 3x3 convs take MXFP8 inputs and weights (what precision = 2 does)"""
+
+    def __enter__(self):
+        self.conv0 = _O.conv2d
+        self.res0 = _O.UNetOracle.res_block
+        state = {"in_res": 0}
+
+        def conv(x, wb, stride=1, padding=0):
+            w, b = wb
+            if state["in_res"] and w.shape[2] == 3 and stride == 1 and w.shape[1] % 32 == 0 and w.shape[0] % 8 == 0:
+                return self.conv0(mx_quantize(x, 1), (mx_quantize(w, 1), b), stride, padding)
+            return self.conv0(x, wb, stride, padding)
+
+        def res_block(obj, *a, **k):
+            state["in_res"] += 1
+            try:
+                return self.res0(obj, *a, **k)
+            finally:
+                state["in_res"] -= 1
+
+        self.vres0 = _O.DecoderOracle.resnet_block
+
+        def resnet_block(obj, *a, **k):      # the VAE's ResnetBlock (autoencoder/mod.rs:514-527): the same two 3x3 convolutions
+            state["in_res"] += 1
+            try:
+                return self.vres0(obj, *a, **k)
+            finally:
+                state["in_res"] -= 1
+
+        _O.conv2d = conv
+        _O.UNetOracle.res_block = res_block
+        _O.DecoderOracle.resnet_block = resnet_block
+        return self
+
+    def __exit__(self, *exc):
+        _O.conv2d = self.conv0
+        _O.UNetOracle.res_block = self.res0
+        _O.DecoderOracle.resnet_block = self.vres0

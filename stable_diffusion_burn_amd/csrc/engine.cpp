@@ -207,6 +207,10 @@ Engine::Engine(const sdmi_config& cfg) : cfg_(cfg) {
 #include "tuning_table_mfma.inc"
             {nullptr, 0, 0}};
         for (const Row* r = rows_mfma; r->key; ++r) tuned_mfma_[r->key] = TileChoice{r->cfg, r->splits};
+        static const Row rows_p[] = {
+#include "tuning_table_planes.inc"
+            {nullptr, 0, 0}};
+        for (const Row* r = rows_p; r->key; ++r) tuned_p_[r->key] = TileChoice{r->cfg, r->splits};
         static const Row rows16[] = {
 #include "tuning_table_bf16.inc"
             {nullptr, 0, 0}};
@@ -925,6 +929,7 @@ void Engine::sync() { SDMI_HIP(hipStreamSynchronize(stream_)); }
 void Engine::begin_call(bool dev_inputs) {
     SDMI_HIP(hipSetDevice(cfg_.device));
     n_kernels_ = 0; flops_ = 0;
+    defer_next_ = false;
     call_mark_ = pool_.serial();
     call_dev_ = dev_inputs;
     if (dev_inputs) {
@@ -940,6 +945,7 @@ void Engine::begin_call(bool dev_inputs) {
     SDMI_HIP(hipEventRecord(ev0_, stream_));
 }
 void Engine::end_call() {
+    flush_pending();
     SDMI_HIP(hipEventRecord(ev1_, stream_));
     if (call_dev_ && has_user_stream_) SDMI_HIP(hipStreamWaitEvent(user_stream_, ev1_, 0));  // later work on the caller's stream sees the outputs
     SDMI_HIP(hipEventSynchronize(ev1_));
@@ -954,6 +960,8 @@ void Engine::abort_call() noexcept {
     if (splitk_counters_) (void)hipMemset(splitk_counters_, 0, kSplitkCounters * sizeof(unsigned));   // a failed launch may have left arrivals behind
     try {
         us_ = UNetState{};
+        pend_.reset();
+        defer_next_ = false;
         pool_.free_since(call_mark_);
     } catch (...) {}
 }
@@ -973,6 +981,8 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "xcd_map") opt_xcd_map_ = std::stoi(value);
     else if (key == "gemm_x32") opt_gemm_x32_ = std::stoi(value);
     else if (key == "gemm_f32s") opt_gemm_f32s_ = std::stoi(value);
+    else if (key == "bench_cold") opt_bench_cold_ = std::stoi(value);
+    else if (key == "fuse_reduce") opt_fuse_reduce_ = std::stoi(value);
     else if (key == "gemm_planes") opt_gemm_planes_ = (value == "default") ? kGemmPlanesDefault : std::stoi(value);
     else if (key == "gemm3x_variant") opt_gemm3x_variant_ = std::stoi(value);
     else if (key == "geglu_fuse") opt_geglu_fuse_ = std::stoi(value);
@@ -999,8 +1009,8 @@ void Engine::set_option(const std::string& key, const std::string& value) {
             !(tc.cfg < kNumGemmTiles || (tc.cfg >= 100 && tc.cfg < 100 + kNumGemmTilesX) || (!b16 && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS) ||
               (!b16 && tc.cfg >= 300 && tc.cfg < 300 + kNumGemmTilesP)))
             throw Error(SDMI_ERR_INVALID, "tune: bad value");
-        (b16 ? tuned_bf16_ : tuned_)[value.substr(0, eq)] = tc;
-    } else if (key == "tune_clear") { tuned_.clear(); tuned_bf16_.clear(); tuned_mfma_.clear(); }
+        (b16 ? tuned_bf16_ : (tc.cfg >= 300 ? tuned_p_ : tuned_))[value.substr(0, eq)] = tc;   // plane tiles (300 + x) have their own table: what a GEMM whose input arrives as planes chooses from
+    } else if (key == "tune_clear") { tuned_.clear(); tuned_bf16_.clear(); tuned_mfma_.clear(); tuned_p_.clear(); }
     else throw Error(SDMI_ERR_INVALID, "unknown option '" + key + "'");
 }
 
@@ -1101,6 +1111,31 @@ TileChoice Engine::choose_tile_bf16(int M, int N, int kt_total) const {
     return bc;
 }
 
+// k_gemm3p.hip tiles (300 + x): what a GEMM whose activations arrive as planes chooses from when its shape is not in the measured table
+// (tuning/gfx950_fp32_planes.txt).  Same cost form as choose_tile's split branch; efficiencies from tools/autotune.py --families p.
+TileChoice Engine::choose_tile_p(int M, int N, int kt_total, bool even_ni_only) const {
+    static const double eff_p[kNumGemmTilesP] = {0.62, 0.60, 0.60, 0.52, 0.50};
+    static const int split_opts[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
+    const int n_cu = 256;
+    double best = 1e300;
+    TileChoice bc{304, 1};
+    for (int c = 0; c < kNumGemmTilesP; ++c) {
+        if (even_ni_only && (c == 0 || c == 3)) continue;
+        const int bm = gemm_tile_info_p(c).bm, bn = gemm_tile_info_p(c).bn;
+        const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+        for (int s : split_opts) {
+            if (s > 1 && kt_total / s < 4) break;
+            const int kt_per = (kt_total + s - 1) / s;
+            const long long wgs = tiles * ((kt_total + kt_per - 1) / kt_per);
+            const double per_cu = (double)((wgs + n_cu - 1) / n_cu);
+            double t = per_cu * ((double)bm * bn * kt_per * 384.0 / 4096.0 / eff_p[c] + 8000.0 + bm * bn * 4.0 / 10.0);
+            if (s > 1) t += 8000.0 + (double)M * N * 4.0 * (s + 1) / (5.0e12 / 2.4e9);
+            if (t < best) { best = t; bc = {300 + c, s}; }
+        }
+    }
+    return bc;
+}
+
 // How the 8 XCDs share one GEMM launch (ConvGemm::xcd_*; kernels.hpp).  Every XCD has its own L2, so an operand byte crosses the
 // fabric once per XCD that touches it: with the box of work items (MT x NT x splits) cut xm x xn x xz ways (xm xn xz = 8) the launch
 // moves xn * (activation bytes) + xm * (weight bytes) into the L2s.  The legacy map is xm = 8 (bands of M tiles; or of N tiles when
@@ -1116,7 +1151,24 @@ void Engine::choose_xcd_map(ConvGemm& p, int MT, int NT, double a_bytes, double 
     p.xcd_m = o[0]; p.xcd_n = o[1]; p.xcd_ml = o[2]; p.xcd_nl = o[3]; p.xcd_zl = o[4];
 }
 
+void Engine::flush_pending() {
+    if (!pend_) return;
+    ProfScope ps(this, PC_SPLITK_REDUCE, 0, (double)(pend_->p.splits + 1) * pend_->p.slab_stride * 4.0);
+    SDMI_HIP(launch_splitk_reduce(pend_->p, stream_));
+    count_kernel();
+    pend_.reset();
+}
+// the pending split-K result, if it is exactly the tensor x [rows][c] (row stride ld) a normalisation is about to read
+const ConvGemm* Engine::pending_for(const float* x, long long rows, int c, int ld) const {
+    if (!pend_) return nullptr;
+    const ConvGemm& q = pend_->p;
+    return (q.C == x && q.M == rows && q.N == c && q.ldc == ld && q.resid != q.C) ? &q : nullptr;   // (in-place residuals only through the row-wise LayerNorm form)
+}
+
 void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits) {
+    const bool defer = defer_next_;
+    defer_next_ = false;
+    flush_pending();
     const int kt_elems = in_dt ? 64 : 32;  // a k tile is 128 bytes of K per row in both storage types
     p.kt_total = (p.K + kt_elems - 1) / kt_elems;
     if (in_dt && (p.Cin % 64)) throw Error(SDMI_ERR_UNSUPPORTED, "bf16 GEMM: K slices must be multiples of 64");
@@ -1142,22 +1194,33 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     const bool s_ok = x32_ok && p.Bt3 && (unsigned long long)p.N * (p.geglu ? 2 : 1) * (unsigned long long)p.kt_total * 192ull < 0xFFFFFF00ull;
     // k_gemm3p.hip (300 + x): the same layers with the activations as planes too -- written by their producer (p.A3) or, for a tensor that
     // arrives as fp32, by split3_rows_kernel right here
-    const bool p_ok = s_ok && opt_gemm_planes_ != 0 && (unsigned long long)p.NB * p.Hs * p.Ws * (unsigned long long)(p.A3 ? p.a3_ld : p.Cin * 6) < 0xFFFFFF00ull;
+    const bool p_ok = s_ok && (unsigned long long)p.NB * p.Hs * p.Ws * (unsigned long long)(p.A3 ? p.a3_ld : p.Cin * 6) < 0xFFFFFF00ull;
+    // the activations arrive as planes (their producer wrote them): the GEMM runs on a plane tile -- from the plane table or the cost model
+    const bool from_planes = !in_dt && p.A3 != nullptr;
+    if (from_planes && !p_ok) throw Error(SDMI_ERR_STATE, "gemm: activation planes given for a layer the plane kernel does not take");
+    if (!from_planes && !p.A) throw Error(SDMI_ERR_STATE, "gemm: no activations");
     auto usable = [&](int cfg) { return cfg < 100 || (in_dt ? opt_gemm_bf16x_ != 0 : (cfg >= 300 ? p_ok : cfg >= 200 ? (opt_gemm_f32s_ != 0 && s_ok) : (opt_gemm_x32_ != 0 && x32_ok))); };
     const auto it2 = in_dt ? tuned_mfma_.end() : tuned_mfma_.find(key);   // the table measured without the split kernels
-    if (it != table.end() && usable(it->second.cfg)) tc = it->second;
+    if (from_planes) {
+        const auto itp = tuned_p_.find(key);
+        const bool even = p.geglu != 0;
+        if (itp != tuned_p_.end() && !(even && (itp->second.cfg == 300 || itp->second.cfg == 303))) tc = itp->second;
+        else tc = choose_tile_p(p.M, p.N, p.kt_total, even);
+    }
+    else if (it != table.end() && usable(it->second.cfg)) tc = it->second;
     else if (it2 != tuned_mfma_.end() && usable(it2->second.cfg)) tc = it2->second;
     else tc = in_dt ? choose_tile_bf16(p.M, p.N, p.kt_total) : choose_tile(p.M, p.N, p.kt_total, x32_ok, s_ok);
-    if (opt_force_tile_ >= 0 && (opt_force_tile_ < 100 || in_dt || (opt_force_tile_ >= 300 ? p_ok : opt_force_tile_ >= 200 ? s_ok : x32_ok))) tc.cfg = opt_force_tile_;  // 100+ / 200+: large-tile kernels, where applicable
+    if (opt_force_tile_ >= 0 && (from_planes ? opt_force_tile_ >= 300 : (opt_force_tile_ < 100 || in_dt || (opt_force_tile_ >= 300 ? p_ok : opt_force_tile_ >= 200 ? s_ok : x32_ok)))) tc.cfg = opt_force_tile_;  // 100+ / 200+: large-tile kernels, where applicable
     if (opt_force_splits_ > 0) tc.splits = opt_force_splits_;
     if (force_cfg >= 0) tc.cfg = force_cfg;
-    // gemm_planes = 1: every launch that chose a k_gemm3x.hip tile runs on the k_gemm3p.hip tile nearest in shape (A/B switch; a per-shape
-    // table entry 300 + x needs no mapping)
-    if (!in_dt && p_ok && opt_gemm_planes_ == 1 && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS) {
+    // gemm_planes = 2 (A/B switch, tests): every launch that chose a k_gemm3x.hip tile runs on the k_gemm3p.hip tile nearest in shape, its
+    // fp32 activations converted by split3_rows_kernel in front of it
+    if (!in_dt && !from_planes && p_ok && opt_gemm_planes_ == 2 && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS) {
         static const int kSplitToP[kNumGemmTilesS] = {300, 303, 301, 302, 303, 304};
         const int c = kSplitToP[tc.cfg - 200];
         if (!p.geglu || c == 301 || c == 302 || c == 304) tc.cfg = c;
     }
+    if (from_planes && tc.cfg < 300) throw Error(SDMI_ERR_STATE, "gemm: activation planes need a plane tile (300 + x)");
     if (record_shapes_) {   // which kernel / tile / split-K each (M, N, K) got: option dump_choices
         char ck[96];
         std::snprintf(ck, sizeof ck, "%d,%d,%d cfg=%d splits=%d%s", p.M, p.N, p.K, tc.cfg, tc.splits, p.Bt3 ? "" : " (no planes)");
@@ -1191,6 +1254,21 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         choose_xcd_map(p, (p.M + ti.bm - 1) / ti.bm, (p.N + bno - 1) / bno, (double)p.NB * p.Hs * p.Ws * p.Cin * aes,
                        (double)p.N * (p.geglu ? 2.0 : 1.0) * (double)p.K * wes, flops, cu_flops);
     }
+    // the output as planes (p.C3): written by the epilogue of the split / plane kernels and by the split-K reduce kernel on their 16-byte
+    // path; otherwise (old kernels, odd strides, GEGLU epilogue) converted from an fp32 result right behind the launch
+    void* const c3_want = in_dt ? nullptr : p.C3;
+    const int ldc3_want = p.ldc3;
+    const bool vec_out = (p.N % 4 == 0) && (!p.C || p.ldc % 4 == 0) && (!p.resid || p.ldr % 4 == 0);
+    const bool c3_native = c3_want && tc.cfg >= 200 && vec_out && !p.geglu;
+    std::unique_ptr<Buf> c_tmp;
+    if (!c3_native) {
+        p.C3 = nullptr;
+        if (c3_want && !p.C) {
+            c_tmp.reset(new Buf(this, (size_t)p.M * p.N * sizeof(float)));
+            p.C = c_tmp->f(); p.ldc = p.N;
+        }
+    }
+    if (!p.C) p.ldc = p.N;
     std::unique_ptr<Buf> a3_tmp;
     if (tc.cfg >= 300 && !p.A3) {   // the source is fp32: split it once for this launch (a producer that writes planes itself saves this pass)
         const long long rows = (long long)p.NB * p.Hs * p.Ws;
@@ -1228,7 +1306,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
         const bool vec = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (!p.resid || p.ldr % 4 == 0);
         const bool slab_ok = (unsigned long long)p.slab_stride * 4ull < 0xFFFFFFE0ull;   // write-through stores go through a 32-bit buffer descriptor
-        if (opt_splitk_fused_ && vec && tiles <= kSplitkCounters && (opt_splitk_fused_ != 2 || slab_ok)) {
+        if (opt_splitk_fused_ && vec && tiles <= kSplitkCounters && (opt_splitk_fused_ != 2 || slab_ok) && !p.C3 && p.C) {
             p.counters = splitk_counters_;
             p.slab_wt = opt_splitk_fused_ == 2 ? 1 : 0;
         }
@@ -1238,11 +1316,24 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         }
         count_kernel(flops);
         if (!p.counters) {
+            const bool vec16 = (p.N % 4 == 0) && p.C && (p.ldc % 4 == 0) && (!p.resid || p.ldr % 4 == 0);
+            if (defer && !in_dt && vec16 && (!c3_want || c3_native) && !c_tmp) {
+                // the caller's next op normalises this tensor: it combines the slabs itself (pending_for / k_norm.hip)
+                pend_.reset(new PendingReduce{p, nullptr});
+                pend_->slabs.reset(new Buf(this, 16));
+                std::swap(pend_->slabs->p, slab.p);       // the slabs live on until the consumer (or flush_pending) is done with them
+                return;
+            }
             ProfScope ps(this, PC_SPLITK_REDUCE, 0, (double)(splits + 1) * p.slab_stride * 4.0);
             if (in_dt) SDMI_HIP(launch_splitk_reduce_bf16(p, stream_));
             else SDMI_HIP(launch_splitk_reduce(p, stream_));
             count_kernel();
         }
+    }
+    if (c3_want && !c3_native) {
+        ProfScope ps(this, PC_SPLIT_ROWS, 0, (double)p.M * p.N * 10.0);
+        SDMI_HIP(launch_split3_rows(p.C, c3_want, p.M, p.N, p.ldc, ldc3_want, stream_));
+        count_kernel();
     }
 }
 
@@ -1259,12 +1350,16 @@ void Engine::conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, con
     ConvGemm p{};
     if (resid && (resid->rows() != y.rows() || resid->c != y.c || resid->dt != y.dt)) throw Error(SDMI_ERR_STATE, "conv: residual shape / type mismatch");
     p.A = x.p; p.Bt = w.bt; p.C = y.p; p.bias = w.bias; p.rowvec = rowvec; p.resid = resid ? resid->p : nullptr;
-    p.A3 = x.p3; p.a3_ld = x.ld3;
+    if (resid && !resid->p) throw Error(SDMI_ERR_STATE, "conv: the residual must exist as fp32");
+    if (!x.dt && plane_gemm(w.cin, w.cout) && split_planes(w.bt)) { p.A3 = x.p3; p.a3_ld = x.ld3; }   // planes in, where the plane kernel takes the layer
+    if (!x.p && !p.A3) throw Error(SDMI_ERR_STATE, "conv: the input exists only as planes, which this layer cannot read");
+    p.C3 = y.p3; p.ldc3 = y.ld3;
     p.M = x.n * ho * wo; p.N = w.cout; p.K = w.cin * w.k * w.k;
     p.NB = x.n; p.Hs = x.h; p.Ws = x.w; p.Cin = w.cin; p.Ho = ho; p.Wo = wo;
     p.KH = w.k; p.KW = w.k; p.stride = stride; p.pad = pad; p.ups = ups;
     p.ldc = y.stride(); p.ldr = resid ? resid->stride() : y.stride(); p.a_ld = x.stride(); p.b_ld = p.K; p.rowvec_stride = rowvec_stride;
     p.CS = std::min(32, w.cin);
+    if (!y.p && !y.p3) throw Error(SDMI_ERR_STATE, "conv: no output buffer");
     if (x.dt != w.dt) throw Error(SDMI_ERR_STATE, "conv: activation / weight storage types disagree");
     p.out_mode = x.dt ? (y.dt ? 0 : 1) : (y.dt ? 2 : 0);
     if (resid && !x.dt && y.dt) throw Error(SDMI_ERR_STATE, "conv: residual not supported on the fp32->bf16 layers");
@@ -1272,11 +1367,14 @@ void Engine::conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, con
 }
 
 void Engine::gemm(const float* A, int a_rows, const float* bt, const float* bias, int cin, int cout, float* C, int ldc,
-                  const float* resid, int ldr, int dt, int out_mode) {
+                  const float* resid, int ldr, int dt, int out_mode, const void* A3, void* C3) {
     if (dt < 0) dt = edt();
     if (cin % 32) throw Error(SDMI_ERR_UNSUPPORTED, "linear: in_features must be a multiple of 32");
     ConvGemm p{};
     p.A = A; p.Bt = bt; p.C = C; p.bias = bias; p.resid = resid;
+    p.A3 = A3; p.a3_ld = (cin / 32) * 192;          // dense planes in ...
+    p.C3 = C3; p.ldc3 = (cout / 32) * 192;          // ... and out
+    if (C3 && (cout % 32)) throw Error(SDMI_ERR_STATE, "linear: plane output needs out_features % 32 == 0");
     p.M = a_rows; p.N = cout; p.K = cin;
     p.NB = 1; p.Hs = 1; p.Ws = a_rows; p.Cin = cin; p.Ho = 1; p.Wo = a_rows;
     p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.ups = 0;
@@ -1285,8 +1383,17 @@ void Engine::gemm(const float* A, int a_rows, const float* bt, const float* bias
     launch_gemm(p, dt);
 }
 
-void Engine::gemm_geglu(const float* x, long long rows, const float* bt, const float* bias, int cin, int hidden, float* out, int dt) {
+void Engine::gemm_geglu(const float* x, long long rows, const float* bt, const float* bias, int cin, int hidden, float* out, int dt,
+                        const void* x3, void* out3) {
     if (dt < 0) dt = edt();
+    if (x3 || out3) {   // plane form: projection on a plane tile, gate kernel writing planes (the MLP's second Linear reads them)
+        Buf proj(this, (size_t)rows * 2 * hidden * 4);
+        gemm(x, (int)rows, bt, bias, cin, 2 * hidden, proj.f(), 2 * hidden, nullptr, 0, dt, 0, x3, nullptr);
+        if (out3) SDMI_HIP(launch_geglu_planes(proj.f(), out3, rows, hidden, stream_));
+        else SDMI_HIP(launch_geglu(proj.f(), out, rows, hidden, stream_));
+        count_kernel();
+        return;
+    }
     const size_t es = dt ? 2 : 4;
     // the fused form needs a large-tile kernel with an even fragment count per wave (256x256 or 256x128 tiles, no split-K)
     int cfg = -1;
@@ -1331,17 +1438,33 @@ void Engine::group_norm(const NormW& w, const Act& x, Act& y, bool silu) {
     Buf part(this, x.dt ? gn_partials_bytes_bf16(x.n, hw, x.c) : gn_partials_bytes(x.n, hw, x.c));
     ProfScope ps(this, PC_GROUP_NORM, 0, 2.0 * (double)x.bytes());  // algorithmic: one read + one write
     if (y.view) throw Error(SDMI_ERR_STATE, "group_norm: output must be dense");
-    if (x.dt) SDMI_HIP(launch_group_norm_bf16(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_));
-    else SDMI_HIP(launch_group_norm(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_));
+    if (!x.p) throw Error(SDMI_ERR_STATE, "group_norm: the input must exist as fp32");
+    // x may be a split-K result that nobody has combined yet: then the statistics pass does it (one kernel and one read of x less)
+    const ConvGemm* pq = x.dt ? nullptr : pending_for(x.p, x.rows(), x.c, x.stride());
+    if (!pq) flush_pending();
+    if (y.p3 && !y.p) {   // the consumer is a plane GEMM: the normalised tensor is written as three bf16 planes only
+        if (x.dt) throw Error(SDMI_ERR_STATE, "group_norm: planes are an fp32-engine format");
+        SDMI_HIP(launch_group_norm_planes(x.p, y.p3, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_, pq));
+    }
+    else if (x.dt) SDMI_HIP(launch_group_norm_bf16(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_));
+    else SDMI_HIP(launch_group_norm(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_, pq));
     count_kernel(); count_kernel();
+    if (pq) pending_done();
 }
 
-void Engine::layer_norm(const NormW& w, const float* x, long long rows, float* y, int dt) {
+void Engine::layer_norm(const NormW& w, const float* x, long long rows, float* y, int dt, void* y3) {
     if (dt < 0) dt = edt();
+    const ConvGemm* pq = nullptr;
+    if (!dt && pend_ && !pend_->p.rowvec && pend_->p.C == x && pend_->p.M == rows && pend_->p.N == w.c && pend_->p.ldc == w.c) pq = &pend_->p;   // x = a split-K result nobody has combined yet
+    if (!pq) flush_pending();
     ProfScope ps(this, PC_LAYER_NORM, 0, 2.0 * (double)rows * w.c * (dt ? 2.0 : 4.0));
-    if (dt) SDMI_HIP(launch_layer_norm_bf16(x, y, w.gamma, w.beta, (int)rows, w.c, w.eps, stream_));
-    else SDMI_HIP(launch_layer_norm(x, y, w.gamma, w.beta, (int)rows, w.c, w.eps, stream_));
+    if (y3) {
+        if (dt) throw Error(SDMI_ERR_STATE, "layer_norm: planes are an fp32-engine format");
+        SDMI_HIP(launch_layer_norm_planes(x, y3, w.gamma, w.beta, (int)rows, w.c, w.eps, stream_, pq));
+    } else if (dt) SDMI_HIP(launch_layer_norm_bf16(x, y, w.gamma, w.beta, (int)rows, w.c, w.eps, stream_));
+    else SDMI_HIP(launch_layer_norm(x, y, w.gamma, w.beta, (int)rows, w.c, w.eps, stream_, pq));
     count_kernel();
+    if (pq) pending_done();
 }
 
 // qkv_attention (attention.rs:5-45).  Head dims with a fused instance use the flash
@@ -1350,9 +1473,11 @@ void Engine::layer_norm(const NormW& w, const float* x, long long rows, float* y
 void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, int ldk, long long k_bs,
                        const float* v, int ldv, long long v_bs, float* o, int ldo, long long o_bs, int n, int nq,
                        int nk, int n_head, int d_head, const int* kv_len_dev, const int* kv_len_host,
-                       const float* mask, int mask_ld, int dt) {
+                       const float* mask, int mask_ld, int dt, void* o3) {
     if (dt < 0) dt = edt();
+    flush_pending();
     if (nq <= 0 || nk <= 0) throw Error(SDMI_ERR_INVALID, "attention: empty sequence");
+    if (o3 && (dt || !attn_supported_head_dim(d_head) || (n_head * d_head) % 32)) throw Error(SDMI_ERR_STATE, "attention: plane output needs a fused fp32 kernel");
     const float scale = (float)std::pow((double)d_head, -0.25);
     if (attn_supported_head_dim(d_head)) {
         AttnParams p{};
@@ -1361,6 +1486,7 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
         p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
         p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs; p.scale = scale;
         p.bf16 = dt;
+        p.o3 = o3; p.ldo3 = (n_head * d_head / 32) * 192;
         if (dt && mask) throw Error(SDMI_ERR_UNSUPPORTED, "attention: additive mask is fp32-only");
         const double fl = 4.0 * n * n_head * (double)nq * nk * d_head;
         ProfScope ps(this, PC_ATTENTION, fl);
@@ -1420,13 +1546,21 @@ void Engine::res_block(const ResW& w, const Act& x, Act& y, int step) {
         conv_fp8(w.conv_in, q1, h2, rowvec, nullptr);
         release(q1);
     } else {
-        Act h1 = new_act(x.n, x.h, x.w, x.c);
+        // the normalised tensors have one consumer, a 3x3 convolution: on the fp32 engine they exist only as bf16 planes (k_gemm3p.hip)
+        Act h1 = plane_gemm(x.c, w.cout) ? new_act3(x.n, x.h, x.w, x.c, 2) : new_act(x.n, x.h, x.w, x.c);
         group_norm(w.norm_in, x, h1, true);
+        if (!use_fp8(w.conv_out, h2)) defer_reduce();     // h2's next reader is GroupNorm(norm_out): it combines the split-K slabs itself
         conv(w.conv_in, h1, h2, 1, 0, rowvec, 0, nullptr);
         release(h1);
     }
-    if (w.has_skip) conv(w.skip, x, y, 1, 0, nullptr, 0, nullptr);
-    const Act* resid = w.has_skip ? &y : &x;
+    // the shortcut's result is the residual of conv_out: it goes through y's fp32 buffer, or through a temporary when y exists as planes only
+    Act sk{};
+    if (w.has_skip) {
+        if (y.p) { sk = y; sk.p3 = nullptr; sk.view = true; }
+        else sk = new_act(y.n, y.h, y.w, y.c);
+        conv(w.skip, x, sk, 1, 0, nullptr, 0, nullptr);
+    }
+    const Act* resid = w.has_skip ? &sk : &x;
     if (use_fp8(w.conv_out, h2)) {
         ActQ q3 = new_actq(x.n, x.h, x.w, w.cout);
         group_norm_fp8(w.norm_out, h2, q3, true);
@@ -1434,12 +1568,13 @@ void Engine::res_block(const ResW& w, const Act& x, Act& y, int step) {
         conv_fp8(w.conv_out, q3, y, nullptr, resid);
         release(q3);
     } else {
-        Act h3 = new_act(x.n, x.h, x.w, w.cout);
+        Act h3 = plane_gemm(w.cout, w.cout) ? new_act3(x.n, x.h, x.w, w.cout, 2) : new_act(x.n, x.h, x.w, w.cout);
         group_norm(w.norm_out, h2, h3, true);
         release(h2);
         conv(w.conv_out, h3, y, 1, 0, nullptr, 0, resid);
         release(h3);
     }
+    if (w.has_skip) release(sk);
 }
 
 // ---- precision = 2: MXFP8 GroupNorm output + 3x3 convolution (k_fp8.hip) ------------------------------------------------
@@ -1541,40 +1676,54 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
     const int C = w.c, nb = x.n, hw = x.h * x.w;
     const long long M = x.rows();
     const int heads = cfg_.n_head, d = C / heads;
-    Act g = new_act(x.n, x.h, x.w, C);
+    // fp32 engine: every tensor whose only consumer is a GEMM (the normalised activations, the attention outputs, the gated MLP
+    // hidden state, the block's last hidden state) is written by its producer as three bf16 planes -- what k_gemm3p.hip reads
+    const bool pl = plane_gemm(C, C) && attn_supported_head_dim(d);
+    Act g = pl ? new_act3(x.n, x.h, x.w, C, 2) : new_act(x.n, x.h, x.w, C);
     group_norm(w.norm, x, g, false);
     Act h = new_act(x.n, x.h, x.w, C);
+    defer_reduce();                 // h's next reader is LayerNorm 1
     conv(w.proj_in, g, h, 1, 0, nullptr, 0, nullptr);
     release(g);
+    Act hp = pl ? new_act3(x.n, x.h, x.w, C, 2) : Act{};      // the hidden state after the MLP: read by proj_out only
     {
         const size_t es = esz();
-        Buf ln(this, (size_t)M * C * es), q(this, (size_t)M * C * es), a(this, (size_t)M * C * es);
+        const size_t row3 = (size_t)(C / 32) * 192;
+        Buf ln(this, pl ? (size_t)M * row3 : (size_t)M * C * es), q(this, (size_t)M * C * es), a(this, pl ? (size_t)M * row3 : (size_t)M * C * es);
+        float* lnf = pl ? nullptr : ln.f();
+        void* ln3 = pl ? ln.p : nullptr;
+        float* af = pl ? nullptr : a.f();
+        void* a3 = pl ? a.p : nullptr;
         // self attention: q, k, v in one GEMM (N = 3C) on the packed [3C][C] weight
-        layer_norm(w.ln1, h.p, M, ln.f());
+        layer_norm(w.ln1, h.p, M, lnf, -1, ln3);
         {
             Buf qkv(this, (size_t)M * 3 * C * es);
-            gemm(ln.f(), (int)M, w.attn1.q.bt, nullptr, C, 3 * C, qkv.f(), 3 * C, nullptr, 0);
+            gemm(lnf, (int)M, w.attn1.q.bt, nullptr, C, 3 * C, qkv.f(), 3 * C, nullptr, 0, -1, 0, ln3);
             const long long bs3 = (long long)hw * 3 * C;
-            attention(qkv.f(), 3 * C, bs3, adv(qkv.f(), C, edt()), 3 * C, bs3, adv(qkv.f(), 2 * C, edt()), 3 * C, bs3, a.f(), C,
-                      (long long)hw * C, nb, hw, hw, heads, d, nullptr, nullptr, nullptr, 0);
+            attention(qkv.f(), 3 * C, bs3, adv(qkv.f(), C, edt()), 3 * C, bs3, adv(qkv.f(), 2 * C, edt()), 3 * C, bs3, af, C,
+                      (long long)hw * C, nb, hw, hw, heads, d, nullptr, nullptr, nullptr, 0, -1, a3);
         }
-        gemm(a.f(), (int)M, w.attn1.out.bt, w.attn1.out.bias, C, C, h.p, C, h.p, C);
+        defer_reduce();             // ... LayerNorm 2
+        gemm(af, (int)M, w.attn1.out.bt, w.attn1.out.bias, C, C, h.p, C, h.p, C, -1, 0, a3);
         // cross attention against the hoisted K/V of the text context
-        layer_norm(w.ln2, h.p, M, ln.f());
-        gemm(ln.f(), (int)M, w.attn2.q.bt, nullptr, C, C, q.f(), C, nullptr, 0);
+        layer_norm(w.ln2, h.p, M, lnf, -1, ln3);
+        gemm(lnf, (int)M, w.attn2.q.bt, nullptr, C, C, q.f(), C, nullptr, 0, -1, 0, ln3);
         const long long cbs = (long long)us_.t_max * C;
-        attention(q.f(), C, (long long)hw * C, us_.kc.at(w.ctx_index), C, cbs, us_.vc.at(w.ctx_index), C, cbs, a.f(),
-                  C, (long long)hw * C, nb, hw, us_.t_max, heads, d, us_.kv_len_dev, us_.kv_len_host.data(), nullptr, 0);
-        gemm(a.f(), (int)M, w.attn2.out.bt, w.attn2.out.bias, C, C, h.p, C, h.p, C);
+        attention(q.f(), C, (long long)hw * C, us_.kc.at(w.ctx_index), C, cbs, us_.vc.at(w.ctx_index), C, cbs, af,
+                  C, (long long)hw * C, nb, hw, us_.t_max, heads, d, us_.kv_len_dev, us_.kv_len_host.data(), nullptr, 0, -1, a3);
+        defer_reduce();             // ... LayerNorm 3
+        gemm(af, (int)M, w.attn2.out.bt, w.attn2.out.bias, C, C, h.p, C, h.p, C, -1, 0, a3);
         // GEGLU MLP
-        layer_norm(w.ln3, h.p, M, ln.f());
+        layer_norm(w.ln3, h.p, M, lnf, -1, ln3);
         {
-            Buf u(this, (size_t)M * 4 * C * es);
-            gemm_geglu(ln.f(), M, w.geglu_proj.bt, w.geglu_proj.bias, C, 4 * C, u.f(), -1);
-            gemm(u.f(), (int)M, w.mlp_lin.bt, w.mlp_lin.bias, 4 * C, C, h.p, C, h.p, C);
+            Buf u(this, pl ? (size_t)M * 4 * row3 : (size_t)M * 4 * C * es);
+            gemm_geglu(lnf, M, w.geglu_proj.bt, w.geglu_proj.bias, C, 4 * C, pl ? nullptr : u.f(), -1, ln3, pl ? u.p : nullptr);
+            if (pl) gemm(nullptr, (int)M, w.mlp_lin.bt, w.mlp_lin.bias, 4 * C, C, nullptr, C, h.p, C, -1, 0, u.p, hp.p3);   // h + mlp -> planes only
+            else gemm(u.f(), (int)M, w.mlp_lin.bt, w.mlp_lin.bias, 4 * C, C, h.p, C, h.p, C);
         }
     }
-    conv(w.proj_out, h, y, 1, 0, nullptr, 0, &x);
+    if (pl) { conv(w.proj_out, hp, y, 1, 0, nullptr, 0, &x); release(hp); }
+    else conv(w.proj_out, h, y, 1, 0, nullptr, 0, &x);
     release(h);
 }
 
@@ -1676,13 +1825,15 @@ void Engine::unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc) {
                 Act r = new_act(in.n, in.h, in.w, b.cout); res_block(b.res, in, r, step);
                 spatial_transformer(b.st, r, y); release(r); return;
             }
-            case BK_RES_UP: {
-                Act r = new_act(in.n, in.h, in.w, b.cout); res_block(b.res, in, r, step);
+            case BK_RES_UP: {   // (fp32 engine: the tensor between the block and its up-convolution exists only as planes)
+                Act r = plane_gemm(b.cout, b.cout) ? new_act3(in.n, in.h, in.w, b.cout, 2) : new_act(in.n, in.h, in.w, b.cout);
+                res_block(b.res, in, r, step);
                 conv(b.up, r, y, 1, 1, nullptr, 0, nullptr); release(r); return;
             }
             case BK_RES_ST_UP: {
                 Act r = new_act(in.n, in.h, in.w, b.cout); res_block(b.res, in, r, step);
-                Act s = new_act(in.n, in.h, in.w, b.cout); spatial_transformer(b.st, r, s); release(r);
+                Act s = plane_gemm(b.cout, b.cout) ? new_act3(in.n, in.h, in.w, b.cout, 2) : new_act(in.n, in.h, in.w, b.cout);
+                spatial_transformer(b.st, r, s); release(r);
                 conv(b.up, s, y, 1, 1, nullptr, 0, nullptr); release(s); return;
             }
         }
@@ -1698,7 +1849,10 @@ void Engine::unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc) {
         const int ctot = out_blocks_[i].cin, cskip = b.cout, cx = ctot - cskip;
         if (cx <= 0) throw Error(SDMI_ERR_STATE, "unet: block table inconsistent");
         const int ho = b.kind == BK_DOWN ? x.h / 2 : x.h, wo = b.kind == BK_DOWN ? x.w / 2 : x.w;
-        cats[i] = new_act(nb, ho, wo, ctot);
+        // fp32 engine: the buffer also exists as planes -- the skip convolution of output block i (cin != cout) and the down-convolutions read those,
+        // written by the epilogues (or split-K reduce kernels) of the GEMMs that produce the two halves
+        const bool catp = plane_gemm(ctot, out_blocks_[i].cout) && cx % 32 == 0 && cskip % 32 == 0;
+        cats[i] = catp ? new_act3(nb, ho, wo, ctot, 3) : new_act(nb, ho, wo, ctot);
         Act y = slice(cats[i], cx, cskip);
         run_block(b, x, y);
         x = y;
@@ -1848,13 +2002,16 @@ void Engine::decode_one(const float* z_nhwc, int n, Act& img) {
     for (int i = 0; i < 4; ++i) {  // DecoderBlock::forward (:308-323)
         const DecBlockW& b = dec_blocks_[i];
         for (int r = 0; r < 3; ++r) {
-            Act y = new_act(x.n, x.h, x.w, b.cout);
+            // fp32 engine: the block's last tensor is read by the up-convolution only -> planes only
+            Act y = (r == 2 && b.has_up && plane_gemm(b.cout, b.cout)) ? new_act3(x.n, x.h, x.w, b.cout, 2) : new_act(x.n, x.h, x.w, b.cout);
             res_block(b.res[r], x, y, 0);
             release(x);
             x = y;
         }
         if (b.has_up) {
-            Act y = new_act(x.n, x.h * 2, x.w * 2, b.cout);
+            // the next block's first ResnetBlock has a 1x1 shortcut (cin != cout): it reads the up-convolution's output as planes too
+            const bool both = i + 1 < 4 && dec_blocks_[i + 1].res[0].has_skip && plane_gemm(b.cout, dec_blocks_[i + 1].cout);
+            Act y = both ? new_act3(x.n, x.h * 2, x.w * 2, b.cout, 3) : new_act(x.n, x.h * 2, x.w * 2, b.cout);
             conv(b.upsampler, x, y, 1, 1, nullptr, 0, nullptr);
             release(x);
             x = y;
@@ -1957,6 +2114,14 @@ void Engine::qkv_attention_dev(const float* q, const float* k, const float* v, c
         SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(oh.p, out, (int)((long long)n * nq), n_state, 1, 1, stream_));
         return;
     }
+    if (plane_gemm(n_state, n_state) && attn_supported_head_dim(n_state / n_head)) {   // option gemm_planes: the kernels' plane-writing epilogue, joined back
+        Buf o3(this, (size_t)n * nq * (n_state / 32) * 192);
+        attention(q, n_state, (long long)nq * n_state, k, n_state, (long long)nk * n_state, v, n_state,
+                  (long long)nk * n_state, nullptr, n_state, (long long)nq * n_state, n, nq, nk, n_head, n_state / n_head,
+                  nullptr, nullptr, mask, mask_ld, 0, o3.p);
+        SDMI_HIP(launch_join3_rows(o3.p, out, (long long)n * nq, n_state, (long long)(n_state / 32) * 192, n_state, stream_));
+        return;
+    }
     attention(q, n_state, (long long)nq * n_state, k, n_state, (long long)nk * n_state, v, n_state,
               (long long)nk * n_state, out, n_state, (long long)nq * n_state, n, nq, nk, n_head, n_state / n_head,
               nullptr, nullptr, mask, mask_ld, 0);
@@ -1978,7 +2143,13 @@ void Engine::op_group_norm(const float* x, const float* gamma, const float* beta
     } else {
         SDMI_HIP(launch_nchw_to_nhwc(x, a.p, n, c, h, w, 1.0f, stream_));
         Buf part(this, gn_partials_bytes(n, h * w, c));
-        SDMI_HIP(launch_group_norm(a.p, b.p, gamma, beta, n, h * w, c, c, groups, eps, silu, part.p, stream_));
+        if (plane_gemm(c, c)) {   // option gemm_planes: the plane-writing form of the kernel, joined back to fp32 (exact)
+            Buf y3(this, (size_t)n * h * w * (c / 32) * 192);
+            SDMI_HIP(launch_group_norm_planes(a.p, y3.p, gamma, beta, n, h * w, c, c, groups, eps, silu, part.p, stream_));
+            SDMI_HIP(launch_join3_rows(y3.p, b.p, (long long)n * h * w, c, (long long)(c / 32) * 192, c, stream_));
+        } else {
+            SDMI_HIP(launch_group_norm(a.p, b.p, gamma, beta, n, h * w, c, c, groups, eps, silu, part.p, stream_));
+        }
         SDMI_HIP(launch_nhwc_to_nchw(b.p, out, n, c, h, w, stream_));
     }
     release(a); release(b);
@@ -2007,6 +2178,12 @@ void Engine::op_layer_norm(const float* x, const float* gamma, const float* beta
         SDMI_HIP(launch_f32_to_bf16(x, xh.p, (long long)rows * c, stream_));
         SDMI_HIP(launch_layer_norm_bf16(xh.p, yh.p, gamma, beta, rows, c, eps, stream_));
         SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(yh.p, out, rows, c, 1, 1, stream_));
+        return;
+    }
+    if (plane_gemm(c, c)) {
+        Buf y3(this, (size_t)rows * (c / 32) * 192);
+        SDMI_HIP(launch_layer_norm_planes(x, y3.p, gamma, beta, rows, c, eps, stream_));
+        SDMI_HIP(launch_join3_rows(y3.p, out, rows, c, (long long)(c / 32) * 192, c, stream_));
         return;
     }
     SDMI_HIP(launch_layer_norm(x, out, gamma, beta, rows, c, eps, stream_));
@@ -2096,6 +2273,12 @@ void Engine::op_geglu(const float* proj, int rows, int hidden, float* out) {
         SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(oh.p, out, rows, hidden, 1, 1, stream_));
         return;
     }
+    if (plane_gemm(hidden, hidden)) {
+        Buf y3(this, (size_t)rows * (hidden / 32) * 192);
+        SDMI_HIP(launch_geglu_planes(proj, y3.p, rows, hidden, stream_));
+        SDMI_HIP(launch_join3_rows(y3.p, out, rows, hidden, (long long)(hidden / 32) * 192, hidden, stream_));
+        return;
+    }
     SDMI_HIP(launch_geglu(proj, out, rows, hidden, stream_));
 }
 
@@ -2168,11 +2351,33 @@ double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int str
     float ms = 0;
     try {
         conv(cw, a, y, stride, ups, nullptr, 0, nullptr);  // warm-up
+        if (opt_bench_cold_) {
+            // what the layer costs INSIDE the model: its weights come from HBM (5 GB of planes per UNet forward pass through the 256 MB
+            // Infinity Cache between two uses), its activations from the L2s / Infinity Cache of the kernel that wrote them.  Between
+            // timed launches a 512 MB fill evicts the weights, then the activation tensor is re-written (split3_rows / a copy).
+            const size_t flush_bytes = (size_t)512 << 20;
+            Buf flush(this, flush_bytes);
+            Buf a_copy(this, a.bytes());
+            SDMI_HIP(hipMemcpyAsync(a_copy.p, a.p, a.bytes(), hipMemcpyDeviceToDevice, stream_));
+            for (int i = 0; i < iters; ++i) {
+                SDMI_HIP(hipMemsetAsync(flush.p, i, flush_bytes, stream_));
+                SDMI_HIP(hipMemcpyAsync(a.p, a_copy.p, a.bytes(), hipMemcpyDeviceToDevice, stream_));
+                if (a.p3) SDMI_HIP(launch_split3_rows(a.p, a.p3, a.rows(), cin, cin, a.ld3, stream_));
+                SDMI_HIP(hipEventRecord(ev0_, stream_));
+                conv(cw, a, y, stride, ups, nullptr, 0, nullptr);
+                SDMI_HIP(hipEventRecord(ev1_, stream_));
+                SDMI_HIP(hipEventSynchronize(ev1_));
+                float t = 0;
+                SDMI_HIP(hipEventElapsedTime(&t, ev0_, ev1_));
+                ms += t;
+            }
+        } else {
         SDMI_HIP(hipEventRecord(ev0_, stream_));
         for (int i = 0; i < iters; ++i) conv(cw, a, y, stride, ups, nullptr, 0, nullptr);
         SDMI_HIP(hipEventRecord(ev1_, stream_));
         SDMI_HIP(hipEventSynchronize(ev1_));
         SDMI_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
+        }
     } catch (...) {
         opt_force_tile_ = save_t; opt_force_splits_ = save_s; opt_gemm_planes_ = save_p;
         release(a); release(y);

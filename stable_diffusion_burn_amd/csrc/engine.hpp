@@ -260,8 +260,22 @@ private:
     void conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, const float* rowvec, int rowvec_stride,
               const Act* resid, bool pad_br = false);
     static Act slice(const Act& parent, int c_off, int c);   // channel-slice view
+    // A3 / C3: the input / output as three bf16 planes (dense rows: 192 bytes per 32 channels); A and / or C may then be null
     void gemm(const float* A, int a_rows, const float* bt, const float* bias, int cin, int cout, float* C, int ldc,
-              const float* resid, int ldr, int dt = -1, int out_mode = 0);
+              const float* resid, int ldr, int dt = -1, int out_mode = 0, const void* A3 = nullptr, void* C3 = nullptr);
+    // fp32 engine, option gemm_planes: does the GEMM cin -> cout take its activations as planes (k_gemm3p.hip)?
+    bool plane_gemm(int cin, int cout) const { return !bf16_ && opt_gemm_planes_ != 0 && opt_gemm_f32s_ != 0 && cin % 32 == 0 && cout >= 32; }
+    // A split-K GEMM whose slabs are not combined yet (option fuse_reduce): launch_gemm leaves it here when its caller said the NEXT
+    // engine op is a GroupNorm / LayerNorm of the result; that op's statistics / row pass then combines the slabs itself (k_norm.hip),
+    // and every other op first runs the stand-alone reduce kernel (flush_pending) -- nothing ever reads an un-combined tensor.
+    struct PendingReduce { ConvGemm p; std::unique_ptr<Buf> slabs; };
+    std::unique_ptr<PendingReduce> pend_;
+    bool defer_next_ = false;          // set by defer_reduce() for exactly the next launch_gemm
+    int opt_fuse_reduce_ = 1;
+    void defer_reduce() { defer_next_ = opt_fuse_reduce_ != 0 && !bf16_; }
+    void flush_pending();
+    const ConvGemm* pending_for(const float* x, long long rows, int c, int ld) const;
+    void pending_done() { pend_.reset(); }
     void choose_xcd_map(ConvGemm& p, int MT, int NT, double a_bytes, double w_bytes, double flops, double cu_flops) const;
     void launch_gemm(ConvGemm& p, int in_dt, int force_cfg = -1, int force_splits = 0);
     int edt() const { return bf16_ ? 1 : 0; }
@@ -276,13 +290,14 @@ private:
     void group_norm_fp8(const NormW& w, const Act& x, ActQ& y, bool silu);
     void conv_fp8(const ConvW& w, const ActQ& x, Act& y, const float* rowvec, const Act* resid);
     bool use_fp8(const ConvW& w, const Act& x) const;
-    void layer_norm(const NormW& w, const float* x, long long rows, float* y, int dt = -1);
+    void layer_norm(const NormW& w, const float* x, long long rows, float* y, int dt = -1, void* y3 = nullptr);   // y3: output as planes instead of y
     // GEGLU::forward (unet/mod.rs:579-591): out[rows, hidden] = (x W + b)[:, :hidden] * gelu((x W + b)[:, hidden:]); bt is the
     // packed [2 hidden][cin] weight.  Fused into a large-tile GEMM when possible, else GEMM into `proj_scratch` + gate kernel.
-    void gemm_geglu(const float* x, long long rows, const float* bt, const float* bias, int cin, int hidden, float* out, int dt);
+    void gemm_geglu(const float* x, long long rows, const float* bt, const float* bias, int cin, int hidden, float* out, int dt,
+                    const void* x3 = nullptr, void* out3 = nullptr);
     void attention(const float* q, int ldq, long long q_bs, const float* k, int ldk, long long k_bs, const float* v,
                    int ldv, long long v_bs, float* o, int ldo, long long o_bs, int n, int nq, int nk, int n_head,
-                   int d_head, const int* kv_len_dev, const int* kv_len_host, const float* mask, int mask_ld, int dt = -1);
+                   int d_head, const int* kv_len_dev, const int* kv_len_host, const float* mask, int mask_ld, int dt = -1, void* o3 = nullptr);
 
     // composite blocks
     void res_block(const ResW& w, const Act& x, Act& y, int step);
@@ -407,11 +422,13 @@ private:
     static constexpr int kGemmPlanesDefault = 0;
     int opt_gemm_planes_ = kGemmPlanesDefault;   // precision = 0: k_gemm3p.hip (activations as bf16 planes too, no split in the k loop): 0 never, 1 every launch that would take a k_gemm3x.hip tile,
                                 // 2 only where the per-shape table says 300 + x
+    int opt_bench_cold_ = 0;    // bench_conv: 1 = evict the weights from the Infinity Cache between timed launches (what a layer sees inside the model)
     int opt_gemm_x32_ = 1;      // precision = 0: 1 = large-tile LDS-DMA fp32 GEMM (k_gemm2x.hip) where measured / modelled faster
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
     int opt_gemm_bf16x_variant_ = 0;   // k_gemm_bf16x.hip: 3 = pipelined k loop (DMA pieces and asm fragment reads with hand-counted waits behind the matrix instructions, barrier near the end of a tile; measured: not faster)
     int opt_xcd_map_ = 0;              // 1: cut every GEMM launch over the 8 XCDs so that the fewest operand bytes cross the fabric (choose_xcd_map); 0: bands of tiles, every XCD reads all weights
     void* zero_page_ = nullptr;
+    TileChoice choose_tile_p(int M, int N, int kt_total, bool even_ni_only) const;   // k_gemm3p.hip tiles (300 + x)
     TileChoice choose_tile_bf16(int M, int N, int kt_total) const;   // cfg >= 100: k_gemm_bf16x.hip tile cfg - 100     // precision = 1: 1 = bf16 matrix-core attention, 0 = bf16 storage widened onto the fp32 kernel  // 1: attn2_kernel, 0: attn_f32_kernel
     // split-K combine: 0 = separate reduce kernel (the measured best, profiles/README.md); 1 = inside the GEMM launch by the
     // last-arriving k slice (plain slab stores + release fence); 2 = the same with write-through (sc1) slab stores
@@ -420,6 +437,7 @@ private:
     unsigned* splitk_counters_ = nullptr;
     std::map<std::string, TileChoice> tuned_;        // fp32 kernels: "M,N,K" -> (tile cfg, split-K)
     std::map<std::string, TileChoice> tuned_bf16_;   // bf16 kernels; cfg >= 100 = k_gemm_bf16x.hip tile
+    std::map<std::string, TileChoice> tuned_p_;      // fp32 shapes whose activations arrive as planes: k_gemm3p.hip tiles (300 + x) only
     std::map<std::string, TileChoice> tuned_mfma_;   // fp32 shapes measured with the fp32-MFMA kernels only (gemm_f32s=0)
     bool record_shapes_ = false;
     std::map<std::string, long long> shape_counts_;  // "n,cin,h,w,cout,k,stride,ups" -> launches

@@ -25,6 +25,7 @@
 //    the PV output to 48 columns (third 16-wide tile half used), QK^T uses K = d
 //    exactly (k steps of 4).
 #include "kernels.hpp"
+#include "k_split3.hpp"
 
 namespace sdmi {
 
@@ -301,7 +302,8 @@ __global__ __launch_bounds__(NW * 64) void attn2_kernel(const AttnParams p) {
                     u32x2h w = {bits(r[0]) | (bits(r[1]) << 16), bits(r[2]) | (bits(r[3]) << 16)};
                     *reinterpret_cast<u32x2h*>(Oh + (long long)qrow * p.ldo + dcol) = w;
                 } else {
-                    *reinterpret_cast<f32x4*>(Ob + (long long)qrow * p.ldo + dcol) = r;
+                    if (p.o3) s3_store4(reinterpret_cast<unsigned char*>(p.o3) + ((long long)b * p.nq + qrow) * p.ldo3, hh * D + dcol, r);
+                    else *reinterpret_cast<f32x4*>(Ob + (long long)qrow * p.ldo + dcol) = r;
                 }
             }
         }

@@ -19,6 +19,7 @@
 // prefetch of the K / V^T fragments one step ahead (what helps k_attn_bf16.hip by 6-14 %) measured 6 % slower here: hipcc's own
 // schedule already overlaps these reads with the six-MFMA groups.
 #include "kernels.hpp"
+#include "k_split3.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -321,7 +322,8 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
                 const int dcol = 32 * dt + 8 * rq + 4 * hi;
                 if (dcol < D) {
                     const f32x4 w = {o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv, o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv};
-                    *reinterpret_cast<f32x4*>(Of + (long long)qrow * p.ldo + dcol) = w;
+                    if (p.o3) s3_store4(reinterpret_cast<unsigned char*>(p.o3) + ((long long)b * p.nq + qrow) * p.ldo3, hh * D + dcol, w);
+                    else *reinterpret_cast<f32x4*>(Of + (long long)qrow * p.ldo + dcol) = w;
                 }
             }
         }

@@ -12,6 +12,7 @@
 // All are HBM/latency bound and tiny next to the convolutions; they use 16-byte
 // accesses and grid-stride loops.
 #include "kernels.hpp"
+#include "k_split3.hpp"
 
 namespace sdmi {
 
@@ -242,6 +243,27 @@ hipError_t launch_concat_channels(const float* a, const float* b, float* dst, lo
     const long long total = rows * ((ca + cb) / 4);
     hipLaunchKernelGGL(concat_channels_kernel, dim3(blocks_for(total)), dim3(256), 0, s, a, b, dst, rows, ca / 4,
                        cb / 4);
+    return hipGetLastError();
+}
+// the same gate with the result as three bf16 planes ([rows][hidden / 32][3][32]; k_split3.hpp) for the k_gemm3p.hip launch of the MLP's second Linear
+__global__ void geglu_planes_kernel(const float* __restrict__ proj, unsigned char* __restrict__ out3, long long rows, int hidden4) {
+    const long long total = rows * hidden4;
+    const long long row3 = (long long)(hidden4 >> 3) * 192;
+    GRID_STRIDE(i, total) {
+        const long long r = i / hidden4;
+        const int c = (int)(i - r * hidden4);
+        const f32x4 a = reinterpret_cast<const f32x4*>(proj)[r * 2 * hidden4 + c];
+        const f32x4 g = reinterpret_cast<const f32x4*>(proj)[r * 2 * hidden4 + hidden4 + c];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = a[j] * gelu_erf(g[j]);
+        s3_store4(out3 + r * row3, c * 4, o);
+    }
+}
+hipError_t launch_geglu_planes(const float* proj, void* out3, long long rows, int hidden, hipStream_t s) {
+    if (hidden & 31) return hipErrorInvalidValue;
+    const long long total = rows * (hidden / 4);
+    hipLaunchKernelGGL(geglu_planes_kernel, dim3(blocks_for(total, 4096)), dim3(256), 0, s, proj, reinterpret_cast<unsigned char*>(out3), rows, hidden / 4);
     return hipGetLastError();
 }
 hipError_t launch_geglu(const float* proj, float* out, long long rows, int hidden, hipStream_t s) {

@@ -29,6 +29,7 @@
 //    order (bit-reproducible) and applies the epilogue inside the launch (k_common.hpp); launch_splitk_reduce is
 //    the separate-kernel form of the same sum (option splitk_fused=0, odd strides).
 #include "kernels.hpp"
+#include "k_split3.hpp"
 
 #include <mutex>
 #include <set>
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvGemm p) {
     const float* slabs = p.slabs;
     float* C = p.C;
     const int HoWo = p.Ho * p.Wo;
-    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0);
+    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!p.resid || (p.ldr & 3) == 0);
     if (vec_ok) {
         const int n4 = p.N >> 2;
         const long long total = (long long)p.M * n4;              // 16-byte outputs
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvGemm p) {
                 if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
                 if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)(m / HoWo) * p.rowvec_stride + n);
                 if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (long long)m * p.ldr + n);
-                *reinterpret_cast<f32x4*>(C + (long long)m * p.ldc + n) = v;
+                if (C) *reinterpret_cast<f32x4*>(C + (long long)m * p.ldc + n) = v;
+                if (p.C3) s3_store4(reinterpret_cast<unsigned char*>(p.C3) + (long long)m * p.ldc3, n, v);
             }
         }
     } else {
@@ -167,7 +169,8 @@ static const GemmTileInfo kTiles[kNumGemmTiles] = {
 const GemmTileInfo& gemm_tile_info(int cfg) { return kTiles[cfg]; }
 
 hipError_t launch_splitk_reduce(const ConvGemm& p, hipStream_t stream) {
-    const bool vec = ((p.N & 3) == 0) && ((p.ldc & 3) == 0);
+    const bool vec = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!p.resid || (p.ldr & 3) == 0);
+    if (!vec && (p.C3 || !p.C)) return hipErrorInvalidValue;   // the plane output is part of the 16-byte path only
     const long long work = ((long long)p.M * p.N + 3) / 4;
     // lanes per output: enough threads to cover the chip (>= 256 K) while every lane still has two slabs to sum
     int g = 1;

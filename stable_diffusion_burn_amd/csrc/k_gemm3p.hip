@@ -361,4 +361,31 @@ hipError_t launch_split3_rows(const float* x, void* y3, long long rows, int c, l
     return hipGetLastError();
 }
 
+// planes -> fp32 rows: x = (h + m) + l exactly (h + m has at most 16 significant bits).  Test / debugging aid: the operator-level entry
+// points use it to hand a plane producer's result back in the reference's layout.
+__global__ void join3_rows_kernel(const unsigned short* __restrict__ x3, float* __restrict__ y, long long rows, int kt, long long ld3_elems, long long ld) {
+    const long long total = rows * kt * 32;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 31);
+        const long long rk = i >> 5;
+        const long long row = rk / kt;
+        const int k = (int)(rk - row * kt);
+        const unsigned short* src = x3 + row * ld3_elems + k * 96 + s3_plane_pos(j);
+        const float h = __builtin_bit_cast(float, (unsigned)src[0] << 16);
+        const float m = __builtin_bit_cast(float, (unsigned)src[32] << 16);
+        const float l = __builtin_bit_cast(float, (unsigned)src[64] << 16);
+        y[row * ld + k * 32 + j] = (h + m) + l;
+    }
+}
+
+hipError_t launch_join3_rows(const void* x3, float* y, long long rows, int c, long long ld3_bytes, long long ld, hipStream_t s) {
+    if ((c % 32) || (ld3_bytes % 192)) return hipErrorInvalidValue;
+    const long long total = rows * c;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(join3_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const unsigned short*>(x3), y, rows, c / 32, ld3_bytes / 2, ld);
+    return hipGetLastError();
+}
+
 }  // namespace sdmi

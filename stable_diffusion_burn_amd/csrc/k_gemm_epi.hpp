@@ -8,6 +8,7 @@
 #pragma once
 #include "kernels.hpp"
 #include "k_common.hpp"
+#include "k_split3.hpp"
 
 namespace sdmi {
 
@@ -105,7 +106,10 @@ __device__ __forceinline__ void gemm_epilogue_f32(const ConvGemm& p, epi_f32x4 (
                     f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * LDSW + c4 * 4);
                     if (has_resid) v += *reinterpret_cast<const f32x4*>(p.resid + (long long)m * p.ldr + n);
                     if (split) slab.store((long long)m * ldc + n, v);
-                    else *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;
+                    else {
+                        if (Cf) *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;
+                        if (p.C3) s3_store4(reinterpret_cast<unsigned char*>(p.C3) + (long long)m * p.ldc3, n, v);
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();

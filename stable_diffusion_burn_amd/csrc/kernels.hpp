@@ -22,7 +22,9 @@ struct ConvGemm {
     const void* Bt3;      // split kernels (k_gemm3x.hip, k_gemm3p.hip): the same weights as three bf16 planes, [N][K / 32][3][32]
     const void* A3;       // plane kernel (k_gemm3p.hip): the source activations as three bf16 planes, [NB][Hs][Ws][a3_ld / 192 slices][3][32]
     int a3_ld;            // bytes between source pixels in A3 (192 per 32 channels of the -- possibly wider -- buffer)
-    float* C;             // output [M][ldc]
+    float* C;             // output [M][ldc]; may be null when C3 is set
+    void* C3;             // k_gemm3x.hip / k_gemm3p.hip / launch_splitk_reduce: not null -> the output ALSO (or only) as three bf16 planes, [M][ldc3 / 192 slices][3][32]
+    int ldc3;             // bytes between output rows in C3 (needs N % 4 == 0: the 16-byte epilogue)
     float* slabs;         // splits > 1: fp32 partial sums [splits][M][N]
     int slab_wt;          // with counters: slab tiles are stored write-through (sc1) and published without a release fence
     unsigned* counters;   // splits > 1: per-tile arrival counters (zero between launches) -> the last-arriving slice combines
@@ -118,6 +120,7 @@ const GemmTileInfo& gemm_tile_info_p(int cfg);
 hipError_t launch_conv_gemm3p(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 // fp32 rows [rows][ld] (c channels, c % 32 == 0) -> planes [rows][ld3_bytes / 192 slices][3][32] bf16 (slices [0, c / 32) written)
 hipError_t launch_split3_rows(const float* x, void* y3, long long rows, int c, long long ld, long long ld3_bytes, hipStream_t s);
+hipError_t launch_join3_rows(const void* x3, float* y, long long rows, int c, long long ld3_bytes, long long ld, hipStream_t s);   // planes -> fp32 (exact)
 // hipFuncAttributeMaxDynamicSharedMemorySize, once per (kernel, device); safe to call from several host threads (multi.cpp)
 hipError_t set_max_dynamic_lds(const void* kernel, int bytes);
 // MXFP8 (e4m3 + E8M0 block scales) 256-row LDS-DMA kernel on v_mfma_scale_f32_16x16x128_f8f6f4 (k_fp8.hip); its own tile list
@@ -150,6 +153,8 @@ struct AttnParams {
     long long q_bs, k_bs, v_bs, o_bs;   // batch strides in floats
     float scale;                        // d_head^-0.25 applied to q and to k (attention.rs:15-26)
     int bf16;                           // q/k/v/o are bf16 in HBM (strides in elements)
+    void* o3;                           // fp32 kernels: not null -> the output is written as three bf16 planes instead of fp32 ([n * nq][ldo3 / 192 slices][3][32],
+    int ldo3;                           // channel = head * d_head + column; bytes between rows), what the out-projection's k_gemm3p.hip launch reads
 };
 bool attn_supported_head_dim(int d);
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
@@ -166,17 +171,27 @@ hipError_t launch_softmax_rows(float* x, int rows, int cols, float scale, hipStr
 // `partials` needs gn_partials_bytes(n, hw, c) bytes of scratch.
 size_t gn_partials_bytes(int n, int hw, int c);
 // ldx: elements between pixels of x (>= c; x may be a channel slice of a wider buffer); y is dense [n][hw][c]
+// pending (optional): x has not been written yet -- it is the result of that split-K GEMM (pending->slabs, splits, bias, rowvec, resid; C == x):
+// the statistics pass / the row pass combines the slabs in slice order, writes x (and C3, its planes) and normalises it, so that the
+// stand-alone launch_splitk_reduce and one read of x disappear.  Needs the 16-byte path (N % 4 == 0, ldc / ldr % 4 == 0).
 hipError_t launch_group_norm(const float* x, float* y, const float* gamma, const float* beta,
                              int n, int hw, int c, int ldx, int n_group, float eps, bool silu,
-                             void* partials, hipStream_t stream);
+                             void* partials, hipStream_t stream, const ConvGemm* pending = nullptr);
 hipError_t launch_layer_norm(const float* x, float* y, const float* gamma, const float* beta,
-                             int rows, int c, float eps, hipStream_t stream);
+                             int rows, int c, float eps, hipStream_t stream, const ConvGemm* pending = nullptr);
+// the same normalisations with the result written as three bf16 planes (k_split3.hpp; y3 dense: (c / 32) * 192 bytes per pixel / row),
+// what the consuming k_gemm3p.hip launch reads.  c % 32 == 0.
+hipError_t launch_group_norm_planes(const float* x, void* y3, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
+                                    int n_group, float eps, bool silu, void* partials, hipStream_t stream, const ConvGemm* pending = nullptr);
+hipError_t launch_layer_norm_planes(const float* x, void* y3, const float* gamma, const float* beta, int rows, int c, float eps,
+                                    hipStream_t stream, const ConvGemm* pending = nullptr);
 
 // ---- elementwise / data movement ---------------------------------------------------
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, float scale, hipStream_t s);
 hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, hipStream_t s);
 hipError_t launch_concat_channels(const float* a, const float* b, float* dst, long long rows, int ca, int cb, hipStream_t s);
 hipError_t launch_geglu(const float* proj, float* out, long long rows, int hidden, hipStream_t s);
+hipError_t launch_geglu_planes(const float* proj, void* out3, long long rows, int hidden, hipStream_t s);   // out3: planes, hidden % 32 == 0
 hipError_t launch_silu(const float* x, float* y, long long n, hipStream_t s);
 hipError_t launch_nhwc_to_nchw_slice(const float* src, float* dst, int n, int c_src, int c_out, int h, int w, hipStream_t s);
 hipError_t launch_nchw3_to_nhwc4(const float* src, float* dst, int n, int h, int w, hipStream_t s);

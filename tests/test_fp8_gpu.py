@@ -133,34 +133,7 @@ def sd8():
     sd.close()
 
 
-class _MxResConvs:
-    """context manager: the oracle's ResBlock / ResnetBlock 3x3 convs take MXFP8 inputs and weights (what precision = 2 does)"""
-
-    def __enter__(self):
-        self.conv0 = O.conv2d
-        self.res0 = O.UNetOracle.res_block
-        state = {"in_res": 0}
-
-        def conv(x, wb, stride=1, padding=0):
-            w, b = wb
-            if state["in_res"] and w.shape[2] == 3 and stride == 1 and w.shape[1] % 32 == 0 and w.shape[0] % 8 == 0:
-                return self.conv0(MX.mx_quantize(x, 1), (MX.mx_quantize(w, 1), b), stride, padding)
-            return self.conv0(x, wb, stride, padding)
-
-        def res_block(obj, *a, **k):
-            state["in_res"] += 1
-            try:
-                return self.res0(obj, *a, **k)
-            finally:
-                state["in_res"] -= 1
-
-        O.conv2d = conv
-        O.UNetOracle.res_block = res_block
-        return self
-
-    def __exit__(self, *exc):
-        O.conv2d = self.conv0
-        O.UNetOracle.res_block = self.res0
+_MxResConvs = MX.MxResConvs
 
 
 def test_unet_forward_mxfp8(sd8):

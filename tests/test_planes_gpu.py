@@ -164,3 +164,134 @@ def test_linear_on_plane_tiles(sd_ops, rows, cin, cout):
         with _Forced(sd_ops, tile, 0):
             got = sd_ops.op_linear(x, wt, b)
         _check(got, ref, f"linear planes tile={tile} rows={rows} cin={cin} cout={cout}")
+
+
+# ---- model level: every producer writing planes (option gemm_planes = 1) -----------------------------------------------------------
+def _tiny_inputs(d, n, T):
+    from stable_diffusion_burn_amd import synthetic as syn
+    lat = np.stack([syn.initial_latent(i, d.latent_h, d.latent_w) for i in range(n)])
+    ctx = np.stack([syn.cond_context(i, T, d.ctx_dim) for i in range(n)])
+    return lat, ctx
+
+
+class _Planes:
+    def __init__(self, sd, on):
+        self.sd, self.on = sd, on
+
+    def __enter__(self):
+        self.sd.set_option("gemm_planes", self.on)
+        return self.sd
+
+    def __exit__(self, *a):
+        self.sd.set_option("gemm_planes", "default")
+
+
+@pytest.mark.parametrize("t", [999, 49])
+def test_unet_forward_with_producer_written_planes(sd_tiny, synth, tiny_dims, t):
+    """UNet::forward (unet/mod.rs:109-143) with GroupNorm / LayerNorm / GEGLU / attention / GEMM epilogues writing bf16 planes and every
+    eligible GEMM on k_gemm3p.hip: the model-level bar of tests/test_model_gpu.py, and agreement with the fp32-staged path to fp32 noise."""
+    from stable_diffusion_burn_amd import synthetic as syn
+    d = tiny_dims
+    lat, ctx = _tiny_inputs(d, 2, 7)
+    a = syn.alphas_cumprod()
+    o32 = O.StableDiffusionOracle(synth, a, d, torch.float32)
+    o64 = O.StableDiffusionOracle(synth, a, d, torch.float64)
+    with _Planes(sd_tiny, 0):
+        base = sd_tiny.unet.forward(lat, [t], ctx)
+    with _Planes(sd_tiny, 1):
+        got = sd_tiny.unet.forward(lat, [t], ctx)
+        again = sd_tiny.unet.forward(lat, [t], ctx)
+    r32 = o32.unet.forward(torch.from_numpy(lat), t, torch.from_numpy(ctx)).numpy()
+    r64 = o64.unet.forward(torch.from_numpy(lat), t, torch.from_numpy(ctx)).numpy()
+    e64 = np.abs(got.astype(np.float64) - r64).max()
+    e32 = np.abs(r32.astype(np.float64) - r64).max()
+    print(f"unet t={t} planes: |gpu-f64|={e64:.2e} |f32-f64|={e32:.2e} |planes - staged|={np.abs(got - base).max():.2e}")
+    assert np.isfinite(got).all() and e64 <= max(1e-4, 2 * e32)
+    assert np.array_equal(got, again)
+    assert np.abs(got - base).max() <= 2e-5 * max(1.0, np.abs(r64).max())
+
+
+def test_sample_image_with_producer_written_planes(sd_tiny, synth, tiny_dims):
+    """sample_image (stablediffusion/mod.rs:51-160): 3 DDIM steps + VAE decode with planes on -- latent within 1e-3 of the fp32 oracle, u8 image within 1 LSB"""
+    from stable_diffusion_burn_amd import synthetic as syn
+    d = tiny_dims
+    lat, ctx = _tiny_inputs(d, 1, 7)
+    unc = syn.uncond_context(2, d.ctx_dim)
+    ora = O.StableDiffusionOracle(synth, syn.alphas_cumprod(), d, torch.float32)
+    ref_lat = ora.sample_latent(torch.from_numpy(ctx), torch.from_numpy(unc), 7.5, 3, torch.from_numpy(lat)).numpy()
+    ref_img, _ = ora.latent_to_image(torch.from_numpy(ref_lat))
+    with _Planes(sd_tiny, 1):
+        got_lat = sd_tiny.sample_latent(ctx, unc, 7.5, 3, init_latent=lat)
+        got_img = sd_tiny.sample_image(ctx, unc, 7.5, 3, init_latent=lat)
+    dl = float(np.abs(got_lat - ref_lat).max())
+    di = int(np.abs(got_img.astype(np.int16) - np.asarray(ref_img).astype(np.int16)).max())
+    print(f"planes: max|latent - oracle| = {dl:.2e}; u8 max diff = {di}")
+    assert np.isfinite(got_lat).all() and dl < 1e-3
+    assert di <= 1
+
+
+# ---- operator level: the plane-writing producers are the fp32 producers, bit for bit -------------------------------------------------
+def test_plane_producers_equal_their_fp32_forms_bit_for_bit(sd_ops):
+    """GroupNorm(+SiLU) (groupnorm/mod.rs:53-82, silu.rs:14-16), LayerNorm (unet/mod.rs:523-525), the GEGLU gate (unet/mod.rs:579-591) and
+    qkv_attention (attention.rs:5-45) writing three bf16 planes instead of fp32: with option gemm_planes the operator-level entry points run
+    the plane-writing kernels and join the planes back (h + m + l, exact), so the results must EQUAL the fp32-writing kernels' -- a wrong
+    plane position, a dropped low plane or a mis-split value shows up as a difference."""
+    g = np.random.default_rng(4242)
+    x = (g.standard_normal((2, 320, 16, 16)) * np.exp2(g.integers(-6, 7, (1, 320, 1, 1)))).astype(np.float32)
+    gam, bet = g.standard_normal(320).astype(np.float32), g.standard_normal(320).astype(np.float32)
+    rows = (g.standard_normal((257, 640)) * 3 + 1).astype(np.float32)
+    lg, lb = g.standard_normal(640).astype(np.float32), g.standard_normal(640).astype(np.float32)
+    proj = g.standard_normal((100, 2 * 1280)).astype(np.float32)
+    q, k, v = (g.standard_normal((2, 300, 320)).astype(np.float32) for _ in range(3))
+    q160, k160, v160 = (g.standard_normal((1, 70, 640)).astype(np.float32) for _ in range(3))
+
+    def run():
+        return [sd_ops.op_group_norm(x, gam, bet, silu=True), sd_ops.op_group_norm(x, gam, bet, silu=False), sd_ops.op_layer_norm(rows, lg, lb),
+                sd_ops.op_geglu(proj), sd_ops.qkv_attention(q, k, v, None, 8), sd_ops.qkv_attention(q160, k160, v160, None, 4)]
+    with _Planes(sd_ops, 0):
+        base = run()
+    with _Planes(sd_ops, 1):
+        got = run()
+    for name, a, b in zip(["gn+silu", "gn", "layer_norm", "geglu", "attention d=40", "attention d=160"], base, got):
+        assert np.isfinite(b).all(), name
+        if name == "geglu":   # (the two gate kernels are compiled separately: hipcc contracts a * gelu(g) differently, one fp32 rounding apart)
+            assert np.abs(a - b).max() <= 2.0 ** -22 * np.abs(a).max(), f"geglu: {np.abs(a - b).max():.3e}"
+            continue
+        assert np.array_equal(a, b), f"{name}: plane-writing kernel differs from the fp32-writing one by {np.abs(a - b).max():.3e}"
+
+
+# ---- the split-K combine folded into the normalisation that reads the result (option fuse_reduce) -----------------------------------
+@pytest.mark.parametrize("planes", [0, 1])
+def test_split_k_combine_inside_group_norm_and_layer_norm(sd_tiny, synth, tiny_dims, planes):
+    """A split-K GEMM whose result goes straight into GroupNorm (ResBlock conv_in -> norm_out, unet/mod.rs:716-729) or LayerNorm
+    (proj_in / attention out-projections -> TransformerBlock norms, unet/mod.rs:522-526) leaves its slabs to that kernel's statistics /
+    row pass: fewer launches, the same network.  Checked against the oracle at the model-level bar and against the stand-alone reduce
+    kernel (a different but fixed summation order: fp32 rounding noise apart), and bit-reproducible."""
+    from stable_diffusion_burn_amd import synthetic as syn
+    d = tiny_dims
+    lat, ctx = _tiny_inputs(d, 2, 7)
+    a = syn.alphas_cumprod()
+    o64 = O.StableDiffusionOracle(synth, a, d, torch.float64)
+    o32 = O.StableDiffusionOracle(synth, a, d, torch.float32)
+    try:
+        sd_tiny.set_option("gemm_planes", planes)
+        sd_tiny.set_option("splitk", 3)                 # make sure the GEMMs in front of the norms are split
+        sd_tiny.set_option("fuse_reduce", 0)
+        base = sd_tiny.unet.forward(lat, [500], ctx)
+        k0 = sd_tiny.last_call_stats()["kernels"]
+        sd_tiny.set_option("fuse_reduce", 1)
+        got = sd_tiny.unet.forward(lat, [500], ctx)
+        k1 = sd_tiny.last_call_stats()["kernels"]
+        again = sd_tiny.unet.forward(lat, [500], ctx)
+    finally:
+        sd_tiny.set_option("fuse_reduce", 1)
+        sd_tiny.set_option("splitk", 0)
+        sd_tiny.set_option("gemm_planes", "default")
+    r64 = o64.unet.forward(torch.from_numpy(lat), 500, torch.from_numpy(ctx)).numpy()
+    r32 = o32.unet.forward(torch.from_numpy(lat), 500, torch.from_numpy(ctx)).numpy()
+    e64, e32 = np.abs(got.astype(np.float64) - r64).max(), np.abs(r32.astype(np.float64) - r64).max()
+    print(f"fused reduce (planes={planes}): {k0} -> {k1} kernels per forward; |gpu-f64|={e64:.2e} |f32-f64|={e32:.2e} |fused - separate|={np.abs(got - base).max():.2e}")
+    assert k1 < k0 - 20, "the fused path did not run"
+    assert np.isfinite(got).all() and e64 <= max(1e-4, 2 * e32)
+    assert np.array_equal(got, again)
+    assert np.abs(got - base).max() <= 2e-5 * max(1.0, np.abs(r64).max())
