@@ -63,7 +63,13 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the bf16 configs[2] / configs[3]-shard measurements after the headline")
     ap.add_argument("--tune-file", default=str(ROOT / "stable_diffusion_burn_amd" / "tuning" / "gfx950_fp32.txt"))
-    return ap.parse_args()
+    ap.add_argument("--config", type=int, choices=[1, 2, 3, 4], default=None,
+                    help="preset = BASELINE.json configs[i]: 1 fp32 B=1 S=20 (the default headline); 2 bf16 B=16 S=50; 3 bf16 B=8 per GPU S=20 "
+                         "(64 images over 8 GPUs); 4 fp8 B=16 per GPU S=20 (128 images over 8 GPUs).  Sets --precision / --batch-per-gpu / --ddim-steps.")
+    a = ap.parse_args()
+    if a.config is not None:
+        a.precision, a.batch_per_gpu, a.ddim_steps = {1: ("fp32", 1, 20), 2: ("bf16", 16, 50), 3: ("bf16", 8, 20), 4: ("fp8", 16, 20)}[a.config]
+    return a
 
 
 def cpu_baseline(weights, ddim_steps: int) -> dict:
@@ -161,20 +167,24 @@ class Runner:
                 BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if split else FP32_MFMA_PEAK_TFLOPS)
         kname = ("conv_gemm_fp8x_kernel (implicit-GEMM 3x3 conv of the ResBlocks, v_mfma_scale_f32_16x16x128_f8f6f4, MXFP8)" if self.fp8 else
                  "conv_gemm_bf16x_kernel + conv_gemm_bf16_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x32_bf16)" if self.bf16 else
-                 "conv_gemm3x_kernel (implicit-GEMM conv/linear in fp32: operands split exactly into 3 bf16 terms, 6 partial products "
-                 "per multiply on v_mfma_f32_16x16x32_bf16, fp32 accumulation)" if split else
+                 "conv_gemm3p_kernel / conv_gemm3x_kernel (implicit-GEMM conv/linear in fp32: operands split exactly into 3 bf16 terms -- the weights at "
+                 "load, the activations by their producers (planes) or in the k loop --, 6 partial products per multiply on v_mfma_f32_16x16x32_bf16, fp32 accumulation)" if split else
                  "conv_gemm2_kernel + conv_gemm2x_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x4_f32)")
-        traffic, source = None, None
+        # HBM-side bytes per launch: PMC counters cannot be collected inside this process, so `traffic` (= measured in THIS run) is null and
+        # the figure of the committed rocprofv3 --pmc passes of the same command is reported under its own name
+        from_profiles = None
         pmc = ROOT / "profiles" / "pmc_summary.json"
         if pmc.exists() and not self.bf16 and self.B == 1:
             try:
                 j = json.loads(pmc.read_text())
-                traffic = j.get("conv_gemm_split_hbm_bytes_per_launch" if split else "conv_gemm_hbm_bytes_per_launch")
-                source = f"profiles/pmc_summary.json ({j.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command')}); NOT measured in this run"
+                t = j.get("conv_gemm_split_hbm_bytes_per_launch" if split else "conv_gemm_hbm_bytes_per_launch")
+                if t:
+                    from_profiles = {"hbm_bytes_per_launch": t, "source": "profiles/pmc_summary.json (" + j.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command") + ")"}
             except Exception:  # noqa: BLE001
-                traffic = None
+                from_profiles = None
         roof = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak, "traffic": traffic, "traffic_source": source,
+                "frac": achieved / peak, "traffic": None, "traffic_from_profiles": from_profiles,
+                "event_pair_overhead_us_subtracted": sd.profile_overhead_us(),
                 "launches_per_image": g["launches"] / self.B, "avg_launch_us": g["ms"] * 1e3 / g["launches"],
                 "flop_per_launch": g["flops"] / g["launches"],
                 "share_of_gpu_time": g["ms"] / max(1e-9, sum(v["ms"] for v in prof.values()))}
@@ -306,6 +316,7 @@ def main():
                      "dtype": "f32" if prec2 == "fp32" else "bf16" if prec2 == "bf16" else "fp8(e4m3, MX)+bf16", "value": v2, "unit": "images/sec", "steps": k2, "warmup": 1, "ms_per_step": e2 / k2 * 1e3,
                      "algorithmic_tflop_per_image": fpi / 1e12, "whole_path_tflops_per_gpu": v2 * fpi / 1e12,
                      "whole_path_frac_of_bf16_mfma_peak": v2 * fpi / 1e12 / BF16_MFMA_PEAK_TFLOPS, "roofline": roof2,
+                     "kernels_per_image": r2.sd.last_call_stats()["kernels"] / b2,
                      "weights_load_s": r2.t_load}
             if prec2 == "fp32":
                 entry["config"]["workload"] += "; every GEMM and attention on v_mfma_f32_16x16x4_f32 (options gemm_f32s=0, attn_split=0)"
@@ -322,7 +333,10 @@ def main():
         images = args.steps * B * world
         value = images / elapsed
         flop_per_image = 2 * args.ddim_steps * F_UNET + F_VAE
-        peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+        # the bound that applies to the path as it runs: precision 0 multiplies on the bf16 pipe with six matrix instructions per fp32 block
+        # (unless the split kernels are switched off), so its matrix bound is 2500 / 6, not the fp32 instruction's 157.3
+        split_on = (not bf16) and not any(o.replace(" ", "") in ("gemm_f32s=0",) for o in args.opt)
+        peak = BF16_MFMA_PEAK_TFLOPS if bf16 else (BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if split_on else FP32_MFMA_PEAK_TFLOPS)
         out = {
             "metric": f"images/sec @512x512, {args.ddim_steps}-step DDIM CFG={args.scale:g}, SD v1.4",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -335,7 +349,10 @@ def main():
                        "output": "u8 RGB copied to pinned host memory inside the timed region"},
             "algorithmic_tflop_per_image": flop_per_image / 1e12,
             "whole_path_tflops_per_gpu": value / world * flop_per_image / 1e12,
-            "whole_path_frac_of_mfma_peak": value / world * flop_per_image / 1e12 / peak,
+            "whole_path_frac_of_applicable_mfma_peak": value / world * flop_per_image / 1e12 / peak,
+            "applicable_mfma_peak_tflops": peak,
+            "applicable_mfma_peak_note": ("dense bf16 MFMA peak" if bf16 else f"dense bf16 MFMA peak / {SPLIT_PRODUCTS} (fp32 operands as three bf16 terms, six partial products)" if split_on
+                                          else "fp32 matrix instruction peak"),
             "kernels_per_image": stats["kernels"] / B, "weights_load_s": t_load, "weights_generate_s": t_gen,
             "roofline": roofline, "cpu_baseline": cpu,
         }

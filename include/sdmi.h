@@ -250,6 +250,12 @@ int sdmi_shard_range(int32_t n_images, int32_t rank, int32_t n_ranks, int32_t* b
 int sdmi_plan_xcd_map(int32_t mt, int32_t nt, int32_t splits, double a_bytes, double w_bytes, double flops, double cu_flops, int32_t out[5]);
 /* number of RCCL broadcasts issued so far (one per sdmi_sample_image_sharded call) */
 int64_t sdmi_multi_broadcast_count(sdmi_multi* m);
+/* Diagnostic, needs no device: drives the multi-context's rank runner (one host thread per rank, csrc/multi_ranks.hpp) with n_ranks
+ * ranks of which `failing_rank` throws (none if out of range).  Returns SDMI_OK when nothing failed; otherwise the failing rank's status
+ * with "rank <r>: injected failure" as the last error -- after verifying that every healthy rank ran to completion and that the
+ * drain hook (MultiEngine: synchronise every device's stream) ran exactly once before the error surfaced.  The reference has no
+ * multi-device path (src/bin/sample/main.rs:104-109 runs one backend); this pins the error contract of sdmi_sample_image_sharded. */
+int sdmi_selftest_rank_errors(int32_t n_ranks, int32_t failing_rank);
 
 /* ---- operator-level entry points (parity tests, profiling) -------------------
  * Same math as the Burn primitives / reference modules named; host pointers
@@ -302,9 +308,14 @@ int sdmi_last_call_stats(sdmi_ctx* ctx, double* gpu_ms, int64_t* n_kernels, doub
  * launch on the context stream.  cls: 0 conv_gemm (implicit-GEMM conv/linear), 1 splitk_reduce,
  * 2 attention, 3 group_norm(+silu), 4 layer_norm, 5 conv_gemm_fp8 (the MXFP8 convs of precision = 2),
  * 6 conv_gemm_split (precision = 0: the conv/linear launches that run on the bf16 matrix pipe with three-way split fp32
- * operands, k_gemm3x.hip; class 0 then holds the launches left on the fp32 matrix instruction).  flops / bytes are the ALGORITHMIC work of
+ * operands, k_gemm3x.hip / k_gemm3p.hip; class 0 then holds the launches left on the fp32 matrix instruction), 7 split_rows (fp32 tensors
+ * converted to bf16 planes for a plane GEMM outside their producer), 8 other.  flops / bytes are the ALGORITHMIC work of
  * those launches (2*M*N*K; one read + one write of the tensor).  "profile_reset" clears. */
 int sdmi_profile_stats(sdmi_ctx* ctx, int32_t cls, double* ms, int64_t* launches, double* flops, double* bytes);
+/* What an empty HIP-event pair reads on the context stream (ms): calibrated when "profile" is switched on and already subtracted from
+ * every sample of sdmi_profile_stats, so that the classes add up to kernel time and not to kernel time + two event records per launch.
+ * (No reference counterpart: the reference has no profiler; bench.py reports it next to the roofline block.) */
+int sdmi_profile_overhead(sdmi_ctx* ctx, double* ms);
 /* micro-benchmark one implicit-GEMM conv shape on device-resident synthetic
  * data: returns average kernel ms over `iters` launches (HIP events). */
 int sdmi_bench_conv(sdmi_ctx* ctx, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,

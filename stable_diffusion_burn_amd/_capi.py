@@ -81,6 +81,7 @@ SIGNATURES = {
     "sdmi_shard_range": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _I32, _I32]),
     "sdmi_plan_xcd_map": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, _I32]),
     "sdmi_multi_broadcast_count": (C.c_int64, [C.c_void_p]),
+    "sdmi_selftest_rank_errors": (C.c_int, [C.c_int32, C.c_int32]),
     "sdmi_op_group_norm": (C.c_int, [_CTX, _F, _F, _F, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _F]),
     "sdmi_op_group_norm_fp8": (C.c_int, [_CTX, _F, _F, _F, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _F]),
     "sdmi_op_layer_norm": (C.c_int, [_CTX, _F, _F, _F, C.c_int32, C.c_int32, C.c_float, _F]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "sdmi_set_option": (C.c_int, [_CTX, C.c_char_p, C.c_char_p]),
     "sdmi_last_call_stats": (C.c_int, [_CTX, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "sdmi_profile_stats": (C.c_int, [_CTX, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "sdmi_profile_overhead": (C.c_int, [_CTX, C.POINTER(C.c_double)]),
     "sdmi_bench_conv": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "sdmi_bench_attention": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
 }

@@ -114,12 +114,33 @@ Engine::ProfScope::~ProfScope() {
     }
 }
 
+// What an (a, b) event pair reads with NOTHING between its two records: the pair's own cost on the stream, which would otherwise be
+// booked as kernel time on every launch (round 2: the classes summed to 7 % more than the step).  Median of 64 empty pairs, taken with the
+// stream otherwise idle when profiling is switched on, and subtracted from every sample.
+void Engine::prof_calibrate() {
+    SDMI_HIP(hipStreamSynchronize(stream_));
+    std::vector<float> t;
+    for (int i = 0; i < 64; ++i) {
+        hipEvent_t a = prof_event(), b = prof_event();
+        SDMI_HIP(hipEventRecord(a, stream_));
+        SDMI_HIP(hipEventRecord(b, stream_));
+        SDMI_HIP(hipEventSynchronize(b));
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, a, b) == hipSuccess) t.push_back(ms);
+        prof_free_.push_back(a);
+        prof_free_.push_back(b);
+    }
+    std::sort(t.begin(), t.end());
+    prof_overhead_ms_ = t.empty() ? 0.0 : (double)t[t.size() / 2];
+}
+
 void Engine::prof_flush() {
     if (prof_pending_.empty()) return;
     SDMI_HIP(hipStreamSynchronize(stream_));
     for (auto& p : prof_pending_) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ms = (float)std::max(0.0, (double)ms - prof_overhead_ms_);
             prof_[p.cls].ms += ms;
             prof_[p.cls].launches += 1;
             prof_[p.cls].flops += p.flops;
@@ -193,9 +214,6 @@ Engine::Engine(const sdmi_config& cfg) : cfg_(cfg) {
     SDMI_HIP(hipMalloc(&zero_page_, 256));
     weight_allocs_.push_back(zero_page_);
     SDMI_HIP(hipMemsetAsync(zero_page_, 0, 256, stream_));
-    SDMI_HIP(hipMalloc((void**)&splitk_counters_, kSplitkCounters * sizeof(unsigned)));
-    weight_allocs_.push_back(splitk_counters_);
-    SDMI_HIP(hipMemsetAsync(splitk_counters_, 0, kSplitkCounters * sizeof(unsigned), stream_));
     SDMI_HIP(hipStreamSynchronize(stream_));
     {   // measured per-shape tile choices (tools/autotune.py -> tuning/gfx950_fp32.txt)
         struct Row { const char* key; int cfg; int splits; };
@@ -929,7 +947,6 @@ void Engine::sync() { SDMI_HIP(hipStreamSynchronize(stream_)); }
 void Engine::begin_call(bool dev_inputs) {
     SDMI_HIP(hipSetDevice(cfg_.device));
     n_kernels_ = 0; flops_ = 0;
-    defer_next_ = false;
     call_mark_ = pool_.serial();
     call_dev_ = dev_inputs;
     if (dev_inputs) {
@@ -945,7 +962,6 @@ void Engine::begin_call(bool dev_inputs) {
     SDMI_HIP(hipEventRecord(ev0_, stream_));
 }
 void Engine::end_call() {
-    flush_pending();
     SDMI_HIP(hipEventRecord(ev1_, stream_));
     if (call_dev_ && has_user_stream_) SDMI_HIP(hipStreamWaitEvent(user_stream_, ev1_, 0));  // later work on the caller's stream sees the outputs
     SDMI_HIP(hipEventSynchronize(ev1_));
@@ -957,11 +973,8 @@ void Engine::abort_call() noexcept {
     // a throw inside a forward pass leaves raw activations and the per-call UNet tables allocated: wait for what was
     // enqueued, then hand every block this call took back to the pool
     (void)hipStreamSynchronize(stream_);
-    if (splitk_counters_) (void)hipMemset(splitk_counters_, 0, kSplitkCounters * sizeof(unsigned));   // a failed launch may have left arrivals behind
     try {
         us_ = UNetState{};
-        pend_.reset();
-        defer_next_ = false;
         pool_.free_since(call_mark_);
     } catch (...) {}
 }
@@ -969,7 +982,6 @@ void Engine::abort_call() noexcept {
 void Engine::set_option(const std::string& key, const std::string& value) {
     if (key == "gemm_tile") opt_force_tile_ = (value == "auto") ? -1 : std::stoi(value);
     else if (key == "splitk") opt_force_splits_ = std::stoi(value);
-    else if (key == "splitk_fused") opt_splitk_fused_ = std::stoi(value);
     else if (key == "roctx") roctx_enable(std::stoi(value) != 0);
     else if (key == "fp8_convs") opt_fp8_convs_ = std::stoi(value);
     else if (key == "fp8_min_rows") opt_fp8_min_rows_ = std::stoi(value);
@@ -977,12 +989,10 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "attn_bf16") opt_attn_bf16_ = std::stoi(value);
     else if (key == "attn_split") opt_attn_split_ = std::stoi(value);
     else if (key == "gemm_bf16x") opt_gemm_bf16x_ = std::stoi(value);
-    else if (key == "gemm_bf16x_variant") opt_gemm_bf16x_variant_ = std::stoi(value);
     else if (key == "xcd_map") opt_xcd_map_ = std::stoi(value);
     else if (key == "gemm_x32") opt_gemm_x32_ = std::stoi(value);
     else if (key == "gemm_f32s") opt_gemm_f32s_ = std::stoi(value);
     else if (key == "bench_cold") opt_bench_cold_ = std::stoi(value);
-    else if (key == "fuse_reduce") opt_fuse_reduce_ = std::stoi(value);
     else if (key == "gemm_planes") opt_gemm_planes_ = (value == "default") ? kGemmPlanesDefault : std::stoi(value);
     else if (key == "gemm3x_variant") opt_gemm3x_variant_ = std::stoi(value);
     else if (key == "geglu_fuse") opt_geglu_fuse_ = std::stoi(value);
@@ -997,7 +1007,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
         if (!f) throw Error(SDMI_ERR_IO, "dump_choices: cannot write " + value);
         for (auto& kv : choice_counts_) f << kv.first << " x" << kv.second << "\n";
     }
-    else if (key == "profile") { prof_flush(); profiling_ = std::stoi(value) != 0; }
+    else if (key == "profile") { prof_flush(); profiling_ = std::stoi(value) != 0; if (profiling_) prof_calibrate(); }
     else if (key == "profile_reset") prof_reset();
     else if (key == "tune" || key == "tune_bf16") {
         // "M,N,K=cfg,splits" (tune_bf16: cfg 100 + x selects a k_gemm_bf16x.hip tile)
@@ -1114,13 +1124,13 @@ TileChoice Engine::choose_tile_bf16(int M, int N, int kt_total) const {
 // k_gemm3p.hip tiles (300 + x): what a GEMM whose activations arrive as planes chooses from when its shape is not in the measured table
 // (tuning/gfx950_fp32_planes.txt).  Same cost form as choose_tile's split branch; efficiencies from tools/autotune.py --families p.
 TileChoice Engine::choose_tile_p(int M, int N, int kt_total, bool even_ni_only) const {
-    static const double eff_p[kNumGemmTilesP] = {0.62, 0.60, 0.60, 0.52, 0.50};
+    static const double eff_p[kNumGemmTilesP] = {0.62, 0.60, 0.60, 0.52, 0.50, 0.34, 0.40, 0.50, 0.40};
     static const int split_opts[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
     const int n_cu = 256;
     double best = 1e300;
     TileChoice bc{304, 1};
     for (int c = 0; c < kNumGemmTilesP; ++c) {
-        if (even_ni_only && (c == 0 || c == 3)) continue;
+        if (even_ni_only && (c == 0 || c == 3 || c == 7)) continue;
         const int bm = gemm_tile_info_p(c).bm, bn = gemm_tile_info_p(c).bn;
         const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
         for (int s : split_opts) {
@@ -1151,24 +1161,7 @@ void Engine::choose_xcd_map(ConvGemm& p, int MT, int NT, double a_bytes, double 
     p.xcd_m = o[0]; p.xcd_n = o[1]; p.xcd_ml = o[2]; p.xcd_nl = o[3]; p.xcd_zl = o[4];
 }
 
-void Engine::flush_pending() {
-    if (!pend_) return;
-    ProfScope ps(this, PC_SPLITK_REDUCE, 0, (double)(pend_->p.splits + 1) * pend_->p.slab_stride * 4.0);
-    SDMI_HIP(launch_splitk_reduce(pend_->p, stream_));
-    count_kernel();
-    pend_.reset();
-}
-// the pending split-K result, if it is exactly the tensor x [rows][c] (row stride ld) a normalisation is about to read
-const ConvGemm* Engine::pending_for(const float* x, long long rows, int c, int ld) const {
-    if (!pend_) return nullptr;
-    const ConvGemm& q = pend_->p;
-    return (q.C == x && q.M == rows && q.N == c && q.ldc == ld && q.resid != q.C) ? &q : nullptr;   // (in-place residuals only through the row-wise LayerNorm form)
-}
-
 void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits) {
-    const bool defer = defer_next_;
-    defer_next_ = false;
-    flush_pending();
     const int kt_elems = in_dt ? 64 : 32;  // a k tile is 128 bytes of K per row in both storage types
     p.kt_total = (p.K + kt_elems - 1) / kt_elems;
     if (in_dt && (p.Cin % 64)) throw Error(SDMI_ERR_UNSUPPORTED, "bf16 GEMM: K slices must be multiples of 64");
@@ -1188,7 +1181,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     auto it = table.find(key);
     const bool x32_ok = !in_dt && p.CS == 32 && p.Cin % 32 == 0 && p.out_mode == 0;   // what k_gemm2x.hip handles
     p.Bt3 = in_dt ? nullptr : split_planes(p.Bt);
-    p.variant = in_dt ? opt_gemm_bf16x_variant_ : opt_gemm3x_variant_;
+    p.variant = in_dt ? 0 : opt_gemm3x_variant_;
     // k_gemm3x.hip: the same layers, when the weight has its bf16 planes (weights in the arenas; not e.g. the K / V operands of
     // the unfused VAE attention) and the 32-bit piece offsets reach
     const bool s_ok = x32_ok && p.Bt3 && (unsigned long long)p.N * (p.geglu ? 2 : 1) * (unsigned long long)p.kt_total * 192ull < 0xFFFFFF00ull;
@@ -1204,7 +1197,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     if (from_planes) {
         const auto itp = tuned_p_.find(key);
         const bool even = p.geglu != 0;
-        if (itp != tuned_p_.end() && !(even && (itp->second.cfg == 300 || itp->second.cfg == 303))) tc = itp->second;
+        if (itp != tuned_p_.end() && !(even && (itp->second.cfg == 300 || itp->second.cfg == 303 || itp->second.cfg == 307))) tc = itp->second;
         else tc = choose_tile_p(p.M, p.N, p.kt_total, even);
     }
     else if (it != table.end() && usable(it->second.cfg)) tc = it->second;
@@ -1218,7 +1211,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     if (!in_dt && !from_planes && p_ok && opt_gemm_planes_ == 2 && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS) {
         static const int kSplitToP[kNumGemmTilesS] = {300, 303, 301, 302, 303, 304};
         const int c = kSplitToP[tc.cfg - 200];
-        if (!p.geglu || c == 301 || c == 302 || c == 304) tc.cfg = c;
+        if (!p.geglu || c == 301 || c == 302 || c == 304) tc.cfg = c;   // (even fragment counts only for the GEGLU epilogue)
     }
     if (from_planes && tc.cfg < 300) throw Error(SDMI_ERR_STATE, "gemm: activation planes need a plane tile (300 + x)");
     if (record_shapes_) {   // which kernel / tile / split-K each (M, N, K) got: option dump_choices
@@ -1288,8 +1281,6 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         return launch_conv_gemm2(q, tc.cfg, stream_);
     };
     p.slabs = nullptr;
-    p.counters = nullptr;
-    p.slab_wt = 0;
     const int pc = (!in_dt && tc.cfg >= 200) ? PC_CONV_SPLIT : PC_CONV_GEMM;   // k_gemm3x.hip launches are timed as their own class
     if (splits == 1) {
         p.slab_stride = 0;
@@ -1300,30 +1291,12 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         p.slab_stride = (long long)p.M * p.N;
         Buf slab(this, (size_t)splits * p.slab_stride * sizeof(float));
         p.slabs = slab.f();
-        // combine inside the launch (k_common.hpp) when the 16-byte epilogue applies and the tile count fits the counter array
-        const GemmTileInfo& ti = tile_info(tc.cfg);
-        const int bm = ti.bm, bn = ti.bn;
-        const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-        const bool vec = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (!p.resid || p.ldr % 4 == 0);
-        const bool slab_ok = (unsigned long long)p.slab_stride * 4ull < 0xFFFFFFE0ull;   // write-through stores go through a 32-bit buffer descriptor
-        if (opt_splitk_fused_ && vec && tiles <= kSplitkCounters && (opt_splitk_fused_ != 2 || slab_ok) && !p.C3 && p.C) {
-            p.counters = splitk_counters_;
-            p.slab_wt = opt_splitk_fused_ == 2 ? 1 : 0;
-        }
         {
             ProfScope ps(this, pc, flops);
             SDMI_HIP(launch(p));
         }
         count_kernel(flops);
-        if (!p.counters) {
-            const bool vec16 = (p.N % 4 == 0) && p.C && (p.ldc % 4 == 0) && (!p.resid || p.ldr % 4 == 0);
-            if (defer && !in_dt && vec16 && (!c3_want || c3_native) && !c_tmp) {
-                // the caller's next op normalises this tensor: it combines the slabs itself (pending_for / k_norm.hip)
-                pend_.reset(new PendingReduce{p, nullptr});
-                pend_->slabs.reset(new Buf(this, 16));
-                std::swap(pend_->slabs->p, slab.p);       // the slabs live on until the consumer (or flush_pending) is done with them
-                return;
-            }
+        {
             ProfScope ps(this, PC_SPLITK_REDUCE, 0, (double)(splits + 1) * p.slab_stride * 4.0);
             if (in_dt) SDMI_HIP(launch_splitk_reduce_bf16(p, stream_));
             else SDMI_HIP(launch_splitk_reduce(p, stream_));
@@ -1439,32 +1412,24 @@ void Engine::group_norm(const NormW& w, const Act& x, Act& y, bool silu) {
     ProfScope ps(this, PC_GROUP_NORM, 0, 2.0 * (double)x.bytes());  // algorithmic: one read + one write
     if (y.view) throw Error(SDMI_ERR_STATE, "group_norm: output must be dense");
     if (!x.p) throw Error(SDMI_ERR_STATE, "group_norm: the input must exist as fp32");
-    // x may be a split-K result that nobody has combined yet: then the statistics pass does it (one kernel and one read of x less)
-    const ConvGemm* pq = x.dt ? nullptr : pending_for(x.p, x.rows(), x.c, x.stride());
-    if (!pq) flush_pending();
     if (y.p3 && !y.p) {   // the consumer is a plane GEMM: the normalised tensor is written as three bf16 planes only
         if (x.dt) throw Error(SDMI_ERR_STATE, "group_norm: planes are an fp32-engine format");
-        SDMI_HIP(launch_group_norm_planes(x.p, y.p3, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_, pq));
+        SDMI_HIP(launch_group_norm_planes(x.p, y.p3, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_));
     }
     else if (x.dt) SDMI_HIP(launch_group_norm_bf16(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_));
-    else SDMI_HIP(launch_group_norm(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_, pq));
+    else SDMI_HIP(launch_group_norm(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_));
     count_kernel(); count_kernel();
-    if (pq) pending_done();
 }
 
 void Engine::layer_norm(const NormW& w, const float* x, long long rows, float* y, int dt, void* y3) {
     if (dt < 0) dt = edt();
-    const ConvGemm* pq = nullptr;
-    if (!dt && pend_ && !pend_->p.rowvec && pend_->p.C == x && pend_->p.M == rows && pend_->p.N == w.c && pend_->p.ldc == w.c) pq = &pend_->p;   // x = a split-K result nobody has combined yet
-    if (!pq) flush_pending();
     ProfScope ps(this, PC_LAYER_NORM, 0, 2.0 * (double)rows * w.c * (dt ? 2.0 : 4.0));
     if (y3) {
         if (dt) throw Error(SDMI_ERR_STATE, "layer_norm: planes are an fp32-engine format");
-        SDMI_HIP(launch_layer_norm_planes(x, y3, w.gamma, w.beta, (int)rows, w.c, w.eps, stream_, pq));
+        SDMI_HIP(launch_layer_norm_planes(x, y3, w.gamma, w.beta, (int)rows, w.c, w.eps, stream_));
     } else if (dt) SDMI_HIP(launch_layer_norm_bf16(x, y, w.gamma, w.beta, (int)rows, w.c, w.eps, stream_));
-    else SDMI_HIP(launch_layer_norm(x, y, w.gamma, w.beta, (int)rows, w.c, w.eps, stream_, pq));
+    else SDMI_HIP(launch_layer_norm(x, y, w.gamma, w.beta, (int)rows, w.c, w.eps, stream_));
     count_kernel();
-    if (pq) pending_done();
 }
 
 // qkv_attention (attention.rs:5-45).  Head dims with a fused instance use the flash
@@ -1475,7 +1440,6 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
                        int nk, int n_head, int d_head, const int* kv_len_dev, const int* kv_len_host,
                        const float* mask, int mask_ld, int dt, void* o3) {
     if (dt < 0) dt = edt();
-    flush_pending();
     if (nq <= 0 || nk <= 0) throw Error(SDMI_ERR_INVALID, "attention: empty sequence");
     if (o3 && (dt || !attn_supported_head_dim(d_head) || (n_head * d_head) % 32)) throw Error(SDMI_ERR_STATE, "attention: plane output needs a fused fp32 kernel");
     const float scale = (float)std::pow((double)d_head, -0.25);
@@ -1549,7 +1513,6 @@ void Engine::res_block(const ResW& w, const Act& x, Act& y, int step) {
         // the normalised tensors have one consumer, a 3x3 convolution: on the fp32 engine they exist only as bf16 planes (k_gemm3p.hip)
         Act h1 = plane_gemm(x.c, w.cout) ? new_act3(x.n, x.h, x.w, x.c, 2) : new_act(x.n, x.h, x.w, x.c);
         group_norm(w.norm_in, x, h1, true);
-        if (!use_fp8(w.conv_out, h2)) defer_reduce();     // h2's next reader is GroupNorm(norm_out): it combines the split-K slabs itself
         conv(w.conv_in, h1, h2, 1, 0, rowvec, 0, nullptr);
         release(h1);
     }
@@ -1682,7 +1645,6 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
     Act g = pl ? new_act3(x.n, x.h, x.w, C, 2) : new_act(x.n, x.h, x.w, C);
     group_norm(w.norm, x, g, false);
     Act h = new_act(x.n, x.h, x.w, C);
-    defer_reduce();                 // h's next reader is LayerNorm 1
     conv(w.proj_in, g, h, 1, 0, nullptr, 0, nullptr);
     release(g);
     Act hp = pl ? new_act3(x.n, x.h, x.w, C, 2) : Act{};      // the hidden state after the MLP: read by proj_out only
@@ -1703,7 +1665,6 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
             attention(qkv.f(), 3 * C, bs3, adv(qkv.f(), C, edt()), 3 * C, bs3, adv(qkv.f(), 2 * C, edt()), 3 * C, bs3, af, C,
                       (long long)hw * C, nb, hw, hw, heads, d, nullptr, nullptr, nullptr, 0, -1, a3);
         }
-        defer_reduce();             // ... LayerNorm 2
         gemm(af, (int)M, w.attn1.out.bt, w.attn1.out.bias, C, C, h.p, C, h.p, C, -1, 0, a3);
         // cross attention against the hoisted K/V of the text context
         layer_norm(w.ln2, h.p, M, lnf, -1, ln3);
@@ -1711,7 +1672,6 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
         const long long cbs = (long long)us_.t_max * C;
         attention(q.f(), C, (long long)hw * C, us_.kc.at(w.ctx_index), C, cbs, us_.vc.at(w.ctx_index), C, cbs, af,
                   C, (long long)hw * C, nb, hw, us_.t_max, heads, d, us_.kv_len_dev, us_.kv_len_host.data(), nullptr, 0, -1, a3);
-        defer_reduce();             // ... LayerNorm 3
         gemm(af, (int)M, w.attn2.out.bt, w.attn2.out.bias, C, C, h.p, C, h.p, C, -1, 0, a3);
         // GEGLU MLP
         layer_norm(w.ln3, h.p, M, lnf, -1, ln3);

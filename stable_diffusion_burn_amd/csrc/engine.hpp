@@ -265,17 +265,6 @@ private:
               const float* resid, int ldr, int dt = -1, int out_mode = 0, const void* A3 = nullptr, void* C3 = nullptr);
     // fp32 engine, option gemm_planes: does the GEMM cin -> cout take its activations as planes (k_gemm3p.hip)?
     bool plane_gemm(int cin, int cout) const { return !bf16_ && opt_gemm_planes_ != 0 && opt_gemm_f32s_ != 0 && cin % 32 == 0 && cout >= 32; }
-    // A split-K GEMM whose slabs are not combined yet (option fuse_reduce): launch_gemm leaves it here when its caller said the NEXT
-    // engine op is a GroupNorm / LayerNorm of the result; that op's statistics / row pass then combines the slabs itself (k_norm.hip),
-    // and every other op first runs the stand-alone reduce kernel (flush_pending) -- nothing ever reads an un-combined tensor.
-    struct PendingReduce { ConvGemm p; std::unique_ptr<Buf> slabs; };
-    std::unique_ptr<PendingReduce> pend_;
-    bool defer_next_ = false;          // set by defer_reduce() for exactly the next launch_gemm
-    int opt_fuse_reduce_ = 1;
-    void defer_reduce() { defer_next_ = opt_fuse_reduce_ != 0 && !bf16_; }
-    void flush_pending();
-    const ConvGemm* pending_for(const float* x, long long rows, int c, int ld) const;
-    void pending_done() { pend_.reset(); }
     void choose_xcd_map(ConvGemm& p, int MT, int NT, double a_bytes, double w_bytes, double flops, double cu_flops) const;
     void launch_gemm(ConvGemm& p, int in_dt, int force_cfg = -1, int force_splits = 0);
     int edt() const { return bf16_ ? 1 : 0; }
@@ -337,6 +326,8 @@ public:
     struct ProfStat { double ms = 0; long long launches = 0; double flops = 0; double bytes = 0; };
     ProfStat prof_[PC_COUNT];
     void prof_flush();
+    void prof_calibrate();
+    double prof_overhead_ms_ = 0;    // what an empty event pair reads (subtracted from every sample)
     void prof_reset() { prof_flush(); for (auto& p : prof_) p = ProfStat{}; }
 
 private:
@@ -419,22 +410,16 @@ private:
     int opt_gemm_f32s_ = 1;     // precision = 0: 1 = fp32 GEMMs on the bf16 matrix pipe (three-way operand split, k_gemm3x.hip) where faster
     int opt_gemm3x_variant_ = 2;     // bit 0: DMA in one block per k tile; bit 1: scalar residual subtractions (+0.7 %); bit 2: two LDS stages on the 128-row tiles (default three: +5..10 % on long K);
                                      // bit 4: s_setprio 1 for waves 4-7; bits 3 + 6 (74 with bit 1): the pipelined k loop with hand-counted LDS waits (k_gemm3x.hip HOIST = 3; measured: not faster)
-    static constexpr int kGemmPlanesDefault = 0;
+    static constexpr int kGemmPlanesDefault = 1;
     int opt_gemm_planes_ = kGemmPlanesDefault;   // precision = 0: k_gemm3p.hip (activations as bf16 planes too, no split in the k loop): 0 never, 1 every launch that would take a k_gemm3x.hip tile,
                                 // 2 only where the per-shape table says 300 + x
     int opt_bench_cold_ = 0;    // bench_conv: 1 = evict the weights from the Infinity Cache between timed launches (what a layer sees inside the model)
     int opt_gemm_x32_ = 1;      // precision = 0: 1 = large-tile LDS-DMA fp32 GEMM (k_gemm2x.hip) where measured / modelled faster
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
-    int opt_gemm_bf16x_variant_ = 0;   // k_gemm_bf16x.hip: 3 = pipelined k loop (DMA pieces and asm fragment reads with hand-counted waits behind the matrix instructions, barrier near the end of a tile; measured: not faster)
     int opt_xcd_map_ = 0;              // 1: cut every GEMM launch over the 8 XCDs so that the fewest operand bytes cross the fabric (choose_xcd_map); 0: bands of tiles, every XCD reads all weights
     void* zero_page_ = nullptr;
     TileChoice choose_tile_p(int M, int N, int kt_total, bool even_ni_only) const;   // k_gemm3p.hip tiles (300 + x)
     TileChoice choose_tile_bf16(int M, int N, int kt_total) const;   // cfg >= 100: k_gemm_bf16x.hip tile cfg - 100     // precision = 1: 1 = bf16 matrix-core attention, 0 = bf16 storage widened onto the fp32 kernel  // 1: attn2_kernel, 0: attn_f32_kernel
-    // split-K combine: 0 = separate reduce kernel (the measured best, profiles/README.md); 1 = inside the GEMM launch by the
-    // last-arriving k slice (plain slab stores + release fence); 2 = the same with write-through (sc1) slab stores
-    int opt_splitk_fused_ = 0;
-    static constexpr long long kSplitkCounters = 16384;
-    unsigned* splitk_counters_ = nullptr;
     std::map<std::string, TileChoice> tuned_;        // fp32 kernels: "M,N,K" -> (tile cfg, split-K)
     std::map<std::string, TileChoice> tuned_bf16_;   // bf16 kernels; cfg >= 100 = k_gemm_bf16x.hip tile
     std::map<std::string, TileChoice> tuned_p_;      // fp32 shapes whose activations arrive as planes: k_gemm3p.hip tiles (300 + x) only

@@ -121,128 +121,4 @@ __device__ __forceinline__ void gn_finalize(const double* __restrict__ part, int
 }
 
 
-// ---- split-K combined inside the launch ---------------------------------------------------------------------
-// Every k slice of an output tile stores its fp32 partial tile into its slab (plain stores), then calls
-// splitk_arrive(); the workgroup that arrives last at the tile's counter sums the slabs in slice order 0..S-1 (so
-// the result does not depend on which slice finished last: bit-reproducible) and applies the epilogue.  The
-// hand-off is the agent-scope release / acquire recipe of the CDNA guide (section 5, "In-launch split-K reduction"):
-// per-wave vmcnt(0) -> barrier -> one lane: release fence + vmcnt(0) + relaxed agent fetch_add; last arriver: one
-// acquire fence, barrier, plain loads.  No spin anywhere: nobody waits for another workgroup.  Counters are zero
-// between launches: the last arriver resets its counter (the engine zeroes the array once at creation).
-// write_through: the slab tile was stored with sc1 (write-through) stores, which are complete once vmcnt drains -- no
-// release fence, i.e. no write-back sweep of the XCD's whole L2 (buffer_wbl2) in every workgroup's tail.
-__device__ __forceinline__ bool splitk_arrive(unsigned* counters, int tile, int splits, unsigned* lds_flag, bool write_through) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (!write_through) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler may drop the wait behind buffer_wbl2 (guide, G16 pitfall 12)
-        }
-        const unsigned old = __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = old == (unsigned)(splits - 1);
-        if (last) {
-            __hip_atomic_store(counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        *lds_flag = last ? 1u : 0u;
-    }
-    __syncthreads();
-    return *lds_flag != 0u;
-}
-
-typedef float kc_f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int kc_u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int kc_u32x4 __attribute__((ext_vector_type(4)));
-
-// 16-byte store of a slab element: plain, or write-through (sc1: aux bit 4 of the raw buffer store) through a descriptor
-// over this k slice's slab.  byte_off < 4 GiB (slabs are M*N*4 bytes; the launch side checks).
-struct SlabStore {
-    __amdgpu_buffer_rsrc_t rsrc;
-    float* base;
-    bool wt;
-    __device__ __forceinline__ SlabStore(float* slab, long long elems, bool write_through)
-        : rsrc(__builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)(unsigned)(elems * 4), 0x00020000)), base(slab), wt(write_through) {}
-    __device__ __forceinline__ void store(long long elem_off, kc_f32x4 v) const {
-        if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(kc_u32x4, v), rsrc, (int)(unsigned)(elem_off * 4), 0, 16);
-        else *reinterpret_cast<kc_f32x4*>(base + elem_off) = v;
-    }
-};
-
-__device__ __forceinline__ unsigned kc_bf16_bits(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return u >> 16;
-}
-
-// The last arriver's job: C[m0.., n0..] = epilogue(sum over slices of slabs[s][m][n]) for one bm x bn tile.  Needs
-// N % 4 == 0, ldc % 4 == 0, ldr % 4 == 0 (the launch side falls back to the separate reduce kernel otherwise).
-// BF16: residual and (unless out_mode == 1) output are bf16.  16 independent 16-byte loads per thread are in
-// flight per pass: a dependent chain of cross-XCD loads would cost ~1-2 us per link.
-template <bool BF16>
-__device__ __forceinline__ void splitk_reduce_tile(const ConvGemm& p, int m0, int n0, int bm, int bn) {
-    const int rows = min(bm, p.M - m0), cols = min(bn, p.N - n0);
-    if (rows <= 0 || cols <= 0) return;
-    const int cpr = cols >> 2;
-    const int total = rows * cpr;
-    const int HoWo = p.Ho * p.Wo;
-    const bool out_f32 = !BF16 || p.out_mode == 1;
-    constexpr int U = 4;
-    for (int q0 = threadIdx.x; q0 < total; q0 += U * blockDim.x) {
-        long long off[U];
-        int mm[U], nn[U];
-        bool ok[U];
-        kc_f32x4 v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int q = q0 + u * blockDim.x;
-            ok[u] = q < total;
-            const int qq = ok[u] ? q : 0;
-            const int r = qq / cpr;
-            mm[u] = m0 + r;
-            nn[u] = n0 + ((qq - r * cpr) << 2);
-            off[u] = (long long)mm[u] * p.N + nn[u];
-            v[u] = *reinterpret_cast<const kc_f32x4*>(p.slabs + off[u]);
-        }
-        for (int s = 1; s < p.splits; s += 4) {
-            kc_f32x4 t[4][U];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int sj = min(s + j, p.splits - 1);   // past the end: a harmless re-read, not added
-#pragma unroll
-                for (int u = 0; u < U; ++u) t[j][u] = *reinterpret_cast<const kc_f32x4*>(p.slabs + (long long)sj * p.slab_stride + off[u]);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (s + j < p.splits) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) v[u] += t[j][u];
-                }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!ok[u]) continue;
-            kc_f32x4 r = v[u];
-            const int m = mm[u], n = nn[u];
-            if (p.bias) r += *reinterpret_cast<const kc_f32x4*>(p.bias + n);
-            if (p.rowvec) r += *reinterpret_cast<const kc_f32x4*>(p.rowvec + (long long)(m / HoWo) * p.rowvec_stride + n);
-            if (p.resid) {
-                if (BF16) {
-                    const kc_u32x2 h = *reinterpret_cast<const kc_u32x2*>(reinterpret_cast<const unsigned short*>(p.resid) + (long long)m * p.ldr + n);
-                    r[0] += __uint_as_float(h[0] << 16); r[1] += __uint_as_float(h[0] & 0xFFFF0000u);
-                    r[2] += __uint_as_float(h[1] << 16); r[3] += __uint_as_float(h[1] & 0xFFFF0000u);
-                } else {
-                    r += *reinterpret_cast<const kc_f32x4*>(p.resid + (long long)m * p.ldr + n);
-                }
-            }
-            if (out_f32) {
-                *reinterpret_cast<kc_f32x4*>(p.C + (long long)m * p.ldc + n) = r;
-            } else {
-                kc_u32x2 o = {kc_bf16_bits(r[0]) | (kc_bf16_bits(r[1]) << 16), kc_bf16_bits(r[2]) | (kc_bf16_bits(r[3]) << 16)};
-                *reinterpret_cast<kc_u32x2*>(reinterpret_cast<unsigned short*>(p.C) + (long long)m * p.ldc + n) = o;
-            }
-        }
-    }
-}
-
 }  // namespace sdmi

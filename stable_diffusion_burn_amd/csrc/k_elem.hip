@@ -272,6 +272,17 @@ hipError_t launch_geglu(const float* proj, float* out, long long rows, int hidde
     hipLaunchKernelGGL(geglu_kernel, dim3(blocks_for(total, 4096)), dim3(256), 0, s, proj, out, rows, hidden / 4);
     return hipGetLastError();
 }
+// dst[i][:] = src[:] for i < n (elems % 4 == 0): the prompt embedding replicated over the images of a shard (sample/main.rs:100-109)
+__global__ void repeat_rows_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int n, long long elems4) {
+    const long long total = elems4 * n;
+    GRID_STRIDE(i, total) dst[i] = src[i % elems4];
+}
+hipError_t launch_repeat_rows(const float* src, float* dst, int n, long long elems, hipStream_t s) {
+    if (elems & 3) return hipErrorInvalidValue;
+    if (n <= 0 || elems <= 0) return hipSuccess;
+    hipLaunchKernelGGL(repeat_rows_kernel, dim3(blocks_for(elems / 4 * n)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(src), reinterpret_cast<f32x4*>(dst), n, elems / 4);
+    return hipGetLastError();
+}
 hipError_t launch_silu(const float* x, float* y, long long n, hipStream_t s) {
     hipLaunchKernelGGL(silu_kernel, dim3(blocks_for(n)), dim3(256), 0, s, x, y, n);
     return hipGetLastError();

@@ -25,9 +25,9 @@
 //  * blockIdx -> tile map is XCD aware: blocks that land on one XCD (bid % 8)
 //    own a contiguous range of tiles (n fastest), so an XCD's L2 keeps its band
 //    of the activation and its neighbours' halo rows.
-//  * split-K over blockIdx.z writes raw fp32 slabs; the slice that arrives last at a tile sums them in fixed
-//    order (bit-reproducible) and applies the epilogue inside the launch (k_common.hpp); launch_splitk_reduce is
-//    the separate-kernel form of the same sum (option splitk_fused=0, odd strides).
+//  * split-K over blockIdx.z writes raw fp32 slabs; launch_splitk_reduce sums them in fixed order (bit-reproducible)
+//    and applies the epilogue -- or the GroupNorm / LayerNorm that reads the result does (k_norm.hip, SlabSrc).  An in-launch
+//    combine by the last-arriving slice was built in round 2, measured slower twice (profiles/r02*_splitk_*.json) and removed.
 #include "kernels.hpp"
 #include "k_split3.hpp"
 

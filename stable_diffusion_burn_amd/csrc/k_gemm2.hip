@@ -236,7 +236,6 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(const ConvGemm p) {
     float* Cbase = split ? (p.slabs + (long long)z * p.slab_stride) : p.C;
     const int ldc = split ? p.N : p.ldc;
     const bool vec_ok = ((p.N & 3) == 0) && ((ldc & 3) == 0);
-    const SlabStore slab(Cbase, split ? p.slab_stride : 0, split && p.counters && p.slab_wt);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + (wm * MI + mi) * 16 + c15;
@@ -262,7 +261,7 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(const ConvGemm p) {
                         Ch[r] = (unsigned short)(u >> 16);
                     }
                 } else if (split) {
-                    slab.store((long long)m * ldc + n, v);
+                    *reinterpret_cast<f32x4*>(Cbase + (long long)m * ldc + n) = v;     // (Cbase = this k slice's slab)
                 } else {
                     *reinterpret_cast<f32x4*>(Cbase + (long long)m * ldc + n) = v;
                 }
@@ -281,9 +280,6 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(const ConvGemm p) {
                 }
             }
         }
-    }
-    if (split && p.counters) {
-        if (splitk_arrive(p.counters, lid, p.splits, reinterpret_cast<unsigned*>(smem), p.slab_wt != 0)) splitk_reduce_tile<false>(p, m0, n0, BM, BN);
     }
 }
 

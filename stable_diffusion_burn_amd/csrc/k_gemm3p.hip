@@ -33,19 +33,21 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void global_cvoid;
 
 static const GemmTileInfo kTilesP[kNumGemmTilesP] = {
-    {256, 160, "256x160p"}, {256, 128, "256x128p"}, {128, 256, "128x256p"}, {128, 160, "128x160p"}, {128, 128, "128x128p"}};
+    {256, 160, "256x160p"}, {256, 128, "256x128p"}, {128, 256, "128x256p"}, {128, 160, "128x160p"}, {128, 128, "128x128p"},
+    {64, 64, "64x64p"}, {64, 128, "64x128p"}, {64, 320, "64x320p"}, {128, 64, "128x64p"}};
 const GemmTileInfo& gemm_tile_info_p(int cfg) { return kTilesP[cfg]; }
 
 // Per-wave state of the k loop; every array is indexed with compile-time constants (member templates) and lives in registers.  The
 // issue order of a k tile is spelled out and fenced with sched_barrier(0) as in k_gemm3x.hip: with LDS-DMA in flight every wait hipcc
 // inserts is lgkmcnt(0), so a plane read is issued NI matrix instructions or more ahead of its first use and never right in front of it.
-template <int MI, int NI, int NAG, int NBW, int A_BYTES>
+template <int MI, int NI, int NAG, int NBW, int A_BYTES, int NWV>
 struct P3Wave {
     static constexpr int NA = 3 * NAG;          // activation pieces per wave per k tile (NAG fragment groups x 3 planes)
     static constexpr int NP = NA + NBW;         // DMA instructions per wave per k tile
     static constexpr int NMF = 6 * NI;          // matrix instructions of one fragment row
     static constexpr int NAF = MI > 2 ? 3 : MI; // activation fragment buffers (row r uses buffer r % NAF)
     static_assert(MI == 2 || MI == 4, "fragment rows per wave");
+    static_assert(NI >= 2, "plane reads of a fragment take three instruction slots (behind())");
 
     f32x4 acc[MI][NI];
     u32x4 wf[3][NI];            // weight planes h, m, l of the wave's NI column fragments
@@ -74,11 +76,11 @@ struct P3Wave {
                 const unsigned off = a_off[jg] + (unsigned)((iy >> ups) * Ws + (ix >> ups)) * pix_bytes + (unsigned)cs * 192u;
                 a_src = (ok ? Abase : zero) + (ok ? off : 0u);
             }
-            __builtin_amdgcn_global_load_lds((global_cvoid*)(a_src + pl * 64), (lds_void*)(next_stage + ((wave + 8 * jg) * 3 + pl) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_cvoid*)(a_src + pl * 64), (lds_void*)(next_stage + ((wave + NWV * jg) * 3 + pl) * 1024), 16, 0, 0);
         } else {
             constexpr int j = J - NA;
             const char* src = Wbase + (w_off[j] + (unsigned)kt_next * 192u);
-            __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(next_stage + A_BYTES + (wave + 8 * j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(next_stage + A_BYTES + (wave + NWV * j) * 1024), 16, 0, 0);
         }
         if constexpr (J == NP - 1) {
             const bool adv = kt_next + 1 < kt_end;
@@ -106,7 +108,7 @@ struct P3Wave {
     // What is issued behind matrix instruction K of fragment row MIDX.
     //   row 0 reads the tile's operands just in time: before it the h plane of fragment 0 and the l weight planes (product 0 = wl ah);
     //   behind the NI instructions of product 0 the h weight planes + fragment 0's l (product 1 = wh al), behind those of product 1 the m
-    //   weight planes + fragment 0's m (product 2 = wm am), behind product 2 fragment 1, behind product 3 fragment 2;
+    //   weight planes + fragment 0's m (product 2 = wm am), behind the first instructions of product 2 fragment 1, then fragment 2;
     //   row r >= 1 reads fragment r + 2 into the buffer row r - 1 has just released;
     //   the next k tile's DMA instructions are spread over the slots of row 0's products 3..5 and of row 1.
     static constexpr int DMA_SLOTS = 3 * NI + NMF;
@@ -116,10 +118,11 @@ struct P3Wave {
         if constexpr (MIDX == 0) {
             if constexpr (pr == 0) { read_w<0, ni>(); if constexpr (ni == NI - 1) read_a<0, 2>(); }
             if constexpr (pr == 1) { read_w<1, ni>(); if constexpr (ni == NI - 1) read_a<0, 1>(); }
-            if constexpr (pr == 2 && ni < 3) read_a<1, ni>();
-            if constexpr (pr == 3 && ni < 3 && MI > 2) read_a<2, ni>();
+            // the three planes of fragment 1 behind instructions 2 NI .. 2 NI + 2, those of fragment 2 behind the next three (NI >= 2)
+            if constexpr (K >= 2 * NI && K < 2 * NI + 3) read_a<1, K - 2 * NI>();
+            if constexpr (MI > 2 && K >= 2 * NI + 3 && K < 2 * NI + 6) read_a<2, K - 2 * NI - 3>();
         } else if constexpr (MIDX + 2 < MI) {
-            if constexpr (pr == 0 && ni < 3) read_a<MIDX + 2, ni>();
+            if constexpr (K < 3) read_a<MIDX + 2, K>();
         }
         if constexpr (MIDX == 0 && pr >= 3) {
             constexpr int slot = K - 3 * NI;
@@ -158,18 +161,23 @@ struct P3Wave {
     }
 };
 
+// WM x WN = 8 waves: the large tiles (one workgroup per CU).  WM x WN = 4 waves: 64-row / 64-column tiles whose stages are 24-36 KB, so that
+// two or three workgroups share a CU and one's DMA prologue / epilogue hides behind the others' matrix work -- for the K = 320 ... 1280
+// linears of the transformer blocks, which as 128-row tiles needed split-K slabs + a reduce launch to fill the chip (round 2: 5 200
+// launches per image at < 20 % matrix-pipe use).
 template <int MI, int NI, int WM, int WN, int NSTG>
-__global__ __launch_bounds__(512) void conv_gemm3p_kernel(const ConvGemm p) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3p_kernel(const ConvGemm p) {
     static_assert(NSTG == 2 || NSTG == 3, "LDS stages");
     constexpr int BM = 16 * MI * WM;
     constexpr int BN = 16 * NI * WN;
-    static_assert(WM * WN == 8, "8 waves per workgroup");
-    static_assert(BM % 128 == 0, "every wave owns whole 16-row fragment groups of the activation tile");
-    constexpr int NAG = BM / 128;             // activation fragment groups (16 rows x 3 planes) per wave per k tile
+    constexpr int NWV = WM * WN;
+    static_assert(NWV == 8 || NWV == 4, "8 or 4 waves per workgroup");
+    static_assert(BM % (16 * NWV) == 0, "every wave owns whole 16-row fragment groups of the activation tile");
+    constexpr int NAG = BM / (16 * NWV);      // activation fragment groups (16 rows x 3 planes) per wave per k tile
     constexpr int PW = (BN / 16) * 3;         // weight pieces per k tile
-    constexpr int NBW = (PW + 7) / 8;         // ... per wave
+    constexpr int NBW = (PW + NWV - 1) / NWV; // ... per wave
     constexpr int A_BYTES = (BM / 16) * 3 * 1024;
-    constexpr int STAGE = A_BYTES + NBW * 8 * 1024;
+    constexpr int STAGE = A_BYTES + NBW * NWV * 1024;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_p3[];
 
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(512) void conv_gemm3p_kernel(const ConvGemm p) {
     const int T = p.KH * p.KW;
     const int HoWo = p.Ho * p.Wo;
 
-    P3Wave<MI, NI, NAG, NBW, A_BYTES> w;
+    P3Wave<MI, NI, NAG, NBW, A_BYTES, NWV> w;
     w.Hin = p.Hs << p.ups;
     w.Win = p.Ws << p.ups;
     w.ups = p.ups;
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(512) void conv_gemm3p_kernel(const ConvGemm p) {
     const int ch = (lane & 3) ^ ((-(r16 >> 2)) & 3);
 #pragma unroll
     for (int j = 0; j < NAG; ++j) {
-        const int m = m0 + (wave + 8 * j) * 16 + r16;
+        const int m = m0 + (wave + NWV * j) * 16 + r16;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
         const int nb = mm / HoWo;
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(512) void conv_gemm3p_kernel(const ConvGemm p) {
     const unsigned w_row_bytes = (unsigned)p.kt_total * 192u;
 #pragma unroll
     for (int j = 0; j < NBW; ++j) {
-        const int q = wave + 8 * j;
+        const int q = wave + NWV * j;
         const int f = q / 3, pl = q - 3 * f;
         int n = n0 + f * 16 + r16;
         long long wrow = n;
@@ -299,18 +307,21 @@ __global__ __launch_bounds__(512) void conv_gemm3p_kernel(const ConvGemm p) {
 template <int MI, int NI, int WM, int WN, int NSTG>
 static hipError_t launch_cfg_3p(const ConvGemm& p, dim3 grid, hipStream_t stream) {
     auto k = conv_gemm3p_kernel<MI, NI, WM, WN, NSTG>;
-    constexpr size_t lds = NSTG * ((size_t)(MI * WM) * 3 * 1024 + (size_t)((NI * WN * 3 + 7) / 8) * 8192);
+    constexpr int NWV = WM * WN;
+    constexpr size_t stage = (size_t)(MI * WM) * 3 * 1024 + (size_t)((NI * WN * 3 + NWV - 1) / NWV) * NWV * 1024;
+    // (the epilogue transposes through one 16 x (16 NI + 4) fp32 scratch per wave in the same memory)
+    constexpr size_t lds = NSTG * stage > (size_t)NWV * 16 * (16 * NI + 4) * 4 ? NSTG * stage : (size_t)NWV * 16 * (16 * NI + 4) * 4;
     static_assert(lds <= 160 * 1024, "the stages must fit the CU's LDS");
     hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, grid, dim3(512), lds, stream, p);
+    hipLaunchKernelGGL(k, grid, dim3(NWV * 64), lds, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_conv_gemm3p(const ConvGemm& p, int cfg, hipStream_t stream) {
     if (cfg < 0 || cfg >= kNumGemmTilesP) return hipErrorInvalidValue;
     if ((p.Cin % 32) || p.CS != 32 || !p.zero_page || !p.Bt3 || !p.A3 || p.a3_ld <= 0 || (p.a3_ld % 192) || p.out_mode != 0) return hipErrorInvalidValue;
-    const bool odd_ni = (cfg == 0 || cfg == 3);
+    const bool odd_ni = (cfg == 0 || cfg == 3 || cfg == 7);
     if (p.geglu && (odd_ni || p.splits != 1 || (p.N & 7) || (p.ldc & 7) || p.rowvec || p.resid)) return hipErrorInvalidValue;
     if ((unsigned long long)p.N * (p.geglu ? 2 : 1) * (unsigned long long)p.kt_total * 192ull >= 0xFFFFFF00ull) return hipErrorInvalidValue;   // 32-bit piece offsets
     if ((unsigned long long)p.NB * p.Hs * p.Ws * (unsigned long long)p.a3_ld >= 0xFFFFFF00ull) return hipErrorInvalidValue;
@@ -324,6 +335,11 @@ hipError_t launch_conv_gemm3p(const ConvGemm& p, int cfg, hipStream_t stream) {
         case 2: return launch_cfg_3p<4, 4, 2, 4, 2>(p, grid, stream);   // 128 x 256: 64 x 64
         case 3: return launch_cfg_3p<2, 5, 4, 2, 2>(p, grid, stream);   // 128 x 160: 32 x 80
         case 4: return launch_cfg_3p<2, 4, 4, 2, 3>(p, grid, stream);   // 128 x 128: 32 x 64, three stages
+        // four-wave tiles, two or three workgroups per CU
+        case 5: return launch_cfg_3p<2, 2, 2, 2, 3>(p, grid, stream);   // 64 x 64: waves of 32 x 32, 3 x 24 KB
+        case 6: return launch_cfg_3p<2, 4, 2, 2, 2>(p, grid, stream);   // 64 x 128: 32 x 64, 2 x 36 KB
+        case 7: return launch_cfg_3p<4, 5, 1, 4, 2>(p, grid, stream);   // 64 x 320: 64 x 80 (a whole N = 320 row per workgroup), 2 x 72 KB
+        case 8: return launch_cfg_3p<2, 4, 4, 1, 2>(p, grid, stream);   // 128 x 64: 32 x 64, 2 x 36 KB
     }
     return hipErrorInvalidValue;
 }

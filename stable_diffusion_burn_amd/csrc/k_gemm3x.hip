@@ -47,19 +47,15 @@ const GemmTileInfo& gemm_tile_info_s(int cfg) { return kTilesS[cfg]; }
 // registers; the issue order of one k tile is spelled out instruction group by instruction group and fenced with
 // sched_barrier(0), because (a) hipcc otherwise hoists all the splits in front of the MFMAs and (b) with LDS-DMA in flight its
 // own waits are all lgkmcnt(0), so a fragment read must be issued well before, and never right in front of, a first use.
-// HOIST = 3 (variant bits 3 + 6) is the pipelined form of the loop, described at tile3() below; HOIST = 0 the plain one (tile()).
-// (Two intermediate forms -- the tile head hoisted into the previous tile's last row with hipcc's own waits, with and without the
-// weight planes prefetched into dead registers -- were built, verified bit-identical and measured no faster in round 2, then
-// removed: profiles/r02y_ab_fp32_b1_hoisted_loops.jsonl, profiles/README.md.)
-template <int MI, int NI, int NA, int NBW, int PW, int A_BYTES, bool SPREAD, bool SCALAR, int HOIST = 0, int NSTG = 2>
+// (Pipelined forms of this loop -- the tile head hoisted into the previous tile's last row, weight planes prefetched into dead registers, inline-asm reads
+// with hand-counted lgkmcnt waits -- were built, verified and measured no faster in round 2 (profiles/r02y_*, r02zz_*) and removed.)
+template <int MI, int NI, int NA, int NBW, int PW, int A_BYTES, bool SPREAD, bool SCALAR, int NSTG = 2>
 struct S3Wave {
     using S3Split = S3SplitT<SCALAR>;
     static constexpr int kS3Steps = S3Split::kSteps;
     static constexpr int NMF = 6 * NI;        // MFMAs of one fragment row
     static constexpr int NP = NA + NBW;       // DMA pieces of one k tile, issued between the MFMAs of row 0 (and 1)
     static constexpr int DMA_ROWS = (MI > 1) ? 2 : 1;
-    static_assert(HOIST == 0 || HOIST == 3, "loop forms");
-    static_assert(HOIST != 3 || (NSTG == 2 && (MI == 2 || MI == 4) && SPREAD), "HOIST = 3: two stages, two or four fragment rows");
 
     f32x4 acc[MI][NI];
     u32x4 wf[3][NI];
@@ -171,143 +167,9 @@ struct S3Wave {
         __builtin_amdgcn_sched_barrier(0);
         rows<0>();
     }
-
-    // ================================================================================================================
-    // HOIST = 3 (variant bits 3 + 6): the pipelined k loop.  The plain loop above opens every k tile behind a barrier with the reads of its
-    // first two fragments, the 44-step split of the first one and the reads of the weight planes -- a stretch without matrix
-    // instructions for both waves of a SIMD.  Here that head is done for tile t + 1 in the LAST fragment row of tile t (a row that has
-    // no split work of its own), the matrix stream runs across k tiles without a gap, and every LDS read is issued a fragment row or
-    // more ahead of its wait.  The last point needs waits hipcc does not write: with LDS-DMA in flight every wait it inserts is
-    // `s_waitcnt lgkmcnt(0)`, so a wait in front of the first use of one fragment also waits for whatever was read a slot ago (the
-    // first hoisted forms used its waits; measured no faster than the plain loop, profiles/r02y_*).  Here
-    //   * the fragment / plane reads are inline asm (invisible to the waitcnt pass) and the waits are counted by hand: a wave's
-    //     LDS reads complete in issue order, so `lgkmcnt(n)` = "everything but the n newest reads has landed"; the n of every
-    //     wait is written next to the list of reads it may leave in flight, and tools/dev/check_lgkm.py re-derives the guarantee
-    //     from the compiled instruction stream (tests/test_lgkm_waits_cpu.py);
-    //   * the partial products run in the order  wl ah, wm am, wm ah, wh al, wh am, wh ah  (the h planes last instead of second:
-    //     the three products of size 2^-16 and the two of size 2^-8 still come before wh ah), so that a row uses the planes in
-    //     the order l, m, m, h, h, h: in a tile's last row l is dead after NI and m after 3 NI instructions -- the next tile's
-    //     l / m planes are read into them there, 5 NI / 4 NI instructions ahead of their use -- and the h planes, read in the
-    //     first slot of a tile, have 3 NI instructions to land.  (A different summation order: results agree with the other
-    //     variants to fp32 rounding, not bit for bit; same parity bar.)
-    //   * a tile's fragments 2 and 3 are read in its first slot as well, so after row 0 nothing reads the stage any more: the
-    //     barrier "the next tile has landed / this stage is free" moves from the last row to row BR = MI - 2 (MI = 4), the next
-    //     tile's fragments 0 / 1 are read right behind it -- a full row ahead of the hoisted split in the last row -- and the
-    //     DMA of the tile AFTER the next one goes into the freed stage in rows BR .. MI - 1: it has two rows and the whole next
-    //     tile's first rows to land instead of one row (two stages for every tile shape, also the 32-row wave tiles).
-    // Read / wait ledger of one tile (MI = 4; reads in issue order, [n] = b128 reads):
-    //   row BR of the tile before:  A0'[2] A1'[2]                      last row of the tile before:  L'[NI] (slot NI - 1)  M'[NI] (slot 3 NI - 1)
-    //   row 0 start   needs A1, L   newer: M                     -> lgkmcnt(NI)
-    //   row 0 slot 0  issues H[NI] A2[2] A3[2]
-    //   row 0 K = NI  needs M       newer: H A2 A3               -> lgkmcnt(NI + 4)        (MI = 2: H only -> NI)
-    //   row 0 K = 3NI needs H       newer: A2 A3                 -> lgkmcnt(4)             (MI = 2: 0)
-    //   row 1 start   needs A2      newer: A3                    -> lgkmcnt(2)
-    //   row BR start  needs A3 (and: nothing of this stage in flight)  -> lgkmcnt(0), vmcnt(0), s_barrier;  issues A0'[2] A1'[2]
-    //   last row K = HK3 needs A0'  newer: A1' (MI = 2: + L')    -> lgkmcnt(2)             (MI = 2: 2 + NI)
-    static constexpr int BR = (MI > 2) ? MI - 2 : MI - 1;
-    static constexpr int HK3 = (MI > 2) ? 0 : 2 * NI;
-    static constexpr int DMA3_SLOTS = (MI - BR) * NMF;
-    unsigned a_l0, a_l1, w_l, an_l0, an_l1, wn_l;     // LDS byte addresses (+ lane offsets): this stage's / the next stage's activation rows (chunk g, 4 + g) and weight pieces
-
-    template <int OFF>
-    static __device__ __forceinline__ void rd3(u32x4& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
-    template <int OFF>
-    static __device__ __forceinline__ void rd3f(f32x4& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
-    template <int F>
-    __device__ __forceinline__ void read_frag3(unsigned l0, unsigned l1) { rd3f<F * 2048>(raw[F & 1][0], l0); rd3f<F * 2048>(raw[F & 1][1], l1); }
-    template <int PL, int N0 = 0>
-    __device__ __forceinline__ void read_planes3(unsigned base) {
-        if constexpr (N0 < NI) { rd3<(N0 * 3 + PL) * 1024>(wf[PL][N0], base); read_planes3<PL, N0 + 1>(base); }
-    }
-    template <int PL, int N>
-    __device__ __forceinline__ void wait_planes3() {      // the wave's NI fragments of plane PL have landed; N newer reads may be in flight
-        static_assert(NI == 4 || NI == 5, "operand list below");
-        if constexpr (NI == 5) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(wf[PL][0]), "+v"(wf[PL][1]), "+v"(wf[PL][2]), "+v"(wf[PL][3]), "+v"(wf[PL][4]) : "n"(N));
-        else asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(wf[PL][0]), "+v"(wf[PL][1]), "+v"(wf[PL][2]), "+v"(wf[PL][3]) : "n"(N));
-    }
-    template <int B, int N>
-    __device__ __forceinline__ void wait_raw3() { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(raw[B][0]), "+v"(raw[B][1]) : "n"(N)); }
-
-    template <int MIDX, int K>
-    __device__ __forceinline__ void mfmas3() {
-        if constexpr (K < NMF) {
-            constexpr int WP3[6] = {2, 1, 1, 0, 0, 0};
-            constexpr int pr = K / NI, ni = K % NI, b = MIDX & 1;
-            if constexpr (MIDX == 0 && K == NI) wait_planes3<1, (MI > 2) ? NI + 4 : NI>();
-            if constexpr (MIDX == 0 && K == 3 * NI) wait_planes3<0, (MI > 2) ? 4 : 0>();
-            const u32x4& a = (pr == 0 || pr == 2 || pr == 5) ? sp[b].h : ((pr == 3) ? sp[b].l : sp[b].m);
-            acc[MIDX][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[WP3[pr]][ni]), __builtin_bit_cast(bf16x8, a),
-                                                                    acc[MIDX][ni], 0, 0, 0);
-            if constexpr (MIDX + 1 < MI) sp[b ^ 1].template steps<K * kS3Steps / NMF, (K + 1) * kS3Steps / NMF>();
-            else if constexpr (K >= HK3) {      // last row: the next tile's fragment 0 -> sp[0]
-                if constexpr (K == HK3) {
-                    wait_raw3<0, (MI > 2) ? 2 : 2 + NI>();
-                    sp[b ^ 1].load(raw[0][0], raw[0][1]);
-                }
-                sp[b ^ 1].template steps<(K - HK3) * kS3Steps / (NMF - HK3), (K - HK3 + 1) * kS3Steps / (NMF - HK3)>();
-            }
-            if constexpr (MIDX == 0 && K == 0) {
-                read_planes3<0>(w_l);
-                if constexpr (MI > 2) { read_frag3<2>(a_l0, a_l1); read_frag3<3>(a_l0, a_l1); }
-            }
-            if constexpr (MIDX == MI - 1 && K == NI - 1) read_planes3<2>(wn_l);
-            if constexpr (MIDX == MI - 1 && K == 3 * NI - 1) read_planes3<1>(wn_l);
-            if constexpr (MIDX >= BR) {
-                constexpr int slot = (MIDX - BR) * NMF + K;
-                pieces<slot * NP / DMA3_SLOTS, (slot + 1) * NP / DMA3_SLOTS>();
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas3<MIDX, K + 1>();
-        }
-    }
-    template <int MIDX>
-    __device__ __forceinline__ void rows3() {
-        if constexpr (MIDX < MI) {
-            if constexpr (MIDX == 0) {
-                // fragment 1 (raw[1]) and the l planes; the m planes, read after them, may still be in flight
-                if constexpr (NI == 5) asm volatile("s_waitcnt lgkmcnt(%7)" : "+v"(raw[1][0]), "+v"(raw[1][1]), "+v"(wf[2][0]), "+v"(wf[2][1]), "+v"(wf[2][2]), "+v"(wf[2][3]), "+v"(wf[2][4]) : "n"(NI));
-                else asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(raw[1][0]), "+v"(raw[1][1]), "+v"(wf[2][0]), "+v"(wf[2][1]), "+v"(wf[2][2]), "+v"(wf[2][3]) : "n"(NI));
-                sp[1].load(raw[1][0], raw[1][1]);
-            } else if constexpr (MIDX + 1 < MI) {
-                if constexpr (MIDX == BR) wait_raw3<(MIDX + 1) & 1, 0>();       // fragment MIDX + 1 was the last read of this stage
-                else wait_raw3<(MIDX + 1) & 1, 2>();                            // MI = 4, row 1: fragment 2; fragment 3 behind it
-                sp[(MIDX & 1) ^ 1].load(raw[(MIDX & 1) ^ 1][0], raw[(MIDX & 1) ^ 1][1]);
-            }
-            if constexpr (MIDX == BR) {
-                __builtin_amdgcn_sched_barrier(0);
-                // nothing of this stage is in flight (MI = 2: the h planes were waited for with lgkmcnt(0) at K = 3 NI of row 0) and the
-                // only DMA pieces outstanding are the next tile's, issued a tile ago
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                read_frag3<0>(an_l0, an_l1);
-                read_frag3<1>(an_l0, an_l1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas3<MIDX, 0>();
-            rows3<MIDX + 1>();
-        }
-    }
-    __device__ __forceinline__ void tile3() { rows3<0>(); }
-    // the first k tile: fragments 0 / 1 and the l / m planes in the order the last rows of a tile issue them, split 0
-    __device__ __forceinline__ void head3() {
-        read_frag3<0>(a_l0, a_l1);
-        read_frag3<1>(a_l0, a_l1);
-        read_planes3<2>(w_l);
-        read_planes3<1>(w_l);
-        wait_raw3<0, 0>();
-        sp[0].load(raw[0][0], raw[0][1]);
-        sp[0].template steps<0, kS3Steps>();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __device__ __forceinline__ void set_lds3(unsigned cur, unsigned nxt, unsigned a_base, unsigned w_fr) {
-        a_l0 = cur + a_base + (unsigned)fr_off0; a_l1 = cur + a_base + (unsigned)fr_off1; w_l = cur + w_fr;
-        an_l0 = nxt + a_base + (unsigned)fr_off0; an_l1 = nxt + a_base + (unsigned)fr_off1; wn_l = nxt + w_fr;
-    }
-
 };
 
-template <int MI, int NI, int WM, int WN, bool SPREAD, bool SCALAR, int NSTG, int HOIST>
+template <int MI, int NI, int WM, int WN, bool SPREAD, bool SCALAR, int NSTG>
 __global__ __launch_bounds__(512) void conv_gemm3x_kernel(const ConvGemm p) {
     static_assert(NSTG == 2 || NSTG == 3, "LDS stages");
     constexpr int BM = 16 * MI * WM;
@@ -350,7 +212,7 @@ __global__ __launch_bounds__(512) void conv_gemm3x_kernel(const ConvGemm p) {
     const int T = p.KH * p.KW;
     const int HoWo = p.Ho * p.Wo;
 
-    S3Wave<MI, NI, NA, NBW, PW, A_BYTES, SPREAD, SCALAR, HOIST, NSTG> w;
+    S3Wave<MI, NI, NA, NBW, PW, A_BYTES, SPREAD, SCALAR, NSTG> w;
     w.Hin = p.Hs << p.ups;
     w.Win = p.Ws << p.ups;
     w.ups = p.ups;
@@ -427,24 +289,7 @@ __global__ __launch_bounds__(512) void conv_gemm3x_kernel(const ConvGemm p) {
     if ((p.variant & 16) && wave >= 4) __builtin_amdgcn_s_setprio(1);
     w.next_stage = smem_x32;
     w.template pieces<0, NA + NBW>();      // k tile 0
-    if constexpr (HOIST == 3) {
-        // two stages; tiles 0 and 1 before the loop, tile t + 2 from rows BR .. MI - 1 of tile t into the stage tile t has just given up
-        w.next_stage = smem_x32 + STAGE;
-        w.template pieces<0, NA + NBW>();      // k tile 1 (or tile 0 again: dead stage)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NBW) : "memory");
-        __builtin_amdgcn_s_barrier();           // k tile 0 is in LDS
-        asm volatile("" ::: "memory");
-        const unsigned lds0 = (unsigned)(unsigned long long)(lds_void*)smem_x32;
-        w.set_lds3(lds0, lds0 + STAGE, (unsigned)a_base, (unsigned)w_fr);
-        w.head3();
-        for (int t = 0; t < n_t; ++t) {
-            const unsigned cur = (unsigned)(t & 1);
-            w.set_lds3(lds0 + cur * STAGE, lds0 + (cur ^ 1u) * STAGE, (unsigned)a_base, (unsigned)w_fr);
-            w.next_stage = smem_x32 + cur * STAGE;
-            w.tile3();
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads past the last tile (never used)
-    } else if constexpr (NSTG == 2) {
+    if constexpr (NSTG == 2) {
         for (int t = 0; t < n_t; ++t) {
             const int cur = t & 1;
             __syncthreads();                    // k tile t is in LDS; every wave is done with stage cur ^ 1
@@ -480,9 +325,9 @@ __global__ __launch_bounds__(512) void conv_gemm3x_kernel(const ConvGemm p) {
     gemm_epilogue_f32<MI, NI, WM, WN>(p, w.acc, smem_x32, m0, n0, z, lid, wave, lane, HoWo);
 }
 
-template <int MI, int NI, int WM, int WN, bool SPREAD, bool SCALAR, int NSTG = 2, int HOIST = 0>
+template <int MI, int NI, int WM, int WN, bool SPREAD, bool SCALAR, int NSTG = 2>
 static hipError_t launch_cfg_3x(const ConvGemm& p, dim3 grid, hipStream_t stream) {
-    auto k = conv_gemm3x_kernel<MI, NI, WM, WN, SPREAD, SCALAR, NSTG, HOIST>;
+    auto k = conv_gemm3x_kernel<MI, NI, WM, WN, SPREAD, SCALAR, NSTG>;
     constexpr size_t lds = NSTG * ((size_t)(16 * MI * WM) * 128 + (size_t)((NI * WN * 3 + 7) / 8) * 8192);
     static_assert(lds <= 160 * 1024, "the stages must fit the CU's LDS");
     if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds); e != hipSuccess) return e;
@@ -503,18 +348,7 @@ hipError_t launch_conv_gemm3x(const ConvGemm& p, int cfg, hipStream_t stream) {
     const dim3 grid = gemm_grid(p, tiles);
     // p.variant bit 0: issue the next k tile's DMA in one block behind the barrier instead of between the MFMAs of rows 0 / 1
     // bit 1: the split's residual subtractions as scalar v_sub_f32 pairs instead of v_pk_add_f32
-    // bits 3 + 6 (with the default placement, bits 0 clear / 1 set): HOIST = 3, the pipelined loop with hand-counted LDS waits (two stages on every tile)
     const bool spread = !(p.variant & 1), scalar = (p.variant & 2) != 0;
-    if ((p.variant & 72) == 72 && spread && scalar) {
-        switch (cfg) {
-            case 0: return launch_cfg_3x<4, 5, 4, 2, true, true, 2, 3>(p, grid, stream);
-            case 1: return launch_cfg_3x<4, 5, 2, 4, true, true, 2, 3>(p, grid, stream);
-            case 2: return launch_cfg_3x<4, 4, 4, 2, true, true, 2, 3>(p, grid, stream);
-            case 3: return launch_cfg_3x<4, 4, 2, 4, true, true, 2, 3>(p, grid, stream);
-            case 4: return launch_cfg_3x<2, 5, 4, 2, true, true, 2, 3>(p, grid, stream);
-            case 5: return launch_cfg_3x<2, 4, 4, 2, true, true, 2, 3>(p, grid, stream);
-        }
-    }
 #define SDMI_3X(MI, NI, WM, WN)                                                                                       \
     (spread ? (scalar ? launch_cfg_3x<MI, NI, WM, WN, true, true>(p, grid, stream) : launch_cfg_3x<MI, NI, WM, WN, true, false>(p, grid, stream)) \
             : (scalar ? launch_cfg_3x<MI, NI, WM, WN, false, true>(p, grid, stream) : launch_cfg_3x<MI, NI, WM, WN, false, false>(p, grid, stream)))

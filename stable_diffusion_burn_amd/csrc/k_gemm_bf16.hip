@@ -245,7 +245,6 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const ConvGemm p) {
     unsigned short* Ch = reinterpret_cast<unsigned short*>(p.C);
     const unsigned short* Rh = reinterpret_cast<const unsigned short*>(p.resid);
     const int ldc = split ? p.N : p.ldc;
-    const SlabStore slab(Cf, split ? p.slab_stride : 0, split && p.counters && p.slab_wt);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + (wm * MI + mi) * 16 + c15;
@@ -266,7 +265,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const ConvGemm p) {
                     }
                 }
                 if (split) {
-                    slab.store((long long)m * ldc + n, v);
+                    *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;     // (Cf = this k slice's slab)
                 } else if (out_f32) {
                     *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;
                 } else {
@@ -289,9 +288,6 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const ConvGemm p) {
                 }
             }
         }
-    }
-    if (split && p.counters) {
-        if (splitk_arrive(p.counters, lid, p.splits, reinterpret_cast<unsigned*>(smem), p.slab_wt != 0)) splitk_reduce_tile<true>(p, m0, n0, BM, BN);
     }
 }
 

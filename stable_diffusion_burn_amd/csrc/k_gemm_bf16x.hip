@@ -44,177 +44,7 @@ static const GemmTileInfo kTilesX[kNumGemmTilesX] = {
     {256, 320, "256x320x"}, {256, 256, "256x256x"}, {256, 128, "256x128x"}, {128, 320, "128x320x"}};
 const GemmTileInfo& gemm_tile_info_x(int cfg) { return kTilesX[cfg]; }
 
-// ---- PIPE = 2 (option gemm_bf16x_variant = 3): the k loop as one gap-free matrix-instruction stream ------------------------------
-// The loop below the barrier of the plain form opens every k tile with the DMA of the next tile in one block (address arithmetic
-// with exec-mask branches for the padding taps: ~150 instructions for 9 pieces) and the reads of the first fragments -- more than
-// a thousand cycles in which neither wave of a SIMD issues a matrix instruction, against 2 560 cycles of matrix work per tile.
-// Here a k tile is a straight line of 2 MI fragment rows (two 32-deep k steps x MI rows) of NI matrix instructions, and everything
-// else sits in the issue slots behind them, pinned with sched_barrier(0) as in k_gemm3x.hip:
-//   * the next tile's DMA pieces, branch-free (zero page by select, 32-bit offsets), one every other slot of the first rows;
-//   * activation fragments through a ring of R registers: the fragment of row r + R is read behind the last instruction of row r;
-//   * weight fragments WITHOUT a second buffer: in the last row of a k step fragment ni is dead as soon as its matrix instruction
-//     has issued, and the next k step's fragment ni is read into it right there, NI instructions ahead of its use;
-//   * the barrier "the next tile has landed" therefore moves from the top of the tile to the end of row 2 MI - R, the last point
-//     before a read of the next tile; by then this wave has issued -- and waited for -- every read of the current stage, so the barrier
-//     still doubles as "this stage may be overwritten", and all DMA pieces were issued rows ago: vmcnt(0) finds them landed.
-// The waits: hipcc's own LDS waits in a kernel with LDS-DMA in flight are all `s_waitcnt lgkmcnt(0)`, so the wait in front of the first use of
-// a fragment also waits for the fragment read that was issued one slot ago -- an LDS round trip at every row of the rolling schedule above
-// (a first form of this loop used hipcc's waits: bit-identical, not faster, removed; profiles/r02y_ab_bf16_b8_pipelined_loop.jsonl).  So the
-// fragment reads are inline asm (invisible to the waitcnt pass) and the waits are
-// COUNTED by hand: LDS reads of a wave complete in issue order, so `lgkmcnt(n)` in front of a matrix instruction is exactly "everything but
-// the n reads issued after my operands has landed".  n is computed at compile time from the schedule itself (reads_in / wait_n below);
-// tools/dev/check_lgkm.py re-derives the guarantee from the COMPILED instruction stream (every use of a fragment register is behind a
-// wait that covers its read), and the parity tests hold the loop bit-identical to the plain one.
-template <int MI, int NI, int NA, int NB, int A_BYTES>
-struct BxWave {
-    static constexpr int ROWS = 2 * MI;
-    static constexpr int R = (MI >= 8) ? 4 : 2;
-    static constexpr int BAR_ROW = ROWS - R;
-    static constexpr int NP = NA + NB;
-    static constexpr int DMA_ROWS = (BAR_ROW < 4) ? BAR_ROW : 4;
-    static_assert(R >= 2 && R <= MI && DMA_ROWS <= BAR_ROW && DMA_ROWS * NI >= NP, "ring / barrier / DMA placement");
-
-    f32x4 acc[MI][NI];
-    u32x4 fb[NI];
-    u32x4 fa[R];
-    int a_iy0[NA], a_ix0[NA];
-    unsigned a_off[NA];               // byte offset of the sample + this lane's chunk (operands are < 4 GiB: launch_gemm checks)
-    unsigned b_off[NB];
-    const char *Abase, *Bbase, *zero;
-    unsigned pix_bytes;
-    int Hin, Win, ups, Ws, KH, KW, wave;
-    int cs, ky, kx, kt_next, kt_end;
-    const unsigned char *a_tile, *b_tile;     // current stage + this wave's activation / weight rows
-    unsigned char* next_stage;                // where the DMA of k tile kt_next goes
-    int fr_off0, fr_off1;
-
-    // ---- the schedule's own arithmetic (slots are numbered r * NI + ni and continue across tiles, periodically) -------------
-    static constexpr int TILE = ROWS * NI;
-    static constexpr int fmod(int a, int m) { return ((a % m) + m) % m; }
-    static constexpr bool roll_row(int r) { return fmod(r, MI) == MI - 1; }            // its slots re-load the weight fragments
-    static constexpr int cnt(int s) { return (roll_row(fmod(s, TILE) / NI) ? 1 : 0) + (fmod(s, NI) == NI - 1 ? 1 : 0); }   // reads issued behind slot s's matrix instruction
-    static constexpr int reads_in(int a, int b) { int n = 0; for (int u = a; u < b; ++u) n += cnt(u); return n; }
-    // reads issued after the operands of matrix instruction (r, ni) and before it: the count its wait may leave outstanding
-    static constexpr int newer_than_a(int r, int ni) { return reads_in((r - R) * NI + NI, r * NI + ni); }     // fa[r % R]: last read of slot (r - R, NI - 1)
-    static constexpr int newer_than_b(int r, int ni) {                                                            // fb[ni]: first read of slot (rho, ni), rho = the roll row before r
-        const int rho = (r >= MI) ? MI - 1 : -1;
-        return (ni == NI - 1 ? 1 : 0) + reads_in(rho * NI + ni + 1, r * NI + ni);
-    }
-    static constexpr int wait_n(int r, int ni) {     // -1: an earlier wait of the row covers this instruction's operands
-        const int a = newer_than_a(r, ni), b = newer_than_b(r, ni);
-        int n = -1;
-        if (ni == 0) n = a < b ? a : b;
-        else if (r == 0 || r == MI) n = b;
-        return n > 15 ? 15 : n;                      // lgkmcnt is a 4-bit field
-    }
-    unsigned a_lds[2], b_lds[2], an_lds, bn_lds;     // LDS byte addresses (+ this lane's chunk) of the wave's rows: current tile k step 0 / 1, next tile k step 0
-    template <int OFF>
-    static __device__ __forceinline__ void rd_asm(u32x4& dst, unsigned addr) {
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-    }
-
-    // DMA piece J of k tile kt_next -> next_stage: straight-line code as in k_gemm3x.hip (S3Wave::piece); after the last piece the
-    // source moves on to the next k tile, unless there is none: then the same tile is fetched once more into the stage nobody reads
-    template <int J>
-    __device__ __forceinline__ void piece() {
-        if constexpr (J < NA) {
-            const int iy = a_iy0[J] + ky;
-            const int ix = a_ix0[J] + kx;
-            const bool ok = ((unsigned)iy < (unsigned)Hin) & ((unsigned)ix < (unsigned)Win);
-            const unsigned off = a_off[J] + (unsigned)((iy >> ups) * Ws + (ix >> ups)) * pix_bytes + (unsigned)cs * 128u;
-            const char* src = (ok ? Abase : zero) + (ok ? off : 0u);
-            __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(next_stage + (wave + 8 * J) * 1024), 16, 0, 0);
-        } else {
-            constexpr int j = J - NA;
-            const char* src = Bbase + (b_off[j] + (unsigned)kt_next * 128u);
-            __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(next_stage + A_BYTES + (wave + 8 * j) * 1024), 16, 0, 0);
-        }
-        if constexpr (J == NP - 1) {
-            const bool adv = kt_next + 1 < kt_end;
-            const bool wrap_x = (kx + 1 == KW);
-            const bool wrap_y = wrap_x && (ky + 1 == KH);
-            const int kx1 = wrap_x ? 0 : kx + 1;
-            const int ky1 = wrap_x ? (wrap_y ? 0 : ky + 1) : ky;
-            const int cs1 = wrap_y ? cs + 1 : cs;
-            kx = adv ? kx1 : kx;
-            ky = adv ? ky1 : ky;
-            cs = adv ? cs1 : cs;
-            kt_next = adv ? kt_next + 1 : kt_next;
-        }
-    }
-    template <int J0, int J1>
-    __device__ __forceinline__ void pieces() {
-        if constexpr (J0 < J1) { piece<J0>(); pieces<J0 + 1, J1>(); }
-    }
-
-    static __device__ __forceinline__ u32x4 rd(const unsigned char* q) { return *reinterpret_cast<const u32x4*>(q); }
-
-    // slot (row RW, column fragment NIX): one matrix instruction and what rides behind it
-    template <int RW, int NIX>
-    __device__ __forceinline__ void slots() {
-        if constexpr (RW < ROWS) {
-            constexpr int kk = RW / MI, mi = RW % MI;
-            constexpr int WN_ = wait_n(RW, NIX);
-            if constexpr (WN_ >= 0) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fb[NIX]), "+v"(fa[RW % R]) : "n"(WN_));
-            acc[mi][NIX] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[NIX]), __builtin_bit_cast(bf16x8, fa[RW % R]),
-                                                                  acc[mi][NIX], 0, 0, 0);
-            if constexpr (RW < DMA_ROWS) {
-                constexpr int sl = RW * NI + NIX, SL = DMA_ROWS * NI;
-                pieces<sl * NP / SL, (sl + 1) * NP / SL>();
-            }
-            if constexpr (mi == MI - 1) {     // last row of a k step: weight fragment NIX of the next k step into the register just used
-                if constexpr (kk == 0) rd_asm<NIX * 2048>(fb[NIX], b_lds[1]);
-                else rd_asm<NIX * 2048>(fb[NIX], bn_lds);
-            }
-            if constexpr (NIX == NI - 1) {
-                if constexpr (RW == BAR_ROW) {
-                    // every read of the current stage has been issued (the last ones a row ago) and every DMA piece of the next tile rows ago
-                    __builtin_amdgcn_sched_barrier(0);
-                    // (the reads of the current stage were issued a row or more ago; waiting for them all here costs nothing and
-                    // keeps "every wave is done with this stage" literally true at the barrier)
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                }
-                constexpr int nr = RW + R;     // the activation fragment this ring slot holds next
-                if constexpr (nr < ROWS) rd_asm<(nr % MI) * 2048>(fa[RW % R], a_lds[nr / MI]);
-                else rd_asm<(nr - ROWS) * 2048>(fa[RW % R], an_lds);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (NIX + 1 < NI) slots<RW, NIX + 1>();
-            else slots<RW + 1, 0>();
-        }
-    }
-    __device__ __forceinline__ void tile() {
-        __builtin_amdgcn_sched_barrier(0);
-        slots<0, 0>();
-    }
-    // the first k tile of the launch: what the tail of a tile does for its successor
-    __device__ __forceinline__ void head() {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) fb[ni] = rd(b_tile + ni * 2048 + fr_off0);
-#pragma unroll
-        for (int i = 0; i < R; ++i) fa[i] = rd(a_tile + i * 2048 + fr_off0);
-        {
-            // these reads are hipcc's (it waits for them itself at their first use, which the asm waits below do not know): make them land
-            // before the counted schedule starts, so that from here on the only LDS reads in flight are the loop's own
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(fb[ni]));
-#pragma unroll
-            for (int i = 0; i < R; ++i) asm volatile("" : "+v"(fa[i]));
-        }
-    }
-    __device__ __forceinline__ void set_lds(unsigned cur_stage, unsigned nxt_stage, unsigned a_base, unsigned b_base) {   // LDS byte addresses of the stages
-        a_lds[0] = cur_stage + a_base + (unsigned)fr_off0;
-        a_lds[1] = cur_stage + a_base + (unsigned)fr_off1;
-        b_lds[0] = cur_stage + b_base + (unsigned)fr_off0;
-        b_lds[1] = cur_stage + b_base + (unsigned)fr_off1;
-        an_lds = nxt_stage + a_base + (unsigned)fr_off0;
-        bn_lds = nxt_stage + b_base + (unsigned)fr_off0;
-    }
-};
-
-template <int MI, int NI, int WM, int WN, int PIPE>
+template <int MI, int NI, int WM, int WN>
 __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) {
     constexpr int BM = 16 * MI * WM;
     constexpr int BN = 16 * NI * WN;
@@ -254,85 +84,9 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
 
     const int T = p.KH * p.KW;
     const int HoWo = p.Ho * p.Wo;
-    BxWave<MI, NI, NA, NB, BM * 128> w;       // the accumulators live here in both forms; the plain loop uses nothing else of it
-    auto& acc = w.acc;
+    f32x4 acc[MI][NI];
     const int c15 = lane & 15, g4 = lane >> 4;
-    if constexpr (PIPE) {
-        w.Hin = p.Hs << p.ups;
-        w.Win = p.Ws << p.ups;
-        w.ups = p.ups;
-        w.Ws = p.Ws;
-        w.KH = p.KH;
-        w.KW = p.KW;
-        w.wave = wave;
-        w.pix_bytes = (unsigned)p.a_ld * 2u;
-        w.Abase = reinterpret_cast<const char*>(p.A);
-        w.Bbase = reinterpret_cast<const char*>(p.Bt);
-        w.zero = reinterpret_cast<const char*>(p.zero_page);
-        const int sub = lane >> 3;
-        const int chunk = (lane & 7) ^ sub;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int m = m0 + (wave + 8 * j) * 8 + sub;
-            const bool ok = m < p.M;
-            const int mm = ok ? m : 0;
-            const int nb = mm / HoWo;
-            const int rem = mm - nb * HoWo;
-            const int oy = rem / p.Wo;
-            const int ox = rem - oy * p.Wo;
-            w.a_off[j] = (unsigned)nb * (unsigned)(p.Hs * p.Ws) * w.pix_bytes + chunk * 16;
-            w.a_iy0[j] = ok ? oy * p.stride - p.pad : -(1 << 28);   // rows past M: never in range -> zero page
-            w.a_ix0[j] = ox * p.stride - p.pad;
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int r0 = (wave + 8 * j) * 8 + sub;   // tile row of operand B
-            int n = n0 + r0;
-            long long wrow = n;
-            if (geglu) {
-                const int f = r0 >> 4, fw = f / NI, ni = f - fw * NI;
-                n = n0 + fw * (WNC / 2) + (ni >> 1) * 16 + (r0 & 15);
-                wrow = (long long)n + ((ni & 1) ? p.N : 0);
-            }
-            // rows past N (ragged last tile) fetch the last valid row instead: real memory, and the accumulator columns they feed are never stored
-            if (n >= p.N) wrow -= (n - (p.N - 1));
-            w.b_off[j] = (unsigned)wrow * (unsigned)p.b_ld * 2u + chunk * 16;
-        }
-        w.cs = kt_begin / T;
-        const int tap0 = kt_begin - w.cs * T;
-        w.ky = tap0 / p.KW;
-        w.kx = tap0 - w.ky * p.KW;
-        w.kt_next = kt_begin;
-        w.kt_end = kt_end;
-        w.fr_off0 = c15 * 128 + (((0 + g4) ^ (c15 & 7)) << 4);
-        w.fr_off1 = c15 * 128 + (((4 + g4) ^ (c15 & 7)) << 4);
-        const int a_base = wm * 16 * MI * 128;
-        const int b_base = BM * 128 + wn * 16 * NI * 128;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-        w.next_stage = smem_x;
-        w.template pieces<0, NA + NB>();      // k tile 0
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        w.a_tile = smem_x + a_base;
-        w.b_tile = smem_x + b_base;
-        const unsigned lds0 = (unsigned)(unsigned long long)(lds_void*)smem_x;     // LDS byte address of the stages
-        w.head();
-        for (int t = 0; t < n_t; ++t) {
-            const int cur = t & 1;
-            w.next_stage = smem_x + (cur ^ 1) * STAGE;
-            w.a_tile = smem_x + cur * STAGE + a_base;
-            w.b_tile = smem_x + cur * STAGE + b_base;
-            w.set_lds(lds0 + cur * STAGE, lds0 + (cur ^ 1) * STAGE, a_base, b_base);
-            w.tile();
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads past the last tile (never used) have landed
-        // the last k tile was fetched twice (piece()); that copy must have landed before the epilogue reuses the stages
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
+    {
     const int Hin = p.Hs << p.ups;
     const int Win = p.Ws << p.ups;
     const long long pix_bytes = (long long)p.a_ld * 2;
@@ -527,7 +281,6 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
         }
         return;
     }
-    const SlabStore slab(Cf, split ? p.slab_stride : 0, split && p.counters && p.slab_wt);
     if (vec_ok) {
         __syncthreads();                // every wave is done with the last k tile
         float* scr = reinterpret_cast<float*>(smem_x + wave * (16 * LDSW * 4));
@@ -582,8 +335,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
                             const u32x2 r = *reinterpret_cast<const u32x2*>(Rh + (long long)m * p.ldr + n);
                             v[0] += xbf16_lo(r[0]); v[1] += xbf16_hi(r[0]); v[2] += xbf16_lo(r[1]); v[3] += xbf16_hi(r[1]);
                         }
-                        if (split) slab.store((long long)m * ldc + n, v);
-                        else *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;
+                        *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;     // (split-K: Cf = this k slice's fp32 slab)
                     }
                 }
             }
@@ -617,14 +369,11 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
         }
     }
     }
-    if (split && p.counters) {
-        if (splitk_arrive(p.counters, lid, p.splits, reinterpret_cast<unsigned*>(smem_x), p.slab_wt != 0)) splitk_reduce_tile<true>(p, m0, n0, BM, BN);
-    }
 }
 
-template <int MI, int NI, int WM, int WN, int PIPE>
+template <int MI, int NI, int WM, int WN>
 static hipError_t launch_cfg_bf16x(const ConvGemm& p, dim3 grid, hipStream_t stream) {
-    auto k = conv_gemm_bf16x_kernel<MI, NI, WM, WN, PIPE>;
+    auto k = conv_gemm_bf16x_kernel<MI, NI, WM, WN>;
     constexpr size_t lds = 2 * (size_t)(16 * MI * WM + 16 * NI * WN) * 128;
     if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, dim3(512), lds, stream, p);
@@ -640,20 +389,11 @@ hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int cfg, hipStream_t stream
     const int MT = (p.M + bm - 1) / bm, NT = (p.N + bno - 1) / bno;
     const int tiles = MT * NT;
     const dim3 grid = gemm_grid(p, tiles);
-    // p.variant (option gemm_bf16x_variant) = 3: the pipelined k loop (BxWave: fragment reads as inline asm with hand-counted waits)
-    if ((p.variant & 3) == 3) {
-        switch (cfg) {
-            case 0: return launch_cfg_bf16x<8, 5, 2, 4, 2>(p, grid, stream);
-            case 1: return launch_cfg_bf16x<8, 4, 2, 4, 2>(p, grid, stream);
-            case 2: return launch_cfg_bf16x<4, 4, 4, 2, 2>(p, grid, stream);
-            case 3: return launch_cfg_bf16x<4, 5, 2, 4, 2>(p, grid, stream);
-        }
-    }
     switch (cfg) {
-        case 0: return launch_cfg_bf16x<8, 5, 2, 4, 0>(p, grid, stream);
-        case 1: return launch_cfg_bf16x<8, 4, 2, 4, 0>(p, grid, stream);
-        case 2: return launch_cfg_bf16x<4, 4, 4, 2, 0>(p, grid, stream);
-        case 3: return launch_cfg_bf16x<4, 5, 2, 4, 0>(p, grid, stream);
+        case 0: return launch_cfg_bf16x<8, 5, 2, 4>(p, grid, stream);
+        case 1: return launch_cfg_bf16x<8, 4, 2, 4>(p, grid, stream);
+        case 2: return launch_cfg_bf16x<4, 4, 4, 2>(p, grid, stream);
+        case 3: return launch_cfg_bf16x<4, 5, 2, 4>(p, grid, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -4,7 +4,7 @@
 //   * bias + time-embedding row + residual, or the GEGLU product, or a raw split-K slab
 //   * every wave transposes one 16-row fragment group at a time through its own LDS scratch (the stages are free by then)
 //     and writes whole row segments with 16-byte lanes; the residual is read the same way
-//   * split-K with p.counters: the last-arriving slice combines the slabs in the launch (k_common.hpp)
+//   * split-K: raw fp32 slabs; launch_splitk_reduce -- or the GroupNorm / LayerNorm that reads the result (k_norm.hip) -- combines them
 #pragma once
 #include "kernels.hpp"
 #include "k_common.hpp"
@@ -73,7 +73,6 @@ __device__ __forceinline__ void gemm_epilogue_f32(const ConvGemm& p, epi_f32x4 (
         }
         return;
     }
-    const SlabStore slab(Cf, split ? p.slab_stride : 0, split && p.counters && p.slab_wt);
     if (vec_ok) {
         __syncthreads();                // every wave is done with the last k tile
         float* scr = reinterpret_cast<float*>(smem_x32 + wave * (16 * LDSW * 4));
@@ -105,7 +104,7 @@ __device__ __forceinline__ void gemm_epilogue_f32(const ConvGemm& p, epi_f32x4 (
                 if (q < 16 * CH && m < p.M && n < p.N) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * LDSW + c4 * 4);
                     if (has_resid) v += *reinterpret_cast<const f32x4*>(p.resid + (long long)m * p.ldr + n);
-                    if (split) slab.store((long long)m * ldc + n, v);
+                    if (split) *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;     // (Cf = this k slice's slab)
                     else {
                         if (Cf) *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;
                         if (p.C3) s3_store4(reinterpret_cast<unsigned char*>(p.C3) + (long long)m * p.ldc3, n, v);
@@ -140,9 +139,6 @@ __device__ __forceinline__ void gemm_epilogue_f32(const ConvGemm& p, epi_f32x4 (
             }
         }
     }
-    }
-    if (split && p.counters) {
-        if (splitk_arrive(p.counters, lid, p.splits, reinterpret_cast<unsigned*>(smem_x32), p.slab_wt != 0)) splitk_reduce_tile<false>(p, m0, n0, BM, BN);
     }
 }
 

@@ -25,6 +25,8 @@
 //    UNet-sized tensors (<= 21 MB) is served from L2 / Infinity Cache.
 //  * LayerNorm: 16 / 32 / 64 lanes per token row (4 / 2 / 1 rows per wave), the row (<= 2048 channels) is held in
 //    registers, exact two-pass mean / variance with xor-shuffle reductions.
+#include <algorithm>
+
 #include "kernels.hpp"
 #include "k_common.hpp"
 #include "k_split3.hpp"
@@ -60,43 +62,11 @@ size_t gn_partials_bytes(int n, int hw, int c) {
     return (size_t)n * gn_geom(hw, c).chunks * 64 * 2 * sizeof(double);
 }
 
-// ---- a split-K GEMM's result, not yet combined (launch_splitk_reduce's job folded into the normalisation that consumes it) --------
-// value(m, n .. n+3) = sum over slices of slabs[s][m][n ..] (slice order 0 .. S-1, fixed: bit-reproducible) + bias + rowvec[sample] + resid;
-// the thread that owns the element also writes it to C (fp32, the tensor the rest of the network reads) and / or C3 (planes).
-struct SlabSrc {
-    const float* slabs; long long slab_stride; int splits;
-    const float* bias; const float* rowvec; int rowvec_stride; const float* resid; int ldr;
-    float* C; int ldc; void* C3; int ldc3; int N;
-};
-__device__ __forceinline__ f32x4 slab_value(const SlabSrc& s, long long m, int smp, int n, bool store) {
-    const long long off = m * s.N + n;
-    f32x4 v = *reinterpret_cast<const f32x4*>(s.slabs + off);
-    int sl = 1;
-    for (; sl + 3 < s.splits; sl += 4) {      // four loads in flight, added in slice order
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(s.slabs + (long long)sl * s.slab_stride + off);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(s.slabs + (long long)(sl + 1) * s.slab_stride + off);
-        const f32x4 a2 = *reinterpret_cast<const f32x4*>(s.slabs + (long long)(sl + 2) * s.slab_stride + off);
-        const f32x4 a3 = *reinterpret_cast<const f32x4*>(s.slabs + (long long)(sl + 3) * s.slab_stride + off);
-        v += a0; v += a1; v += a2; v += a3;
-    }
-    for (; sl < s.splits; ++sl) v += *reinterpret_cast<const f32x4*>(s.slabs + (long long)sl * s.slab_stride + off);
-    if (s.bias) v += *reinterpret_cast<const f32x4*>(s.bias + n);
-    if (s.rowvec) v += *reinterpret_cast<const f32x4*>(s.rowvec + (long long)smp * s.rowvec_stride + n);
-    if (s.resid) v += *reinterpret_cast<const f32x4*>(s.resid + m * s.ldr + n);
-    if (store) {
-        if (s.C) *reinterpret_cast<f32x4*>(s.C + m * s.ldc + n) = v;
-        if (s.C3) s3_store4(reinterpret_cast<unsigned char*>(s.C3) + m * s.ldc3, n, v);
-    }
-    return v;
-}
-
 // Partial statistics of one (sample, chunk, group): part[((smp*chunks + chunk)*G + g)*2 + {0: mean, 1: M2}]
 // over the chunk's rows x (C/G) channels, M2 = sum (x - mean)^2.  `ldx` = floats between pixels of x (>= C: the
 // tensor may be a channel slice of a wider buffer).
-// SLABS: x is not in memory yet -- it is the result of a split-K GEMM whose slabs this kernel combines (and writes out) as it goes.
-template <bool SLABS>
 __global__ void gn_stats_kernel(const float* __restrict__ x, int hw, int C, int ldx, int G, int rows_per_chunk,
-                                double* __restrict__ part, const SlabSrc src) {
+                                double* __restrict__ part) {
     extern __shared__ float sh[];  // [2][R][C] floats, [C] pivots, then [2][C] doubles
     const int cq = C >> 2;
     const int R = blockDim.x / cq;
@@ -109,22 +79,16 @@ __global__ void gn_stats_kernel(const float* __restrict__ x, int hw, int C, int 
 
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, q0 = s0, s1 = s0, q1 = s0;
     const float* xb = x + (long long)smp * hw * ldx + c4 * 4;
-    const long long m0 = (long long)smp * hw;
-    auto val = [&](int r, bool store) -> f32x4 {
-        if constexpr (SLABS) return slab_value(src, m0 + r, smp, c4 * 4, store);
-        else return *reinterpret_cast<const f32x4*>(xb + (long long)r * ldx);
-    };
+    const f32x4 pv = *reinterpret_cast<const f32x4*>(xb + (long long)row_begin * ldx);  // pivot: same address for the R threads of a column
     int row = row_begin + r0;
-    // pivot: the chunk's first row of this column (the same value for the R threads of a column; with SLABS only its owner stores it)
-    const f32x4 pv = val(row_begin, false);
     for (; row + R < row_end; row += 2 * R) {  // two independent loads in flight per thread
-        const f32x4 v0 = val(row, true) - pv;
-        const f32x4 v1 = val(row + R, true) - pv;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(xb + (long long)row * ldx) - pv;
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(xb + (long long)(row + R) * ldx) - pv;
         s0 += v0; q0 += v0 * v0;
         s1 += v1; q1 += v1 * v1;
     }
     if (row < row_end) {
-        const f32x4 v0 = val(row, true) - pv;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(xb + (long long)row * ldx) - pv;
         s0 += v0; q0 += v0 * v0;
     }
     s0 += s1; q0 += q1;
@@ -205,34 +169,15 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__
     if (row < row_end) put(row, norm(*reinterpret_cast<const f32x4*>(x + xbase + (long long)row * ldx)));
 }
 
-static SlabSrc slab_src_of(const ConvGemm& q) {
-    SlabSrc s;
-    s.slabs = q.slabs; s.slab_stride = q.slab_stride; s.splits = q.splits;
-    s.bias = q.bias; s.rowvec = q.rowvec; s.rowvec_stride = q.rowvec_stride; s.resid = q.resid; s.ldr = q.ldr;
-    s.C = q.C; s.ldc = q.ldc; s.C3 = q.C3; s.ldc3 = q.ldc3; s.N = q.N;
-    return s;
-}
-static bool slab_src_ok(const ConvGemm& q) {
-    return q.slabs && q.splits > 1 && (q.N & 3) == 0 && (!q.C || (q.ldc & 3) == 0) && (!q.resid || (q.ldr & 3) == 0) && (q.C || q.C3);
-}
-
-// pending != null: x (= pending->C, [n * hw][ldx]) is the not-yet-combined result of that split-K GEMM; the statistics pass combines the
-// slabs, writes x (and its planes) and takes the statistics in one go -- the stand-alone reduce kernel and one read of x are gone
 static hipError_t launch_group_norm_any(const float* x, void* y, bool planes, const float* gamma, const float* beta, int n, int hw, int c,
-                                        int ldx, int n_group, float eps, bool silu, void* partials, hipStream_t stream, const ConvGemm* pending = nullptr) {
+                                        int ldx, int n_group, float eps, bool silu, void* partials, hipStream_t stream) {
     if ((c & 3) || (ldx & 3) || ldx < c || n_group > 64 || c % n_group) return hipErrorInvalidValue;
     if (c / 4 > 1024 || (planes && (c & 31))) return hipErrorInvalidValue;
     const GnGeom g = gn_geom(hw, c);
     double* part = reinterpret_cast<double*>(partials);
     const size_t lds = (size_t)(2 * g.R + 1) * c * sizeof(float) + (size_t)2 * c * sizeof(double);
-    if (pending) {
-        if (!slab_src_ok(*pending) || pending->N != c || pending->M != n * hw || !pending->C || pending->C != x || pending->ldc != ldx || pending->Ho * pending->Wo != hw)
-            return hipErrorInvalidValue;
-        hipLaunchKernelGGL(gn_stats_kernel<true>, dim3(g.chunks, n), dim3(g.threads), lds, stream, x, hw, c, ldx, n_group, g.rows_per_chunk, part,
-                           slab_src_of(*pending));
-    } else
-    hipLaunchKernelGGL(gn_stats_kernel<false>, dim3(g.chunks, n), dim3(g.threads), lds, stream, x, hw, c, ldx, n_group,
-                       g.rows_per_chunk, part, SlabSrc{});
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(g.chunks, n), dim3(g.threads), lds, stream, x, hw, c, ldx, n_group,
+                       g.rows_per_chunk, part);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     float* yf = reinterpret_cast<float*>(y);
@@ -246,12 +191,12 @@ static hipError_t launch_group_norm_any(const float* x, void* y, bool planes, co
 }
 
 hipError_t launch_group_norm(const float* x, float* y, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
-                             int n_group, float eps, bool silu, void* partials, hipStream_t stream, const ConvGemm* pending) {
-    return launch_group_norm_any(x, y, false, gamma, beta, n, hw, c, ldx, n_group, eps, silu, partials, stream, pending);
+                             int n_group, float eps, bool silu, void* partials, hipStream_t stream) {
+    return launch_group_norm_any(x, y, false, gamma, beta, n, hw, c, ldx, n_group, eps, silu, partials, stream);
 }
 hipError_t launch_group_norm_planes(const float* x, void* y3, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
-                                    int n_group, float eps, bool silu, void* partials, hipStream_t stream, const ConvGemm* pending) {
-    return launch_group_norm_any(x, y3, true, gamma, beta, n, hw, c, ldx, n_group, eps, silu, partials, stream, pending);
+                                    int n_group, float eps, bool silu, void* partials, hipStream_t stream) {
+    return launch_group_norm_any(x, y3, true, gamma, beta, n, hw, c, ldx, n_group, eps, silu, partials, stream);
 }
 
 // ---- LayerNorm: L lanes per row ---------------------------------------------------------------
@@ -260,12 +205,10 @@ hipError_t launch_group_norm_planes(const float* x, void* y3, const float* gamma
 // 16-byte loads in flight and the wave covers 4 rows (exact two-pass mean / variance as before, xor-shuffles inside the L lanes).
 constexpr int kLnMaxVec = 8;  // float4 per lane
 
-// SLABS: x is the not-yet-combined result of a split-K GEMM (SlabSrc): the row is summed from the slabs (+ bias + residual), written
-// out as the fp32 tensor the residual stream continues with, and normalised -- one kernel instead of reduce + LayerNorm.
-template <int L, bool P3, bool SLABS>
+template <int L, bool P3>
 __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                          const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, int rows, int C, float eps, const SlabSrc src) {
+                                                         const float* __restrict__ beta, int rows, int C, float eps) {
     constexpr int RPW = 64 / L;                       // rows per wave
     const int lane = threadIdx.x & 63;
     const int sub = lane / L, l = lane % L;
@@ -280,8 +223,7 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
         const int f = l + i * L;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (f < cq && row_ok) {
-            if constexpr (SLABS) v[i] = slab_value(src, row, 0, f * 4, true);
-            else v[i] = *reinterpret_cast<const f32x4*>(xr + f * 4);
+            v[i] = *reinterpret_cast<const f32x4*>(xr + f * 4);
             sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
@@ -317,37 +259,24 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
 }
 
 template <bool P3>
-static hipError_t launch_layer_norm_any(const float* x, float* y, const float* gamma, const float* beta, int rows, int c, float eps, hipStream_t stream,
-                                        const ConvGemm* pending) {
+static hipError_t launch_layer_norm_any(const float* x, float* y, const float* gamma, const float* beta, int rows, int c, float eps, hipStream_t stream) {
     if ((c & 3) || c > kLnMaxVec * 256 || (P3 && (c & 31))) return hipErrorInvalidValue;
     const int cq = c >> 2;
-    if (pending) {
-        // (no per-sample row vector on this path: the Linear layers that feed a LayerNorm have none)
-        if (!slab_src_ok(*pending) || pending->N != c || pending->M != rows || !pending->C || pending->C != x || pending->ldc != c || pending->rowvec) return hipErrorInvalidValue;
-        const SlabSrc src = slab_src_of(*pending);
-        if (cq <= 16 * kLnMaxVec)
-            hipLaunchKernelGGL((layer_norm_kernel<16, P3, true>), dim3((rows + 15) / 16), dim3(256), 0, stream, x, y, gamma, beta, rows, c, eps, src);
-        else if (cq <= 32 * kLnMaxVec)
-            hipLaunchKernelGGL((layer_norm_kernel<32, P3, true>), dim3((rows + 7) / 8), dim3(256), 0, stream, x, y, gamma, beta, rows, c, eps, src);
-        else
-            hipLaunchKernelGGL((layer_norm_kernel<64, P3, true>), dim3((rows + 3) / 4), dim3(256), 0, stream, x, y, gamma, beta, rows, c, eps, src);
-        return hipGetLastError();
-    }
     if (cq <= 16 * kLnMaxVec)
-        hipLaunchKernelGGL((layer_norm_kernel<16, P3, false>), dim3((rows + 15) / 16), dim3(256), 0, stream, x, y, gamma, beta, rows, c, eps, SlabSrc{});
+        hipLaunchKernelGGL((layer_norm_kernel<16, P3>), dim3((rows + 15) / 16), dim3(256), 0, stream, x, y, gamma, beta, rows, c, eps);
     else if (cq <= 32 * kLnMaxVec)
-        hipLaunchKernelGGL((layer_norm_kernel<32, P3, false>), dim3((rows + 7) / 8), dim3(256), 0, stream, x, y, gamma, beta, rows, c, eps, SlabSrc{});
+        hipLaunchKernelGGL((layer_norm_kernel<32, P3>), dim3((rows + 7) / 8), dim3(256), 0, stream, x, y, gamma, beta, rows, c, eps);
     else
-        hipLaunchKernelGGL((layer_norm_kernel<64, P3, false>), dim3((rows + 3) / 4), dim3(256), 0, stream, x, y, gamma, beta, rows, c, eps, SlabSrc{});
+        hipLaunchKernelGGL((layer_norm_kernel<64, P3>), dim3((rows + 3) / 4), dim3(256), 0, stream, x, y, gamma, beta, rows, c, eps);
     return hipGetLastError();
 }
 hipError_t launch_layer_norm(const float* x, float* y, const float* gamma, const float* beta, int rows, int c,
-                             float eps, hipStream_t stream, const ConvGemm* pending) {
-    return launch_layer_norm_any<false>(x, y, gamma, beta, rows, c, eps, stream, pending);
+                             float eps, hipStream_t stream) {
+    return launch_layer_norm_any<false>(x, y, gamma, beta, rows, c, eps, stream);
 }
 hipError_t launch_layer_norm_planes(const float* x, void* y3, const float* gamma, const float* beta, int rows, int c, float eps,
-                                    hipStream_t stream, const ConvGemm* pending) {
-    return launch_layer_norm_any<true>(x, reinterpret_cast<float*>(y3), gamma, beta, rows, c, eps, stream, pending);
+                                    hipStream_t stream) {
+    return launch_layer_norm_any<true>(x, reinterpret_cast<float*>(y3), gamma, beta, rows, c, eps, stream);
 }
 
 }  // namespace sdmi

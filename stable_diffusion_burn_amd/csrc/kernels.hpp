@@ -26,9 +26,6 @@ struct ConvGemm {
     void* C3;             // k_gemm3x.hip / k_gemm3p.hip / launch_splitk_reduce: not null -> the output ALSO (or only) as three bf16 planes, [M][ldc3 / 192 slices][3][32]
     int ldc3;             // bytes between output rows in C3 (needs N % 4 == 0: the 16-byte epilogue)
     float* slabs;         // splits > 1: fp32 partial sums [splits][M][N]
-    int slab_wt;          // with counters: slab tiles are stored write-through (sc1) and published without a release fence
-    unsigned* counters;   // splits > 1: per-tile arrival counters (zero between launches) -> the last-arriving slice combines
-                          // the slabs and applies the epilogue inside the launch; null: a separate reduce kernel does
     const float* bias;    // [N] or null
     const float* rowvec;  // per-sample per-channel add (time embedding) or null
     const float* resid;   // residual [M][ldr] or null
@@ -115,7 +112,7 @@ const GemmTileInfo& gemm_tile_info_s(int cfg);
 hipError_t launch_conv_gemm3x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 hipError_t launch_pack_split3(const float* bt, void* w3, long long rows, int K, hipStream_t s);
 // the same arithmetic with the ACTIVATIONS as planes too, written once by their producer (k_gemm3p.hip; tile_cfg 300 + x; needs p.A3)
-constexpr int kNumGemmTilesP = 5;
+constexpr int kNumGemmTilesP = 9;
 const GemmTileInfo& gemm_tile_info_p(int cfg);
 hipError_t launch_conv_gemm3p(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 // fp32 rows [rows][ld] (c channels, c % 32 == 0) -> planes [rows][ld3_bytes / 192 slices][3][32] bf16 (slices [0, c / 32) written)
@@ -136,7 +133,7 @@ hipError_t launch_quantize_fp8(const float* x, void* q, void* s, long long rows,
 hipError_t launch_dequant_fp8(const void* q, const void* s, float* out, long long rows, int c, hipStream_t stream);
 hipError_t launch_pack_conv_weight_bf16(const float* w_oihw, void* bt, int cout, int cin, int kh, int kw, hipStream_t s);
 hipError_t launch_pack_linear_weight_bf16(const float* w_in_out, void* bt, int cin, int cout, hipStream_t s);
-// sums split-K slabs in fixed order and applies the epilogue (the fallback when p.counters == null)
+// sums split-K slabs in fixed order and applies the epilogue
 hipError_t launch_splitk_reduce(const ConvGemm& p, hipStream_t stream);
 // weight packing (done once at load)
 hipError_t launch_pack_conv_weight(const float* w_oihw, float* bt, int cout, int cin, int kh, int kw, hipStream_t s);
@@ -171,20 +168,17 @@ hipError_t launch_softmax_rows(float* x, int rows, int cols, float scale, hipStr
 // `partials` needs gn_partials_bytes(n, hw, c) bytes of scratch.
 size_t gn_partials_bytes(int n, int hw, int c);
 // ldx: elements between pixels of x (>= c; x may be a channel slice of a wider buffer); y is dense [n][hw][c]
-// pending (optional): x has not been written yet -- it is the result of that split-K GEMM (pending->slabs, splits, bias, rowvec, resid; C == x):
-// the statistics pass / the row pass combines the slabs in slice order, writes x (and C3, its planes) and normalises it, so that the
-// stand-alone launch_splitk_reduce and one read of x disappear.  Needs the 16-byte path (N % 4 == 0, ldc / ldr % 4 == 0).
 hipError_t launch_group_norm(const float* x, float* y, const float* gamma, const float* beta,
                              int n, int hw, int c, int ldx, int n_group, float eps, bool silu,
-                             void* partials, hipStream_t stream, const ConvGemm* pending = nullptr);
+                             void* partials, hipStream_t stream);
 hipError_t launch_layer_norm(const float* x, float* y, const float* gamma, const float* beta,
-                             int rows, int c, float eps, hipStream_t stream, const ConvGemm* pending = nullptr);
+                             int rows, int c, float eps, hipStream_t stream);
 // the same normalisations with the result written as three bf16 planes (k_split3.hpp; y3 dense: (c / 32) * 192 bytes per pixel / row),
 // what the consuming k_gemm3p.hip launch reads.  c % 32 == 0.
 hipError_t launch_group_norm_planes(const float* x, void* y3, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
-                                    int n_group, float eps, bool silu, void* partials, hipStream_t stream, const ConvGemm* pending = nullptr);
+                                    int n_group, float eps, bool silu, void* partials, hipStream_t stream);
 hipError_t launch_layer_norm_planes(const float* x, void* y3, const float* gamma, const float* beta, int rows, int c, float eps,
-                                    hipStream_t stream, const ConvGemm* pending = nullptr);
+                                    hipStream_t stream);
 
 // ---- elementwise / data movement ---------------------------------------------------
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, float scale, hipStream_t s);
@@ -193,6 +187,7 @@ hipError_t launch_concat_channels(const float* a, const float* b, float* dst, lo
 hipError_t launch_geglu(const float* proj, float* out, long long rows, int hidden, hipStream_t s);
 hipError_t launch_geglu_planes(const float* proj, void* out3, long long rows, int hidden, hipStream_t s);   // out3: planes, hidden % 32 == 0
 hipError_t launch_silu(const float* x, float* y, long long n, hipStream_t s);
+hipError_t launch_repeat_rows(const float* src, float* dst, int n, long long elems, hipStream_t s);   // dst[i][:] = src[:], i < n
 hipError_t launch_nhwc_to_nchw_slice(const float* src, float* dst, int n, int c_src, int c_out, int h, int w, hipStream_t s);
 hipError_t launch_nchw3_to_nhwc4(const float* src, float* dst, int n, int h, int w, hipStream_t s);
 // CLIP text encoder pieces (clip/mod.rs): QuickGELU in place, token + position embedding, decoder mask

@@ -168,8 +168,14 @@ struct MpkParser {
         MpkTensor t;
         t.name = dump_name(path);
         t.shape = read_shape(find(es, "shape")->val);
+        // checked product: a record is at most the file, so no honest tensor has more elements than the file has bytes -- a shape such as
+        // [2^62 + 1] would otherwise wrap count * 4 to a small number and pass the byte-length check below with a 4-byte payload
+        const size_t file_bytes = (size_t)(root.end - root.base);
         t.count = 1;
-        for (int64_t d : t.shape) t.count *= (size_t)d;
+        for (int64_t d : t.shape) {
+            if (d != 0 && t.count > file_bytes / (size_t)d) throw Error(SDMI_ERR_IO, "mpk record: tensor '" + t.name + "' has a shape larger than the file");
+            t.count *= (size_t)d;
+        }
         if (const Entry* dt = find(es, "dtype")) {
             Cur c = at(dt->val);
             Cur probe = c;
@@ -190,7 +196,7 @@ struct MpkParser {
                 t.data = c.p;
                 t.file_offset = (size_t)(c.p - root.base);
             } else if (h.kind == K_ARRAY) {    // Vec<u8> written WITHOUT serde_bytes: an array of small integers
-                if (h.n != t.count * 4) bad(c, "tensor byte length does not match its shape");
+                if (h.n != t.count * 4 || h.n > (uint64_t)(root.end - c.p)) bad(c, "tensor byte length does not match its shape");   // (each element is >= 1 byte of file)
                 f.owned_.emplace_back((size_t)t.count);
                 unsigned char* dst = reinterpret_cast<unsigned char*>(f.owned_.back().data());
                 for (uint64_t i = 0; i < h.n; ++i) {
@@ -204,7 +210,7 @@ struct MpkParser {
         } else {   // burn <= 0.13 DataSerialize: "value": [f32, ...]
             Cur c = at(find(es, "value")->val);
             const Head h = head(c);
-            if (h.kind != K_ARRAY || h.n != t.count) bad(c, "tensor value count does not match its shape");
+            if (h.kind != K_ARRAY || h.n != t.count || h.n > (uint64_t)(root.end - c.p)) bad(c, "tensor value count does not match its shape");
             f.owned_.emplace_back((size_t)t.count);
             float* dst = f.owned_.back().data();
             for (uint64_t i = 0; i < h.n; ++i) {

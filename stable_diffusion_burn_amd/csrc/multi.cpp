@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -20,6 +21,7 @@
 #include <vector>
 
 #include "engine.hpp"
+#include "multi_ranks.hpp"
 
 namespace sdmi {
 
@@ -80,6 +82,7 @@ public:
                 c.device = devices[i];
                 engines_.push_back(new Engine(c));
             }
+            shards_.resize((size_t)n);
             g_rccl.open();
             comms_.resize(n, nullptr);
             g_rccl.check(g_rccl.CommInitAll(comms_.data(), n, devs_.data()), "ncclCommInitAll");
@@ -95,23 +98,12 @@ public:
     int size() const { return (int)engines_.size(); }
     Engine& engine(int i) { return *engines_.at((size_t)i); }
 
-    // runs f(rank) on one host thread per device and rethrows the first failure in the caller's thread
+    // runs f(rank) on one host thread per device and rethrows the first failure in the caller's thread (multi_ranks.hpp); on a failure
+    // every device's stream is drained first, so nothing is still writing into the caller's buffers when the error reaches it
     template <class F>
     void for_each_device(F&& f) {
-        const int R = size();
-        std::vector<std::string> msg((size_t)R);
-        std::vector<int> status((size_t)R, SDMI_OK);
-        auto body = [&](int r) {
-            try { f(r); }
-            catch (const Error& e) { status[r] = e.status; msg[r] = e.what(); }
-            catch (const std::exception& e) { status[r] = SDMI_ERR_INVALID; msg[r] = e.what(); }
-        };
-        std::vector<std::thread> th;
-        for (int r = 1; r < R; ++r) th.emplace_back(body, r);
-        body(0);
-        for (auto& t : th) t.join();
-        for (int r = 0; r < R; ++r)
-            if (status[r] != SDMI_OK) throw Error(status[r], "device " + std::to_string(devs_[r]) + ": " + msg[r]);
+        run_on_ranks(size(), [&](int r) { return "device " + std::to_string(devs_[(size_t)r]); }, std::forward<F>(f),
+                     [&] { for (int r = 0; r < size(); ++r) { (void)hipSetDevice(devs_[(size_t)r]); (void)hipStreamSynchronize(engine(r).stream()); } });
     }
 
     void sample_image(const float* context, int T, const float* uncond, int Tu, double scale, size_t n_steps, int n_images,
@@ -123,20 +115,34 @@ public:
         const size_t n_cond = (size_t)T * cd, n_unc = (size_t)Tu * cd, n_prompt = n_cond + n_unc;
         const size_t lat_elems = (size_t)4 * H * W, img_bytes = (size_t)3 * 64 * H * W;
 
-        // the packed prompt [cond | uncond] on every device; rank 0 holds the data
-        std::vector<Engine::Buf*> prompt((size_t)R, nullptr);
-        struct Free { std::vector<Engine::Buf*>& v; ~Free() { for (auto* b : v) delete b; } } free_prompt{prompt};
+        // Per-device buffers live in the context and only ever grow (round 2 allocated four pool blocks per device per call and freed
+        // them while the work that used them was still in flight); the prompt is staged through pinned host memory.
         for (int r = 0; r < R; ++r) {
-            SDMI_HIP(hipSetDevice(devs_[r]));
-            prompt[r] = new Engine::Buf(&engine(r), n_prompt * sizeof(float));
+            int g0, g1;
+            shard_range(n_images, r, R, &g0, &g1);
+            const size_t n = (size_t)(g1 - g0);
+            SDMI_HIP(hipSetDevice(devs_[(size_t)r]));
+            Shard& sh = shards_[(size_t)r];
+            sh.prompt.reserve(n_prompt * sizeof(float));
+            sh.ctx.reserve(n * n_cond * sizeof(float));
+            sh.x0.reserve(n * lat_elems * sizeof(float));
+            sh.lat.reserve(n * lat_elems * sizeof(float));
+            sh.rgb.reserve(n * img_bytes);
         }
         SDMI_HIP(hipSetDevice(devs_[0]));
-        SDMI_HIP(hipMemcpyAsync(prompt[0]->p, context, n_cond * sizeof(float), hipMemcpyHostToDevice, engine(0).stream()));
-        SDMI_HIP(hipMemcpyAsync(prompt[0]->f() + n_cond, uncond, n_unc * sizeof(float), hipMemcpyHostToDevice, engine(0).stream()));
+        if (pinned_bytes_ < n_prompt * sizeof(float)) {
+            if (pinned_) (void)hipHostFree(pinned_);
+            pinned_ = nullptr; pinned_bytes_ = 0;
+            SDMI_HIP(hipHostMalloc(&pinned_, n_prompt * sizeof(float), hipHostMallocDefault));
+            pinned_bytes_ = n_prompt * sizeof(float);
+        }
+        std::memcpy(pinned_, context, n_cond * sizeof(float));
+        std::memcpy(reinterpret_cast<float*>(pinned_) + n_cond, uncond, n_unc * sizeof(float));
+        SDMI_HIP(hipMemcpyAsync(shards_[0].prompt.p, pinned_, n_prompt * sizeof(float), hipMemcpyHostToDevice, engine(0).stream()));
         // THE collective of the path: one broadcast, each rank's part enqueued on that device's own stream
         g_rccl.check(g_rccl.GroupStart(), "ncclGroupStart");
         for (int r = 0; r < R; ++r)
-            g_rccl.check(g_rccl.Broadcast(prompt[r]->p, prompt[r]->p, n_prompt, ncclFloat32, 0, comms_[r], engine(r).stream()), "ncclBroadcast");
+            g_rccl.check(g_rccl.Broadcast(shards_[(size_t)r].prompt.p, shards_[(size_t)r].prompt.p, n_prompt, ncclFloat32, 0, comms_[(size_t)r], engine(r).stream()), "ncclBroadcast");
         g_rccl.check(g_rccl.GroupEnd(), "ncclGroupEnd");
         ++broadcasts_;
 
@@ -145,21 +151,24 @@ public:
             shard_range(n_images, r, R, &g0, &g1);
             const int n = g1 - g0;
             Engine& e = engine(r);
+            Shard& sh = shards_[(size_t)r];
             Engine::Call call(e);          // also hipSetDevice
             if (n > 0) {
-                Engine::Buf ctx(&e, (size_t)n * n_cond * sizeof(float)), x0(&e, (size_t)n * lat_elems * sizeof(float));
-                Engine::Buf lat(&e, (size_t)n * lat_elems * sizeof(float)), rgb(&e, (size_t)n * img_bytes);
-                for (int i = 0; i < n; ++i)   // the same prompt for every image of the shard (sample/main.rs:100-109)
-                    SDMI_HIP(hipMemcpyAsync(ctx.f() + (size_t)i * n_cond, prompt[r]->p, n_cond * sizeof(float), hipMemcpyDeviceToDevice, e.stream()));
+                float* prompt = reinterpret_cast<float*>(sh.prompt.p);
+                float* ctx = reinterpret_cast<float*>(sh.ctx.p);
+                float* x0 = reinterpret_cast<float*>(sh.x0.p);
+                float* lat = reinterpret_cast<float*>(sh.lat.p);
+                // the same prompt for every image of the shard (sample/main.rs:100-109): one kernel, not n copies
+                SDMI_HIP(launch_repeat_rows(prompt, ctx, n, (long long)n_cond, e.stream()));
                 if (init_latents) {
-                    SDMI_HIP(hipMemcpyAsync(x0.p, init_latents + (size_t)g0 * lat_elems, (size_t)n * lat_elems * sizeof(float), hipMemcpyHostToDevice, e.stream()));
+                    SDMI_HIP(hipMemcpyAsync(x0, init_latents + (size_t)g0 * lat_elems, (size_t)n * lat_elems * sizeof(float), hipMemcpyHostToDevice, e.stream()));
                 } else {
                     for (int i = 0; i < n; ++i)   // noise keyed by the global image index: independent of the device count
-                        SDMI_HIP(launch_fill_normal(x0.f() + (size_t)i * lat_elems, (long long)lat_elems, seed + (uint64_t)(g0 + i), e.stream()));
+                        SDMI_HIP(launch_fill_normal(x0 + (size_t)i * lat_elems, (long long)lat_elems, seed + (uint64_t)(g0 + i), e.stream()));
                 }
-                e.sample_latent_dev(ctx.f(), n, T, prompt[r]->f() + n_cond, Tu, scale, n_steps, x0.f(), lat.f());
-                e.decode_latent_dev(lat.f(), n, (float)(1.0 / 0.18215), nullptr, reinterpret_cast<uint8_t*>(rgb.p));
-                SDMI_HIP(hipMemcpyAsync(rgb_out + (size_t)g0 * img_bytes, rgb.p, (size_t)n * img_bytes, hipMemcpyDeviceToHost, e.stream()));
+                e.sample_latent_dev(ctx, n, T, prompt + n_cond, Tu, scale, n_steps, x0, lat);
+                e.decode_latent_dev(lat, n, (float)(1.0 / 0.18215), nullptr, reinterpret_cast<uint8_t*>(sh.rgb.p));
+                SDMI_HIP(hipMemcpyAsync(rgb_out + (size_t)g0 * img_bytes, sh.rgb.p, (size_t)n * img_bytes, hipMemcpyDeviceToHost, e.stream()));
             }
             call.finish();   // waits for this device's stream (incl. its share of the broadcast and the D2H copy)
         });
@@ -168,13 +177,38 @@ public:
     long long broadcasts() const { return broadcasts_; }
 
 private:
+    // a device buffer that only grows (hipMalloc on the current device: the caller sets it)
+    struct DevBuf {
+        void* p = nullptr; size_t cap = 0;
+        void reserve(size_t bytes) {
+            if (bytes <= cap) return;
+            if (p) { SDMI_HIP(hipDeviceSynchronize()); (void)hipFree(p); p = nullptr; cap = 0; }
+            const size_t want = std::max<size_t>(bytes, 256);
+            SDMI_HIP(hipMalloc(&p, want));
+            cap = want;
+        }
+        void release() noexcept { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    };
+    struct Shard { DevBuf prompt, ctx, x0, lat, rgb; };
     void destroy() noexcept {
         for (size_t i = 0; i < comms_.size(); ++i)
             if (comms_[i] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comms_[i]);
         comms_.clear();
+        for (size_t r = 0; r < shards_.size() && r < devs_.size(); ++r) {
+            (void)hipSetDevice(devs_[r]);
+            (void)hipDeviceSynchronize();
+            Shard& sh = shards_[r];
+            sh.prompt.release(); sh.ctx.release(); sh.x0.release(); sh.lat.release(); sh.rgb.release();
+        }
+        shards_.clear();
+        if (pinned_) (void)hipHostFree(pinned_);
+        pinned_ = nullptr; pinned_bytes_ = 0;
         for (Engine* e : engines_) delete e;
         engines_.clear();
     }
+    std::vector<Shard> shards_;
+    void* pinned_ = nullptr;          // host staging of the packed prompt
+    size_t pinned_bytes_ = 0;
     std::vector<int> devs_;
     std::vector<Engine*> engines_;
     std::vector<ncclComm_t> comms_;
@@ -242,6 +276,29 @@ int sdmi_sample_image_sharded(sdmi_multi* m, const float* context, int32_t T, co
     return multi_guard([&] {
         if (!m) throw sdmi::Error(SDMI_ERR_INVALID, "null sdmi_multi");
         m->m->sample_image(context, T, uncond, Tu, scale, n_steps, n_images, init_latents, seed, rgb_out);
+    });
+}
+
+int sdmi_selftest_rank_errors(int32_t n_ranks, int32_t failing_rank) {
+    return multi_guard([&] {
+        if (n_ranks <= 0 || n_ranks > 64) throw sdmi::Error(SDMI_ERR_INVALID, "selftest_rank_errors: n_ranks out of range");
+        std::vector<int> done((size_t)n_ranks, 0);
+        int drained = 0;
+        try {
+            sdmi::run_on_ranks(n_ranks, [](int r) { return "rank " + std::to_string(r); },
+                               [&](int r) {
+                                   if (r == failing_rank) throw sdmi::Error(SDMI_ERR_HIP, "injected failure");
+                                   done[(size_t)r] = 1;
+                               },
+                               [&] { ++drained; });
+        } catch (const sdmi::Error& e) {
+            // every other rank must have run to completion and the drain hook exactly once before the error surfaces
+            for (int r = 0; r < n_ranks; ++r)
+                if (r != failing_rank && !done[(size_t)r]) throw sdmi::Error(SDMI_ERR_STATE, "selftest: a healthy rank was abandoned");
+            if (drained != 1) throw sdmi::Error(SDMI_ERR_STATE, "selftest: the drain hook did not run exactly once");
+            throw;
+        }
+        if (failing_rank >= 0 && failing_rank < n_ranks) throw sdmi::Error(SDMI_ERR_STATE, "selftest: the failure was swallowed");
     });
 }
 

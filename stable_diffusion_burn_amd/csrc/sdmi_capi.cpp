@@ -550,6 +550,13 @@ int sdmi_profile_stats(sdmi_ctx* ctx, int32_t cls, double* ms, int64_t* launches
     });
 }
 
+int sdmi_profile_overhead(sdmi_ctx* ctx, double* ms) {
+    return guarded([&] {
+        if (!ms) throw Error(SDMI_ERR_INVALID, "profile_overhead: null output");
+        *ms = eng(ctx).prof_overhead_ms_;
+    });
+}
+
 int sdmi_bench_conv(sdmi_ctx* ctx, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t k,
                     int32_t stride, int32_t upsample2x, int32_t tile_cfg, int32_t splitk, int32_t iters, double* ms_out) {
     return guarded([&] {

@@ -315,6 +315,12 @@ class StableDiffusion:
 
     PROFILE_CLASSES = ("conv_gemm", "splitk_reduce", "attention", "group_norm", "layer_norm", "conv_gemm_fp8", "conv_gemm_split", "split_rows", "other")
 
+    def profile_overhead_us(self) -> float:
+        """what an empty HIP-event pair reads on the engine's stream (calibrated when profiling was switched on; subtracted from every sample)"""
+        v = C.c_double()
+        check(self._lib.sdmi_profile_overhead(self._ctx, C.byref(v)))
+        return v.value * 1e3
+
     def profile_stats(self) -> dict:
         """Per-kernel-class HIP-event timings gathered while set_option("profile", 1)."""
         out = {}

@@ -125,36 +125,6 @@ XCASES_SHORT_K = [
 ]
 
 
-@pytest.mark.parametrize("variant", [3])
-@pytest.mark.parametrize("tile", [100, 101, 102, 103])
-def test_conv2d_bf16_large_tiles_pipelined_loop(ops16, tile, variant):
-    """gemm_bf16x_variant = 3: the pipelined k loop of k_gemm_bf16x.hip (DMA pieces and fragment reads behind the matrix
-    instructions, barrier near the end of a tile, fragment reads as inline asm with hand-counted waits).  Same products in the same order as the plain loop: bit-identical results,
-    on every conv flavour, with ragged M / N tiles, split-K, and 1 ... 3 k tiles per slice; and the plain loop's parity bar."""
-    for case in [c + (s,) for c in XCASES for s in (1, 3)] + [c[:6] + (1, 0, c[6]) for c in XCASES_SHORT_K]:
-        n, cin, h, w, cout, k, stride, ups, splitk = case
-        g = np.random.default_rng(3500 + tile + 7 * splitk + cin + cout)
-        x = bf16_round(g.standard_normal((n, cin, h, w)))
-        wt = bf16_round(g.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k))
-        b = g.standard_normal(cout).astype(np.float32)
-        try:
-            ops16.set_option("gemm_tile", tile)
-            ops16.set_option("splitk", splitk)
-            plain = ops16.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
-            ops16.set_option("gemm_bf16x_variant", variant)
-            got = ops16.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
-            again = ops16.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups))
-        finally:
-            ops16.set_option("gemm_bf16x_variant", 0)
-            ops16.set_option("gemm_tile", "auto")
-            ops16.set_option("splitk", 0)
-        xin = O.upsample2x(_t(x)) if ups else _t(x)
-        ref = O.conv2d(xin, (_t(wt), _t(b)), stride=stride, padding=1 if k == 3 else 0).numpy()
-        _check(got, ref, f"conv bf16 pipelined loop tile={tile} {case}", 2 ** -8)
-        assert np.array_equal(got, again), f"pipelined loop not repeatable: tile={tile} {case}"
-        assert np.array_equal(got, plain), f"pipelined loop differs from the plain loop: tile={tile} {case}"
-
-
 @pytest.mark.parametrize("tile", [100, 103])
 def test_linear_bf16_large_tiles(ops16, tile):
     g = np.random.default_rng(tile)
@@ -296,23 +266,6 @@ def test_unet_forward_bf16_large_tiles_forced(sd16, tile):
     r, r0 = _rel_rms(got, ref), _rel_rms(base, ref)
     print(f"bf16 UNet forward, tile {tile} forced: rel-RMS {r:.3e} (auto tiles {r0:.3e})")
     assert np.isfinite(got).all() and r < BAR_UNET
-
-
-@pytest.mark.parametrize("variant", [3])
-@pytest.mark.parametrize("tile", ["auto", 100, 103])
-def test_unet_forward_bf16_pipelined_loop(sd16, tile, variant):
-    """the whole UNet with gemm_bf16x_variant = 3: bit-identical to the plain k loop (auto tiles and forced large tiles)."""
-    lat = np.stack([syn.initial_latent(i, 8, 8) for i in range(2)])
-    ctx = np.stack([syn.cond_context(i, 77, 768) for i in range(2)])
-    try:
-        sd16.set_option("gemm_tile", tile)
-        base = sd16.unet.forward(lat, [500], ctx)
-        sd16.set_option("gemm_bf16x_variant", variant)
-        got = sd16.unet.forward(lat, [500], ctx)
-    finally:
-        sd16.set_option("gemm_bf16x_variant", 0)
-        sd16.set_option("gemm_tile", "auto")
-    assert np.isfinite(got).all() and np.array_equal(got, base)
 
 
 @pytest.mark.parametrize("tile", ["auto", 2, 100, 103])

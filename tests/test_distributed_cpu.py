@@ -87,3 +87,19 @@ def test_c_abi_partition_rule_matches_the_launcher():
             assert covered == list(range(n))
     b, e = C.c_int32(), C.c_int32()
     assert lib.sdmi_shard_range(4, 4, 4, C.byref(b), C.byref(e)) != 0
+
+
+def test_rank_runner_surfaces_a_failing_rank_after_the_others_have_finished():
+    """sdmi_sample_image_sharded runs one host thread per device (csrc/multi_ranks.hpp); a rank that fails must not strand the others or
+    leave work in flight behind the caller's back: the library checks (and reports through its status) that every healthy rank ran to
+    completion and that the drain hook -- MultiEngine: hipStreamSynchronize on every device -- ran exactly once BEFORE the failing rank's
+    error was rethrown.  No device needed (sdmi_selftest_rank_errors)."""
+    from stable_diffusion_burn_amd import _capi
+    lib = _capi.load_library()
+    assert lib.sdmi_selftest_rank_errors(8, -1) == 0                  # nobody fails
+    for n, bad in ((1, 0), (2, 1), (8, 0), (8, 5), (8, 7)):
+        rc = lib.sdmi_selftest_rank_errors(n, bad)
+        msg = lib.sdmi_last_error().decode()
+        assert rc == -2, (n, bad, rc)                                  # SDMI_ERR_HIP: the status the failing rank threw
+        assert f"rank {bad}: injected failure" in msg, msg             # the failing rank is named, with its own message
+    assert lib.sdmi_selftest_rank_errors(0, 0) < 0                    # bad arguments are errors, not crashes

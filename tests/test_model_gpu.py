@@ -74,26 +74,6 @@ def test_unet_forward_large_tiles_forced(sd_tiny, synth, tiny_dims, tile):
     _assert_close(got, r32, r64, f"unet_forward tile={tile}", atol=1e-4)
 
 
-def test_unet_forward_counted_waits_split_gemm(sd_tiny, synth, tiny_dims):
-    """gemm3x_variant = 74 (k_gemm3x.hip HOIST = 3) under the whole UNet: the model-level bar, and the default loop's result up to
-    fp32 summation order."""
-    d = tiny_dims
-    lat, ctx, _ = _inputs(d, 2, 7, 2)
-    o32, o64 = _oracles(synth, d)
-    base = sd_tiny.unet.forward(lat, [300], ctx)
-    try:
-        sd_tiny.set_option("gemm3x_variant", 74)
-        got = sd_tiny.unet.forward(lat, [300], ctx)
-        again = sd_tiny.unet.forward(lat, [300], ctx)
-    finally:
-        sd_tiny.set_option("gemm3x_variant", 2)
-    r32 = o32.unet.forward(torch.from_numpy(lat), 300, torch.from_numpy(ctx)).numpy()
-    r64 = o64.unet.forward(torch.from_numpy(lat), 300, torch.from_numpy(ctx)).numpy()
-    _assert_close(got, r32, r64, "unet_forward gemm3x_variant=74", atol=1e-4)
-    assert np.array_equal(got, again)
-    assert np.abs(got - base).max() <= 2e-5 * max(1.0, np.abs(r64).max())
-
-
 def test_unet_forward_fp32_matrix_instruction_only(sd_tiny, synth, tiny_dims):
     """gemm_f32s=0 / attn_split=0: every product on v_mfma_f32_16x16x4_f32 (round 1's arithmetic).  Same bar; and the default
     path (fp32 operands as three bf16 terms, six partial products) agrees with it to fp32 rounding noise."""

@@ -116,7 +116,7 @@ def test_cpp_reader_accepts_the_tolerated_variants(tmp_path):
                    "clip/blocks/0/attn_ln/weight": (1,), "clip/position_embedding/weight": (2, 2), "alphas_cumprod": (3,)}
 
 
-@pytest.mark.parametrize("damage", ["truncate", "half_precision", "bad_length", "garbage", "empty"])
+@pytest.mark.parametrize("damage", ["truncate", "half_precision", "bad_length", "garbage", "empty", "wrapping_shape", "huge_value_array", "huge_byte_array"])
 def test_cpp_reader_rejects_bad_records(tmp_path, damage):
     import msgpack
     from stable_diffusion_burn_amd import SdmiError
@@ -131,6 +131,17 @@ def test_cpp_reader_rejects_bad_records(tmp_path, damage):
     elif damage == "bad_length":
         good["item"]["diffusion"]["conv_out"]["weight"]["param"]["shape"] = [3, 5]
         blob = msgpack.packb(good, use_bin_type=True)
+    elif damage == "wrapping_shape":
+        # 2^62 + 1 elements: count * 4 wraps to 4, which is exactly the payload's length -- must be rejected, not indexed
+        good["item"]["diffusion"]["conv_out"]["weight"]["param"] = {"bytes": b"\x00" * 4, "shape": [2 ** 62 + 1], "dtype": "F32"}
+        blob = msgpack.packb(good, use_bin_type=True)
+    elif damage == "huge_value_array":
+        # a `value` array header that claims 2^31 elements in a 100-byte file: no allocation of that size may happen before the elements are checked
+        hdr = msgpack.packb({"metadata": {}, "item": {"diffusion": {"conv_out": {"weight": {"id": "c", "param": {"shape": [2 ** 31], "value": []}}}}}}, use_bin_type=True)
+        blob = hdr[:-1] + bytes([0xdd, 0x80, 0x00, 0x00, 0x00])          # array32 with 2^31 entries, then nothing
+    elif damage == "huge_byte_array":
+        hdr = msgpack.packb({"metadata": {}, "item": {"diffusion": {"conv_out": {"weight": {"id": "c", "param": {"shape": [2 ** 29], "dtype": "F32", "bytes": []}}}}}}, use_bin_type=True)
+        blob = hdr[:-1] + bytes([0xdd, 0x80, 0x00, 0x00, 0x00])
     elif damage == "garbage":
         blob = bytes([0xc1]) * 64          # 0xc1 is the one reserved MessagePack type byte
     elif damage == "empty":

@@ -101,7 +101,7 @@ def main():
     if not bf16 and "s" in fams:
         tiles_all.update({200: "256x160", 201: "128x320", 202: "256x128", 203: "128x256", 204: "128x160", 205: "128x128"})   # k_gemm3x.hip
     if not bf16 and "p" in fams:
-        tiles_all.update({300: "256x160", 301: "256x128", 302: "128x256", 303: "128x160", 304: "128x128"})   # k_gemm3p.hip
+        tiles_all.update({300: "256x160", 301: "256x128", 302: "128x256", 303: "128x160", 304: "128x128", 305: "64x64", 306: "64x128", 307: "64x320", 308: "128x64"})   # k_gemm3p.hip
     merged = {}
     if args.merge:
         for ln in Path(args.merge).read_text().splitlines():

@@ -9,6 +9,34 @@ matrix / other VALU / SALU / LDS / VMEM / waits per trip -- the numbers DESIGN.m
 """
 import argparse, re, subprocess, tempfile, os, sys
 
+
+def function_lines(asm, name) :
+    i = asm.index(name + ":")
+    j = asm.index(".Lfunc_end", i)
+    out = []
+    for l in asm[i:j].split("\n")[1:]:
+        l = l.split(";")[0].strip() if not l.strip().startswith(".LBB") else l.strip()
+        if l:
+            out.append(l)
+    return out
+
+
+def innermost_loop(lines) :
+    """(index of the loop header label, index of its backward branch): the LAST backward branch whose target is the closest label above"""
+    labels = {l.split(":")[0]: i for i, l in enumerate(lines) if l.startswith(".LBB")}
+    best = None
+    for i, l in enumerate(lines):
+        m = re.match(r"s_cbranch_\w+\s+(\.LBB\S+)", l) or re.match(r"s_branch\s+(\.LBB\S+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            span = i - labels[m.group(1)]
+            n_mfma = sum("v_mfma" in x for x in lines[labels[m.group(1)]:i])
+            if n_mfma and (best is None or n_mfma > best[2]):
+                best = (labels[m.group(1)], i, n_mfma)
+    if best is None:
+        raise SystemExit("no loop with matrix instructions found")
+    return best[0], best[1]
+
+
 ap = argparse.ArgumentParser()
 ap.add_argument("src")
 ap.add_argument("--kernel", default=None, help="substring of the mangled name: dump that kernel's stream")
@@ -29,13 +57,11 @@ for b in re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]:
     print(f"{name[:110]:110s} VGPR {g('VGPRs'):>3s} AGPR {g('AGPRs'):>3s} SGPR {g('SGPRs'):>3s} scratch {scr} occ {occ}")
 if args.kernel and args.mix:
     import collections
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    import check_lgkm as ck
     asm_text = open(os.path.join(d, [f for f in os.listdir(d) if f.endswith("gfx950.s")][0])).read()
     for name in [m for m in re.findall(r"^(\w+):\s*; @", asm_text, re.M) if args.kernel in m]:
-        lines = ck.function_lines(asm_text, name)
+        lines = function_lines(asm_text, name)
         try:
-            h, b = ck.innermost_loop(lines)
+            h, b = innermost_loop(lines)
         except SystemExit:
             continue
         c = collections.Counter()
