@@ -67,7 +67,8 @@ typedef struct sdmi_config {
     int32_t latent_w;        /* 64                                              */
     int32_t vae_ch;          /* 128  (decoder channels 4c,4c,2c,c)              */
     int32_t max_batch;       /* largest n a call may pass; 0 = no limit          */
-    int32_t precision;       /* 0 = fp32; 1 = bf16 storage, fp32 accumulate; 2 = 1 + the ResBlock 3x3 convs in MXFP8 */
+    int32_t precision;       /* 0 = fp32; 1 = bf16 storage, fp32 accumulate; 2 = 1 + MXFP8 operands for the ResBlock convolutions, the transformer
+                              * blocks' Linear layers and the 1x1 / up / down convolutions (option "fp8_linear=0": the ResBlock 3x3 convolutions only) */
     /* CLIP text encoder, CLIPConfig::new(49408, 768, 12, 77, 12) stablediffusion/mod.rs:29;
      * its width is ctx_dim.  clip_layers = 0 builds a context without it.              */
     int32_t clip_layers;     /* 12                                              */
@@ -243,11 +244,6 @@ int sdmi_sample_image_sharded(sdmi_multi* m, const float* context, int32_t T, co
 /* the contiguous global image range [begin, end) device `rank` of `n_ranks` samples (host only): the partition rule of
  * sdmi_sample_image_sharded, and of the one-process-per-GPU launcher (bench.py / sharding.py use the same rule) */
 int sdmi_shard_range(int32_t n_images, int32_t rank, int32_t n_ranks, int32_t* begin, int32_t* end);
-/* how one GEMM launch of mt x nt output tiles and `splits` split-K slices is cut over the 8 XCDs of an MI355X (option "xcd_map"; host only,
- * no device needed): out = {cuts along M tiles, cuts along N tiles, M tiles / N tiles / slices per XCD}; the cut along the slices is
- * 8 / (out[0] out[1]).  a_bytes / w_bytes: the activation / weight bytes the launch reads; flops: its 2 M N K; cu_flops: what one
- * CU sustains in the kernel (FLOP/s).  What the CPU tests check the map with. */
-int sdmi_plan_xcd_map(int32_t mt, int32_t nt, int32_t splits, double a_bytes, double w_bytes, double flops, double cu_flops, int32_t out[5]);
 /* number of RCCL broadcasts issued so far (one per sdmi_sample_image_sharded call) */
 int64_t sdmi_multi_broadcast_count(sdmi_multi* m);
 /* Diagnostic, needs no device: drives the multi-context's rank runner (one host thread per rank, csrc/multi_ranks.hpp) with n_ranks
@@ -299,7 +295,21 @@ int sdmi_op_timestep_embedding(sdmi_ctx* ctx, int32_t t, int32_t dim, float* out
  * Arithmetic selectors of precision = 0 (both default 1): "gemm_f32s" = conv / linear GEMMs with Cin % 32 == 0 multiply on the bf16
  * matrix pipe with fp32 operands split exactly into three bf16 terms, six partial products, fp32 accumulation (k_gemm3x.hip);
  * "attn_split" = the same for qkv_attention at head dims 40 / 80 (k_attn_split.hip).  0 = the fp32 matrix instruction
- * (v_mfma_f32_16x16x4_f32) everywhere.  Same parity bars either way. */
+ * (v_mfma_f32_16x16x4_f32) everywhere.  Same parity bars either way.
+ * "gemm_planes" (default 1): the activations of those GEMMs are written as three bf16 planes by the kernel that produces them
+ * (GroupNorm / LayerNorm / GEGLU / attention / GEMM epilogues) and read by k_gemm3p.hip; 0 = staged as fp32 and split inside the
+ * GEMM's k loop (k_gemm3x.hip); 2 = test mode, fp32 tensors converted in front of every GEMM.
+ *
+ * fp32 semantics of precision = 0 with the split kernels (tests/test_planes_gpu.py::test_plane_path_at_the_edges_of_the_fp32_range):
+ *   - finite operands up to FLT_MAX: as the fp32 matrix instruction, to about one fp32 rounding per product (a value whose bf16
+ *     round-to-nearest would overflow takes a truncated high term instead);
+ *   - NaN stays NaN; an INFINITE operand gives a non-finite result, but possibly NaN where fp32 arithmetic gives +-inf (its low-order
+ *     partial products contain 0 * inf);
+ *   - |x| < 2^-109: the low-order terms of x fall below bf16's normal range and are dropped (absolute error < 2^-118 |w| per term);
+ *   - which kernel a layer runs on is a function of its shape and options only, never of the data.
+ * A caller that needs IEEE behaviour on infinities sets gemm_f32s = 0 / attn_split = 0.
+ * precision = 2 selectors: "fp8_convs" (0: the fp8-capable layers on the bf16 kernels), "fp8_linear" (see sdmi_config.precision),
+ * "fp8_min_rows" (GEMMs with fewer output rows stay bf16), "fp8_tile". */
 int sdmi_set_option(sdmi_ctx* ctx, const char* key, const char* value);
 /* time (ms, HIP events on the context stream) and kernel count of the last
  * hot-path call; flops = algorithmic FLOPs it executed (2*MAC of conv/GEMM/attention). */

@@ -79,7 +79,6 @@ SIGNATURES = {
     "sdmi_multi_load_weights": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "sdmi_sample_image_sharded": (C.c_int, [C.c_void_p, _F, C.c_int32, _F, C.c_int32, C.c_double, C.c_size_t, C.c_int32, _F, C.c_uint64, _U8]),
     "sdmi_shard_range": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _I32, _I32]),
-    "sdmi_plan_xcd_map": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, _I32]),
     "sdmi_multi_broadcast_count": (C.c_int64, [C.c_void_p]),
     "sdmi_selftest_rank_errors": (C.c_int, [C.c_int32, C.c_int32]),
     "sdmi_op_group_norm": (C.c_int, [_CTX, _F, _F, _F, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _F]),

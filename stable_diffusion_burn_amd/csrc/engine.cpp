@@ -131,7 +131,10 @@ void Engine::prof_calibrate() {
         prof_free_.push_back(b);
     }
     std::sort(t.begin(), t.end());
-    prof_overhead_ms_ = t.empty() ? 0.0 : (double)t[t.size() / 2];
+    // An empty pair reads the cost of TWO back-to-back event records (4.6 us on MI355X); a pair around a kernel adds about half of that
+    // to the kernel's duration -- rocprofv3's kernel trace of the same run is the yardstick: round 2, 46.0 us by raw events against 43.4 us
+    // by rocprofv3 per split-GEMM launch; round 3, 43.4 against 41.1 (profiles/README.md).  So half the empty-pair reading is subtracted.
+    prof_overhead_ms_ = t.empty() ? 0.0 : 0.5 * (double)t[t.size() / 2];
 }
 
 void Engine::prof_flush() {
@@ -319,6 +322,13 @@ void Engine::build_model() {
         e.dst8 = &w.bt8;
         e.dsts = &w.bs8;
     };
+    // ... and (option fp8_linear) the Linear layers of the transformer blocks
+    auto fp8_copy_lin = [&](LinW& w, const std::string& weight_name) {
+        if (!fp8_ || w.cin % 32 || w.cout % 8 || !w.dt) return;
+        WeightEntry& e = entries_[entry_index_.at(weight_name)];
+        e.dst8 = &w.bt8;
+        e.dsts = &w.bs8;
+    };
     auto res = [&](ResW& r, const std::string& path, int cin, int cout, bool unet) {
         r.cin = cin; r.cout = cout; r.has_embed = unet; r.has_skip = cin != cout;
         if (unet) {  // ResBlock, unet/mod.rs:679-734; names unet/load.rs:20-25
@@ -330,6 +340,7 @@ void Engine::build_model() {
             if (r.has_skip) conv(r.skip, path + "/skip_connection", cin, cout, 1);
             fp8_copy(r.conv_in, path + "/conv_in/weight");
             fp8_copy(r.conv_out, path + "/conv_out/weight");
+            if (r.has_skip) fp8_copy(r.skip, path + "/skip_connection/weight");
         } else {  // ResnetBlock, autoencoder/mod.rs:472-528; names autoencoder/load.rs:39-45
             norm(r.norm_in, path + "/norm1", cin);
             conv(r.conv_in, path + "/conv1", cin, cout, 3);
@@ -338,6 +349,8 @@ void Engine::build_model() {
             if (r.has_skip) conv(r.skip, path + "/nin_shortcut", cin, cout, 1);
             fp8_copy(r.conv_in, path + "/conv1/weight");
             fp8_copy(r.conv_out, path + "/conv2/weight");
+            // (the decoder's 1x1 shortcuts and up-convolutions stay bf16 under fp8_linear too: measured on MI355X, MXFP8 there moves the decoded
+            // RGB from 2.1e-2 to 9.8e-2 relative RMS of the exact decode and saves 0.4 ms per image)
         }
     };
     auto mha = [&](MhaW& m, const std::string& path, int c, int cctx) {  // unet/mod.rs:603-653
@@ -356,11 +369,28 @@ void Engine::build_model() {
             }
             m.k.bt = adv(m.q.bt, (long long)c * c, edt());
             m.v.bt = adv(m.q.bt, (long long)2 * c * c, edt());
+            if (fp8_ && c % 32 == 0) {   // the packed [3c][Kp] MXFP8 copy + its scales: one N = 3c GEMM as well
+                const size_t kp = (size_t)(c + 127) / 128 * 128;
+                void *q8 = nullptr, *s8 = nullptr;
+                SDMI_HIP(hipMalloc(&q8, (size_t)3 * c * kp));
+                weight_allocs_.push_back(q8);
+                SDMI_HIP(hipMalloc(&s8, (size_t)3 * c * kp / 32));
+                weight_allocs_.push_back(s8);
+                m.q.bt8 = reinterpret_cast<float*>(q8);
+                m.k.bt8 = reinterpret_cast<float*>((char*)q8 + (size_t)c * kp);
+                m.v.bt8 = reinterpret_cast<float*>((char*)q8 + (size_t)2 * c * kp);
+                m.q.bs8 = reinterpret_cast<float*>(s8);
+                m.k.bs8 = reinterpret_cast<float*>((char*)s8 + (size_t)c * kp / 32);
+                m.v.bs8 = reinterpret_cast<float*>((char*)s8 + (size_t)2 * c * kp / 32);
+            }
         }
         lin(m.q, path + "/query", c, c, false);
         lin(m.k, path + "/key", cctx, c, false);
         lin(m.v, path + "/value", cctx, c, false);
         lin(m.out, path + "/out", c, c, true);
+        fp8_copy_lin(m.q, path + "/query/weight");
+        if (c == cctx) { fp8_copy_lin(m.k, path + "/key/weight"); fp8_copy_lin(m.v, path + "/value/weight"); }   // (cross-attention K / V: hoisted, once per call, bf16)
+        fp8_copy_lin(m.out, path + "/out/weight");
         add_meta(path + "/n_head", 1, (float)cfg_.n_head, 0.f, nullptr);
     };
     auto spatial = [&](SpatialW& s, const std::string& path, int c) {  // unet/mod.rs:436-527
@@ -376,6 +406,10 @@ void Engine::build_model() {
         lin(s.geglu_proj, t + "/mlp/geglu/proj", c, 8 * c, true);
         lin(s.mlp_lin, t + "/mlp/lin", 4 * c, c, true);
         conv(s.proj_out, path + "/proj_out", c, c, 1);
+        fp8_copy(s.proj_in, path + "/proj_in/weight");
+        fp8_copy(s.proj_out, path + "/proj_out/weight");
+        fp8_copy_lin(s.geglu_proj, t + "/mlp/geglu/proj/weight");
+        fp8_copy_lin(s.mlp_lin, t + "/mlp/lin/weight");
     };
 
     add(this, "alphas_cumprod", 3, {1000}, nullptr);
@@ -401,12 +435,12 @@ void Engine::build_model() {
         const std::string path = root + "/" + s.name;
         switch (s.kind) {
             case BK_CONV: conv(b.conv, path, s.cin, s.cout, 3); break;
-            case BK_DOWN: conv(b.conv, path, s.cin, s.cout, 3, 2); break;  // load_downsample: path itself (unet/load.rs:138-143); stride 2, pad 1 (unet/mod.rs:413-418)
+            case BK_DOWN: conv(b.conv, path, s.cin, s.cout, 3, 2); fp8_copy(b.conv, path + "/weight"); break;  // load_downsample: path itself (unet/load.rs:138-143); stride 2, pad 1 (unet/mod.rs:413-418)
             case BK_RES: res(b.res, path, s.cin, s.cout, true); break;
             default:
                 res(b.res, path + "/res", s.cin, s.cout, true);
                 if (s.kind == BK_RES_ST || s.kind == BK_RES_ST_UP) spatial(b.st, path + "/transformer", s.cout);
-                if (s.kind == BK_RES_UP || s.kind == BK_RES_ST_UP) conv(b.up, path + "/upsample/conv", s.cout, s.cout, 3);
+                if (s.kind == BK_RES_UP || s.kind == BK_RES_ST_UP) { conv(b.up, path + "/upsample/conv", s.cout, s.cout, 3); fp8_copy(b.up, path + "/upsample/conv/weight"); }
         }
     };
     for (int i = 0; i < 12; ++i) def_block(in_blocks_[i], in_spec[i], "unet/input_blocks");
@@ -678,6 +712,20 @@ void Engine::stage_commit(WeightEntry& e, size_t offset, int half) {
         } else {
             err = e.wdt ? launch_pack_linear_weight_bf16(stage, *e.dst, (int)e.dims[0], (int)e.dims[1], stream_)
                         : launch_pack_linear_weight(stage, *e.dst, (int)e.dims[0], (int)e.dims[1], stream_);
+            if (err == hipSuccess && e.dst8) {
+                const int cin = (int)e.dims[0], cout = (int)e.dims[1];
+                const size_t kp = (size_t)(cin + 127) / 128 * 128;
+                if (!*e.dst8) {
+                    void *q = nullptr, *sc = nullptr;
+                    SDMI_HIP(hipMalloc(&q, (size_t)cout * kp));
+                    weight_allocs_.push_back(q);
+                    SDMI_HIP(hipMalloc(&sc, (size_t)cout * kp / 32));
+                    weight_allocs_.push_back(sc);
+                    *e.dst8 = reinterpret_cast<float*>(q);
+                    *e.dsts = reinterpret_cast<float*>(sc);
+                }
+                err = launch_pack_linear_weight_fp8(stage, *e.dst8, *e.dsts, cin, cout, stream_);
+            }
         }
         SDMI_HIP(err);
         if (!e.wdt) {   // the bf16 planes of the packed fp32 rows (k_gemm3x.hip)
@@ -985,11 +1033,12 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "roctx") roctx_enable(std::stoi(value) != 0);
     else if (key == "fp8_convs") opt_fp8_convs_ = std::stoi(value);
     else if (key == "fp8_min_rows") opt_fp8_min_rows_ = std::stoi(value);
+    else if (key == "fp8_linear") opt_fp8_linear_ = std::stoi(value);
+    else if (key == "fp8_ops") opt_fp8_ops_ = std::stoi(value);
     else if (key == "fp8_tile") opt_fp8_tile_ = (value == "auto") ? -1 : std::stoi(value);
     else if (key == "attn_bf16") opt_attn_bf16_ = std::stoi(value);
     else if (key == "attn_split") opt_attn_split_ = std::stoi(value);
     else if (key == "gemm_bf16x") opt_gemm_bf16x_ = std::stoi(value);
-    else if (key == "xcd_map") opt_xcd_map_ = std::stoi(value);
     else if (key == "gemm_x32") opt_gemm_x32_ = std::stoi(value);
     else if (key == "gemm_f32s") opt_gemm_f32s_ = std::stoi(value);
     else if (key == "bench_cold") opt_bench_cold_ = std::stoi(value);
@@ -1146,21 +1195,6 @@ TileChoice Engine::choose_tile_p(int M, int N, int kt_total, bool even_ni_only) 
     return bc;
 }
 
-// How the 8 XCDs share one GEMM launch (ConvGemm::xcd_*; kernels.hpp).  Every XCD has its own L2, so an operand byte crosses the
-// fabric once per XCD that touches it: with the box of work items (MT x NT x splits) cut xm x xn x xz ways (xm xn xz = 8) the launch
-// moves xn * (activation bytes) + xm * (weight bytes) into the L2s.  The legacy map is xm = 8 (bands of M tiles; or of N tiles when
-// there is one M tile), xz = 1: every XCD streams ALL the weights -- at batch 1 the weights are the big operand (88 MB of planes for
-// a 1280 -> 1280 3x3 convolution against 2.6 MB of activations) and most launches are split-K, whose slices are a third axis to cut
-// along: a slice reads 1 / splits of BOTH operands.  Chosen here (xcd_map_choose, kernels.hpp): the cut with the smallest modelled time,
-// rounds of work items on the busiest XCD x the time of one item + bytes / fabric bandwidth.  Option xcd_map = 1: on; 0: legacy map.
-void Engine::choose_xcd_map(ConvGemm& p, int MT, int NT, double a_bytes, double w_bytes, double flops, double cu_flops) const {
-    p.xcd_m = 0;
-    if (opt_xcd_map_ <= 0) return;
-    int o[5];
-    xcd_map_choose(MT, NT, p.splits, a_bytes, w_bytes, flops, cu_flops, o);
-    p.xcd_m = o[0]; p.xcd_n = o[1]; p.xcd_ml = o[2]; p.xcd_nl = o[3]; p.xcd_zl = o[4];
-}
-
 void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits) {
     const int kt_elems = in_dt ? 64 : 32;  // a k tile is 128 bytes of K per row in both storage types
     p.kt_total = (p.K + kt_elems - 1) / kt_elems;
@@ -1237,16 +1271,6 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     if (a_ext >= 0xFFFFFFE0ull || b_ext >= 0xFFFFFFE0ull) throw Error(SDMI_ERR_UNSUPPORTED, "GEMM: operand larger than 4 GiB (the buffer-load range check needs 32-bit extents)");
     p.a_bytes = (unsigned)a_ext;
     p.b_bytes = (unsigned)b_ext;
-    {
-        const GemmTileInfo& ti = tile_info(tc.cfg);
-        const int bno = p.geglu ? ti.bn / 2 : ti.bn;
-        const double wes = in_dt ? 2.0 : (tc.cfg >= 200 ? 6.0 : 4.0);     // bytes per weight as this kernel reads them (three bf16 planes: 6)
-        const double aes = (!in_dt && tc.cfg >= 300) ? 6.0 : (double)es;
-        // what a CU sustains in the kernel's k loop (chip rate / 256; measured per family: profiles/README.md)
-        const double cu_flops = (in_dt ? 1.2e15 : (tc.cfg >= 200 ? 2.3e14 : 1.3e14)) / 256.0;
-        choose_xcd_map(p, (p.M + ti.bm - 1) / ti.bm, (p.N + bno - 1) / bno, (double)p.NB * p.Hs * p.Ws * p.Cin * aes,
-                       (double)p.N * (p.geglu ? 2.0 : 1.0) * (double)p.K * wes, flops, cu_flops);
-    }
     // the output as planes (p.C3): written by the epilogue of the split / plane kernels and by the split-K reduce kernel on their 16-byte
     // path; otherwise (old kernels, odd strides, GEGLU epilogue) converted from an fp32 result right behind the launch
     void* const c3_want = in_dt ? nullptr : p.C3;
@@ -1521,7 +1545,14 @@ void Engine::res_block(const ResW& w, const Act& x, Act& y, int step) {
     if (w.has_skip) {
         if (y.p) { sk = y; sk.p3 = nullptr; sk.view = true; }
         else sk = new_act(y.n, y.h, y.w, y.c);
-        conv(w.skip, x, sk, 1, 0, nullptr, 0, nullptr);
+        if (use_fp8_wide(w.skip.bt8, x.rows()) && x.dt == 1 && x.c % 32 == 0) {
+            ActQ xq = new_actq(x.n, x.h, x.w, x.c);
+            quantize(x, xq);
+            conv_fp8(w.skip, xq, sk, nullptr, nullptr);
+            release(xq);
+        } else {
+            conv(w.skip, x, sk, 1, 0, nullptr, 0, nullptr);
+        }
     }
     const Act* resid = w.has_skip ? &sk : &x;
     if (use_fp8(w.conv_out, h2)) {
@@ -1566,21 +1597,41 @@ void Engine::group_norm_fp8(const NormW& w, const Act& x, ActQ& y, bool silu) {
     count_kernel(); count_kernel();
 }
 
-void Engine::conv_fp8(const ConvW& w, const ActQ& x, Act& y, const float* rowvec, const Act* resid) {
-    if (x.c != w.cin || w.k != 3 || !w.bt8) throw Error(SDMI_ERR_STATE, "conv_fp8: not an MXFP8-packed 3x3 convolution");
-    if (y.n != x.n || y.h != x.h || y.w != x.w || y.c != w.cout || y.dt != 1) throw Error(SDMI_ERR_INVALID, "conv_fp8: output shape / type mismatch");
+void Engine::conv_fp8(const ConvW& w, const ActQ& x, Act& y, const float* rowvec, const Act* resid, int stride, int ups) {
+    if (x.c != w.cin || (w.k != 3 && w.k != 1) || !w.bt8) throw Error(SDMI_ERR_STATE, "conv_fp8: not an MXFP8-packed convolution");
+    const int pad = w.k == 3 ? 1 : 0;
+    const int hin = x.h << ups, win = x.w << ups;
+    const int ho = (hin + 2 * pad - w.k) / stride + 1, wo = (win + 2 * pad - w.k) / stride + 1;
+    if (y.n != x.n || y.h != ho || y.w != wo || y.c != w.cout || y.dt != 1) throw Error(SDMI_ERR_INVALID, "conv_fp8: output shape / type mismatch");
     if (resid && (resid->rows() != y.rows() || resid->c != y.c || resid->dt != 1)) throw Error(SDMI_ERR_STATE, "conv_fp8: residual shape / type mismatch");
     ConvGemm p{};
     p.A = reinterpret_cast<const float*>(x.q); p.Bt = w.bt8; p.C = y.p; p.bias = w.bias; p.rowvec = rowvec; p.resid = resid ? resid->p : nullptr;
     p.a_scale = x.s; p.b_scale = w.bs8;
-    p.M = (int)x.rows(); p.N = w.cout; p.K = x.cp * 9;
-    p.NB = x.n; p.Hs = x.h; p.Ws = x.w; p.Cin = x.cp; p.Ho = x.h; p.Wo = x.w;
-    p.KH = 3; p.KW = 3; p.stride = 1; p.pad = 1; p.ups = 0;
+    p.M = x.n * ho * wo; p.N = w.cout; p.K = x.cp * w.k * w.k;
+    p.NB = x.n; p.Hs = x.h; p.Ws = x.w; p.Cin = x.cp; p.Ho = ho; p.Wo = wo;
+    p.KH = w.k; p.KW = w.k; p.stride = stride; p.pad = pad; p.ups = ups;
     p.ldc = y.stride(); p.ldr = resid ? resid->stride() : y.stride(); p.a_ld = x.cp; p.b_ld = p.K; p.rowvec_stride = 0; p.CS = 128;
+    launch_fp8(p, 2.0 * p.M * (double)p.N * w.cin * w.k * w.k);   // algorithmic (unpadded) work
+}
+
+// C[rows][n_rows_w] (bf16) = x W^T + bias (+ resid): a Linear layer on MXFP8 operands (n_rows_w = w.cout, or 3 cout for the packed q | k | v)
+void Engine::gemm_fp8(const ActQ& x, const LinW& w, int n_rows_w, void* C, int ldc, const float* resid, int ldr) {
+    if (x.c != w.cin || !w.bt8) throw Error(SDMI_ERR_STATE, "gemm_fp8: not an MXFP8-packed Linear layer");
+    ConvGemm p{};
+    p.A = reinterpret_cast<const float*>(x.q); p.Bt = w.bt8; p.C = reinterpret_cast<float*>(C); p.bias = w.bias; p.resid = resid;
+    p.a_scale = x.s; p.b_scale = w.bs8;
+    p.M = (int)x.rows(); p.N = n_rows_w; p.K = x.cp;
+    p.NB = 1; p.Hs = 1; p.Ws = p.M; p.Cin = x.cp; p.Ho = 1; p.Wo = p.M;
+    p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.ups = 0;
+    p.ldc = ldc; p.ldr = ldr; p.a_ld = x.cp; p.b_ld = p.K; p.rowvec_stride = 0; p.CS = 128;
+    launch_fp8(p, 2.0 * p.M * (double)p.N * w.cin);
+}
+
+void Engine::launch_fp8(ConvGemm& p, double flops) {
     p.out_mode = 0;
     p.zero_page = zero_page_;
     p.kt_total = p.K / 128;
-    if ((unsigned long long)p.M * x.cp >= 0xFFFFFFE0ull || (unsigned long long)p.N * p.K >= 0xFFFFFFE0ull) throw Error(SDMI_ERR_UNSUPPORTED, "conv_fp8: operand larger than 4 GiB");
+    if ((unsigned long long)p.NB * p.Hs * p.Ws * (unsigned long long)p.a_ld >= 0xFFFFFFE0ull || (unsigned long long)p.N * p.K >= 0xFFFFFFE0ull) throw Error(SDMI_ERR_UNSUPPORTED, "fp8 GEMM: operand larger than 4 GiB");
     // tile + split-K: rounds of workgroups on 256 CUs x the time of one tile at the rate each tile shape sustains when the
     // chip is full (tools/bench_gemm_fp8.py on MI355X: 256x320 2.4, 256x256 2.1, 256x128 1.7 PFLOP/s); K is split only when
     // the tiles would leave more than half of the chip idle
@@ -1611,7 +1662,6 @@ void Engine::conv_fp8(const ConvW& w, const ActQ& x, Act& y, const float* rowvec
     p.kt_per_split = (p.kt_total + splits - 1) / splits;
     splits = (p.kt_total + p.kt_per_split - 1) / p.kt_per_split;
     p.splits = splits;
-    const double flops = 2.0 * p.M * (double)p.N * w.cin * 9;   // algorithmic (unpadded) work
     if (splits == 1) {
         ProfScope ps(this, PC_CONV_FP8, flops);
         SDMI_HIP(launch_conv_gemm_fp8x(p, cfg, stream_));
@@ -1631,6 +1681,33 @@ void Engine::conv_fp8(const ConvW& w, const ActQ& x, Act& y, const float* rowvec
     }
 }
 
+// a convolution whose input is a raw (not normalised) activation -- the down / up convolutions (unet/mod.rs:397,425; autoencoder/mod.rs:319):
+// precision = 2 with option fp8_linear quantises the input in front of it, everything else is conv()
+void Engine::conv_raw(const ConvW& w, const Act& x, Act& y, int stride, int ups) {
+    if (use_fp8_wide(w.bt8, y.rows()) && x.dt == 1 && y.dt == 1 && x.p && x.c % 32 == 0) {
+        ActQ xq = new_actq(x.n, x.h, x.w, x.c);
+        quantize(x, xq);
+        conv_fp8(w, xq, y, nullptr, nullptr, stride, ups);
+        release(xq);
+        return;
+    }
+    conv(w, x, y, stride, ups, nullptr, 0, nullptr);
+}
+
+void Engine::quantize(const Act& x, ActQ& y) {
+    if (x.dt != 1 || !x.p || y.c != x.c || y.rows() != x.rows()) throw Error(SDMI_ERR_STATE, "quantize: bf16 input of matching shape expected");
+    ProfScope ps(this, PC_OTHER, 0, (double)x.rows() * (x.c * 2.0 + y.cp * 1.03));
+    SDMI_HIP(launch_quantize_bf16_fp8(x.p, y.q, y.s, x.rows(), x.c, x.stride(), stream_));
+    count_kernel();
+}
+
+void Engine::layer_norm_fp8(const NormW& w, const float* x, long long rows, ActQ& y) {
+    if (y.c != w.c || y.rows() != rows) throw Error(SDMI_ERR_STATE, "layer_norm_fp8: output shape mismatch");
+    ProfScope ps(this, PC_LAYER_NORM, 0, (double)rows * (w.c * 2.0 + y.cp * 1.03));
+    SDMI_HIP(launch_layer_norm_fp8(x, y.q, y.s, w.gamma, w.beta, (int)rows, w.c, w.eps, stream_));
+    count_kernel();
+}
+
 // SpatialTransformer::forward (unet/mod.rs:462-480) + TransformerBlock (:522-526) +
 // MultiHeadAttention (:642-652) + MLP/GEGLU (:552-591).  NHWC makes the reference's
 // two NCHW<->token transposes disappear.
@@ -1639,6 +1716,59 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
     const int C = w.c, nb = x.n, hw = x.h * x.w;
     const long long M = x.rows();
     const int heads = cfg_.n_head, d = C / heads;
+    if (use_fp8_wide(w.proj_in.bt8, M) && w.attn1.q.bt8 && w.attn1.out.bt8 && w.attn2.q.bt8 && w.attn2.out.bt8 && w.geglu_proj.bt8 && w.mlp_lin.bt8 &&
+        w.proj_out.bt8 && x.dt == 1 && y.dt == 1) {
+        // precision = 2, option fp8_linear: every GEMM of the block on MXFP8 operands.  Their inputs are quantised by the kernel that
+        // produces them (GroupNorm, LayerNorm, the GEGLU gate) or by quantize() (attention outputs, the hidden state in front of proj_out);
+        // the residual stream h, q / k / v and the attention itself stay bf16 (why attention is not fp8).
+        ActQ gq = new_actq(x.n, x.h, x.w, C);
+        group_norm_fp8(w.norm, x, gq, false);
+        Act h = new_act(x.n, x.h, x.w, C);
+        conv_fp8(w.proj_in, gq, h, nullptr, nullptr);
+        release(gq);
+        {
+            ActQ lnq = new_rowsq(M, C), aq = new_rowsq(M, C);
+            Buf q(this, (size_t)M * C * 2), a(this, (size_t)M * C * 2);
+            Act av; av.p = a.f(); av.n = 1; av.h = 1; av.w = (int)M; av.c = C; av.dt = 1;
+            layer_norm_fp8(w.ln1, h.p, M, lnq);
+            {
+                Buf qkv(this, (size_t)M * 3 * C * 2);
+                gemm_fp8(lnq, w.attn1.q, 3 * C, qkv.p, 3 * C, nullptr, 0);      // q | k | v: the packed [3C][Kp] weight
+                const long long bs3 = (long long)hw * 3 * C;
+                attention(qkv.f(), 3 * C, bs3, adv(qkv.f(), C, 1), 3 * C, bs3, adv(qkv.f(), 2 * C, 1), 3 * C, bs3, a.f(), C,
+                          (long long)hw * C, nb, hw, hw, heads, d, nullptr, nullptr, nullptr, 0);
+            }
+            quantize(av, aq);
+            gemm_fp8(aq, w.attn1.out, C, h.p, C, h.p, C);
+            layer_norm_fp8(w.ln2, h.p, M, lnq);
+            gemm_fp8(lnq, w.attn2.q, C, q.p, C, nullptr, 0);
+            const long long cbs = (long long)us_.t_max * C;
+            attention(q.f(), C, (long long)hw * C, us_.kc.at(w.ctx_index), C, cbs, us_.vc.at(w.ctx_index), C, cbs, a.f(),
+                      C, (long long)hw * C, nb, hw, us_.t_max, heads, d, us_.kv_len_dev, us_.kv_len_host.data(), nullptr, 0);
+            quantize(av, aq);
+            gemm_fp8(aq, w.attn2.out, C, h.p, C, h.p, C);
+            layer_norm_fp8(w.ln3, h.p, M, lnq);
+            {
+                Buf proj(this, (size_t)M * 8 * C * 2);
+                gemm_fp8(lnq, w.geglu_proj, 8 * C, proj.p, 8 * C, nullptr, 0);
+                ActQ uq = new_rowsq(M, 4 * C);
+                {
+                    ProfScope ps(this, PC_OTHER, 0, (double)M * (8.0 * C * 2.0 + 4.0 * C * 1.03));
+                    SDMI_HIP(launch_geglu_fp8(proj.p, uq.q, uq.s, M, 4 * C, stream_));
+                    count_kernel();
+                }
+                gemm_fp8(uq, w.mlp_lin, C, h.p, C, h.p, C);
+                release(uq);
+            }
+            release(lnq); release(aq);
+        }
+        ActQ hq = new_actq(x.n, x.h, x.w, C);
+        quantize(h, hq);
+        release(h);
+        conv_fp8(w.proj_out, hq, y, nullptr, &x);
+        release(hq);
+        return;
+    }
     // fp32 engine: every tensor whose only consumer is a GEMM (the normalised activations, the attention outputs, the gated MLP
     // hidden state, the block's last hidden state) is written by its producer as three bf16 planes -- what k_gemm3p.hip reads
     const bool pl = plane_gemm(C, C) && attn_supported_head_dim(d);
@@ -1779,7 +1909,7 @@ void Engine::unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc) {
     auto run_block = [&](const UBlock& b, const Act& in, Act& y) {
         switch (b.kind) {
             case BK_CONV: conv(b.conv, in, y, 1, 0, nullptr, 0, nullptr); return;
-            case BK_DOWN: conv(b.conv, in, y, 2, 0, nullptr, 0, nullptr); return;
+            case BK_DOWN: conv_raw(b.conv, in, y, 2, 0); return;
             case BK_RES: res_block(b.res, in, y, step); return;
             case BK_RES_ST: {
                 Act r = new_act(in.n, in.h, in.w, b.cout); res_block(b.res, in, r, step);
@@ -1788,13 +1918,13 @@ void Engine::unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc) {
             case BK_RES_UP: {   // (fp32 engine: the tensor between the block and its up-convolution exists only as planes)
                 Act r = plane_gemm(b.cout, b.cout) ? new_act3(in.n, in.h, in.w, b.cout, 2) : new_act(in.n, in.h, in.w, b.cout);
                 res_block(b.res, in, r, step);
-                conv(b.up, r, y, 1, 1, nullptr, 0, nullptr); release(r); return;
+                conv_raw(b.up, r, y, 1, 1); release(r); return;
             }
             case BK_RES_ST_UP: {
                 Act r = new_act(in.n, in.h, in.w, b.cout); res_block(b.res, in, r, step);
                 Act s = plane_gemm(b.cout, b.cout) ? new_act3(in.n, in.h, in.w, b.cout, 2) : new_act(in.n, in.h, in.w, b.cout);
                 spatial_transformer(b.st, r, s); release(r);
-                conv(b.up, s, y, 1, 1, nullptr, 0, nullptr); release(s); return;
+                conv_raw(b.up, s, y, 1, 1); release(s); return;
             }
         }
         throw Error(SDMI_ERR_STATE, "bad block kind");
@@ -1972,7 +2102,7 @@ void Engine::decode_one(const float* z_nhwc, int n, Act& img) {
             // the next block's first ResnetBlock has a 1x1 shortcut (cin != cout): it reads the up-convolution's output as planes too
             const bool both = i + 1 < 4 && dec_blocks_[i + 1].res[0].has_skip && plane_gemm(b.cout, dec_blocks_[i + 1].cout);
             Act y = both ? new_act3(x.n, x.h * 2, x.w * 2, b.cout, 3) : new_act(x.n, x.h * 2, x.w * 2, b.cout);
-            conv(b.upsampler, x, y, 1, 1, nullptr, 0, nullptr);
+            conv_raw(b.upsampler, x, y, 1, 1);
             release(x);
             x = y;
         }
@@ -2133,6 +2263,15 @@ void Engine::op_group_norm_fp8(const float* x, const float* gamma, const float* 
 
 void Engine::op_layer_norm(const float* x, const float* gamma, const float* beta, int rows, int c, float eps, float* out) {
     if (rows <= 0 || c <= 0) throw Error(SDMI_ERR_INVALID, "layer_norm: bad shape");
+    if (fp8_ && opt_fp8_ops_ && c % 32 == 0) {   // option fp8_ops (tests): the quantising LayerNorm of the fp8_linear path, dequantised
+        Buf xh(this, (size_t)rows * c * 2);
+        SDMI_HIP(launch_f32_to_bf16(x, xh.p, (long long)rows * c, stream_));
+        ActQ q = new_rowsq(rows, c);
+        SDMI_HIP(launch_layer_norm_fp8(xh.p, q.q, q.s, gamma, beta, rows, c, eps, stream_));
+        SDMI_HIP(launch_dequant_fp8(q.q, q.s, out, rows, c, stream_));
+        release(q);
+        return;
+    }
     if (bf16_ && c % 8 == 0) {
         Buf xh(this, (size_t)rows * c * 2), yh(this, (size_t)rows * c * 2);
         SDMI_HIP(launch_f32_to_bf16(x, xh.p, (long long)rows * c, stream_));
@@ -2196,6 +2335,20 @@ void Engine::op_conv2d(const float* x, const float* wt, const float* bias, int n
 }
 
 void Engine::op_linear(const float* x, const float* wt, const float* bias, int rows, int cin, int cout, float* out) {
+    if (fp8_ && opt_fp8_ops_ && cin % 32 == 0 && cout % 8 == 0) {   // option fp8_ops (tests): the Linear layer as the fp8_linear path runs it
+        const size_t kp = (size_t)(cin + 127) / 128 * 128;
+        Buf xh(this, (size_t)rows * cin * 2), yh(this, (size_t)rows * cout * 2), w8(this, (size_t)cout * kp), s8(this, (size_t)cout * kp / 32);
+        SDMI_HIP(launch_f32_to_bf16(x, xh.p, (long long)rows * cin, stream_));
+        SDMI_HIP(launch_pack_linear_weight_fp8(wt, w8.p, s8.p, cin, cout, stream_));
+        Act xa; xa.p = xh.f(); xa.n = 1; xa.h = 1; xa.w = rows; xa.c = cin; xa.dt = 1;
+        ActQ q = new_rowsq(rows, cin);
+        quantize(xa, q);
+        LinW lw; lw.cin = cin; lw.cout = cout; lw.dt = 1; lw.bias = const_cast<float*>(bias); lw.bt8 = w8.f(); lw.bs8 = s8.f();
+        gemm_fp8(q, lw, cout, yh.p, cout, nullptr, 0);
+        SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(yh.p, out, rows, cout, 1, 1, stream_));
+        release(q);
+        return;
+    }
     Buf bt(this, (size_t)cin * cout * 4);
     if (bf16_ && cin % 64 == 0) {
         Buf xh(this, (size_t)rows * cin * 2), yh(this, (size_t)rows * cout * 2);
@@ -2226,6 +2379,15 @@ void Engine::op_geglu_forward(const float* x, const float* wt, const float* bias
 }
 
 void Engine::op_geglu(const float* proj, int rows, int hidden, float* out) {
+    if (fp8_ && opt_fp8_ops_ && hidden % 32 == 0) {   // option fp8_ops (tests): the quantising gate of the fp8_linear path, dequantised
+        Buf ph(this, (size_t)rows * 2 * hidden * 2);
+        SDMI_HIP(launch_f32_to_bf16(proj, ph.p, (long long)rows * 2 * hidden, stream_));
+        ActQ q = new_rowsq(rows, hidden);
+        SDMI_HIP(launch_geglu_fp8(ph.p, q.q, q.s, rows, hidden, stream_));
+        SDMI_HIP(launch_dequant_fp8(q.q, q.s, out, rows, hidden, stream_));
+        release(q);
+        return;
+    }
     if (bf16_ && hidden % 8 == 0) {
         Buf ph(this, (size_t)rows * 2 * hidden * 2), oh(this, (size_t)rows * hidden * 2);
         SDMI_HIP(launch_f32_to_bf16(proj, ph.p, (long long)rows * 2 * hidden, stream_));

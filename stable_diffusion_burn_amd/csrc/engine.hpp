@@ -86,7 +86,7 @@ struct ActQ {
     int n = 0, h = 0, w = 0, c = 0, cp = 0;
     long long rows() const { return (long long)n * h * w; }
 };
-struct LinW { float* bt = nullptr; float* bias = nullptr; int cin = 0, cout = 0; int dt = 0; };
+struct LinW { float* bt = nullptr; float* bias = nullptr; int cin = 0, cout = 0; int dt = 0; float* bt8 = nullptr; float* bs8 = nullptr; };   // bt8 / bs8: MXFP8 copy (precision = 2, option fp8_linear)
 struct NormW { float* gamma = nullptr; float* beta = nullptr; int c = 0; float eps = 1e-5f; };  // eps: Q3 default, overridden by the dump's eps file
 
 struct ResW {  // UNet ResBlock (unet/mod.rs:700-734) and VAE ResnetBlock (autoencoder/mod.rs:503-528)
@@ -265,7 +265,6 @@ private:
               const float* resid, int ldr, int dt = -1, int out_mode = 0, const void* A3 = nullptr, void* C3 = nullptr);
     // fp32 engine, option gemm_planes: does the GEMM cin -> cout take its activations as planes (k_gemm3p.hip)?
     bool plane_gemm(int cin, int cout) const { return !bf16_ && opt_gemm_planes_ != 0 && opt_gemm_f32s_ != 0 && cin % 32 == 0 && cout >= 32; }
-    void choose_xcd_map(ConvGemm& p, int MT, int NT, double a_bytes, double w_bytes, double flops, double cu_flops) const;
     void launch_gemm(ConvGemm& p, int in_dt, int force_cfg = -1, int force_splits = 0);
     int edt() const { return bf16_ ? 1 : 0; }
     size_t esz() const { return bf16_ ? 2 : 4; }
@@ -277,8 +276,17 @@ private:
     ActQ new_actq(int n, int h, int w, int c);
     void release(ActQ& a);
     void group_norm_fp8(const NormW& w, const Act& x, ActQ& y, bool silu);
-    void conv_fp8(const ConvW& w, const ActQ& x, Act& y, const float* rowvec, const Act* resid);
+    // stride / ups as conv(); 3x3 (pad 1) or 1x1 (pad 0) -- whatever was packed as MXFP8 (ConvW::bt8)
+    void conv_fp8(const ConvW& w, const ActQ& x, Act& y, const float* rowvec, const Act* resid, int stride = 1, int ups = 0);
     bool use_fp8(const ConvW& w, const Act& x) const;
+    // option fp8_linear: the layers beyond the ResBlock 3x3 convolutions -- Linear layers, 1x1 / up / down convolutions
+    bool use_fp8_wide(const float* bt8, long long rows) const { return fp8_ && opt_fp8_convs_ && opt_fp8_linear_ && bt8 && rows >= opt_fp8_min_rows_; }
+    void launch_fp8(ConvGemm& p, double flops);                                   // tile / split-K choice + launch (+ reduce) of conv_gemm_fp8x_kernel
+    void gemm_fp8(const ActQ& x, const LinW& w, int n_rows_w, void* C, int ldc, const float* resid, int ldr);   // C[rows][n_rows_w] = x W^T + b (+ resid), bf16 out
+    void conv_raw(const ConvW& w, const Act& x, Act& y, int stride, int ups);     // conv() or, at precision = 2, quantize() + conv_fp8()
+    void quantize(const Act& x, ActQ& y);                                         // bf16 activation -> MXFP8 (quantize_bf16_fp8_kernel)
+    void layer_norm_fp8(const NormW& w, const float* x, long long rows, ActQ& y);
+    ActQ new_rowsq(long long rows, int c) { return new_actq(1, 1, (int)rows, c); }
     void layer_norm(const NormW& w, const float* x, long long rows, float* y, int dt = -1, void* y3 = nullptr);   // y3: output as planes instead of y
     // GEGLU::forward (unet/mod.rs:579-591): out[rows, hidden] = (x W + b)[:, :hidden] * gelu((x W + b)[:, hidden:]); bt is the
     // packed [2 hidden][cin] weight.  Fused into a large-tile GEMM when possible, else GEMM into `proj_scratch` + gate kernel.
@@ -348,6 +356,8 @@ private:
     int opt_fp8_convs_ = 1;          // 0: run the fp8-capable convs on the bf16 kernels (A/B, accuracy comparison)
     int opt_fp8_min_rows_ = 1024;    // GEMMs with fewer output rows stay bf16 (256-row tiles need rows to fill the chip)
     int opt_fp8_tile_ = -1;
+    int opt_fp8_ops_ = 0;            // tests: op_linear / op_layer_norm / op_geglu run the fp8_linear path's kernels (outputs dequantised)
+    int opt_fp8_linear_ = 1;         // precision = 2: 1 = also the transformer blocks' Linear layers and the 1x1 / up / down convolutions in MXFP8; 0 = the ResBlock 3x3 convolutions only (round 2)
     hipStream_t stream_ = nullptr;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr, ev_user_ = nullptr;
     hipStream_t user_stream_ = nullptr;
@@ -408,15 +418,14 @@ private:
     int opt_geglu_fuse_ = 1;    // GEGLU gate in the projection GEMM's epilogue: 0 never, 1 where there are >= 4 rounds of tiles, 2 / 3 always (256x128 / 256x256 tiles; tests)
     int opt_attn_split_ = 1;    // precision = 0: 1 = d_head 40 / 80 attention on the bf16 matrix pipe with three-way split operands (k_attn_split.hip)
     int opt_gemm_f32s_ = 1;     // precision = 0: 1 = fp32 GEMMs on the bf16 matrix pipe (three-way operand split, k_gemm3x.hip) where faster
-    int opt_gemm3x_variant_ = 2;     // bit 0: DMA in one block per k tile; bit 1: scalar residual subtractions (+0.7 %); bit 2: two LDS stages on the 128-row tiles (default three: +5..10 % on long K);
-                                     // bit 4: s_setprio 1 for waves 4-7; bits 3 + 6 (74 with bit 1): the pipelined k loop with hand-counted LDS waits (k_gemm3x.hip HOIST = 3; measured: not faster)
+    int opt_gemm3x_variant_ = 2;     // k_gemm3x.hip: bit 0: DMA in one block per k tile; bit 1: scalar residual subtractions (+0.7 %); bit 2: two LDS stages on the 128-row tiles
+                                     // (default three: +5..10 % on long K); bit 4: s_setprio 1 for waves 4-7 (measured: no gain)
     static constexpr int kGemmPlanesDefault = 1;
     int opt_gemm_planes_ = kGemmPlanesDefault;   // precision = 0: k_gemm3p.hip (activations as bf16 planes too, no split in the k loop): 0 never, 1 every launch that would take a k_gemm3x.hip tile,
                                 // 2 only where the per-shape table says 300 + x
     int opt_bench_cold_ = 0;    // bench_conv: 1 = evict the weights from the Infinity Cache between timed launches (what a layer sees inside the model)
     int opt_gemm_x32_ = 1;      // precision = 0: 1 = large-tile LDS-DMA fp32 GEMM (k_gemm2x.hip) where measured / modelled faster
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
-    int opt_xcd_map_ = 0;              // 1: cut every GEMM launch over the 8 XCDs so that the fewest operand bytes cross the fabric (choose_xcd_map); 0: bands of tiles, every XCD reads all weights
     void* zero_page_ = nullptr;
     TileChoice choose_tile_p(int M, int N, int kt_total, bool even_ni_only) const;   // k_gemm3p.hip tiles (300 + x)
     TileChoice choose_tile_bf16(int M, int N, int kt_total) const;   // cfg >= 100: k_gemm_bf16x.hip tile cfg - 100     // precision = 1: 1 = bf16 matrix-core attention, 0 = bf16 storage widened onto the fp32 kernel  // 1: attn2_kernel, 0: attn_f32_kernel

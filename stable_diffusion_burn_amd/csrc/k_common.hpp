@@ -8,33 +8,21 @@ namespace sdmi {
 
 // ---- which (M tile, N tile, split-K slice) a GEMM block works on ------------------------------------------------------
 // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed; a speed assumption only, never a correctness one:
-// every work item is covered exactly once whatever the placement).  lid = tm * NT + tn indexes the tile's split-K arrival counter.
+// every work item is covered exactly once whatever the placement): an XCD works on a contiguous band of tiles, blockIdx.z is the slice.
+// (Rounds 2-3 also carried a planner that cut M tiles x N tiles x slices over the XCDs to minimise the bytes crossing the fabric: 3-6x
+// fewer L2 misses on the batch-1 shapes and 2 % SLOWER end to end in both rounds -- profiles/r02zz_*, r03m_ab_fp32_b1_xcd_map.jsonl --
+// because the duplicate fetches it saves are Infinity-Cache hits; removed.)
 struct GemmWork { int tm, tn, z, lid; bool live; };
 __device__ __forceinline__ GemmWork gemm_work_of_block(const ConvGemm& p, int MT, int NT) {
     GemmWork w;
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-    if (p.xcd_m > 0) {
-        const int im = x % p.xcd_m;
-        const int t = x / p.xcd_m;
-        const int in = t % p.xcd_n;
-        const int iz = t / p.xcd_n;
-        const int mn = p.xcd_ml * p.xcd_nl;
-        const int zl = j / mn;
-        const int r = j - zl * mn;
-        const int tml = r / p.xcd_nl;
-        w.tm = im * p.xcd_ml + tml;
-        w.tn = in * p.xcd_nl + (r - tml * p.xcd_nl);
-        w.z = iz * p.xcd_zl + zl;
-        w.live = (w.tm < MT) & (w.tn < NT) & (w.z < p.splits) & (zl < p.xcd_zl);
-    } else {
-        const int tpx = gridDim.x >> 3;
-        const int lid = x * tpx + j;
-        w.tm = lid / NT;
-        w.tn = lid - w.tm * NT;
-        w.z = blockIdx.z;
-        w.live = lid < MT * NT;
-    }
-    w.lid = w.tm * NT + w.tn;
+    const int tpx = gridDim.x >> 3;
+    const int lid = x * tpx + j;
+    w.tm = lid / NT;
+    w.tn = lid - w.tm * NT;
+    w.z = blockIdx.z;
+    w.live = lid < MT * NT;
+    w.lid = lid;
     return w;
 }
 

@@ -533,6 +533,219 @@ hipError_t launch_group_norm_fp8(const void* x, void* y8, void* y_scale, const f
     return hipGetLastError();
 }
 
+// =====================================================================================================================
+// precision = 2 beyond the ResBlock convolutions (option fp8_linear): the transformer blocks' Linear layers and the 1x1 / up / down
+// convolutions take MXFP8 operands too (BASELINE.json configs[4]: "fp8 conv+attn"; reference layers unet/mod.rs:397,425,468,479,
+// 553,580,645-651 and autoencoder/mod.rs:319,568-604).  Their inputs are quantised by the kernel that produces them where that is a
+// row-wise kernel -- LayerNorm, the GEGLU gate, GroupNorm (above) -- and by quantize_bf16_fp8_kernel otherwise (attention outputs,
+// the residual stream in front of proj_out / skip / up / down convolutions).
+// =====================================================================================================================
+// 8 bf16 -> the thread's 8 e4m3 bytes + (one thread in four) the block's scale byte.  The four threads of a 32-channel block are an
+// aligned lane quad.  Pad channels [C, Cp) are written as zeros with scale byte 127 by the threads `c8 < pad8`.
+__device__ __forceinline__ void mx_store8(const Q8& v, unsigned char* yrow, unsigned char* srow, int c8, int C, int Cp) {
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v.v[i]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    float inv;
+    const unsigned sb = mx_scale_byte(amax, &inv);
+    u32x2 o;
+    o[0] = cvt4_e4m3(v.v[0] * inv, v.v[1] * inv, v.v[2] * inv, v.v[3] * inv);
+    o[1] = cvt4_e4m3(v.v[4] * inv, v.v[5] * inv, v.v[6] * inv, v.v[7] * inv);
+    *reinterpret_cast<u32x2*>(yrow + c8 * 8) = o;
+    if ((c8 & 3) == 0) srow[c8 >> 2] = (unsigned char)sb;
+    const int pad8 = (Cp - C) >> 3;
+    if (c8 < pad8) {
+        *reinterpret_cast<u32x2*>(yrow + C + c8 * 8) = u32x2{0u, 0u};
+        if ((c8 & 3) == 0) srow[(C + c8 * 8) >> 5] = (unsigned char)127;
+    }
+}
+
+// bf16 [rows][ldx] (C channels, C % 32 == 0) -> MXFP8 [rows][Cp] + scales [rows][Cp / 32]; one thread per 8 channels
+__global__ void quantize_bf16_fp8_kernel(const unsigned short* __restrict__ x, unsigned char* __restrict__ y, unsigned char* __restrict__ ys,
+                                         long long rows, int C, int ldx, int Cp) {
+    const int cq = C >> 3;
+    const long long total = rows * cq;
+    const long long rounded = (total + 3) / 4 * 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = (i < total ? i : total - 1) / cq;
+        const int c8 = (int)((i < total ? i : total - 1) - r * cq);
+        const Q8 v = qunpack8(*reinterpret_cast<const u32x4*>(x + r * ldx + c8 * 8));
+        mx_store8(v, y + r * Cp, ys + r * (Cp >> 5), c8, C, Cp);       // (cq % 4 == 0: a quad never straddles rows or the end)
+    }
+}
+hipError_t launch_quantize_bf16_fp8(const void* x, void* q, void* s, long long rows, int c, int ldx, hipStream_t stream) {
+    if ((c & 31) || (ldx & 7) || ldx < c) return hipErrorInvalidValue;
+    const int cp = (c + 127) / 128 * 128;
+    long long blocks = (rows * (c / 8) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(quantize_bf16_fp8_kernel, dim3((int)blocks), dim3(256), 0, stream, reinterpret_cast<const unsigned short*>(x),
+                       reinterpret_cast<unsigned char*>(q), reinterpret_cast<unsigned char*>(s), rows, c, ldx, cp);
+    return hipGetLastError();
+}
+
+// LayerNorm (unet/mod.rs:523-525) of a bf16 tensor with MXFP8 output: the row kernel of k_bf16.hip (L lanes per row, the row in
+// registers, exact two-pass statistics) with the quantiser in its tail.  Lane l holds the 8-channel pieces f = l + i L: four consecutive
+// lanes hold one 32-channel block (L % 4 == 0).
+constexpr int kLnMaxVecQ = 4;
+template <int L>
+__global__ __launch_bounds__(256) void layer_norm_fp8_kernel(const unsigned short* __restrict__ x, unsigned char* __restrict__ y, unsigned char* __restrict__ ys,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int rows, int C, int Cp, float eps) {
+    constexpr int RPW = 64 / L;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / L, l = lane % L;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + sub;
+    const bool row_ok = row < rows;
+    const int cq = C >> 3;
+    const unsigned short* xr = x + (long long)(row_ok ? row : 0) * C;
+    Q8 v[kLnMaxVecQ];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnMaxVecQ; ++i) {
+        const int f = l + i * L;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i].v[j] = 0.f;
+        if (f < cq && row_ok) {
+            v[i] = qunpack8(*reinterpret_cast<const u32x4*>(xr + f * 8));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[i].v[j];
+        }
+    }
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnMaxVecQ; ++i) {
+        const int f = l + i * L;
+        if (f < cq) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[i].v[j] - mean; sq += d * d; }
+        }
+    }
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+    const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+    const long long rr = row_ok ? row : 0;
+#pragma unroll
+    for (int i = 0; i < kLnMaxVecQ; ++i) {      // uniform trip count: the quad shuffles of mx_store8 need all four lanes of a block
+        const int f = l + i * L;
+        const int ff = f < cq ? f : 0;
+        Q8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] = (v[i].v[j] - mean) * rstd * gamma[ff * 8 + j] + beta[ff * 8 + j];
+        if ((i * L) < cq) {                     // uniform over the L lanes: cq % L need not be 0, but cq % 4 == 0 keeps quads whole
+            float amax = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(o.v[j]));
+            amax = fmaxf(amax, __shfl_xor(amax, 1));
+            amax = fmaxf(amax, __shfl_xor(amax, 2));
+            if (f < cq && row_ok) {
+                float inv;
+                const unsigned sb = mx_scale_byte(amax, &inv);
+                u32x2 w;
+                w[0] = cvt4_e4m3(o.v[0] * inv, o.v[1] * inv, o.v[2] * inv, o.v[3] * inv);
+                w[1] = cvt4_e4m3(o.v[4] * inv, o.v[5] * inv, o.v[6] * inv, o.v[7] * inv);
+                unsigned char* yrow = y + rr * Cp;
+                unsigned char* srow = ys + rr * (Cp >> 5);
+                *reinterpret_cast<u32x2*>(yrow + f * 8) = w;
+                if ((f & 3) == 0) srow[f >> 2] = (unsigned char)sb;
+                const int pad8 = (Cp - C) >> 3;
+                if (f < pad8) {
+                    *reinterpret_cast<u32x2*>(yrow + C + f * 8) = u32x2{0u, 0u};
+                    if ((f & 3) == 0) srow[(C + f * 8) >> 5] = (unsigned char)127;
+                }
+            }
+        }
+    }
+}
+hipError_t launch_layer_norm_fp8(const void* x, void* y8, void* y_scale, const float* gamma, const float* beta, int rows, int c, float eps,
+                                 hipStream_t stream) {
+    if ((c & 31) || c > kLnMaxVecQ * 512) return hipErrorInvalidValue;
+    const int cq = c >> 3, cp = (c + 127) / 128 * 128;
+    auto xs = reinterpret_cast<const unsigned short*>(x);
+    auto yq = reinterpret_cast<unsigned char*>(y8);
+    auto ysc = reinterpret_cast<unsigned char*>(y_scale);
+    if (cq <= 16 * kLnMaxVecQ)
+        hipLaunchKernelGGL(layer_norm_fp8_kernel<16>, dim3((rows + 15) / 16), dim3(256), 0, stream, xs, yq, ysc, gamma, beta, rows, c, cp, eps);
+    else if (cq <= 32 * kLnMaxVecQ)
+        hipLaunchKernelGGL(layer_norm_fp8_kernel<32>, dim3((rows + 7) / 8), dim3(256), 0, stream, xs, yq, ysc, gamma, beta, rows, c, cp, eps);
+    else
+        hipLaunchKernelGGL(layer_norm_fp8_kernel<64>, dim3((rows + 3) / 4), dim3(256), 0, stream, xs, yq, ysc, gamma, beta, rows, c, cp, eps);
+    return hipGetLastError();
+}
+
+// the GEGLU gate (unet/mod.rs:579-591) with MXFP8 output: proj bf16 [rows][2 H] -> out e4m3 [rows][Hp] + scales
+__device__ __forceinline__ float gelu_erf_q(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__global__ void geglu_fp8_kernel(const unsigned short* __restrict__ proj, unsigned char* __restrict__ y, unsigned char* __restrict__ ys, long long rows,
+                                 int H, int Hp) {
+    const int hq = H >> 3;
+    const long long total = rows * hq;
+    const long long rounded = (total + 3) / 4 * 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += (long long)gridDim.x * blockDim.x) {
+        const long long ii = i < total ? i : total - 1;
+        const long long r = ii / hq;
+        const int c8 = (int)(ii - r * hq);
+        const Q8 a = qunpack8(*reinterpret_cast<const u32x4*>(proj + r * 2 * H + c8 * 8));
+        const Q8 g = qunpack8(*reinterpret_cast<const u32x4*>(proj + r * 2 * H + H + c8 * 8));
+        Q8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] = a.v[j] * gelu_erf_q(g.v[j]);
+        // (the bf16 gate kernel rounds its output to bf16 before the next GEMM reads it; the same rounding here keeps the two forms comparable)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] = __uint_as_float(qbf16_bits(o.v[j]) << 16);
+        mx_store8(o, y + r * Hp, ys + r * (Hp >> 5), c8, H, Hp);
+    }
+}
+hipError_t launch_geglu_fp8(const void* proj, void* y8, void* y_scale, long long rows, int hidden, hipStream_t stream) {
+    if (hidden & 31) return hipErrorInvalidValue;
+    const int hp = (hidden + 127) / 128 * 128;
+    long long blocks = (rows * (hidden / 8) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(geglu_fp8_kernel, dim3((int)blocks), dim3(256), 0, stream, reinterpret_cast<const unsigned short*>(proj),
+                       reinterpret_cast<unsigned char*>(y8), reinterpret_cast<unsigned char*>(y_scale), rows, hidden, hp);
+    return hipGetLastError();
+}
+
+// Linear weight fp32 [in][out] (the reference's layout, python/save.py:19) -> e4m3 Bt8[out][Kp] + scales, Kp = roundup(in, 128):
+// the k order of a 1x1 convolution (k = channel), so conv_gemm_fp8x_kernel reads it as one
+__global__ void pack_linear_weight_fp8_kernel(const float* __restrict__ w, unsigned char* __restrict__ bt, unsigned char* __restrict__ bs, int cin, int cout, int kp) {
+    const int nblk = kp / 32;
+    const long long total = (long long)cout * nblk;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int blk = (int)(i % nblk);
+        const int n = (int)(i / nblk);
+        const int c0 = blk * 32;
+        float v[32];
+        float amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int c = c0 + j;
+            v[j] = c < cin ? w[(long long)c * cout + n] : 0.f;
+            amax = fmaxf(amax, fabsf(v[j]));
+        }
+        float inv;
+        const unsigned sb = mx_scale_byte(amax, &inv);
+        unsigned* dst = reinterpret_cast<unsigned*>(bt + (long long)n * kp + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j] = cvt4_e4m3(v[4 * j] * inv, v[4 * j + 1] * inv, v[4 * j + 2] * inv, v[4 * j + 3] * inv);
+        bs[(long long)n * nblk + blk] = (unsigned char)sb;
+    }
+}
+hipError_t launch_pack_linear_weight_fp8(const float* w_in_out, void* bt8, void* bs, int cin, int cout, hipStream_t s) {
+    const int kp = (cin + 127) / 128 * 128;
+    const long long total = (long long)cout * (kp / 32);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pack_linear_weight_fp8_kernel, dim3(blocks), dim3(256), 0, s, w_in_out, reinterpret_cast<unsigned char*>(bt8),
+                       reinterpret_cast<unsigned char*>(bs), cin, cout, kp);
+    return hipGetLastError();
+}
+
 // plain quantiser (operator-level entry point / tests): fp32 [rows][C] -> e4m3 [rows][Cp] + scales [rows][Cp / 32];
 // one thread per (row, 32-channel block) of the padded row
 __global__ void quantize_fp8_kernel(const float* __restrict__ x, unsigned char* __restrict__ q, unsigned char* __restrict__ s, long long rows,

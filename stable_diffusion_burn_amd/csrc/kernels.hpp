@@ -48,45 +48,13 @@ struct ConvGemm {
     const void* a_scale;        // fp8 kernel: E8M0 scales of A, [pixels][a_ld / 32] bytes (a_ld = padded channel count = bytes per pixel)
     const void* b_scale;        // fp8 kernel: E8M0 scales of Bt, [N][b_ld / 32] bytes
     int variant;                // k_gemm3x.hip A/B switches (option gemm3x_variant): bit 0 DMA issued in one block per k tile, 1 scalar residual subtractions,
-                                // 2 two LDS stages on the 128-row tiles, 4 s_setprio 1 for waves 4-7, 3 + 6 the pipelined k loop (HOIST = 3);
-                                // k_gemm_bf16x.hip (option gemm_bf16x_variant): 3 = the pipelined k loop
-    // XCD-aware work map (option xcd_map; host side: Engine::choose_xcd_map, device side: gemm_work_of_block in k_common.hpp).  The box of
-    // work items (M tiles x N tiles x split-K slices) is cut xcd_m x xcd_n x (8 / (xcd_m xcd_n)) ways over the 8 XCDs; the blocks that land on
-    // XCD b % 8 walk that XCD's sub-box of xcd_ml x xcd_nl x xcd_zl items (n fastest, then m, then slices).  What the cut decides is how often
-    // each operand crosses the fabric into an XCD's L2: xcd_n times the activations + xcd_m times the weights.  xcd_m == 0: the legacy map
-    // (XCD = band of tiles, blockIdx.z = slice: every XCD that holds an M band reads ALL the weights).
-    int xcd_m, xcd_n, xcd_ml, xcd_nl, xcd_zl;
+                                // 2 two LDS stages on the 128-row tiles, 4 s_setprio 1 for waves 4-7
     int geglu;                  // large-tile kernels: Bt holds 2 N rows (N value rows, then N gate rows; bias likewise) and the
                                 // epilogue writes value * gelu_erf(gate) -- GEGLU::forward (unet/mod.rs:579-591) without the [M, 2N] tensor
 };
 
-// The cut of one GEMM launch over the 8 XCDs (ConvGemm::xcd_*): of the cuts xm x xn x xz = 8 of the box MT x NT x splits, the one with
-// the smallest modelled time  rounds * (time of one work item on a CU) + (bytes into the L2s) / (fabric bandwidth),  where
-// rounds = work items on the busiest XCD / its 32 CUs (at least 1) and bytes = (XCD ranges along N) * a_bytes + (XCD ranges along M) *
-// w_bytes.  cu_flops: what one CU sustains in this kernel.  out = {xcd_m, xcd_n, xcd_ml, xcd_nl, xcd_zl}.  Host only;
-// Engine::choose_xcd_map and sdmi_plan_xcd_map (the CPU tests) call it.
-constexpr double kXcdFabricBytesPerSec = 4.0e12;   // what the split GEMMs of the batch-1 UNet were measured to move at best (profiles/pmc_summary.json: 2.8e12 on average)
-inline void xcd_map_choose(int MT, int NT, int S, double a_bytes, double w_bytes, double flops, double cu_flops, int out[5]) {
-    double best = -1.0;
-    const double t_item = flops / ((double)MT * NT * S) / cu_flops;
-    for (int xm = 1; xm <= 8; xm *= 2)
-        for (int xn = 1; xm * xn <= 8; xn *= 2) {
-            const int xz = 8 / (xm * xn);
-            const int ml = (MT + xm - 1) / xm, nl = (NT + xn - 1) / xn, zl = (S + xz - 1) / xz;
-            const double per = (double)ml * nl * zl;
-            const int xme = (MT + ml - 1) / ml, xne = (NT + nl - 1) / nl;      // XCD ranges along M / N that are not empty
-            const double bytes = xne * a_bytes + xme * w_bytes;
-            const double t = (per > 32.0 ? per / 32.0 : 1.0) * t_item + bytes / kXcdFabricBytesPerSec;
-            if (best < 0.0 || t < best) {
-                best = t;
-                out[0] = xm; out[1] = xn; out[2] = ml; out[3] = nl; out[4] = zl;
-            }
-        }
-}
-
-// launch grid of a GEMM kernel: one block per work item of the largest XCD sub-box (x 8 XCDs), or the legacy (tiles rounded to 8) x slices
+// launch grid of a GEMM kernel: (tiles rounded up to the 8 XCDs) x slices
 inline dim3 gemm_grid(const ConvGemm& p, int tiles) {
-    if (p.xcd_m > 0) return dim3((unsigned)(8 * p.xcd_ml * p.xcd_nl * p.xcd_zl), 1, 1);
     return dim3((unsigned)(((tiles + 7) / 8) * 8), 1, (unsigned)p.splits);
 }
 
@@ -130,6 +98,11 @@ hipError_t launch_pack_conv_weight_fp8(const float* w_oihw, void* bt8, void* bs,
 hipError_t launch_group_norm_fp8(const void* x, void* y8, void* y_scale, const float* gamma, const float* beta, int n, int hw, int c,
                                  int ldx, int n_group, float eps, bool silu, void* partials, hipStream_t stream);
 hipError_t launch_quantize_fp8(const float* x, void* q, void* s, long long rows, int c, hipStream_t stream);   // fp32 [rows][c] -> MXFP8
+// precision = 2 beyond the ResBlock convolutions (option fp8_linear; k_fp8.hip): quantising producers and the Linear weight packer
+hipError_t launch_quantize_bf16_fp8(const void* x, void* q, void* s, long long rows, int c, int ldx, hipStream_t stream);   // bf16 [rows][ldx] -> MXFP8 (c % 32 == 0)
+hipError_t launch_layer_norm_fp8(const void* x, void* y8, void* y_scale, const float* gamma, const float* beta, int rows, int c, float eps, hipStream_t stream);
+hipError_t launch_geglu_fp8(const void* proj, void* y8, void* y_scale, long long rows, int hidden, hipStream_t stream);
+hipError_t launch_pack_linear_weight_fp8(const float* w_in_out, void* bt8, void* bs, int cin, int cout, hipStream_t s);
 hipError_t launch_dequant_fp8(const void* q, const void* s, float* out, long long rows, int c, hipStream_t stream);
 hipError_t launch_pack_conv_weight_bf16(const float* w_oihw, void* bt, int cout, int cin, int kh, int kw, hipStream_t s);
 hipError_t launch_pack_linear_weight_bf16(const float* w_in_out, void* bt, int cin, int cout, hipStream_t s);

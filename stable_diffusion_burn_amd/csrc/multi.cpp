@@ -312,12 +312,4 @@ int sdmi_shard_range(int32_t n_images, int32_t rank, int32_t n_ranks, int32_t* b
     return SDMI_OK;
 }
 
-int sdmi_plan_xcd_map(int32_t mt, int32_t nt, int32_t splits, double a_bytes, double w_bytes, double flops, double cu_flops, int32_t out[5]) {
-    if (!out || mt <= 0 || nt <= 0 || splits <= 0 || !(a_bytes >= 0.0) || !(w_bytes >= 0.0) || !(flops > 0.0) || !(cu_flops > 0.0)) { sdmi_set_last_error("sdmi_plan_xcd_map: bad argument"); return SDMI_ERR_INVALID; }
-    int o[5];
-    sdmi::xcd_map_choose(mt, nt, splits, a_bytes, w_bytes, flops, cu_flops, o);
-    for (int i = 0; i < 5; ++i) out[i] = o[i];
-    return SDMI_OK;
-}
-
 }  // extern "C"

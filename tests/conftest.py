@@ -17,19 +17,6 @@ if str(ROOT) not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: takes more than ~30 s")
-    config.addinivalue_line("markers", "variants: the extended parity matrix of kernel variants that are OFF by default (verified on an MI355X, "
-                                       "gpurun_out r02y / r02z / r02zz: 479 + 20 + 161 passed); skipped unless SDMI_VARIANTS=1 to keep the default GPU suite short -- "
-                                       "one bit-identity test per variant family always runs")
-
-
-def pytest_collection_modifyitems(config, items):
-    for env, mark, why in (("SDMI_VARIANTS", "variants", "extended matrix of an off-by-default kernel variant; set SDMI_VARIANTS=1 to run"),):
-        if os.environ.get(env) == "1":
-            continue
-        skip = pytest.mark.skip(reason=why)
-        for item in items:
-            if mark in item.keywords:
-                item.add_marker(skip)
 
 
 def gpu_available() -> bool:

@@ -268,22 +268,6 @@ def test_unet_forward_bf16_large_tiles_forced(sd16, tile):
     assert np.isfinite(got).all() and r < BAR_UNET
 
 
-@pytest.mark.parametrize("tile", ["auto", 2, 100, 103])
-def test_unet_forward_bf16_xcd_map(sd16, tile):
-    """option xcd_map = 1 with the bf16 GEMM kernels: bit-identical to the legacy block -> tile map."""
-    lat = np.stack([syn.initial_latent(i, 8, 8) for i in range(2)])
-    ctx = np.stack([syn.cond_context(i, 77, 768) for i in range(2)])
-    try:
-        sd16.set_option("gemm_tile", tile)
-        base = sd16.unet.forward(lat, [500], ctx)
-        sd16.set_option("xcd_map", 1)
-        got = sd16.unet.forward(lat, [500], ctx)
-    finally:
-        sd16.set_option("xcd_map", 0)
-        sd16.set_option("gemm_tile", "auto")
-    assert np.isfinite(got).all() and np.array_equal(got, base)
-
-
 def test_sample_image_bf16(sd16):
     lat = syn.initial_latent(0, 8, 8)[None]
     ctx = syn.cond_context(0, 77, 768)[None]

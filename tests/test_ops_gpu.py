@@ -193,7 +193,6 @@ STILES = [200, 201, 202, 203, 204, 205]
 
 # gemm3x_variant bits -- 0: next k tile's DMA in one block behind the barrier; 1: scalar residual subtractions; 2: two LDS stages on the
 # 128-row tiles too (default: three); 4: s_setprio 1 for waves 4-7
-VARIANTS = pytest.mark.variants
 SPLIT_VARIANTS = [0, 1, 2, 6]
 
 

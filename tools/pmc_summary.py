@@ -15,7 +15,7 @@ from collections import defaultdict
 
 
 def classify(name: str) -> str:
-    if "conv_gemm3x" in name:
+    if "conv_gemm3x" in name or "conv_gemm3p" in name:
         return "conv_gemm_split"
     if "conv_gemm" in name:
         return "conv_gemm"
