@@ -1042,6 +1042,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "gemm_x32") opt_gemm_x32_ = std::stoi(value);
     else if (key == "gemm_f32s") opt_gemm_f32s_ = std::stoi(value);
     else if (key == "bench_cold") opt_bench_cold_ = std::stoi(value);
+    else if (key == "gemm_probe") opt_gemm_probe_ = std::stoi(value);
     else if (key == "gemm_planes") opt_gemm_planes_ = (value == "default") ? kGemmPlanesDefault : std::stoi(value);
     else if (key == "gemm3x_variant") opt_gemm3x_variant_ = std::stoi(value);
     else if (key == "geglu_fuse") opt_geglu_fuse_ = std::stoi(value);
@@ -1296,6 +1297,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         count_kernel();
         p.A3 = a3_tmp->p;
     }
+    p.probe = probe_buf_;
     auto launch = [&](const ConvGemm& q) {
         if (tc.cfg >= 300) return launch_conv_gemm3p(q, tc.cfg - 300, stream_);
         if (in_dt && tc.cfg >= 100) return launch_conv_gemm_bf16x(q, tc.cfg - 100, stream_);
@@ -2499,6 +2501,43 @@ double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int str
         SDMI_HIP(hipEventRecord(ev1_, stream_));
         SDMI_HIP(hipEventSynchronize(ev1_));
         SDMI_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
+        }
+        if (opt_gemm_probe_ && a.p3) {
+            // diagnostic: one more launch in which every workgroup of the plane GEMM stamps its phases (ConvGemm::probe; 100 MHz clock)
+            constexpr size_t kMaxBlocks = 1 << 13;
+            Buf pb(this, kMaxBlocks * 24 * sizeof(unsigned long long));
+            SDMI_HIP(hipMemsetAsync(pb.p, 0, kMaxBlocks * 24 * sizeof(unsigned long long), stream_));
+            if (opt_bench_cold_) {
+                Buf flush(this, (size_t)512 << 20);
+                SDMI_HIP(hipMemsetAsync(flush.p, 1, (size_t)512 << 20, stream_));
+                SDMI_HIP(launch_split3_rows(a.p, a.p3, a.rows(), cin, cin, a.ld3, stream_));
+            }
+            probe_buf_ = static_cast<unsigned long long*>(pb.p);
+            try { conv(cw, a, y, stride, ups, nullptr, 0, nullptr); } catch (...) { probe_buf_ = nullptr; throw; }
+            probe_buf_ = nullptr;
+            std::vector<unsigned long long> hb(kMaxBlocks * 24);
+            SDMI_HIP(hipMemcpyAsync(hb.data(), pb.p, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+            SDMI_HIP(hipStreamSynchronize(stream_));
+            std::vector<double> pro, loop, epi, tot, wait_frac, mhz;
+            unsigned long long first = ~0ull, last = 0, last_start = 0;
+            for (size_t b = 0; b < kMaxBlocks; ++b) {
+                const unsigned long long* d = &hb[24 * b];
+                if (!d[0] || !d[3]) continue;
+                pro.push_back((d[1] - d[0]) * 0.01); loop.push_back((d[2] - d[1]) * 0.01); epi.push_back((d[3] - d[2]) * 0.01); tot.push_back((d[3] - d[0]) * 0.01);
+                first = std::min(first, d[0]); last = std::max(last, d[3]); last_start = std::max(last_start, d[0]);
+                for (int wv = 0; wv < 8; ++wv)
+                    if (d[4 + 2 * wv]) {
+                        wait_frac.push_back((double)d[5 + 2 * wv] / (double)d[4 + 2 * wv]);
+                        if (d[2] > d[1]) mhz.push_back((double)d[4 + 2 * wv] / ((d[2] - d[1]) * 0.01));
+                    }
+            }
+            auto q = [](std::vector<double>& v, double f) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[std::min(v.size() - 1, (size_t)(f * v.size()))]; };
+            std::fprintf(stderr, "gemm_probe n=%d cin=%d %dx%d cout=%d k=%d tile=%d splitk=%d cold=%d: %zu workgroups; us min/median/max: first tile %.2f/%.2f/%.2f, "
+                                 "k loop %.2f/%.2f/%.2f, epilogue %.2f/%.2f/%.2f, workgroup %.2f/%.2f/%.2f; first entry -> last entry %.2f, first entry -> last exit %.2f; "
+                                 "per wave: share of the k loop waiting at the per-tile barrier %.3f/%.3f/%.3f, shader clock in the k loop %.0f/%.0f/%.0f MHz\n",
+                         n, cin, h, w, cout, k, tile_cfg, splitk, opt_bench_cold_, tot.size(), q(pro, 0), q(pro, 0.5), q(pro, 1), q(loop, 0), q(loop, 0.5), q(loop, 1),
+                         q(epi, 0), q(epi, 0.5), q(epi, 1), q(tot, 0), q(tot, 0.5), q(tot, 1), (last_start - first) * 0.01, (last - first) * 0.01,
+                         q(wait_frac, 0), q(wait_frac, 0.5), q(wait_frac, 1), q(mhz, 0), q(mhz, 0.5), q(mhz, 1));
         }
     } catch (...) {
         opt_force_tile_ = save_t; opt_force_splits_ = save_s; opt_gemm_planes_ = save_p;

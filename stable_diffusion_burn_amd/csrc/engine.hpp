@@ -423,6 +423,8 @@ private:
     static constexpr int kGemmPlanesDefault = 1;
     int opt_gemm_planes_ = kGemmPlanesDefault;   // precision = 0: k_gemm3p.hip (activations as bf16 planes too, no split in the k loop): 0 never, 1 every launch that would take a k_gemm3x.hip tile,
                                 // 2 only where the per-shape table says 300 + x
+    int opt_gemm_probe_ = 0;    // bench_conv: 1 = one extra launch with per-workgroup phase stamps (ConvGemm::probe), summary on stderr
+    unsigned long long* probe_buf_ = nullptr;
     int opt_bench_cold_ = 0;    // bench_conv: 1 = evict the weights from the Infinity Cache between timed launches (what a layer sees inside the model)
     int opt_gemm_x32_ = 1;      // precision = 0: 1 = large-tile LDS-DMA fp32 GEMM (k_gemm2x.hip) where measured / modelled faster
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never

@@ -165,7 +165,10 @@ struct P3Wave {
 // two or three workgroups share a CU and one's DMA prologue / epilogue hides behind the others' matrix work -- for the K = 320 ... 1280
 // linears of the transformer blocks, which as 128-row tiles needed split-K slabs + a reduce launch to fill the chip (round 2: 5 200
 // launches per image at < 20 % matrix-pipe use).
-template <int MI, int NI, int WM, int WN, int NSTG>
+// PROBE (diagnostic instantiations behind option gemm_probe, tools/probes/gemm_phase_probe.py): every workgroup stores s_memrealtime stamps
+// (100 MHz) of kernel entry / first k tile landed / k loop done / epilogue stores acknowledged, and every wave the shader-clock cycles it spent
+// in the k loop and, of those, waiting at the per-tile barrier: probe[24 * block + {0..3, 4 + 2 wave, 5 + 2 wave}].
+template <int MI, int NI, int WM, int WN, int NSTG, bool PROBE = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3p_kernel(const ConvGemm p) {
     static_assert(NSTG == 2 || NSTG == 3, "LDS stages");
     constexpr int BM = 16 * MI * WM;
@@ -269,12 +272,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3p_kernel(const Conv
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) w.acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    unsigned long long pt0 = 0, pt1 = 0, pc0 = 0, pwait = 0;
+    if constexpr (PROBE) pt0 = __builtin_amdgcn_s_memrealtime();
     w.next_stage = smem_p3;
     w.template pieces<0, NAG * 3 + NBW>();      // k tile 0
+    if constexpr (PROBE) {                      // the wait for k tile 0, taken out of the loop's first barrier
+        __syncthreads();
+        pt1 = __builtin_amdgcn_s_memrealtime();
+        pc0 = __builtin_amdgcn_s_memtime();
+    }
     if constexpr (NSTG == 2) {
         for (int t = 0; t < n_t; ++t) {
             const int cur = t & 1;
+            unsigned long long pa = 0;
+            if constexpr (PROBE) pa = __builtin_amdgcn_s_memtime();
             __syncthreads();                    // k tile t is in LDS; every wave is done with stage cur ^ 1
+            if constexpr (PROBE) pwait += __builtin_amdgcn_s_memtime() - pa;
             w.next_stage = smem_p3 + (cur ^ 1) * STAGE;
             w.a_tile = smem_p3 + cur * STAGE + a_fr;
             w.w_tile = smem_p3 + cur * STAGE + w_fr;
@@ -287,9 +300,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3p_kernel(const Conv
         w.template pieces<0, NAG * 3 + NBW>();  // k tile 1 (or tile 0 again when there is none: dead stage)
         int cur = 0;
         for (int t = 0; t < n_t; ++t) {
+            unsigned long long pa = 0;
+            if constexpr (PROBE) pa = __builtin_amdgcn_s_memtime();
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAG * 3 + NBW) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if constexpr (PROBE) pwait += __builtin_amdgcn_s_memtime() - pa;
             const int nxt = cur == 0 ? 2 : cur - 1;      // (cur + 2) % 3
             w.next_stage = smem_p3 + nxt * STAGE;
             w.a_tile = smem_p3 + cur * STAGE + a_fr;
@@ -300,13 +316,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3p_kernel(const Conv
     }
     // the last k tile was fetched twice (piece()); that copy must have landed before the epilogue reuses the stages
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long pt2 = 0, pc2 = 0;
+    if constexpr (PROBE) { pt2 = __builtin_amdgcn_s_memrealtime(); pc2 = __builtin_amdgcn_s_memtime(); }
 
     gemm_epilogue_f32<MI, NI, WM, WN>(p, w.acc, smem_p3, m0, n0, z, lid, wave, lane, HoWo);
+    if constexpr (PROBE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have been acknowledged
+        __syncthreads();
+        unsigned long long* d = p.probe + 24ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.z);
+        if (lane == 0) { d[4 + 2 * wave] = pc2 - pc0; d[5 + 2 * wave] = pwait; }
+        if (tid == 0) { d[0] = pt0; d[1] = pt1; d[2] = pt2; d[3] = __builtin_amdgcn_s_memrealtime(); }
+    }
 }
 
-template <int MI, int NI, int WM, int WN, int NSTG>
+template <int MI, int NI, int WM, int WN, int NSTG, bool PROBE = false>
 static hipError_t launch_cfg_3p(const ConvGemm& p, dim3 grid, hipStream_t stream) {
-    auto k = conv_gemm3p_kernel<MI, NI, WM, WN, NSTG>;
+    auto k = conv_gemm3p_kernel<MI, NI, WM, WN, NSTG, PROBE>;
     constexpr int NWV = WM * WN;
     constexpr size_t stage = (size_t)(MI * WM) * 3 * 1024 + (size_t)((NI * WN * 3 + NWV - 1) / NWV) * NWV * 1024;
     // (the epilogue transposes through one 16 x (16 NI + 4) fp32 scratch per wave in the same memory)
@@ -329,6 +354,14 @@ hipError_t launch_conv_gemm3p(const ConvGemm& p, int cfg, hipStream_t stream) {
     const int bno = p.geglu ? bn / 2 : bn;
     const int MT = (p.M + bm - 1) / bm, NT = (p.N + bno - 1) / bno;
     const dim3 grid = gemm_grid(p, MT * NT);
+    if (p.probe) {   // diagnostic instantiations (option gemm_probe): the three 8-wave tiles the batch-1 model uses most
+        switch (cfg) {
+            case 0: return launch_cfg_3p<4, 5, 4, 2, 2, true>(p, grid, stream);
+            case 3: return launch_cfg_3p<2, 5, 4, 2, 2, true>(p, grid, stream);
+            case 4: return launch_cfg_3p<2, 4, 4, 2, 3, true>(p, grid, stream);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (cfg) {
         case 0: return launch_cfg_3p<4, 5, 4, 2, 2>(p, grid, stream);   // 256 x 160: waves of 64 x 80
         case 1: return launch_cfg_3p<4, 4, 4, 2, 2>(p, grid, stream);   // 256 x 128: 64 x 64

@@ -51,6 +51,8 @@ struct ConvGemm {
                                 // 2 two LDS stages on the 128-row tiles, 4 s_setprio 1 for waves 4-7
     int geglu;                  // large-tile kernels: Bt holds 2 N rows (N value rows, then N gate rows; bias likewise) and the
                                 // epilogue writes value * gelu_erf(gate) -- GEGLU::forward (unet/mod.rs:579-591) without the [M, 2N] tensor
+    unsigned long long* probe;  // diagnostic (option gemm_probe; k_gemm3p.hip tiles 300 / 303 / 304 only): when non-null the PROBE instantiation runs and
+                                // stores 24 words per workgroup (see conv_gemm3p_kernel)
 };
 
 // launch grid of a GEMM kernel: (tiles rounded up to the 8 XCDs) x slices
