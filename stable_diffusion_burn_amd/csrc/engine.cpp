@@ -207,7 +207,6 @@ Engine::Engine(const sdmi_config& cfg) : cfg_(cfg) {
     SDMI_HIP(hipSetDevice(cfg.device));
     hipDeviceProp_t prop;
     SDMI_HIP(hipGetDeviceProperties(&prop, cfg.device));
-    n_cus_ = prop.multiProcessorCount;
     if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
         throw Error(SDMI_ERR_UNSUPPORTED, std::string("libsdmi is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
     try {
@@ -218,24 +217,7 @@ Engine::Engine(const sdmi_config& cfg) : cfg_(cfg) {
     SDMI_HIP(hipMalloc(&zero_page_, 256));
     weight_allocs_.push_back(zero_page_);
     SDMI_HIP(hipMemsetAsync(zero_page_, 0, 256, stream_));
-    {
-        void* w = nullptr;
-        SDMI_HIP(hipMalloc(&w, (size_t)2 * kCskWords * sizeof(unsigned long long)));
-        weight_allocs_.push_back(w);
-        SDMI_HIP(hipMemsetAsync(w, 0, (size_t)2 * kCskWords * sizeof(unsigned long long), stream_));
-        csk_[0] = static_cast<unsigned long long*>(w);
-        csk_[1] = csk_[0] + kCskWords;
-        SDMI_HIP(hipHostMalloc(reinterpret_cast<void**>(&csk_flag_host_), sizeof(unsigned), hipHostMallocMapped));
-        *csk_flag_host_ = 0u;
-        SDMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&csk_flag_dev_), csk_flag_host_, 0));
-        SDMI_HIP(launch_xcc_selftest(csk_flag_dev_, stream_));
-    }
     SDMI_HIP(hipStreamSynchronize(stream_));
-    if (*csk_flag_host_) {   // workgroups are not dealt to the XCDs in linear order here (a partitioned mode?): keep the separate reduce launch
-        *csk_flag_host_ = 0u;
-        opt_splitk_coop_ = 0;
-        xcc_linear_ = false;
-    }
     {   // measured per-shape tile choices (tools/autotune.py -> tuning/gfx950_fp32.txt)
         struct Row { const char* key; int cfg; int splits; };
         static const Row rows[] = {
@@ -273,8 +255,6 @@ void Engine::destroy() noexcept {
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (ev_user_) (void)hipEventDestroy(ev_user_);
-    if (csk_flag_host_) (void)hipHostFree(csk_flag_host_);
-    csk_flag_host_ = csk_flag_dev_ = nullptr;
     if (stream_) (void)hipStreamDestroy(stream_);
     weight_allocs_.clear(); prof_pending_.clear(); prof_free_.clear();
     ev0_ = ev1_ = ev_user_ = nullptr; stream_ = nullptr;
@@ -1036,15 +1016,6 @@ void Engine::end_call() {
     float ms = 0;
     SDMI_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
     last_ms = ms; last_kernels = n_kernels_; last_flops = flops_;
-    check_csk_flag();
-}
-// A combined split-K launch found the slices of one output tile on different XCDs (csk_combine, k_gemm_epi.hpp): what it summed may have been
-// stale, so the call fails instead of returning it.  (Never seen on an MI355X in SPX mode, where workgroups are dealt to the XCDs in linear order.)
-void Engine::check_csk_flag() {
-    if (csk_flag_host_ && *csk_flag_host_) {
-        *csk_flag_host_ = 0u;
-        throw Error(SDMI_ERR_STATE, "split-K combine: the workgroups of one output tile ran on different XCDs, results discarded; set option splitk_coop=0");
-    }
 }
 void Engine::abort_call() noexcept {
     // a throw inside a forward pass leaves raw activations and the per-call UNet tables allocated: wait for what was
@@ -1072,7 +1043,6 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "gemm_f32s") opt_gemm_f32s_ = std::stoi(value);
     else if (key == "bench_cold") opt_bench_cold_ = std::stoi(value);
     else if (key == "gemm_probe") opt_gemm_probe_ = std::stoi(value);
-    else if (key == "splitk_coop") opt_splitk_coop_ = (xcc_linear_ || value == "force") ? (value == "force" ? 1 : std::stoi(value)) : 0;
     else if (key == "gemm_planes") opt_gemm_planes_ = (value == "default") ? kGemmPlanesDefault : std::stoi(value);
     else if (key == "gemm3x_variant") opt_gemm3x_variant_ = std::stoi(value);
     else if (key == "geglu_fuse") opt_geglu_fuse_ = std::stoi(value);
@@ -1347,24 +1317,12 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         p.slab_stride = (long long)p.M * p.N;
         Buf slab(this, (size_t)splits * p.slab_stride * sizeof(float));
         p.slabs = slab.f();
-        // the large-tile fp32 kernels (k_gemm2x.hip, k_gemm3x.hip, k_gemm3p.hip: gemm_epilogue_f32) combine the slabs themselves
-        const GemmTileInfo& cti = tile_info(tc.cfg);
-        const long long c_tiles = (long long)((p.M + cti.bm - 1) / cti.bm) * ((p.N + cti.bn - 1) / cti.bn);
-        // ... when every slice of every tile is resident at once (a slice waits for the others; it gives up after a bounded wait and the result is
-        // still right, but that wait is a millisecond) and a tile's slab region consists of whole cache lines (csk_combine)
-        const bool coop = opt_splitk_coop_ && !in_dt && tc.cfg >= 100 && !p.geglu && splits <= 32 && c_tiles <= kCskWords &&
-                          c_tiles * splits <= (long long)n_cus_ * gemm_tile_wgs_per_cu(tc.cfg) &&
-                          (p.N & 31) == 0 && (!p.C || (p.ldc & 3) == 0) && (!p.resid || (p.ldr & 3) == 0);
-        if (coop) {
-            p.csk = csk_[csk_next_]; p.csk_other = csk_[csk_next_ ^ 1]; p.csk_flag = csk_flag_dev_;
-            csk_next_ ^= 1;
-        }
         {
             ProfScope ps(this, pc, flops);
             SDMI_HIP(launch(p));
         }
         count_kernel(flops);
-        if (!coop) {
+        {
             ProfScope ps(this, PC_SPLITK_REDUCE, 0, (double)(splits + 1) * p.slab_stride * 4.0);
             if (in_dt) SDMI_HIP(launch_splitk_reduce_bf16(p, stream_));
             else SDMI_HIP(launch_splitk_reduce(p, stream_));
@@ -2560,14 +2518,13 @@ double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int str
             std::vector<unsigned long long> hb(kMaxBlocks * 24);
             SDMI_HIP(hipMemcpyAsync(hb.data(), pb.p, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
             SDMI_HIP(hipStreamSynchronize(stream_));
-            std::vector<double> pro, loop, epi, tot, wait_frac, mhz, slab, arrive, comb, fence;
+            std::vector<double> pro, loop, epi, tot, wait_frac, mhz;
             unsigned long long first = ~0ull, last = 0, last_start = 0;
             for (size_t b = 0; b < kMaxBlocks; ++b) {
                 const unsigned long long* d = &hb[24 * b];
                 if (!d[0] || !d[3]) continue;
                 pro.push_back((d[1] - d[0]) * 0.01); loop.push_back((d[2] - d[1]) * 0.01); epi.push_back((d[3] - d[2]) * 0.01); tot.push_back((d[3] - d[0]) * 0.01);
                 first = std::min(first, d[0]); last = std::max(last, d[3]); last_start = std::max(last_start, d[0]);
-                if (d[20] && d[21]) { slab.push_back((d[20] - d[2]) * 0.01); arrive.push_back((d[21] - d[20]) * 0.01); if (d[22] && d[23]) { fence.push_back((d[22] - d[21]) * 0.01); comb.push_back((d[23] - d[22]) * 0.01); } }
                 for (int wv = 0; wv < 8; ++wv)
                     if (d[4 + 2 * wv]) {
                         wait_frac.push_back((double)d[5 + 2 * wv] / (double)d[4 + 2 * wv]);
@@ -2581,10 +2538,6 @@ double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int str
                          n, cin, h, w, cout, k, tile_cfg, splitk, opt_bench_cold_, tot.size(), q(pro, 0), q(pro, 0.5), q(pro, 1), q(loop, 0), q(loop, 0.5), q(loop, 1),
                          q(epi, 0), q(epi, 0.5), q(epi, 1), q(tot, 0), q(tot, 0.5), q(tot, 1), (last_start - first) * 0.01, (last - first) * 0.01,
                          q(wait_frac, 0), q(wait_frac, 0.5), q(wait_frac, 1), q(mhz, 0), q(mhz, 0.5), q(mhz, 1));
-            if (!slab.empty())
-                std::fprintf(stderr, "           in-launch combine, us min/median/max: slab tile stored %.2f/%.2f/%.2f, arrival + wait for the other slices %.2f/%.2f/%.2f, "
-                                     "L1 invalidate %.2f/%.2f/%.2f, sum of my rows + output %.2f/%.2f/%.2f\n", q(slab, 0), q(slab, 0.5), q(slab, 1), q(arrive, 0), q(arrive, 0.5), q(arrive, 1),
-                             q(fence, 0), q(fence, 0.5), q(fence, 1), q(comb, 0), q(comb, 0.5), q(comb, 1));
         }
     } catch (...) {
         opt_force_tile_ = save_t; opt_force_splits_ = save_s; opt_gemm_planes_ = save_p;
@@ -2593,7 +2546,6 @@ double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int str
     }
     opt_force_tile_ = save_t; opt_force_splits_ = save_s; opt_gemm_planes_ = save_p;
     release(a); release(y);
-    check_csk_flag();
     return (double)ms / std::max(1, iters);
 }
 

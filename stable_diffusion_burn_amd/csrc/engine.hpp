@@ -423,23 +423,12 @@ private:
     static constexpr int kGemmPlanesDefault = 1;
     int opt_gemm_planes_ = kGemmPlanesDefault;   // precision = 0: k_gemm3p.hip (activations as bf16 planes too, no split in the k loop): 0 never, 1 every launch that would take a k_gemm3x.hip tile,
                                 // 2 only where the per-shape table says 300 + x
-    int opt_splitk_coop_ = 1;   // precision = 0, large-tile kernels: 1 = the slices of a split-K launch combine their slabs inside the launch (csk_combine, k_gemm_epi.hpp);
-                                // 0 = a second launch does (splitk_reduce_kernel)
     int opt_gemm_probe_ = 0;    // bench_conv: 1 = one extra launch with per-workgroup phase stamps (ConvGemm::probe), summary on stderr
     unsigned long long* probe_buf_ = nullptr;
     int opt_bench_cold_ = 0;    // bench_conv: 1 = evict the weights from the Infinity Cache between timed launches (what a layer sees inside the model)
     int opt_gemm_x32_ = 1;      // precision = 0: 1 = large-tile LDS-DMA fp32 GEMM (k_gemm2x.hip) where measured / modelled faster
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
     void* zero_page_ = nullptr;
-    // split-K combined inside the launch (ConvGemm::csk): two arrays of arrival words used alternately + the "slices of one tile ran on
-    // different XCDs" flag in mapped host memory, checked whenever the engine has synchronised (end_call, bench_conv)
-    unsigned long long* csk_[2] = {nullptr, nullptr};
-    int csk_next_ = 0;
-    int n_cus_ = 256;
-    bool xcc_linear_ = true;    // workgroup b of a dispatch runs on XCD b % 8 (checked at creation; splitk_coop stays off otherwise)
-    unsigned* csk_flag_host_ = nullptr;
-    unsigned* csk_flag_dev_ = nullptr;
-    void check_csk_flag();
     TileChoice choose_tile_p(int M, int N, int kt_total, bool even_ni_only) const;   // k_gemm3p.hip tiles (300 + x)
     TileChoice choose_tile_bf16(int M, int N, int kt_total) const;   // cfg >= 100: k_gemm_bf16x.hip tile cfg - 100     // precision = 1: 1 = bf16 matrix-core attention, 0 = bf16 storage widened onto the fp32 kernel  // 1: attn2_kernel, 0: attn_f32_kernel
     std::map<std::string, TileChoice> tuned_;        // fp32 kernels: "M,N,K" -> (tile cfg, split-K)

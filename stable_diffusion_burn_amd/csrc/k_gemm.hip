@@ -188,19 +188,6 @@ hipError_t launch_splitk_reduce(const ConvGemm& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// the premise of the in-launch split-K combine (k_gemm_epi.hpp csk_combine): workgroup b of a dispatch runs on XCD b % 8
-__global__ void xcc_selftest_kernel(unsigned* flag) {
-    if (threadIdx.x == 0) {
-        unsigned v;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
-        if ((v & 15u) != (blockIdx.x & 7u)) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-hipError_t launch_xcc_selftest(unsigned* flag, hipStream_t stream) {
-    hipLaunchKernelGGL(xcc_selftest_kernel, dim3(1024), dim3(64), 0, stream, flag);
-    return hipGetLastError();
-}
-
 hipError_t launch_pack_conv_weight(const float* w, float* bt, int cout, int cin, int kh, int kw, hipStream_t s) {
     const long long total = (long long)cout * cin * kh * kw;
     int blocks = (int)((total + 255) / 256);

@@ -4,8 +4,7 @@
 //   * bias + time-embedding row + residual, or the GEGLU product, or a raw split-K slab
 //   * every wave transposes one 16-row fragment group at a time through its own LDS scratch (the stages are free by then)
 //     and writes whole row segments with 16-byte lanes; the residual is read the same way
-//   * split-K: raw fp32 slabs, combined by launch_splitk_reduce in a second launch -- or, with p.csk, inside this launch by the workgroups
-//     that produced them (csk_combine below)
+//   * split-K: raw fp32 slabs; launch_splitk_reduce -- or the GroupNorm / LayerNorm that reads the result (k_norm.hip) -- combines them
 #pragma once
 #include "kernels.hpp"
 #include "k_common.hpp"
@@ -14,144 +13,6 @@
 namespace sdmi {
 
 typedef float epi_f32x4 __attribute__((ext_vector_type(4)));
-
-// ---- split-K combined inside the launch, cooperatively -------------------------------------------------------------------------------------
-// The S slices of an output tile are S workgroups with the same blockIdx.x, i.e. (gemm_grid: gridDim.x is a multiple of 8, workgroups are dealt
-// round-robin to the 8 XCDs in linear order, starting at XCD 0) S workgroups of ONE XCD: their slab tiles meet in that XCD's L2 and need no write-back to be visible
-// to each other.  Each slice stores its partial tile, announces itself on the tile's arrival word and, once all S have arrived, sums rows
-// [z R, (z + 1) R) of the tile over the slabs IN SLICE ORDER (bit-reproducible whatever the arrival order), applies bias / time-embedding row /
-// residual and writes C and / or the planes C3: every slice reduces 1 / S of the tile, nothing is read by a workgroup that did not just write
-// 1 / S of it, and the separate reduce launch with its two kernel boundaries is gone.
-//   arrival word (64 bit, zero at launch): bits 0-7 arrivals, 32-63 slices that gave up waiting (their rows are summed by the slice that arrives last).
-//   * nobody depends on co-residency: a slice polls the word a bounded number of times, then sets its bit and leaves; the two atomics (arrive:
-//     add, give up: or) are totally ordered on the word, so either the last arriver sees the bit in the value its add returns and does those
-//     rows too, or the or returns a full count and the slice does its rows itself.
-//   * the same-XCD premise is CHECKED, not assumed: every workgroup compares its XCC id (s_getreg HW_REG_XCC_ID) with blockIdx.x % 8 and sets
-//     *csk_flag otherwise; the engine then fails the call (Engine::check_csk_flag) -- stale slab bytes are never returned silently -- and a
-//     self-test at context creation (launch_xcc_selftest) switches the option off where the dispatcher deals differently (partitioned modes).
-//   * the words are zero again for the next launch without a memset: two arrays alternate, every launch zeroes the other one (the previous
-//     launch that used it has completed: same stream).
-__device__ __forceinline__ unsigned csk_xcc_id() {
-    unsigned v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
-    return v & 15u;
-}
-
-// rows [mr0, mr0 + rows) x 16-byte columns [n0, n0 + 4 cpr) of the output: sum of the S slabs in slice order + bias / row vector / residual -> C, C3.
-// U outputs per thread per pass, J slabs in flight per output.
-template <int U, int J>
-__device__ __forceinline__ void csk_sum(const ConvGemm& p, const int mr0, const int n0, const int rows, const int cpr, const int HoWo) {
-    typedef epi_f32x4 f32x4;
-    const int S = p.splits;
-    const int total = rows * cpr;
-    for (int e0 = threadIdx.x; e0 < total; e0 += U * (int)blockDim.x) {
-        long long off[U];
-        int mm[U], nn[U];
-        bool ok[U];
-        f32x4 v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = e0 + u * (int)blockDim.x;
-            ok[u] = e < total;
-            const int ee = ok[u] ? e : 0;
-            const int r = ee / cpr;
-            mm[u] = mr0 + r;
-            nn[u] = n0 + ((ee - r * cpr) << 2);
-            off[u] = (long long)mm[u] * p.N + nn[u];
-            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        for (int s = 0; s < S; s += J) {
-            f32x4 t[J][U];
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                const int sj = min(s + j, S - 1);         // past the end: a harmless re-read, not added
-#pragma unroll
-                for (int u = 0; u < U; ++u) t[j][u] = *reinterpret_cast<const f32x4*>(p.slabs + (long long)sj * p.slab_stride + off[u]);
-            }
-#pragma unroll
-            for (int j = 0; j < J; ++j)
-                if (s + j < S) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) v[u] = (s + j == 0) ? t[j][u] : v[u] + t[j][u];
-                }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!ok[u]) continue;
-            f32x4 r = v[u];
-            const int m = mm[u], n = nn[u];
-            if (p.bias) r += *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (p.rowvec) r += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)(m / HoWo) * p.rowvec_stride + n);
-            if (p.resid) r += *reinterpret_cast<const f32x4*>(p.resid + (long long)m * p.ldr + n);
-            if (p.C) *reinterpret_cast<f32x4*>(p.C + (long long)m * p.ldc + n) = r;
-            if (p.C3) s3_store4(reinterpret_cast<unsigned char*>(p.C3) + (long long)m * p.ldc3, n, r);
-        }
-    }
-}
-
-template <int BM, int BN>
-__device__ __forceinline__ void csk_combine(const ConvGemm& p, unsigned char* smem, const int m0, const int n0, const int z, const int lid,
-                                            const int MT_NT, const int HoWo) {
-    typedef epi_f32x4 f32x4;
-    const int tid = threadIdx.x;
-    const int S = p.splits;
-    // zero the other array for the launch after this one (slice 0 of every tile: words lid, lid + tiles, ...)
-    if (z == 0)
-        for (int j = lid + tid * MT_NT; j < kCskWords; j += (int)blockDim.x * MT_NT) p.csk_other[j] = 0ull;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's slab stores are in the L2
-    __syncthreads();
-    unsigned long long* const pd = p.probe ? p.probe + 24ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.z) : nullptr;   // (diagnostic builds)
-    if (pd && tid == 0) pd[20] = __builtin_amdgcn_s_memrealtime();
-    unsigned* flags = reinterpret_cast<unsigned*>(smem);
-    if (tid == 0) {
-        unsigned long long* W = p.csk + lid;
-        if (csk_xcc_id() != (blockIdx.x & 7u)) __hip_atomic_store(p.csk_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        const unsigned long long old = __hip_atomic_fetch_add(W, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned mine = 1u, others = 0u;
-        if ((int)(old & 0xFFull) + 1 == S) {
-            others = (unsigned)(old >> 32);               // I am last: the rows of every slice that gave up before I arrived are mine too
-        } else {
-            unsigned long long w;
-            int it = 0;
-            do {
-                __builtin_amdgcn_s_sleep(4);
-                w = __hip_atomic_load(W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } while ((int)(w & 0xFFull) != S && ++it < 1000);
-            if ((int)(w & 0xFFull) != S) {
-                const unsigned long long o2 = __hip_atomic_fetch_or(W, 1ull << (32 + z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int)(o2 & 0xFFull) != S) mine = 0u;  // the slice that arrives last will see my bit
-            }
-        }
-        flags[0] = mine;
-        flags[1] = others;
-    }
-    __syncthreads();
-    const unsigned mine = flags[0], others = flags[1];
-    if (pd && tid == 0) pd[21] = __builtin_amdgcn_s_memrealtime();
-    if (!(mine | others)) return;
-    // No cache maintenance here, on purpose.  The other slices' slab tiles are read through this CU's L1, which cannot hold them: it was
-    // invalidated when the kernel was dispatched, this workgroup has not read slab memory before, a tile's slab region consists of whole cache
-    // lines (launch side: N % 32 == 0) and nobody reads a tile's region before all of its slices have arrived -- so the reads miss to the XCD's
-    // L2, where the writers' stores are (they waited for vmcnt(0) before arriving).  An agent-scope acquire (buffer_inv sc1) in this place
-    // measured 8 us per workgroup and slowed the loads behind it by another 5 (profiles/r03p_*): more than the launch it replaces.
-    if (pd) { __syncthreads(); if (tid == 0) pd[22] = __builtin_amdgcn_s_memrealtime(); }
-    const int R = (BM + S - 1) / S;
-    const int cols = min(BN, p.N - n0);
-    const int cpr = cols >> 2;                            // 16-byte outputs per row (launch side: N % 32 == 0)
-    for (int q = 0; q < S; ++q) {
-        if (!((q == z && mine) || ((others >> q) & 1u))) continue;
-        const int r0 = q * R;
-        const int rows = min(min(R, BM - r0), p.M - m0 - r0);
-        if (rows <= 0 || cpr <= 0) continue;
-        // a thread's (outputs) x (slabs) loads are all in flight together: ~20 per thread whatever S is (rows shrink as S grows)
-        const int per_thread = (rows * cpr + (int)blockDim.x - 1) / (int)blockDim.x;
-        if (per_thread >= 4) csk_sum<5, 4>(p, m0 + r0, n0, rows, cpr, HoWo);
-        else if (per_thread == 3) csk_sum<3, 8>(p, m0 + r0, n0, rows, cpr, HoWo);
-        else if (per_thread == 2) csk_sum<2, 12>(p, m0 + r0, n0, rows, cpr, HoWo);
-        else csk_sum<1, 16>(p, m0 + r0, n0, rows, cpr, HoWo);
-    }
-    if (pd) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (tid == 0) pd[23] = __builtin_amdgcn_s_memrealtime(); }
-}
 
 template <int MI, int NI, int WM, int WN>
 __device__ __forceinline__ void gemm_epilogue_f32(const ConvGemm& p, epi_f32x4 (&acc)[MI][NI], unsigned char* smem_x32, const int m0,
@@ -279,7 +140,6 @@ __device__ __forceinline__ void gemm_epilogue_f32(const ConvGemm& p, epi_f32x4 (
         }
     }
     }
-    if (split && p.csk) csk_combine<BM, BN>(p, smem_x32, m0, n0, z, lid, ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), HoWo);
 }
 
 }  // namespace sdmi

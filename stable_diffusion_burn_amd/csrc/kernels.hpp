@@ -51,20 +51,9 @@ struct ConvGemm {
                                 // 2 two LDS stages on the 128-row tiles, 4 s_setprio 1 for waves 4-7
     int geglu;                  // large-tile kernels: Bt holds 2 N rows (N value rows, then N gate rows; bias likewise) and the
                                 // epilogue writes value * gelu_erf(gate) -- GEGLU::forward (unet/mod.rs:579-591) without the [M, 2N] tensor
-    // split-K combined INSIDE the launch (option splitk_coop; gemm_epilogue_f32 / csk_combine in k_gemm_epi.hpp): not null -> one 64-bit arrival word per
-    // output tile (kCskWords of them, zero at launch); the launch also zeroes csk_other, the array the NEXT such launch will use; csk_flag is
-    // set non-zero when the slices of one tile turn out to have run on different XCDs (their slabs are then not coherent: the engine fails the call)
-    unsigned long long* csk;
-    unsigned long long* csk_other;
-    unsigned* csk_flag;
     unsigned long long* probe;  // diagnostic (option gemm_probe; k_gemm3p.hip tiles 300 / 303 / 304 only): when non-null the PROBE instantiation runs and
                                 // stores 24 words per workgroup (see conv_gemm3p_kernel)
 };
-
-hipError_t launch_xcc_selftest(unsigned* flag, hipStream_t stream);   // k_gemm.hip: sets *flag when workgroup b of a launch does not run on XCD b % 8
-// workgroups of GEMM tile configuration cfg that share a CU (LDS-limited): the four-wave plane tiles with 72 KB of stages run two at a time
-inline int gemm_tile_wgs_per_cu(int cfg) { return (cfg == 305 || cfg == 306 || cfg == 308) ? 2 : 1; }
-constexpr int kCskWords = 1024;   // arrival words per array = the largest number of output tiles a combined split-K launch may have
 
 // launch grid of a GEMM kernel: (tiles rounded up to the 8 XCDs) x slices
 inline dim3 gemm_grid(const ConvGemm& p, int tiles) {

@@ -26,12 +26,7 @@ CASES = [
 
 sd = StableDiffusion(ModelConfig(32, 1, 32, 8, 8, 32))
 sd.set_option("gemm_probe", 1)
-if len(sys.argv) > 1:
-    sd.set_option("splitk_coop", sys.argv[1])
-if len(sys.argv) > 2:
-    sd.set_option("gemm3x_variant", sys.argv[2])
-    CASES = CASES[:1]
-for cold in (0,) if len(sys.argv) > 2 else (0, 1):
+for cold in (0, 1):
     sd.set_option("bench_cold", cold)
     for shape, tiles in CASES:
         n, cin, h, w, cout, k = shape
