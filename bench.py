@@ -165,7 +165,7 @@ class Runner:
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
         peak = (FP8_MFMA_PEAK_TFLOPS if self.fp8 else BF16_MFMA_PEAK_TFLOPS if self.bf16 else
                 BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if split else FP32_MFMA_PEAK_TFLOPS)
-        kname = ("conv_gemm_fp8x_kernel (implicit-GEMM 3x3 conv of the ResBlocks, v_mfma_scale_f32_16x16x128_f8f6f4, MXFP8)" if self.fp8 else
+        kname = ("conv_gemm_fp8x_kernel (implicit-GEMM conv / linear on MXFP8 operands, v_mfma_scale_f32_16x16x128_f8f6f4)" if self.fp8 else
                  "conv_gemm_bf16x_kernel + conv_gemm_bf16_kernel (implicit-GEMM conv/linear, v_mfma_f32_16x16x32_bf16)" if self.bf16 else
                  "conv_gemm3p_kernel / conv_gemm3x_kernel (implicit-GEMM conv/linear in fp32: operands split exactly into 3 bf16 terms -- the weights at "
                  "load, the activations by their producers (planes) or in the k loop --, 6 partial products per multiply on v_mfma_f32_16x16x32_bf16, fp32 accumulation)" if split else
@@ -192,6 +192,9 @@ class Runner:
             o = prof["conv_gemm"]
             roof["peak_note"] = (f"dense bf16 MFMA peak {BF16_MFMA_PEAK_TFLOPS:g} TFLOP/s / {SPLIT_PRODUCTS} matrix instructions per fp32 block; "
                                  f"achieved counts ALGORITHMIC fp32 flops (2 M N K), not the 6x issued bf16 flops")
+            roof["clock_note"] = ("the peak is quoted at 2.4 GHz; stamped inside this kernel (option gemm_probe, profiles/r03n_gemm_phase_probe.txt) the shader clock is "
+                                  "1.76-1.89 GHz with all 256 CUs on matrix instructions (a power limit), i.e. the bound the chip grants is ~318 TFLOP/s, and the k loop "
+                                  "runs at 83 % of it; the rest of a batch-1 launch is prologue, slab store, split-K combine and launch boundaries")
             roof["achieved_vs_fp32_mfma_peak"] = achieved / FP32_MFMA_PEAK_TFLOPS   # > 1 is possible: the fp32 matrix instruction is not used
             roof["issued_bf16_tflops"] = achieved * SPLIT_PRODUCTS
             if o["launches"] > 0 and o["ms"] > 0:
@@ -219,7 +222,19 @@ ARITHMETIC = {
             "error <= 2^-23 worst case / 2^-28 on average (tests/test_split_oracle_cpu.py), measured against the fp64 oracle: not larger than the fp32 matrix instruction's -- tests/test_ops_gpu.py); "
             "attention, norms and the remaining GEMMs in plain fp32",
     "bf16": "bf16 storage, fp32 accumulation and statistics",
-    "fp8": "bf16 storage, fp32 accumulation; ResBlock 3x3 convolutions on MXFP8 operands",
+    "fp8": "bf16 storage, fp32 accumulation; on MXFP8 operands (e4m3, E8M0 scale per 32 channels): the ResBlock / ResnetBlock 3x3 convolutions and (option "
+           "fp8_linear, default) the UNet's transformer-block Linear layers and 1x1 / up / down convolutions; attention in bf16",
+}
+
+# What the reduced precisions cost, measured on MI355X against the fp64 oracle's golden vectors at the FULL model size (tests/test_golden_gpu.py
+# asserts 1.5 x these; profiles/r03m_precision_bars_measured.txt): relative RMS of the final latent / of the decoded RGB.
+ACCURACY = {
+    ("bf16", 50): {"latent_rel_rms_vs_fp64": 5.5e-3, "rgb_rel_rms_vs_fp64": 8.7e-3, "case": "batch 16, 50 steps, samples 0-1 (test_config3_bf16_batch16_50_steps)"},
+    ("bf16", 20): {"latent_rel_rms_vs_fp64": 9e-3, "rgb_rel_rms_vs_fp64": 9e-3, "case": "batch 1, 20 steps (test_golden_gpu.py, bf16 cases)"},
+    ("fp8", 20): {"latent_rel_rms_vs_fp64": 8.1e-2, "rgb_rel_rms_vs_fp64": 2.1e-2, "unet_forward_rel_rms_vs_fp64": 1.2e-1,
+                  "with_fp8_linear_0": {"latent_rel_rms_vs_fp64": 5.2e-2, "unet_forward_rel_rms_vs_fp64": 8.5e-2},
+                  "format_cost_in_fp64": "the same quantisation applied to the fp64 oracle: 5.1e-2 (fp8_linear=0 set, 20-step latent), 1.25e-1 / 9.1e-2 (one UNet forward, wide / narrow set)",
+                  "case": "batch 16, 20 steps, samples 0-1 (test_config5_mxfp8_batch16_20_steps); UNet forward: tests/test_fp8_gpu.py"},
 }
 
 
@@ -228,7 +243,8 @@ def workload_name(precision, B, ddim_steps, scale):
              ("bf16", 8, 20): "the per-GPU shard of BASELINE.json configs[3] (64 images over 8 GPUs)",
              ("fp8", 16, 20): "the per-GPU shard of BASELINE.json configs[4] (128 images over 8 GPUs)"}.get((precision, B, ddim_steps), "not a BASELINE.json configuration")
     arith = {"fp32": "fp32", "bf16": "bf16 storage / fp32 accumulate",
-             "fp8": "bf16 storage / fp32 accumulate + the ResBlock 3x3 convs in MXFP8 (e4m3, E8M0 scales per 32 channels)"}[precision]
+             "fp8": "bf16 storage / fp32 accumulate + MXFP8 (e4m3, E8M0 scales per 32 channels) on the ResBlock 3x3 convs, the transformer blocks' Linear layers "
+                    "and the UNet's 1x1 / up / down convs"}[precision]
     return f"SD v1.4 512x512, {ddim_steps}-step DDIM, CFG={scale}, batch={B} per GPU, {arith} ({which})"
 
 
@@ -321,6 +337,8 @@ def main():
             if prec2 == "fp32":
                 entry["config"]["workload"] += "; every GEMM and attention on v_mfma_f32_16x16x4_f32 (options gemm_f32s=0, attn_split=0)"
                 entry["whole_path_frac_of_fp32_mfma_peak"] = entry.pop("whole_path_frac_of_bf16_mfma_peak") * BF16_MFMA_PEAK_TFLOPS / FP32_MFMA_PEAK_TFLOPS
+            if (prec2, s2) in ACCURACY:
+                entry["accuracy_measured_on_mi355x"] = ACCURACY[(prec2, s2)]
             entry.update(r2.class_summary(prof2))
             secondary.append(entry)
             r2.close()
@@ -356,6 +374,8 @@ def main():
             "kernels_per_image": stats["kernels"] / B, "weights_load_s": t_load, "weights_generate_s": t_gen,
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if (args.precision, args.ddim_steps) in ACCURACY:
+            out["accuracy_measured_on_mi355x"] = ACCURACY[(args.precision, args.ddim_steps)]
         out.update(classes)
         if secondary:
             out["secondary"] = secondary
