@@ -7,6 +7,7 @@ fp64 oracle isolates the kernel (fp32 accumulation + one bf16 rounding of the ou
 Model level (full-width UNet / decoder at an 8x8 latent): relative RMS error against the fp64 oracle on
 the un-rounded weights; bars set from the first measurements ("expect ~1e-2 bf16").
 """
+import functools
 import math
 
 import numpy as np
@@ -239,12 +240,19 @@ def _rel_rms(got, ref):
     return float(np.sqrt(np.mean((got - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))
 
 
+@functools.lru_cache(maxsize=None)
+def _unet_oracle64(t):
+    """the fp64 oracle's UNet forward on the two test latents at timestep t (seconds of host time: shared by the tests that need it)"""
+    lat = np.stack([syn.initial_latent(i, 8, 8) for i in range(2)])
+    ctx = np.stack([syn.cond_context(i, 77, 768) for i in range(2)])
+    return O.UNetOracle(syn.SyntheticWeights(), DIMS16, torch.float64).forward(torch.from_numpy(lat), t, torch.from_numpy(ctx)).numpy()
+
+
 def test_unet_forward_bf16(sd16):
     lat = np.stack([syn.initial_latent(i, 8, 8) for i in range(2)])
     ctx = np.stack([syn.cond_context(i, 77, 768) for i in range(2)])
     got = sd16.unet.forward(lat, [999], ctx)
-    o64 = O.UNetOracle(syn.SyntheticWeights(), DIMS16, torch.float64)
-    ref = o64.forward(torch.from_numpy(lat), 999, torch.from_numpy(ctx)).numpy()
+    ref = _unet_oracle64(999)
     r = _rel_rms(got, ref)
     print(f"bf16 UNet forward: rel-RMS vs fp64 oracle = {r:.3e}, max|d| = {np.abs(got - ref).max():.3e} (|ref|max {np.abs(ref).max():.2f})")
     assert np.isfinite(got).all() and r < BAR_UNET
@@ -261,8 +269,7 @@ def test_unet_forward_bf16_large_tiles_forced(sd16, tile):
         got = sd16.unet.forward(lat, [500], ctx)
     finally:
         sd16.set_option("gemm_tile", "auto")
-    o64 = O.UNetOracle(syn.SyntheticWeights(), DIMS16, torch.float64)
-    ref = o64.forward(torch.from_numpy(lat), 500, torch.from_numpy(ctx)).numpy()
+    ref = _unet_oracle64(500)
     r, r0 = _rel_rms(got, ref), _rel_rms(base, ref)
     print(f"bf16 UNet forward, tile {tile} forced: rel-RMS {r:.3e} (auto tiles {r0:.3e})")
     assert np.isfinite(got).all() and r < BAR_UNET

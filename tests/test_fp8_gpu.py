@@ -14,6 +14,7 @@ element and ~5 % per dot product of two quantised operands, whatever the scales 
 convolutions in MXFP8 lands at ~1e-1 relative RMS on the synthetic weights (bf16: 1e-2) -- measured and asserted below,
 -- and the GPU must pay what the format costs according to the oracle with the same quantisation, not more.
 """
+import functools
 import math
 
 import numpy as np
@@ -138,6 +139,18 @@ def sd8():
 _MxResConvs = MX.MxResConvs
 
 
+@functools.lru_cache(maxsize=None)
+def _unet8_oracle64(quant):
+    """fp64 oracle UNet forward (full width, 8x8 latent) on the two test latents: quant None = exact, 0 / 1 = with the MXFP8 quantisation of
+    fp8_linear = 0 / 1.  Shared by the parametrised cases (each is a minute of host time)."""
+    lat = torch.from_numpy(np.stack([syn.initial_latent(i, 8, 8) for i in range(2)]))
+    ctx = torch.from_numpy(np.stack([syn.cond_context(i, 77, 768) for i in range(2)]))
+    if quant is None:
+        return O.UNetOracle(syn.SyntheticWeights(), DIMS8, torch.float64).forward(lat, 999, ctx).numpy()
+    with _MxResConvs(wide=bool(quant)):
+        return O.UNetOracle(syn.SyntheticWeights(), DIMS8, torch.float64).forward(lat, 999, ctx).numpy()
+
+
 # ---- option fp8_linear: the quantising producers and the Linear layers on MXFP8 operands, operator level ------------------------------
 def test_linear_mxfp8_on_grid_operands(ops8):
     """A Linear layer as the fp8_linear path runs it (bf16 activation -> quantize_bf16_fp8_kernel -> conv_gemm_fp8x_kernel with KH = KW = 1
@@ -201,10 +214,8 @@ def test_unet_forward_mxfp8(sd8, wide):
         n_fp8 = sd8.last_call_stats()["kernels"]
     finally:
         sd8.set_option("fp8_linear", 1)
-    o64 = O.UNetOracle(syn.SyntheticWeights(), DIMS8, torch.float64)
-    exact = o64.forward(torch.from_numpy(lat), 999, torch.from_numpy(ctx)).numpy()
-    with _MxResConvs(wide=bool(wide)):
-        same_quant = O.UNetOracle(syn.SyntheticWeights(), DIMS8, torch.float64).forward(torch.from_numpy(lat), 999, torch.from_numpy(ctx)).numpy()
+    exact = _unet8_oracle64(None)
+    same_quant = _unet8_oracle64(wide)
     try:
         sd8.set_option("fp8_convs", 0)
         bf = sd8.unet.forward(lat, [999], ctx)
