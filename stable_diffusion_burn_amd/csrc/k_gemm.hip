@@ -26,8 +26,10 @@
 //    own a contiguous range of tiles (n fastest), so an XCD's L2 keeps its band
 //    of the activation and its neighbours' halo rows.
 //  * split-K over blockIdx.z writes raw fp32 slabs; launch_splitk_reduce sums them in fixed order (bit-reproducible)
-//    and applies the epilogue -- or the GroupNorm / LayerNorm that reads the result does (k_norm.hip, SlabSrc).  An in-launch
-//    combine by the last-arriving slice was built in round 2, measured slower twice (profiles/r02*_splitk_*.json) and removed.
+//    and applies the epilogue.  Three other places for the combine were built and measured slower (profiles/README.md): inside the launch by
+//    the last-arriving slice (round 2), inside the GroupNorm / LayerNorm that reads the result, and inside the launch by all slices of one XCD
+//    (round 3) -- the combine moves (slices + 1) x the tensor between the L2s and the Infinity Cache in every form, and this kernel does it
+//    at the rate that traffic allows without making any GEMM workgroup wait.
 #include "kernels.hpp"
 #include "k_split3.hpp"
 
