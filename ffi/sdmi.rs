@@ -41,6 +41,7 @@ extern "C" {
     fn sdmi_load_weights_dir(ctx: *mut c_void, dump_dir: *const c_char) -> c_int;
     fn sdmi_load_weights_mpk(ctx: *mut c_void, mpk_path: *const c_char) -> c_int;
     fn sdmi_finalize_weights(ctx: *mut c_void) -> c_int;
+    fn sdmi_set_option(ctx: *mut c_void, key: *const c_char, value: *const c_char) -> c_int;
     fn sdmi_create_multi(out: *mut *mut c_void, cfg: *const SdmiConfig, devices: *const i32, n_devices: i32) -> c_int;
     fn sdmi_destroy_multi(m: *mut c_void);
     fn sdmi_multi_load_weights(m: *mut c_void, kind: *const c_char, path: *const c_char) -> c_int;
@@ -133,9 +134,19 @@ impl StableDiffusionMi355 {
         }
     }
 
+    /// An engine option (`sdmi_set_option`; INTEGRATION.md "Options"), e.g. `("gemm_f32s", "0")` + `("attn_split", "0")` for the fp32 matrix
+    /// instruction everywhere, or `("fp8_linear", "0")` for round 2's MXFP8 set.  Unknown keys are an error, not ignored.
+    pub fn set_option(&mut self, key: &str, value: &str) -> Result<(), Box<dyn Error>> {
+        let (k, v) = (CString::new(key)?, CString::new(value)?);
+        if unsafe { sdmi_set_option(self.ctx, k.as_ptr(), v.as_ptr()) } != 0 {
+            return Err(last_error().into());
+        }
+        Ok(())
+    }
+
     /// `load_stable_diffusion_model_file(filename, device)` (src/bin/sample/main.rs:27-34): the Burn
     /// `NamedMpkFileRecorder<FullPrecisionSettings>` record, read natively by the library (the recorder appends ".mpk").
-    /// `precision`: 0 fp32 (the reference's arithmetic), 1 bf16, 2 bf16 + MXFP8 ResBlock convolutions.
+    /// `precision`: 0 fp32 (the reference's arithmetic), 1 bf16, 2 bf16 + MXFP8 convolutions and Linear layers (INTEGRATION.md "Precision").
     pub fn load_record(model_name: &str, device: i32, precision: i32) -> Result<Self, Box<dyn Error>> {
         unsafe {
             let mut cfg: SdmiConfig = std::mem::zeroed();
