@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of what was run: the last command's option xcd_map was removed afterwards -- its result is profiles/r03m_ab_fp32_b1_xcd_map.jsonl)
 # round 3, GPU call m: the numbers the precision = 1 / 2 bars are set from (outputs saved, the fp64 side is evaluated off the box:
 # tools/probes/r03m_compare.py), the operator-level tests of the fp8_linear kernels, and the HBM-traffic counters of the committed code
 R=$PWD; out=gpurun_out/r03m; mkdir -p $out
