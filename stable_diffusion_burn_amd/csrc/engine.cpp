@@ -1398,6 +1398,7 @@ void Engine::f16s_launch(const F16sOperands& o, const float* bias, const Act& x,
     p.ldc = y.stride(); p.ldr = y.stride(); p.a_ld = x.stride(); p.b_ld = p.K; p.CS = 32;
     p.kt_total = p.K / 32;
     p.zero_page = zero_page_;
+    p.probe = probe_buf_;
     const GemmTileInfo& ti = gemm_tile_info_p(cfg);
     const long long tiles = (long long)((p.M + ti.bm - 1) / ti.bm) * ((p.N + ti.bn - 1) / ti.bn);
     int splits = splitk > 0 ? splitk : (int)std::max<long long>(1, std::min<long long>(32, 256 / std::max<long long>(1, tiles)));
@@ -2486,6 +2487,33 @@ void Engine::op_timestep_embedding(int t, int dim, float* out) {
     SDMI_HIP(hipStreamSynchronize(stream_));
 }
 
+// option gemm_probe: what the diagnostic instantiation of a plane GEMM stored (24 words per workgroup: kernels.hpp ConvGemm::probe), summarised on stderr
+void Engine::probe_report(void* pb_dev, size_t kMaxBlocks, int n, int cin, int h, int w, int cout, int k, int tile_cfg, int splitk) {
+    std::vector<unsigned long long> hb(kMaxBlocks * 24);
+    SDMI_HIP(hipMemcpyAsync(hb.data(), pb_dev, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
+    SDMI_HIP(hipStreamSynchronize(stream_));
+    std::vector<double> pro, loop, epi, tot, wait_frac, mhz;
+    unsigned long long first = ~0ull, last = 0, last_start = 0;
+    for (size_t b = 0; b < kMaxBlocks; ++b) {
+        const unsigned long long* d = &hb[24 * b];
+        if (!d[0] || !d[3]) continue;
+        pro.push_back((d[1] - d[0]) * 0.01); loop.push_back((d[2] - d[1]) * 0.01); epi.push_back((d[3] - d[2]) * 0.01); tot.push_back((d[3] - d[0]) * 0.01);
+        first = std::min(first, d[0]); last = std::max(last, d[3]); last_start = std::max(last_start, d[0]);
+        for (int wv = 0; wv < 8; ++wv)
+            if (d[4 + 2 * wv]) {
+                wait_frac.push_back((double)d[5 + 2 * wv] / (double)d[4 + 2 * wv]);
+                if (d[2] > d[1]) mhz.push_back((double)d[4 + 2 * wv] / ((d[2] - d[1]) * 0.01));
+            }
+    }
+    auto q = [](std::vector<double>& v, double f) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[std::min(v.size() - 1, (size_t)(f * v.size()))]; };
+    std::fprintf(stderr, "gemm_probe n=%d cin=%d %dx%d cout=%d k=%d tile=%d splitk=%d cold=%d: %zu workgroups; us min/median/max: first tile %.2f/%.2f/%.2f, "
+                         "k loop %.2f/%.2f/%.2f, epilogue %.2f/%.2f/%.2f, workgroup %.2f/%.2f/%.2f; first entry -> last entry %.2f, first entry -> last exit %.2f; "
+                         "per wave: share of the k loop waiting at the per-tile barrier %.3f/%.3f/%.3f, shader clock in the k loop %.0f/%.0f/%.0f MHz\n",
+                 n, cin, h, w, cout, k, tile_cfg, splitk, opt_bench_cold_, tot.size(), q(pro, 0), q(pro, 0.5), q(pro, 1), q(loop, 0), q(loop, 0.5), q(loop, 1),
+                 q(epi, 0), q(epi, 0.5), q(epi, 1), q(tot, 0), q(tot, 0.5), q(tot, 1), (last_start - first) * 0.01, (last - first) * 0.01,
+                 q(wait_frac, 0), q(wait_frac, 0.5), q(wait_frac, 1), q(mhz, 0), q(mhz, 0.5), q(mhz, 1));
+}
+
 double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int stride, int ups, int tile_cfg, int splitk,
                           int iters) {
     SDMI_HIP(hipSetDevice(cfg_.device));
@@ -2546,6 +2574,15 @@ double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int str
             SDMI_HIP(hipEventRecord(ev1_, stream_));
             SDMI_HIP(hipEventSynchronize(ev1_));
             SDMI_HIP(hipEventElapsedTime(&ms2, ev0_, ev1_));
+            if (opt_gemm_probe_) {   // one more launch of the diagnostic instantiation (tiles 400 / 403 / 404)
+                constexpr size_t kMaxBlocks = 1 << 13;
+                Buf pb(this, kMaxBlocks * 24 * sizeof(unsigned long long));
+                SDMI_HIP(hipMemsetAsync(pb.p, 0, kMaxBlocks * 24 * sizeof(unsigned long long), stream_));
+                probe_buf_ = static_cast<unsigned long long*>(pb.p);
+                try { f16s_launch(o, bias.f(), a, y, k, stride, ups, tile_cfg, splitk); } catch (...) { probe_buf_ = nullptr; throw; }
+                probe_buf_ = nullptr;
+                probe_report(pb.p, kMaxBlocks, n, cin, h, w, cout, k, tile_cfg, splitk);
+            }
         } catch (...) { release(a); release(y); throw; }
         release(a); release(y);
         return (double)ms2 / std::max(1, iters);
@@ -2602,29 +2639,7 @@ double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int str
             probe_buf_ = static_cast<unsigned long long*>(pb.p);
             try { conv(cw, a, y, stride, ups, nullptr, 0, nullptr); } catch (...) { probe_buf_ = nullptr; throw; }
             probe_buf_ = nullptr;
-            std::vector<unsigned long long> hb(kMaxBlocks * 24);
-            SDMI_HIP(hipMemcpyAsync(hb.data(), pb.p, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
-            SDMI_HIP(hipStreamSynchronize(stream_));
-            std::vector<double> pro, loop, epi, tot, wait_frac, mhz;
-            unsigned long long first = ~0ull, last = 0, last_start = 0;
-            for (size_t b = 0; b < kMaxBlocks; ++b) {
-                const unsigned long long* d = &hb[24 * b];
-                if (!d[0] || !d[3]) continue;
-                pro.push_back((d[1] - d[0]) * 0.01); loop.push_back((d[2] - d[1]) * 0.01); epi.push_back((d[3] - d[2]) * 0.01); tot.push_back((d[3] - d[0]) * 0.01);
-                first = std::min(first, d[0]); last = std::max(last, d[3]); last_start = std::max(last_start, d[0]);
-                for (int wv = 0; wv < 8; ++wv)
-                    if (d[4 + 2 * wv]) {
-                        wait_frac.push_back((double)d[5 + 2 * wv] / (double)d[4 + 2 * wv]);
-                        if (d[2] > d[1]) mhz.push_back((double)d[4 + 2 * wv] / ((d[2] - d[1]) * 0.01));
-                    }
-            }
-            auto q = [](std::vector<double>& v, double f) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[std::min(v.size() - 1, (size_t)(f * v.size()))]; };
-            std::fprintf(stderr, "gemm_probe n=%d cin=%d %dx%d cout=%d k=%d tile=%d splitk=%d cold=%d: %zu workgroups; us min/median/max: first tile %.2f/%.2f/%.2f, "
-                                 "k loop %.2f/%.2f/%.2f, epilogue %.2f/%.2f/%.2f, workgroup %.2f/%.2f/%.2f; first entry -> last entry %.2f, first entry -> last exit %.2f; "
-                                 "per wave: share of the k loop waiting at the per-tile barrier %.3f/%.3f/%.3f, shader clock in the k loop %.0f/%.0f/%.0f MHz\n",
-                         n, cin, h, w, cout, k, tile_cfg, splitk, opt_bench_cold_, tot.size(), q(pro, 0), q(pro, 0.5), q(pro, 1), q(loop, 0), q(loop, 0.5), q(loop, 1),
-                         q(epi, 0), q(epi, 0.5), q(epi, 1), q(tot, 0), q(tot, 0.5), q(tot, 1), (last_start - first) * 0.01, (last - first) * 0.01,
-                         q(wait_frac, 0), q(wait_frac, 0.5), q(wait_frac, 1), q(mhz, 0), q(mhz, 0.5), q(mhz, 1));
+            probe_report(pb.p, kMaxBlocks, n, cin, h, w, cout, k, tile_cfg, splitk);
         }
     } catch (...) {
         opt_force_tile_ = save_t; opt_force_splits_ = save_s; opt_gemm_planes_ = save_p;

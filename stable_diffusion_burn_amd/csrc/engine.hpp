@@ -260,6 +260,7 @@ private:
     // STAGED (never run on a GPU): a convolution / Linear layer on the two-term fp16 form (k_gemm3p.hip NPL = 2, k_split2h.hip).
     // fp32 NHWC in and out; the packed fp32 weight bt [N][K] and the activation are scaled and split here (f16s_prepare), f16s_launch runs the
     // GEMM (+ split-K reduce).  Reached only through option gemm_f16s of op_conv2d / op_linear and bench_conv with tile_cfg >= 400.
+    void probe_report(void* pb_dev, size_t max_blocks, int n, int cin, int h, int w, int cout, int k, int tile_cfg, int splitk);
     struct F16sOperands { std::unique_ptr<Buf> w2, inv_sw, scales, amax, a2; };
     void f16s_prepare(F16sOperands& o, const float* bt, int n_rows, long long K, const Act& x);
     void f16s_launch(const F16sOperands& o, const float* bias, const Act& x, Act& y, int k, int stride, int ups, int tile_cfg, int splitk);

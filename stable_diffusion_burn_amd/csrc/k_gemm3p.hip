@@ -421,13 +421,21 @@ hipError_t launch_conv_gemm3p(const ConvGemm& p, int cfg, hipStream_t stream) {
 // operator-level entry points and sdmi_bench_conv with tile_cfg >= 400.
 hipError_t launch_conv_gemm2h(const ConvGemm& p, int cfg, hipStream_t stream) {
     if (cfg < 0 || cfg >= kNumGemmTilesP) return hipErrorInvalidValue;
-    if ((p.Cin % 32) || p.CS != 32 || !p.zero_page || !p.Bt3 || !p.A3 || !p.a_scale || !p.b_scale || p.a3_ld <= 0 || (p.a3_ld % 128) || p.out_mode != 0 || p.geglu || p.probe || p.C3)
+    if ((p.Cin % 32) || p.CS != 32 || !p.zero_page || !p.Bt3 || !p.A3 || !p.a_scale || !p.b_scale || p.a3_ld <= 0 || (p.a3_ld % 128) || p.out_mode != 0 || p.geglu || p.C3)
         return hipErrorInvalidValue;
     if ((unsigned long long)p.N * (unsigned long long)p.kt_total * 128ull >= 0xFFFFFF00ull) return hipErrorInvalidValue;   // 32-bit piece offsets
     if ((unsigned long long)p.NB * p.Hs * p.Ws * (unsigned long long)p.a3_ld >= 0xFFFFFF00ull) return hipErrorInvalidValue;
     const int bm = kTilesP[cfg].bm, bn = kTilesP[cfg].bn;
     const int MT = (p.M + bm - 1) / bm, NT = (p.N + bn - 1) / bn;
     const dim3 grid = gemm_grid(p, MT * NT);
+    if (p.probe) {   // diagnostic instantiations (option gemm_probe)
+        switch (cfg) {
+            case 0: return launch_cfg_3p<4, 5, 4, 2, 2, true, 2>(p, grid, stream);
+            case 3: return launch_cfg_3p<2, 5, 4, 2, 3, true, 2>(p, grid, stream);
+            case 4: return launch_cfg_3p<2, 4, 4, 2, 3, true, 2>(p, grid, stream);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (cfg) {
         case 0: return launch_cfg_3p<4, 5, 4, 2, 2, false, 2>(p, grid, stream);   // 256 x 160: two stages of 56 KB (three would be 168 KB)
         case 1: return launch_cfg_3p<4, 4, 4, 2, 3, false, 2>(p, grid, stream);   // 256 x 128, three stages of 48 KB

@@ -21,3 +21,15 @@ for cold in (0, 1):
 sd.close()
 PY
 echo "bench rc=$?"; cat $out/bench_300_vs_400.txt | grep -v amdgpu.ids | cut -c1-200
+# 3. where the new kernel spends its time (gemm_probe: tiles 300 / 400 on the dominant batch-1 shape)
+timeout 120 python - 2> $out/gemm_phase_probe_300_vs_400.txt <<'PY'
+import sys
+sys.path.insert(0, ".")
+from stable_diffusion_burn_amd import ModelConfig, StableDiffusion
+sd = StableDiffusion(ModelConfig(32, 1, 32, 8, 8, 32))
+sd.set_option("gemm_probe", 1)
+for tile in (300, 400, 303, 403):
+    sd.bench_conv(2, 320, 64, 64, 320, k=3, tile_cfg=tile, splitk=4 if tile % 100 == 0 else 2, iters=5)
+sd.close()
+PY
+grep gemm_probe $out/gemm_phase_probe_300_vs_400.txt | cut -c1-600
