@@ -50,40 +50,3 @@ def gemm_split(a, w):
     for ia, iw in ((0, 2), (2, 0), (1, 1), (0, 1), (1, 0), (0, 0)):   # (a plane, w plane): h = 0, m = 1, l = 2
         out += ap[ia] @ wp[iw].T
     return out
-
-
-# ---- the STAGED two-term fp16 form (csrc/k_split2h.hip, k_gemm3p.hip NPL = 2) -------------------------------------
-def pow2_scale_bits(max_abs):
-    """restates s2h_scale_of (k_split2h.hip) on the bit pattern of a non-negative finite fp32 maximum: (scale, 1 / scale), scale = 2^(14 - e)
-    with e = ceil(log2(max)); 1 for a zero tensor; a subnormal maximum counts as 2^-126; the exponent is clamped to +-126."""
-    bits = int(np.float32(max_abs).view(np.uint32))
-    e = ((bits >> 23) & 0xFF) - 127
-    if bits & 0x7FFFFF:
-        e += 1
-    if (bits >> 23) == 0:
-        e = -126 if bits else 14
-    se = max(-126, min(126, 14 - e))
-    return np.float32(2.0) ** np.float32(se), np.float32(2.0) ** np.float32(-se)
-
-
-def split2_fp16(x, scale):
-    """s x = h + l (+ what two fp16 terms cannot hold): h = fp16(s x), l = fp16(s x - h), both round-to-nearest-even, returned as fp32."""
-    xs = (np.ascontiguousarray(x, dtype=np.float32) * np.float32(scale)).astype(np.float32)
-    h = xs.astype(np.float16).astype(np.float32)
-    r = (xs - h).astype(np.float32)
-    l = r.astype(np.float16).astype(np.float32)
-    return h, l, xs, r
-
-
-def gemm_two_term(a, w):
-    """a [M, K] @ w [N, K]^T the way the staged kernel forms it: one power-of-two scale for a, one per row of w, the three partial products
-    wl ah, wh al, wh ah summed here in float64, the scales divided out exactly.  Small shapes only."""
-    a = np.ascontiguousarray(a, dtype=np.float32)
-    w = np.ascontiguousarray(w, dtype=np.float32)
-    sa, ia = pow2_scale_bits(np.abs(a).max())
-    sw = np.array([pow2_scale_bits(np.abs(r).max()) for r in w], np.float32)
-    ah, al, _, _ = split2_fp16(a, sa)
-    wh, wl, _, _ = split2_fp16(w, sw[:, :1])
-    ah, al, wh, wl = (v.astype(np.float64) for v in (ah, al, wh, wl))
-    out = ah @ wl.T + al @ wh.T + ah @ wh.T
-    return out * float(ia) * sw[:, 1].astype(np.float64)[None, :]

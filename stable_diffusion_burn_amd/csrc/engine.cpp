@@ -1043,7 +1043,6 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "gemm_f32s") opt_gemm_f32s_ = std::stoi(value);
     else if (key == "bench_cold") opt_bench_cold_ = std::stoi(value);
     else if (key == "gemm_probe") opt_gemm_probe_ = std::stoi(value);
-    else if (key == "gemm_f16s") opt_gemm_f16s_ = std::stoi(value);
     else if (key == "gemm_planes") opt_gemm_planes_ = (value == "default") ? kGemmPlanesDefault : std::stoi(value);
     else if (key == "gemm3x_variant") opt_gemm3x_variant_ = std::stoi(value);
     else if (key == "geglu_fuse") opt_geglu_fuse_ = std::stoi(value);
@@ -1364,65 +1363,6 @@ void Engine::conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, con
     p.out_mode = x.dt ? (y.dt ? 0 : 1) : (y.dt ? 2 : 0);
     if (resid && !x.dt && y.dt) throw Error(SDMI_ERR_STATE, "conv: residual not supported on the fp32->bf16 layers");
     launch_gemm(p, x.dt);
-}
-
-// ---- STAGED: the two-term fp16 form ---------------------------------------------------------------------------------
-void Engine::f16s_prepare(F16sOperands& o, const float* bt, int n_rows, long long K, const Act& x) {
-    if (bf16_ || x.dt || !x.p || (x.c % 32) || (K % 32) || n_rows <= 0) throw Error(SDMI_ERR_UNSUPPORTED, "gemm_f16s: fp32 activations with channels % 32 == 0 expected");
-    o.w2.reset(new Buf(this, (size_t)n_rows * (size_t)K * 4));            // two fp16 planes: 4 bytes per weight
-    o.inv_sw.reset(new Buf(this, (size_t)n_rows * sizeof(float)));
-    o.scales.reset(new Buf(this, 2 * sizeof(float)));
-    o.amax.reset(new Buf(this, sizeof(unsigned)));
-    o.a2.reset(new Buf(this, (size_t)x.rows() * (size_t)(x.c / 32) * 128));
-    SDMI_HIP(launch_pack_split2h(bt, o.w2->p, o.inv_sw->f(), n_rows, (int)K, stream_));
-    SDMI_HIP(launch_absmax_bits(x.p, x.rows(), x.c, x.stride(), static_cast<unsigned*>(o.amax->p), stream_));
-    SDMI_HIP(launch_scale2h(static_cast<const unsigned*>(o.amax->p), o.scales->f(), stream_));
-    SDMI_HIP(launch_split2h_rows(x.p, o.a2->p, x.rows(), x.c, x.stride(), (long long)(x.c / 32) * 128, o.scales->f(), stream_));
-    count_kernel(); count_kernel(); count_kernel(); count_kernel();
-}
-
-void Engine::f16s_launch(const F16sOperands& o, const float* bias, const Act& x, Act& y, int k, int stride, int ups, int tile_cfg, int splitk) {
-    const int cfg = tile_cfg >= 400 ? tile_cfg - 400 : 0;
-    if (cfg >= kNumGemmTilesP) throw Error(SDMI_ERR_INVALID, "gemm_f16s: tile index out of range");
-    const int pad = k == 3 ? 1 : 0;
-    const int hin = x.h << ups, win = x.w << ups;
-    const int ho = (hin + 2 * pad - k) / stride + 1, wo = (win + 2 * pad - k) / stride + 1;
-    if (y.n != x.n || y.h != ho || y.w != wo || y.dt || !y.p) throw Error(SDMI_ERR_INVALID, "gemm_f16s: output shape mismatch");
-    ConvGemm p{};
-    p.A3 = o.a2->p; p.a3_ld = (x.c / 32) * 128; p.Bt3 = o.w2->p;
-    p.a_scale = o.scales->f() + 1; p.b_scale = o.inv_sw->f();
-    p.C = y.p; p.bias = bias;
-    p.M = x.n * ho * wo; p.N = y.c; p.K = x.c * k * k;
-    p.NB = x.n; p.Hs = x.h; p.Ws = x.w; p.Cin = x.c; p.Ho = ho; p.Wo = wo;
-    p.KH = k; p.KW = k; p.stride = stride; p.pad = pad; p.ups = ups;
-    p.ldc = y.stride(); p.ldr = y.stride(); p.a_ld = x.stride(); p.b_ld = p.K; p.CS = 32;
-    p.kt_total = p.K / 32;
-    p.zero_page = zero_page_;
-    p.probe = probe_buf_;
-    const GemmTileInfo& ti = gemm_tile_info_p(cfg);
-    const long long tiles = (long long)((p.M + ti.bm - 1) / ti.bm) * ((p.N + ti.bn - 1) / ti.bn);
-    int splits = splitk > 0 ? splitk : (int)std::max<long long>(1, std::min<long long>(32, 256 / std::max<long long>(1, tiles)));
-    splits = std::max(1, std::min(splits, p.kt_total));
-    p.kt_per_split = (p.kt_total + splits - 1) / splits;
-    splits = (p.kt_total + p.kt_per_split - 1) / p.kt_per_split;
-    p.splits = splits;
-    const double flops = 2.0 * p.M * (double)p.N * p.K;
-    std::unique_ptr<Buf> slab;
-    if (splits > 1) {
-        p.slab_stride = (long long)p.M * p.N;
-        slab.reset(new Buf(this, (size_t)splits * p.slab_stride * sizeof(float)));
-        p.slabs = slab->f();
-    }
-    {
-        ProfScope ps(this, PC_CONV_SPLIT, flops);
-        SDMI_HIP(launch_conv_gemm2h(p, cfg, stream_));
-    }
-    count_kernel(flops);
-    if (splits > 1) {
-        ProfScope ps(this, PC_SPLITK_REDUCE, 0, (double)(splits + 1) * p.slab_stride * 4.0);
-        SDMI_HIP(launch_splitk_reduce(p, stream_));
-        count_kernel();
-    }
 }
 
 void Engine::gemm(const float* A, int a_rows, const float* bt, const float* bias, int cin, int cout, float* C, int ldc,
@@ -2390,11 +2330,6 @@ void Engine::op_conv2d(const float* x, const float* wt, const float* bias, int n
     const int hin = h << ups, win = wd << ups;
     const int ho = (hin + 2 * pad - k) / stride + 1, wo = (win + 2 * pad - k) / stride + 1;
     Act y = new_act(n, ho, wo, cout, (bf16_ && cout > 4) ? 1 : 0);
-    if (opt_gemm_f16s_ && !w.dt && cin % 32 == 0) {     // STAGED: the two-term fp16 form (never the default)
-        F16sOperands o;
-        f16s_prepare(o, bt.f(), cout, (long long)cin * k * k, a);
-        f16s_launch(o, bias, a, y, k, stride, ups, opt_force_tile_ >= 400 ? opt_force_tile_ : 400, opt_force_splits_);
-    } else
     conv(w, a, y, stride, ups, nullptr, 0, nullptr);
     if (y.dt) SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(y.p, out, n, cout, ho, wo, stream_));
     else SDMI_HIP(launch_nhwc_to_nchw(y.p, out, n, cout, ho, wo, stream_));
@@ -2426,14 +2361,6 @@ void Engine::op_linear(const float* x, const float* wt, const float* bias, int r
         return;
     }
     SDMI_HIP(launch_pack_linear_weight(wt, bt.f(), cin, cout, stream_));
-    if (opt_gemm_f16s_ && !bf16_ && cin % 32 == 0) {    // STAGED: the two-term fp16 form (never the default)
-        Act xa{}; xa.p = const_cast<float*>(x); xa.n = 1; xa.h = 1; xa.w = rows; xa.c = cin; xa.dt = 0; xa.view = true;
-        Act ya{}; ya.p = out; ya.n = 1; ya.h = 1; ya.w = rows; ya.c = cout; ya.dt = 0; ya.view = true;
-        F16sOperands o;
-        f16s_prepare(o, bt.f(), cout, cin, xa);
-        f16s_launch(o, bias, xa, ya, 1, 1, 0, opt_force_tile_ >= 400 ? opt_force_tile_ : 400, opt_force_splits_);
-        return;
-    }
     TempSplit planes(this, bt.f(), cout, cin);
     gemm(x, rows, bt.f(), bias, cin, cout, out, cout, nullptr, 0, 0);
 }
@@ -2563,30 +2490,6 @@ double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int str
         SDMI_HIP(hipStreamSynchronize(stream_));
     }
     SDMI_HIP(launch_fill_normal(bias.f(), cout, 13, stream_));
-    if (!wdt && tile_cfg >= 400) {   // STAGED: the two-term fp16 form, timed like the plane tiles -- on operands split beforehand
-        F16sOperands o;
-        float ms2 = 0;
-        try {
-            f16s_prepare(o, bt.f(), cout, (long long)cin * k * k, a);
-            f16s_launch(o, bias.f(), a, y, k, stride, ups, tile_cfg, splitk);  // warm-up
-            SDMI_HIP(hipEventRecord(ev0_, stream_));
-            for (int i = 0; i < iters; ++i) f16s_launch(o, bias.f(), a, y, k, stride, ups, tile_cfg, splitk);
-            SDMI_HIP(hipEventRecord(ev1_, stream_));
-            SDMI_HIP(hipEventSynchronize(ev1_));
-            SDMI_HIP(hipEventElapsedTime(&ms2, ev0_, ev1_));
-            if (opt_gemm_probe_) {   // one more launch of the diagnostic instantiation (tiles 400 / 403 / 404)
-                constexpr size_t kMaxBlocks = 1 << 13;
-                Buf pb(this, kMaxBlocks * 24 * sizeof(unsigned long long));
-                SDMI_HIP(hipMemsetAsync(pb.p, 0, kMaxBlocks * 24 * sizeof(unsigned long long), stream_));
-                probe_buf_ = static_cast<unsigned long long*>(pb.p);
-                try { f16s_launch(o, bias.f(), a, y, k, stride, ups, tile_cfg, splitk); } catch (...) { probe_buf_ = nullptr; throw; }
-                probe_buf_ = nullptr;
-                probe_report(pb.p, kMaxBlocks, n, cin, h, w, cout, k, tile_cfg, splitk);
-            }
-        } catch (...) { release(a); release(y); throw; }
-        release(a); release(y);
-        return (double)ms2 / std::max(1, iters);
-    }
     TempSplit planes(this, bt.f(), wdt ? 0 : cout, (long long)cin * k * k);
     if (!wdt && tile_cfg >= 300 && cin % 32 == 0) {   // plane tiles are timed on planes their producer would have written
         a.p3 = pool_.alloc(a.bytes3()); a.ld3 = (cin / 32) * 192;

@@ -257,13 +257,7 @@ private:
     Act new_act3(int n, int h, int w, int c, int what);
     void release(Act& a);
     // pad_br: zero padding on the bottom / right only (PaddingCfg::new(0, 1, 0, 1), the VAE encoder's downsampler)
-    // STAGED (never run on a GPU): a convolution / Linear layer on the two-term fp16 form (k_gemm3p.hip NPL = 2, k_split2h.hip).
-    // fp32 NHWC in and out; the packed fp32 weight bt [N][K] and the activation are scaled and split here (f16s_prepare), f16s_launch runs the
-    // GEMM (+ split-K reduce).  Reached only through option gemm_f16s of op_conv2d / op_linear and bench_conv with tile_cfg >= 400.
     void probe_report(void* pb_dev, size_t max_blocks, int n, int cin, int h, int w, int cout, int k, int tile_cfg, int splitk);
-    struct F16sOperands { std::unique_ptr<Buf> w2, inv_sw, scales, amax, a2; };
-    void f16s_prepare(F16sOperands& o, const float* bt, int n_rows, long long K, const Act& x);
-    void f16s_launch(const F16sOperands& o, const float* bias, const Act& x, Act& y, int k, int stride, int ups, int tile_cfg, int splitk);
     void conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, const float* rowvec, int rowvec_stride,
               const Act* resid, bool pad_br = false);
     static Act slice(const Act& parent, int c_off, int c);   // channel-slice view
@@ -430,7 +424,6 @@ private:
     static constexpr int kGemmPlanesDefault = 1;
     int opt_gemm_planes_ = kGemmPlanesDefault;   // precision = 0: k_gemm3p.hip (activations as bf16 planes too, no split in the k loop): 0 never, 1 every launch that would take a k_gemm3x.hip tile,
                                 // 2 only where the per-shape table says 300 + x
-    int opt_gemm_f16s_ = 0;     // STAGED: 1 = op_conv2d / op_linear run on the two-term fp16 form (f16s_prepare / f16s_launch); never the model
     int opt_gemm_probe_ = 0;    // bench_conv: 1 = one extra launch with per-workgroup phase stamps (ConvGemm::probe), summary on stderr
     unsigned long long* probe_buf_ = nullptr;
     int opt_bench_cold_ = 0;    // bench_conv: 1 = evict the weights from the Infinity Cache between timed launches (what a layer sees inside the model)

@@ -29,7 +29,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void global_cvoid;
 
@@ -41,25 +40,18 @@ const GemmTileInfo& gemm_tile_info_p(int cfg) { return kTilesP[cfg]; }
 // Per-wave state of the k loop; every array is indexed with compile-time constants (member templates) and lives in registers.  The
 // issue order of a k tile is spelled out and fenced with sched_barrier(0) as in k_gemm3x.hip: with LDS-DMA in flight every wait hipcc
 // inserts is lgkmcnt(0), so a plane read is issued NI matrix instructions or more ahead of its first use and never right in front of it.
-// NPL = 3: the operands are three bf16 planes (h, m, l), six partial products per block (this file's header).  NPL = 2: two fp16 planes (h, l of a
-// power-of-two scaled operand, k_split2h.hpp) and the three partial products wl ah, wh al, wh ah -- the staged "two-term" form (launch_conv_gemm2h,
-// tile_cfg 400 + x): the same pieces, swizzle, stages and epilogue with 128 instead of 192 bytes per 32-channel slice.
-template <int NPL, int MI, int NI, int NAG, int NBW, int A_BYTES, int NWV>
+template <int MI, int NI, int NAG, int NBW, int A_BYTES, int NWV>
 struct P3Wave {
-    static_assert(NPL == 3 || NPL == 2, "three bf16 planes or two fp16 planes");
-    static constexpr int SB = 64 * NPL;         // bytes of a 32-channel slice of one row: NPL plane rows of 64 B
-    static constexpr int NPROD = NPL == 3 ? 6 : 3;   // partial products per fragment pair
-    static constexpr int NA = NPL * NAG;        // activation pieces per wave per k tile (NAG fragment groups x NPL planes)
+    static constexpr int NA = 3 * NAG;          // activation pieces per wave per k tile (NAG fragment groups x 3 planes)
     static constexpr int NP = NA + NBW;         // DMA instructions per wave per k tile
-    static constexpr int NMF = NPROD * NI;      // matrix instructions of one fragment row
+    static constexpr int NMF = 6 * NI;          // matrix instructions of one fragment row
     static constexpr int NAF = MI > 2 ? 3 : MI; // activation fragment buffers (row r uses buffer r % NAF)
     static_assert(MI == 2 || MI == 4, "fragment rows per wave");
     static_assert(NI >= 2, "plane reads of a fragment take three instruction slots (behind())");
-    static_assert(NPL == 3 || MI <= 2 || NI >= 4, "two-plane form: fragments 1 and 2 are read behind four instructions of product 1");
 
     f32x4 acc[MI][NI];
-    u32x4 wf[NPL][NI];          // weight planes (h, m, l / h, l) of the wave's NI column fragments
-    u32x4 af[NAF][NPL];         // activation planes of a fragment row
+    u32x4 wf[3][NI];            // weight planes h, m, l of the wave's NI column fragments
+    u32x4 af[NAF][3];           // activation planes h, m, l of a fragment row
     int a_iy0[NAG], a_ix0[NAG];
     unsigned a_off[NAG];        // byte offset of the sample + this lane's chunk (operands are < 4 GiB: launch side checks)
     unsigned w_off[NBW];
@@ -76,18 +68,18 @@ struct P3Wave {
     template <int J>
     __device__ __forceinline__ void piece() {
         if constexpr (J < NA) {
-            constexpr int jg = J / NPL, pl = J - NPL * jg;
+            constexpr int jg = J / 3, pl = J - 3 * jg;
             if constexpr (pl == 0) {
                 const int iy = a_iy0[jg] + ky;
                 const int ix = a_ix0[jg] + kx;
                 const bool ok = ((unsigned)iy < (unsigned)Hin) & ((unsigned)ix < (unsigned)Win);
-                const unsigned off = a_off[jg] + (unsigned)((iy >> ups) * Ws + (ix >> ups)) * pix_bytes + (unsigned)cs * (unsigned)SB;
+                const unsigned off = a_off[jg] + (unsigned)((iy >> ups) * Ws + (ix >> ups)) * pix_bytes + (unsigned)cs * 192u;
                 a_src = (ok ? Abase : zero) + (ok ? off : 0u);
             }
-            __builtin_amdgcn_global_load_lds((global_cvoid*)(a_src + pl * 64), (lds_void*)(next_stage + ((wave + NWV * jg) * NPL + pl) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_cvoid*)(a_src + pl * 64), (lds_void*)(next_stage + ((wave + NWV * jg) * 3 + pl) * 1024), 16, 0, 0);
         } else {
             constexpr int j = J - NA;
-            const char* src = Wbase + (w_off[j] + (unsigned)kt_next * (unsigned)SB);
+            const char* src = Wbase + (w_off[j] + (unsigned)kt_next * 192u);
             __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(next_stage + A_BYTES + (wave + NWV * j) * 1024), 16, 0, 0);
         }
         if constexpr (J == NP - 1) {
@@ -109,9 +101,9 @@ struct P3Wave {
     }
 
     template <int F, int PL>
-    __device__ __forceinline__ void read_a() { af[F % NAF][PL] = *reinterpret_cast<const u32x4*>(a_tile + (F * NPL + PL) * 1024); }
+    __device__ __forceinline__ void read_a() { af[F % NAF][PL] = *reinterpret_cast<const u32x4*>(a_tile + (F * 3 + PL) * 1024); }
     template <int PL, int N>
-    __device__ __forceinline__ void read_w() { wf[PL][N] = *reinterpret_cast<const u32x4*>(w_tile + (N * NPL + PL) * 1024); }
+    __device__ __forceinline__ void read_w() { wf[PL][N] = *reinterpret_cast<const u32x4*>(w_tile + (N * 3 + PL) * 1024); }
 
     // What is issued behind matrix instruction K of fragment row MIDX.
     //   row 0 reads the tile's operands just in time: before it the h plane of fragment 0 and the l weight planes (product 0 = wl ah);
@@ -119,29 +111,10 @@ struct P3Wave {
     //   weight planes + fragment 0's m (product 2 = wm am), behind the first instructions of product 2 fragment 1, then fragment 2;
     //   row r >= 1 reads fragment r + 2 into the buffer row r - 1 has just released;
     //   the next k tile's DMA instructions are spread over the slots of row 0's products 3..5 and of row 1.
-    //   Two planes (NPL = 2): before row 0 the h plane of fragment 0 and the l weight planes (product 0 = wl ah); behind the instructions of
-    //   product 0 the h weight planes + fragment 0's l (product 1 = wh al); behind the first two (four) of product 1 fragment 1 (and 2); row
-    //   r >= 1 reads fragment r + 2 behind its first two instructions; the DMA is spread over row 0's product 2 (= wh ah) and row 1.
-    static constexpr int DMA_SLOTS = (NPL == 3 ? 3 * NI : NI) + NMF;
+    static constexpr int DMA_SLOTS = 3 * NI + NMF;
     template <int MIDX, int K>
     __device__ __forceinline__ void behind() {
         constexpr int pr = K / NI, ni = K % NI;
-        if constexpr (NPL == 2) {
-            if constexpr (MIDX == 0) {
-                if constexpr (pr == 0) { read_w<0, ni>(); if constexpr (ni == NI - 1) read_a<0, 1>(); }
-                if constexpr (K >= NI && K < NI + 2) read_a<1, K - NI>();
-                if constexpr (MI > 2 && K >= NI + 2 && K < NI + 4) read_a<2, K - NI - 2>();
-            } else if constexpr (MIDX + 2 < MI) {
-                if constexpr (K < 2) read_a<MIDX + 2, K>();
-            }
-            if constexpr (MIDX == 0 && pr == 2) {
-                constexpr int slot = K - 2 * NI;
-                pieces<slot * NP / DMA_SLOTS, (slot + 1) * NP / DMA_SLOTS>();
-            } else if constexpr (MIDX == 1) {
-                constexpr int slot = NI + K;
-                pieces<slot * NP / DMA_SLOTS, (slot + 1) * NP / DMA_SLOTS>();
-            }
-        } else {
         if constexpr (MIDX == 0) {
             if constexpr (pr == 0) { read_w<0, ni>(); if constexpr (ni == NI - 1) read_a<0, 2>(); }
             if constexpr (pr == 1) { read_w<1, ni>(); if constexpr (ni == NI - 1) read_a<0, 1>(); }
@@ -158,23 +131,15 @@ struct P3Wave {
             constexpr int slot = 3 * NI + K;
             pieces<slot * NP / DMA_SLOTS, (slot + 1) * NP / DMA_SLOTS>();
         }
-        }
     }
     template <int MIDX, int K>
     __device__ __forceinline__ void mfmas() {
         if constexpr (K < NMF) {
-            constexpr int pr = K / NI, ni = K % NI;
-            if constexpr (NPL == 3) {
             constexpr int WP[6] = {2, 0, 1, 1, 0, 0};      // weight plane of product K / NI
             constexpr int AP[6] = {0, 2, 1, 0, 1, 0};      // activation plane
+            constexpr int pr = K / NI, ni = K % NI;
             acc[MIDX][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[WP[pr]][ni]), __builtin_bit_cast(bf16x8, af[MIDX % NAF][AP[pr]]),
                                                                     acc[MIDX][ni], 0, 0, 0);
-            } else {
-                constexpr int WP[3] = {1, 0, 0};           // wl ah, wh al, wh ah
-                constexpr int AP[3] = {0, 1, 0};
-                acc[MIDX][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[WP[pr]][ni]), __builtin_bit_cast(f16x8, af[MIDX % NAF][AP[pr]]),
-                                                                       acc[MIDX][ni], 0, 0, 0);
-            }
             behind<MIDX, K>();
             __builtin_amdgcn_sched_barrier(0);
             mfmas<MIDX, K + 1>();
@@ -186,7 +151,7 @@ struct P3Wave {
     }
     template <int N>
     __device__ __forceinline__ void head_w() {
-        if constexpr (N < NI) { read_w<NPL - 1, N>(); head_w<N + 1>(); }
+        if constexpr (N < NI) { read_w<2, N>(); head_w<N + 1>(); }
     }
     __device__ __forceinline__ void tile() {
         read_a<0, 0>();
@@ -203,7 +168,7 @@ struct P3Wave {
 // PROBE (diagnostic instantiations behind option gemm_probe, tools/probes/gemm_phase_probe.py): every workgroup stores s_memrealtime stamps
 // (100 MHz) of kernel entry / first k tile landed / k loop done / epilogue stores acknowledged, and every wave the shader-clock cycles it spent
 // in the k loop and, of those, waiting at the per-tile barrier: probe[24 * block + {0..3, 4 + 2 wave, 5 + 2 wave}].
-template <int MI, int NI, int WM, int WN, int NSTG, bool PROBE = false, int NPL = 3>
+template <int MI, int NI, int WM, int WN, int NSTG, bool PROBE = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3p_kernel(const ConvGemm p) {
     static_assert(NSTG == 2 || NSTG == 3, "LDS stages");
     constexpr int BM = 16 * MI * WM;
@@ -211,11 +176,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3p_kernel(const Conv
     constexpr int NWV = WM * WN;
     static_assert(NWV == 8 || NWV == 4, "8 or 4 waves per workgroup");
     static_assert(BM % (16 * NWV) == 0, "every wave owns whole 16-row fragment groups of the activation tile");
-    constexpr int NAG = BM / (16 * NWV);      // activation fragment groups (16 rows x NPL planes) per wave per k tile
-    constexpr int PW = (BN / 16) * NPL;       // weight pieces per k tile
+    constexpr int NAG = BM / (16 * NWV);      // activation fragment groups (16 rows x 3 planes) per wave per k tile
+    constexpr int PW = (BN / 16) * 3;         // weight pieces per k tile
     constexpr int NBW = (PW + NWV - 1) / NWV; // ... per wave
-    constexpr int A_BYTES = (BM / 16) * NPL * 1024;
-    constexpr unsigned SB = 64u * NPL;        // bytes of a 32-channel slice of one row
+    constexpr int A_BYTES = (BM / 16) * 3 * 1024;
     constexpr int STAGE = A_BYTES + NBW * NWV * 1024;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_p3[];
@@ -243,7 +207,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3p_kernel(const Conv
     const int T = p.KH * p.KW;
     const int HoWo = p.Ho * p.Wo;
 
-    P3Wave<NPL, MI, NI, NAG, NBW, A_BYTES, NWV> w;
+    P3Wave<MI, NI, NAG, NBW, A_BYTES, NWV> w;
     w.Hin = p.Hs << p.ups;
     w.Win = p.Ws << p.ups;
     w.ups = p.ups;
@@ -273,11 +237,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3p_kernel(const Conv
         w.a_iy0[j] = ok ? oy * p.stride - p.pad : -(1 << 28);   // rows past M: never in range -> zero page
         w.a_ix0[j] = ox * p.stride - p.pad;
     }
-    const unsigned w_row_bytes = (unsigned)p.kt_total * SB;
+    const unsigned w_row_bytes = (unsigned)p.kt_total * 192u;
 #pragma unroll
     for (int j = 0; j < NBW; ++j) {
         const int q = wave + NWV * j;
-        const int f = q / NPL, pl = q - NPL * f;
+        const int f = q / 3, pl = q - 3 * f;
         int n = n0 + f * 16 + r16;
         long long wrow = n;
         if (geglu) {
@@ -300,8 +264,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3p_kernel(const Conv
     // fragment reads: row c of a piece, slot g ^ f(c)
     const int c15 = lane & 15, g4 = lane >> 4;
     const int fr = c15 * 64 + ((g4 ^ ((-(c15 >> 2)) & 3)) << 4);
-    const int a_fr = wm * MI * NPL * 1024 + fr;
-    const int w_fr = A_BYTES + wn * NI * NPL * 1024 + fr;
+    const int a_fr = wm * MI * 3 * 1024 + fr;
+    const int w_fr = A_BYTES + wn * NI * 3 * 1024 + fr;
 
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -311,7 +275,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3p_kernel(const Conv
     unsigned long long pt0 = 0, pt1 = 0, pc0 = 0, pwait = 0;
     if constexpr (PROBE) pt0 = __builtin_amdgcn_s_memrealtime();
     w.next_stage = smem_p3;
-    w.template pieces<0, NAG * NPL + NBW>();      // k tile 0
+    w.template pieces<0, NAG * 3 + NBW>();      // k tile 0
     if constexpr (PROBE) {                      // the wait for k tile 0, taken out of the loop's first barrier
         __syncthreads();
         pt1 = __builtin_amdgcn_s_memrealtime();
@@ -333,12 +297,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3p_kernel(const Conv
         // three stages: the DMA of k tile t + 2 is issued during tile t.  Every wave issues exactly NP DMA instructions per tile and
         // they complete in order, so "tile t has landed" is vmcnt(NP) -- __syncthreads() would drain the tile behind it as well
         w.next_stage = smem_p3 + STAGE;
-        w.template pieces<0, NAG * NPL + NBW>();  // k tile 1 (or tile 0 again when there is none: dead stage)
+        w.template pieces<0, NAG * 3 + NBW>();  // k tile 1 (or tile 0 again when there is none: dead stage)
         int cur = 0;
         for (int t = 0; t < n_t; ++t) {
             unsigned long long pa = 0;
             if constexpr (PROBE) pa = __builtin_amdgcn_s_memtime();
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAG * NPL + NBW) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAG * 3 + NBW) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if constexpr (PROBE) pwait += __builtin_amdgcn_s_memtime() - pa;
@@ -355,7 +319,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3p_kernel(const Conv
     unsigned long long pt2 = 0, pc2 = 0;
     if constexpr (PROBE) { pt2 = __builtin_amdgcn_s_memrealtime(); pc2 = __builtin_amdgcn_s_memtime(); }
 
-    gemm_epilogue_f32<MI, NI, WM, WN, NPL == 2>(p, w.acc, smem_p3, m0, n0, z, lid, wave, lane, HoWo);
+    gemm_epilogue_f32<MI, NI, WM, WN>(p, w.acc, smem_p3, m0, n0, z, lid, wave, lane, HoWo);
     if constexpr (PROBE) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have been acknowledged
         __syncthreads();
@@ -365,11 +329,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3p_kernel(const Conv
     }
 }
 
-template <int MI, int NI, int WM, int WN, int NSTG, bool PROBE = false, int NPL = 3>
+template <int MI, int NI, int WM, int WN, int NSTG, bool PROBE = false>
 static hipError_t launch_cfg_3p(const ConvGemm& p, dim3 grid, hipStream_t stream) {
-    auto k = conv_gemm3p_kernel<MI, NI, WM, WN, NSTG, PROBE, NPL>;
+    auto k = conv_gemm3p_kernel<MI, NI, WM, WN, NSTG, PROBE>;
     constexpr int NWV = WM * WN;
-    constexpr size_t stage = (size_t)(MI * WM) * NPL * 1024 + (size_t)((NI * WN * NPL + NWV - 1) / NWV) * NWV * 1024;
+    constexpr size_t stage = (size_t)(MI * WM) * 3 * 1024 + (size_t)((NI * WN * 3 + NWV - 1) / NWV) * NWV * 1024;
     // (the epilogue transposes through one 16 x (16 NI + 4) fp32 scratch per wave in the same memory)
     constexpr size_t lds = NSTG * stage > (size_t)NWV * 16 * (16 * NI + 4) * 4 ? NSTG * stage : (size_t)NWV * 16 * (16 * NI + 4) * 4;
     static_assert(lds <= 160 * 1024, "the stages must fit the CU's LDS");
@@ -409,43 +373,6 @@ hipError_t launch_conv_gemm3p(const ConvGemm& p, int cfg, hipStream_t stream) {
         case 6: return launch_cfg_3p<2, 4, 2, 2, 2>(p, grid, stream);   // 64 x 128: 32 x 64, 2 x 36 KB
         case 7: return launch_cfg_3p<4, 5, 1, 4, 2>(p, grid, stream);   // 64 x 320: 64 x 80 (a whole N = 320 row per workgroup), 2 x 72 KB
         case 8: return launch_cfg_3p<2, 4, 4, 1, 2>(p, grid, stream);   // 128 x 64: 32 x 64, 2 x 36 KB
-    }
-    return hipErrorInvalidValue;
-}
-
-// ---- STAGED: the two-term fp16 form (tile_cfg 400 + x; k_split2h.hip) -------------------------------------------
-// The same tiles on two fp16 planes and three partial products (NPL = 2).  Operands: p.A3 / p.Bt3 = the planes written by
-// launch_split2h_rows / launch_pack_split2h (128 bytes per 32-channel slice), p.a_scale -> the reciprocal of the activation tensor's scale
-// (one float), p.b_scale -> the reciprocals of the weight rows' scales (N floats).  With 128-byte slices the 256 x 128 / 128 x 256 tiles run THREE stages (48 KB each).
-// Has never run on a GPU (written at the end of round 3, after its GPU minutes): reachable only through option gemm_f16s of the
-// operator-level entry points and sdmi_bench_conv with tile_cfg >= 400.
-hipError_t launch_conv_gemm2h(const ConvGemm& p, int cfg, hipStream_t stream) {
-    if (cfg < 0 || cfg >= kNumGemmTilesP) return hipErrorInvalidValue;
-    if ((p.Cin % 32) || p.CS != 32 || !p.zero_page || !p.Bt3 || !p.A3 || !p.a_scale || !p.b_scale || p.a3_ld <= 0 || (p.a3_ld % 128) || p.out_mode != 0 || p.geglu || p.C3)
-        return hipErrorInvalidValue;
-    if ((unsigned long long)p.N * (unsigned long long)p.kt_total * 128ull >= 0xFFFFFF00ull) return hipErrorInvalidValue;   // 32-bit piece offsets
-    if ((unsigned long long)p.NB * p.Hs * p.Ws * (unsigned long long)p.a3_ld >= 0xFFFFFF00ull) return hipErrorInvalidValue;
-    const int bm = kTilesP[cfg].bm, bn = kTilesP[cfg].bn;
-    const int MT = (p.M + bm - 1) / bm, NT = (p.N + bn - 1) / bn;
-    const dim3 grid = gemm_grid(p, MT * NT);
-    if (p.probe) {   // diagnostic instantiations (option gemm_probe)
-        switch (cfg) {
-            case 0: return launch_cfg_3p<4, 5, 4, 2, 2, true, 2>(p, grid, stream);
-            case 3: return launch_cfg_3p<2, 5, 4, 2, 3, true, 2>(p, grid, stream);
-            case 4: return launch_cfg_3p<2, 4, 4, 2, 3, true, 2>(p, grid, stream);
-        }
-        return hipErrorInvalidValue;
-    }
-    switch (cfg) {
-        case 0: return launch_cfg_3p<4, 5, 4, 2, 2, false, 2>(p, grid, stream);   // 256 x 160: two stages of 56 KB (three would be 168 KB)
-        case 1: return launch_cfg_3p<4, 4, 4, 2, 3, false, 2>(p, grid, stream);   // 256 x 128, three stages of 48 KB
-        case 2: return launch_cfg_3p<4, 4, 2, 4, 3, false, 2>(p, grid, stream);   // 128 x 256
-        case 3: return launch_cfg_3p<2, 5, 4, 2, 3, false, 2>(p, grid, stream);   // 128 x 160, three stages of 36 KB
-        case 4: return launch_cfg_3p<2, 4, 4, 2, 3, false, 2>(p, grid, stream);   // 128 x 128
-        case 5: return launch_cfg_3p<2, 2, 2, 2, 3, false, 2>(p, grid, stream);   // 64 x 64
-        case 6: return launch_cfg_3p<2, 4, 2, 2, 2, false, 2>(p, grid, stream);   // 64 x 128
-        case 7: return launch_cfg_3p<4, 5, 1, 4, 2, false, 2>(p, grid, stream);   // 64 x 320
-        case 8: return launch_cfg_3p<2, 4, 4, 1, 2, false, 2>(p, grid, stream);   // 128 x 64
     }
     return hipErrorInvalidValue;
 }

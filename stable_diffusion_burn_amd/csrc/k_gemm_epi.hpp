@@ -14,10 +14,7 @@ namespace sdmi {
 
 typedef float epi_f32x4 __attribute__((ext_vector_type(4)));
 
-// SCALED (the staged two-term fp16 form, k_gemm3p.hip NPL = 2): the operands were multiplied by powers of two before they were split -- the
-// activation tensor by one scale, weight row n by its own -- so the accumulators are multiplied by ((const float*)p.a_scale)[0] *
-// ((const float*)p.b_scale)[n] (the reciprocals: exact) before anything else happens to them, split-K slabs included.
-template <int MI, int NI, int WM, int WN, bool SCALED = false>
+template <int MI, int NI, int WM, int WN>
 __device__ __forceinline__ void gemm_epilogue_f32(const ConvGemm& p, epi_f32x4 (&acc)[MI][NI], unsigned char* smem_x32, const int m0,
                                                   const int n0, const int z, const int lid, const int wave, const int lane,
                                                   const int HoWo) {
@@ -90,9 +87,6 @@ __device__ __forceinline__ void gemm_epilogue_f32(const ConvGemm& p, epi_f32x4 (
                 for (int ni = 0; ni < NI; ++ni) {
                     const int n = nw0 + ni * 16 + g4 * 4;
                     f32x4 v = acc[mi][ni];
-                    if constexpr (SCALED) {
-                        if (n < p.N) v *= *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.b_scale) + n) * reinterpret_cast<const float*>(p.a_scale)[0];
-                    }
                     if (!split && n < p.N) {
                         if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
                         if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)smp * p.rowvec_stride + n);
@@ -135,7 +129,6 @@ __device__ __forceinline__ void gemm_epilogue_f32(const ConvGemm& p, epi_f32x4 (
             for (int r = 0; r < 4; ++r) {
                 if (n + r < p.N) {
                     float sv = v[r];
-                    if constexpr (SCALED) sv *= reinterpret_cast<const float*>(p.b_scale)[n + r] * reinterpret_cast<const float*>(p.a_scale)[0];
                     if (!split) {
                         if (p.bias) sv += p.bias[n + r];
                         if (p.rowvec) sv += p.rowvec[(long long)smp * p.rowvec_stride + n + r];

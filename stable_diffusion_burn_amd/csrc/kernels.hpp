@@ -85,12 +85,6 @@ hipError_t launch_pack_split3(const float* bt, void* w3, long long rows, int K, 
 constexpr int kNumGemmTilesP = 9;
 const GemmTileInfo& gemm_tile_info_p(int cfg);
 hipError_t launch_conv_gemm3p(const ConvGemm& p, int tile_cfg, hipStream_t stream);
-// STAGED (never run on a GPU): the same tiles on two fp16 planes + three products (k_gemm3p.hip NPL = 2), and its operand side (k_split2h.hip)
-hipError_t launch_conv_gemm2h(const ConvGemm& p, int cfg, hipStream_t stream);
-hipError_t launch_absmax_bits(const float* x, long long rows, int c, long long ld, unsigned* amax_bits, hipStream_t s);
-hipError_t launch_scale2h(const unsigned* amax_bits, float* scales, hipStream_t s);                 // scales[0] = s, scales[1] = 1 / s
-hipError_t launch_split2h_rows(const float* x, void* y2, long long rows, int c, long long ld, long long ld2_bytes, const float* scales, hipStream_t s);
-hipError_t launch_pack_split2h(const float* bt, void* w2, float* inv_scale, long long rows, int K, hipStream_t s);
 // fp32 rows [rows][ld] (c channels, c % 32 == 0) -> planes [rows][ld3_bytes / 192 slices][3][32] bf16 (slices [0, c / 32) written)
 hipError_t launch_split3_rows(const float* x, void* y3, long long rows, int c, long long ld, long long ld3_bytes, hipStream_t s);
 hipError_t launch_join3_rows(const void* x3, float* y, long long rows, int c, long long ld3_bytes, long long ld, hipStream_t s);   // planes -> fp32 (exact)

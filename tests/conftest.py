@@ -17,17 +17,6 @@ if str(ROOT) not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: takes more than ~30 s")
-    config.addinivalue_line("markers", "staged: tests of code that has never run on a GPU (written after a round's GPU minutes were spent; DESIGN.md section 10): "
-                                       "skipped unless SDMI_STAGED=1, so that the default GPU suite only runs what has been seen to pass")
-
-
-def pytest_collection_modifyitems(config, items):
-    if os.environ.get("SDMI_STAGED") == "1":
-        return
-    skip = pytest.mark.skip(reason="staged code that has never run on a GPU; set SDMI_STAGED=1 (tools/probes/r04a_session.sh)")
-    for item in items:
-        if "staged" in item.keywords:
-            item.add_marker(skip)
 
 
 def gpu_available() -> bool:

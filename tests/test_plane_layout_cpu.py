@@ -1,7 +1,6 @@
 """The data path of the plane GEMM (k_gemm3p.hip) on the host: HBM planes -> per-wave DMA pieces with the slot swizzle -> LDS bytes -> per-lane
 fragment reads -> the 16x16x32 matrix instruction's operand / accumulator layout -> epilogue, for one launch of a small 3x3 convolution and of a
-Linear layer, in both operand forms: NPL = 3 (three bf16 planes, six products: the form that runs on the GPU -- that the emulation reproduces
-A W^T for it is the check of the emulation) and NPL = 2 (two fp16 planes, three products, scales divided out: the STAGED form, never run).
+Linear layer (three bf16 planes, six products).
 Every index formula is transcribed from the kernel (piece<J>(), the prologue's a_off / w_off / fr / a_fr / w_fr, read_a / read_w, the
 epilogue's lane -> (pixel, channel) map); what the test adds to reading them is that they are exercised together, with padding taps, a ragged
 last M tile, a ragged last N tile and more weight pieces than waves."""
@@ -18,14 +17,10 @@ def plane_pos(j):                                   # k_split3.hpp s3_plane_pos
 POS = np.array([plane_pos(j) for j in range(32)])
 
 
-def to_planes(x, npl, scale):
-    """x [rows, C] fp32 -> [rows, C / 32, npl, 32] float64 plane values in the kernels' order (k_split3.hpp / k_split2h.hip)"""
+def to_planes(x, npl):
+    """x [rows, C] fp32 -> [rows, C / 32, npl, 32] float64 plane values in the kernels' order (k_split3.hpp)"""
     rows, c = x.shape
-    if npl == 3:
-        terms = S.split3(x)
-    else:
-        h, l, _, _ = S.split2_fp16(x, scale)
-        terms = (h, l)
+    terms = S.split3(x)
     out = np.zeros((rows, c // 32, npl, 32))
     for pl, t in enumerate(terms):
         t = t.reshape(rows, c // 32, 32).astype(np.float64)
@@ -33,7 +28,7 @@ def to_planes(x, npl, scale):
     return out
 
 
-PRODUCTS = {3: ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)), 2: ((1, 0), (0, 1), (0, 0))}     # (weight plane, activation plane), k_gemm3p.hip mfmas()
+PRODUCTS = {3: ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0))}     # (weight plane, activation plane), k_gemm3p.hip mfmas()
 
 
 def emulate(npl, MI, NI, WM, WN, A3, W3, nb, hs, ws, cin, N, k, stride):
@@ -126,7 +121,7 @@ def packed_weight(w_oihw):
     return w_oihw.reshape(cout, cin // 32, 32, k * k).transpose(0, 1, 3, 2).reshape(cout, -1)
 
 
-@pytest.mark.parametrize("npl", [3, 2])
+@pytest.mark.parametrize("npl", [3])
 @pytest.mark.parametrize("tile", [(2, 2, 2, 2), (2, 4, 4, 2)])          # 64 x 64 with four waves, 128 x 128 with eight
 @pytest.mark.parametrize("k,stride,shape", [(3, 1, (1, 9, 8, 64, 80)), (1, 1, (1, 1, 150, 96, 144)), (3, 2, (2, 7, 6, 32, 40))])
 def test_one_launch_reproduces_a_w_transposed(npl, tile, k, stride, shape):
@@ -136,18 +131,13 @@ def test_one_launch_reproduces_a_w_transposed(npl, tile, k, stride, shape):
     x = g.standard_normal((nb, hs, ws, cin)).astype(np.float32)
     w = (g.standard_normal((N, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
     bt = packed_weight(w)
-    if npl == 3:
-        sa, inv_a, sw = np.float32(1), 1.0, np.ones((N, 2), np.float32)
-    else:
-        sa, inv_a = S.pow2_scale_bits(np.abs(x).max())
-        sw = np.array([S.pow2_scale_bits(np.abs(r).max()) for r in bt], np.float32)
-    A3 = to_planes(x.reshape(-1, cin), npl, sa)
-    W3 = to_planes(bt, npl, sw[:, :1])
-    got = emulate(npl, MI, NI, WM, WN, A3, W3, nb, hs, ws, cin, N, k, stride) * float(inv_a) * sw[:, 1].astype(np.float64)[None, :]
+    A3 = to_planes(x.reshape(-1, cin), npl)
+    W3 = to_planes(bt, npl)
+    got = emulate(npl, MI, NI, WM, WN, A3, W3, nb, hs, ws, cin, N, k, stride)
     # what the kept partial products of the represented operands add up to, independent of the kernel's indexing
     a_terms = [A3[:, :, pl][:, :, POS].reshape(nb, hs, ws, cin) for pl in range(npl)]
     w_terms = [W3[:, :, pl][:, :, POS].reshape(N, cin // 32, k * k, 32).transpose(0, 1, 3, 2).reshape(N, cin, k, k) for pl in range(npl)]
-    want = sum(reference(a_terms[ap], w_terms[wp], k, stride) for wp, ap in PRODUCTS[npl]) * float(inv_a) * sw[:, 1].astype(np.float64)[None, :]
+    want = sum(reference(a_terms[ap], w_terms[wp], k, stride) for wp, ap in PRODUCTS[npl])
     assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
     exact = reference(x.astype(np.float64), w.astype(np.float64), k, stride)
-    assert np.abs(got - exact).max() <= (1e-7 if npl == 3 else 4e-7) * np.abs(exact).max()
+    assert np.abs(got - exact).max() <= 1e-7 * np.abs(exact).max()

@@ -2,16 +2,14 @@
 
 The kernel's operand registers are re-used inside a k tile (NAF activation fragment buffers for MI fragment rows; fragment r + 2 is read into
 the buffer row r - 1 has released) and its plane reads are issued a fixed number of matrix instructions ahead of their first use.  This test
-transcribes the compile-time schedule (which read is issued behind which matrix instruction) and checks, for every tile shape and for both
-operand forms -- NPL = 3: three bf16 planes, six products; NPL = 2: two fp16 planes, three products (the staged form) --
-that every matrix instruction of fragment row r, column n, product p finds (a) the weight plane WP[p] of column n and (b) the activation plane
+transcribes the compile-time schedule (which read is issued behind which matrix instruction) and checks, for every tile shape (three bf16
+planes, six products), that every matrix instruction of fragment row r, column n, product p finds (a) the weight plane WP[p] of column n and (b) the activation plane
 AP[p] of fragment row r in its registers, read EARLIER in the stream; that every product of every (row, column) is issued exactly once; and that
-the next tile's DMA instructions are all issued, in order, exactly once.  (The NPL = 3 schedule is the one that runs on the GPU; that the replay
-accepts it is the check of the replay.)"""
+the next tile's DMA instructions are all issued, in order, exactly once."""
 import pytest
 
 SHAPES = [(4, 5), (4, 4), (2, 5), (2, 4), (2, 2)]      # (MI, NI) of the instantiated wave tiles
-PRODUCTS = {3: ([2, 0, 1, 1, 0, 0], [0, 2, 1, 0, 1, 0]), 2: ([1, 0, 0], [0, 1, 0])}   # weight plane, activation plane of product p (k_gemm3p.hip mfmas())
+PRODUCTS = {3: ([2, 0, 1, 1, 0, 0], [0, 2, 1, 0, 1, 0])}   # weight plane, activation plane of product p (k_gemm3p.hip mfmas())
 
 
 def replay(npl, mi, ni, nag, nbw):
@@ -20,7 +18,7 @@ def replay(npl, mi, ni, nag, nbw):
     naf = 3 if mi > 2 else mi
     nmf = nprod * ni
     np_ = npl * nag + nbw
-    dma_slots = (3 * ni if npl == 3 else ni) + nmf
+    dma_slots = 3 * ni + nmf
     wf = {}                      # (plane, n) -> True once read
     af = {}                      # buffer index -> {plane: fragment row it holds}
     dma = []
@@ -37,26 +35,7 @@ def replay(npl, mi, ni, nag, nbw):
 
     def behind(midx, k):
         pr, n = divmod(k, ni)
-        if npl == 2:
-            if midx == 0:
-                if pr == 0:
-                    read_w(0, n)
-                    if n == ni - 1:
-                        read_a(0, 1)
-                if ni <= k < ni + 2:
-                    read_a(1, k - ni)
-                if mi > 2 and ni + 2 <= k < ni + 4:
-                    read_a(2, k - ni - 2)
-            elif midx + 2 < mi:
-                if k < 2:
-                    read_a(midx + 2, k)
-            if midx == 0 and pr == 2:
-                slot = k - 2 * ni
-                pieces(slot * np_ // dma_slots, (slot + 1) * np_ // dma_slots)
-            elif midx == 1:
-                slot = ni + k
-                pieces(slot * np_ // dma_slots, (slot + 1) * np_ // dma_slots)
-        else:
+        if True:
             if midx == 0:
                 if pr == 0:
                     read_w(0, n)
@@ -97,7 +76,7 @@ def replay(npl, mi, ni, nag, nbw):
     assert dma == list(range(np_)), f"DMA instructions issued {dma}, expected 0..{np_ - 1}"
 
 
-@pytest.mark.parametrize("npl", [3, 2])
+@pytest.mark.parametrize("npl", [3])
 @pytest.mark.parametrize("mi,ni", SHAPES)
 def test_every_matrix_instruction_finds_its_operands(npl, mi, ni):
     for nwv, wm, wn in ((8, 4, 2), (8, 2, 4), (4, 2, 2), (4, 1, 4), (4, 4, 1)):
@@ -110,12 +89,12 @@ def test_every_matrix_instruction_finds_its_operands(npl, mi, ni):
 
 
 def test_a_wrong_schedule_is_caught():
-    """the replay is not vacuous: shifting the two-plane form's fragment-1 reads one product later must trip it"""
+    """the replay is not vacuous: products that want the m plane of a fragment before it is read must trip it"""
     global PRODUCTS
     saved = dict(PRODUCTS)
     try:
-        PRODUCTS = {**saved, 2: ([1, 0, 0], [1, 0, 0])}      # products that want the l plane of the fragment before it is read
+        PRODUCTS = {3: ([2, 0, 1, 1, 0, 0], [1, 2, 1, 0, 1, 0])}      # product 0 would multiply by the fragment's m plane, read behind product 1
         with pytest.raises(AssertionError):
-            replay(2, 4, 5, 2, 3)
+            replay(3, 4, 5, 2, 3)
     finally:
         PRODUCTS = saved

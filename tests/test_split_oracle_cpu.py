@@ -75,42 +75,3 @@ def test_small_integers_need_the_low_planes_and_come_out_exact():
     assert np.array_equal(S.gemm_split(a, w), exact)
     h = S.split3(a)[0]
     assert not np.array_equal(h, a)                   # bf16 alone (the h plane) cannot hold 9-bit integers
-
-
-# ---- the staged two-term fp16 form (csrc/k_split2h.hip): what it claims, as theorems ---------------------------------
-def test_pow2_scale_moves_the_maximum_into_fp16s_upper_range():
-    for m in (1.0, 0.75, 3.0, 1e-3, 1e-30, 65504.0, 1e20, 3e38, 2.0 ** -140, 0.0, 2.0 ** 14, 2.0 ** 14 * (1 + 2.0 ** -23)):
-        s, inv = S.pow2_scale_bits(m)
-        assert float(s) * float(inv) == 1.0 and np.log2(float(s)) == np.round(np.log2(float(s)))      # an exact power of two and its reciprocal
-        if m >= 2.0 ** -112:                                                                           # (below that the exponent clamp binds: still finite)
-            assert 2.0 ** 13 < np.float64(m) * np.float64(s) <= 2.0 ** 14 or m == 0.0
-        assert np.isfinite(np.float32(m) * s)
-    assert S.pow2_scale_bits(0.0) == (np.float32(1.0), np.float32(1.0))
-
-
-def test_two_fp16_terms_hold_22_bits_and_the_residual_subtraction_is_exact():
-    g = np.random.default_rng(31)
-    x = np.concatenate([g.standard_normal(200000), g.standard_normal(200000) * np.exp2(g.integers(-30, 1, 200000)), [1.0, -1.0, 0.0, 1 + 2.0 ** -11, 1 + 2.0 ** -12]]).astype(np.float32)
-    x /= np.abs(x).max()                                                     # maximum 1: scale 2^14
-    s, _ = S.pow2_scale_bits(1.0)
-    h, l, xs, r = S.split2_fp16(x, s)
-    assert np.array_equal(r.astype(np.float64), xs.astype(np.float64) - h.astype(np.float64))          # s x - h is exact in fp32
-    err = np.abs(xs.astype(np.float64) - h.astype(np.float64) - l.astype(np.float64))
-    big = np.abs(xs) >= 2.0 ** -3                                            # l normal: 22 significant bits
-    assert (err[big] <= np.abs(xs[big]) * 2.0 ** -22).all()
-    assert (err <= np.maximum(np.abs(xs) * 2.0 ** -22, 2.0 ** -25)).all()    # below: l subnormal, absolute error <= half its spacing
-    assert np.isfinite(h).all() and np.isfinite(l).all()
-
-
-def test_two_term_gemm_split_error_is_below_an_fp32_gemms_summation_error():
-    g = np.random.default_rng(5)
-    for K in (320, 2880):
-        a = np.maximum(g.standard_t(3, (64, K)), -0.2).astype(np.float32)   # SiLU-like, heavy tail: the worst case of tools/study_fp16_split.py
-        w = (g.standard_normal((48, K)) / np.sqrt(K)).astype(np.float32)
-        exact = a.astype(np.float64) @ w.astype(np.float64).T
-        two = np.abs(S.gemm_two_term(a, w) - exact).max() / np.abs(exact).max()
-        six = np.abs(S.gemm_split(a, w) - exact).max() / np.abs(exact).max()
-        f32 = np.abs((a @ w.T).astype(np.float64) - exact).max() / np.abs(exact).max()
-        assert six < two < 3e-7, (K, six, two)                               # measured 0.7-1.8e-7 (profiles/r03_study_fp16_two_term_split.txt)
-        assert two < 2e-5 / 50                                               # two orders of magnitude inside the operator bar of tests/test_ops_gpu.py
-        assert f32 > 0.0

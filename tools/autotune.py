@@ -68,8 +68,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per GPU: scales the n of every shape (the lists are for 1 image)")
     ap.add_argument("--append", action="store_true", help="append to --emit instead of overwriting")
     ap.add_argument("--families", default="old,x,s", help="fp32 candidates: old = k_gemm2.hip tiles 0..9, x = k_gemm2x.hip 100..103, "
-                    "s = k_gemm3x.hip 200..205 (fp32 on the bf16 matrix pipe), p = k_gemm3p.hip 300..308 (the same with the activations as planes too), "
-                    "h = the STAGED two-term fp16 tiles 400..408 (timing only: bench_conv splits the operands beforehand)")
+                    "s = k_gemm3x.hip 200..205 (fp32 on the bf16 matrix pipe), p = k_gemm3p.hip 300..304 (the same with the activations as planes too)")
     ap.add_argument("--merge", default="", help="existing 'M,N,K=cfg,splits' table: its entry is timed as one more candidate for "
                     "its shape, and --emit writes the whole table with the winners replaced")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
@@ -103,8 +102,6 @@ def main():
         tiles_all.update({200: "256x160", 201: "128x320", 202: "256x128", 203: "128x256", 204: "128x160", 205: "128x128"})   # k_gemm3x.hip
     if not bf16 and "p" in fams:
         tiles_all.update({300: "256x160", 301: "256x128", 302: "128x256", 303: "128x160", 304: "128x128", 305: "64x64", 306: "64x128", 307: "64x320", 308: "128x64"})   # k_gemm3p.hip
-    if "h" in fams:
-        tiles_all.update({400 + i: t for i, t in enumerate(("256x160", "256x128", "128x256", "128x160", "128x128", "64x64", "64x128", "64x320", "128x64"))})   # staged: k_gemm3p.hip NPL = 2
     merged = {}
     if args.merge:
         for ln in Path(args.merge).read_text().splitlines():
@@ -144,7 +141,7 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     print(f"  {s} cfg={cfg} sp={sp}: {e}")
                     continue
-                cands.append({"cfg": cfg, "tile": tiles_all[cfg] + ("h" if cfg >= 400 else "p" if cfg >= 300 else "s" if cfg >= 200 else "x" if cfg >= 100 else ""), "splits": sp, "ms": ms, "tflops": flops / ms / 1e9})
+                cands.append({"cfg": cfg, "tile": tiles_all[cfg] + ("p" if cfg >= 300 else "s" if cfg >= 200 else "x" if cfg >= 100 else ""), "splits": sp, "ms": ms, "tflops": flops / ms / 1e9})
         prev = merged.get(f"{M},{N},{K}")
         if prev:
             try:

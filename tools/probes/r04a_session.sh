@@ -1,5 +1,5 @@
 #!/bin/bash
-# FIRST GPU call of round 4 (written at the end of round 3, whose GPU minutes were spent): the staged two-term fp16 form of the fp32 GEMM
+# RECORD ONLY (the code it drives was removed after this ran: profiles/README.md "Round 4").  First GPU call of round 4 (written at the end of round 3, whose GPU minutes were spent): the staged two-term fp16 form of the fp32 GEMM
 # (csrc/k_split2h.hip, k_gemm3p.hip NPL = 2, tile_cfg 400 + x).  1. its parity tests; 2. per shape, the plane tile the
 # tuned table picks (300 + x, six bf16 products) against the same tile on two fp16 planes (400 + x, three products), operands hot and cold.
 out=gpurun_out/r04a; mkdir -p $out
