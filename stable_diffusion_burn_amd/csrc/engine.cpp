@@ -1045,7 +1045,6 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "gemm_probe") opt_gemm_probe_ = std::stoi(value);
     else if (key == "gemm_planes") opt_gemm_planes_ = (value == "default") ? kGemmPlanesDefault : std::stoi(value);
     else if (key == "gemm3x_variant") opt_gemm3x_variant_ = std::stoi(value);
-    else if (key == "gemm_ablate") opt_gemm_ablate_ = std::stoi(value);
     else if (key == "geglu_fuse") opt_geglu_fuse_ = std::stoi(value);
     else if (key == "record_shapes") { record_shapes_ = std::stoi(value) != 0; if (record_shapes_) { shape_counts_.clear(); choice_counts_.clear(); } }
     else if (key == "dump_shapes") {
@@ -1067,7 +1066,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
         const bool b16 = key == "tune_bf16";
         TileChoice tc{0, 1};
         if (std::sscanf(value.c_str() + eq + 1, "%d,%d", &tc.cfg, &tc.splits) != 2 || tc.cfg < 0 || tc.splits < 1 ||
-            !(tc.cfg < kNumGemmTiles || (tc.cfg >= 100 && tc.cfg < 100 + (b16 ? kNumGemmTilesXB : kNumGemmTilesX)) || (!b16 && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS) ||
+            !(tc.cfg < kNumGemmTiles || (tc.cfg >= 100 && tc.cfg < 100 + kNumGemmTilesX) || (!b16 && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS) ||
               (!b16 && tc.cfg >= 300 && tc.cfg < 300 + kNumGemmTilesP)))
             throw Error(SDMI_ERR_INVALID, "tune: bad value");
         (b16 ? tuned_bf16_ : (tc.cfg >= 300 ? tuned_p_ : tuned_))[value.substr(0, eq)] = tc;   // plane tiles (300 + x) have their own table: what a GEMM whose input arrives as planes chooses from
@@ -1207,7 +1206,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         ++shape_counts_[sk];
     }
     auto tile_info = [&](int cfg) -> const GemmTileInfo& {
-        if (in_dt) return cfg >= 100 ? gemm_tile_info_xb(cfg - 100) : gemm_tile_info(cfg);
+        if (in_dt) return cfg >= 100 ? gemm_tile_info_x(cfg - 100) : gemm_tile_info(cfg);
         return cfg >= 300 ? gemm_tile_info_p(cfg - 300) : cfg >= 200 ? gemm_tile_info_s(cfg - 200) : cfg >= 100 ? gemm_tile_info_x(cfg - 100) : gemm_tile_info(cfg);
     };
     TileChoice tc;
@@ -1217,7 +1216,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     auto it = table.find(key);
     const bool x32_ok = !in_dt && p.CS == 32 && p.Cin % 32 == 0 && p.out_mode == 0;   // what k_gemm2x.hip handles
     p.Bt3 = in_dt ? nullptr : split_planes(p.Bt);
-    p.variant = in_dt ? opt_gemm_ablate_ : opt_gemm3x_variant_;
+    p.variant = in_dt ? 0 : opt_gemm3x_variant_;
     // k_gemm3x.hip: the same layers, when the weight has its bf16 planes (weights in the arenas; not e.g. the K / V operands of
     // the unfused VAE attention) and the 32-bit piece offsets reach
     const bool s_ok = x32_ok && p.Bt3 && (unsigned long long)p.N * (p.geglu ? 2 : 1) * (unsigned long long)p.kt_total * 192ull < 0xFFFFFF00ull;
@@ -1268,7 +1267,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     const unsigned long long b_ext = ((unsigned long long)p.N * (p.geglu ? 2 : 1) - 1) * (unsigned long long)p.b_ld * es + (unsigned long long)p.K * es;
     p.zero_page = zero_page_;
     if (tc.cfg >= 300 ? (in_dt || tc.cfg - 300 >= kNumGemmTilesP || !p_ok)
-        : tc.cfg >= 200 ? (in_dt || tc.cfg - 200 >= kNumGemmTilesS || !s_ok) : (tc.cfg >= 100 && (tc.cfg - 100 >= (in_dt ? kNumGemmTilesXB : kNumGemmTilesX) || (!in_dt && !x32_ok))))
+        : tc.cfg >= 200 ? (in_dt || tc.cfg - 200 >= kNumGemmTilesS || !s_ok) : (tc.cfg >= 100 && (tc.cfg - 100 >= kNumGemmTilesX || (!in_dt && !x32_ok))))
         throw Error(SDMI_ERR_INVALID, "gemm: large-tile kernel index out of range or not applicable to this layer");
     if (a_ext >= 0xFFFFFFE0ull || b_ext >= 0xFFFFFFE0ull) throw Error(SDMI_ERR_UNSUPPORTED, "GEMM: operand larger than 4 GiB (the buffer-load range check needs 32-bit extents)");
     p.a_bytes = (unsigned)a_ext;
@@ -1301,7 +1300,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     p.probe = probe_buf_;
     auto launch = [&](const ConvGemm& q) {
         if (tc.cfg >= 300) return launch_conv_gemm3p(q, tc.cfg - 300, stream_);
-        if (in_dt && tc.cfg >= 100) return launch_conv_gemm_bf16_large(q, tc.cfg - 100, stream_);
+        if (in_dt && tc.cfg >= 100) return launch_conv_gemm_bf16x(q, tc.cfg - 100, stream_);
         if (tc.cfg >= 200) return launch_conv_gemm3x(q, tc.cfg - 200, stream_);
         if (tc.cfg >= 100) return launch_conv_gemm2x(q, tc.cfg - 100, stream_);
         if (in_dt) return launch_conv_gemm_bf16(q, tc.cfg, stream_);
@@ -2529,33 +2528,6 @@ double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int str
         SDMI_HIP(hipEventRecord(ev1_, stream_));
         SDMI_HIP(hipEventSynchronize(ev1_));
         SDMI_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
-        }
-        if (opt_gemm_probe_ && wdt && (tile_cfg == 100 + kNumGemmTilesX || tile_cfg == 102 + kNumGemmTilesX)) {
-            // diagnostic: one more launch of the ping-pong bf16 GEMM in which every wave sums the cycles of its k-loop segments (k_gemm_bf16p.hip)
-            constexpr size_t kWords = 1024 * 64;
-            Buf pb(this, kWords * sizeof(unsigned long long));
-            SDMI_HIP(hipMemsetAsync(pb.p, 0, kWords * sizeof(unsigned long long), stream_));
-            probe_buf_ = static_cast<unsigned long long*>(pb.p);
-            try { conv(cw, a, y, stride, ups, nullptr, 0, nullptr); } catch (...) { probe_buf_ = nullptr; throw; }
-            probe_buf_ = nullptr;
-            std::vector<unsigned long long> hb(kWords);
-            SDMI_HIP(hipMemcpyAsync(hb.data(), pb.p, kWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
-            SDMI_HIP(hipStreamSynchronize(stream_));
-            double sum[2][8] = {}; long cnt[2] = {0, 0};
-            for (size_t b = 0; b < 1024; ++b)
-                for (int wv = 0; wv < 8; ++wv) {
-                    const unsigned long long* d = &hb[(b * 8 + wv) * 8];
-                    if (!d[7]) continue;
-                    for (int i = 0; i < 8; ++i) sum[wv >> 2][i] += (double)d[i];
-                    ++cnt[wv >> 2];
-                }
-            const double slabs = 2.0 * ((cin * k * k + 63) / 64) / std::max(1, splitk);
-            for (int g = 0; g < 2; ++g)
-                if (cnt[g])
-                    std::fprintf(stderr, "pp_probe n=%d cin=%d %dx%d cout=%d k=%d group %d (%ld waves), cycles per slab: reads issued %.0f, DMA issued %.0f, wait reads %.0f, wait DMA %.0f, "
-                                         "barrier after LOAD %.0f, matrix phase %.0f, barrier after COMPUTE %.0f; loop %.0f\n", n, cin, h, w, cout, k, g, cnt[g],
-                                 sum[g][0] / cnt[g] / slabs, sum[g][1] / cnt[g] / slabs, sum[g][2] / cnt[g] / slabs, sum[g][3] / cnt[g] / slabs, sum[g][4] / cnt[g] / slabs,
-                                 sum[g][5] / cnt[g] / slabs, sum[g][6] / cnt[g] / slabs, sum[g][7] / cnt[g] / slabs);
         }
         if (opt_gemm_probe_ && a.p3) {
             // diagnostic: one more launch in which every workgroup of the plane GEMM stamps its phases (ConvGemm::probe; 100 MHz clock)

@@ -73,17 +73,6 @@ hipError_t launch_splitk_reduce_bf16(const ConvGemm& p, hipStream_t stream);
 constexpr int kNumGemmTilesX = 4;
 const GemmTileInfo& gemm_tile_info_x(int cfg);
 hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
-// the "ping-pong" form of the same tiles (k_gemm_bf16p.hip): the two waves of a SIMD alternate between an LDS / DMA phase and a
-// matrix phase; bf16 tile_cfg 100 + kNumGemmTilesX + x
-constexpr int kNumGemmTilesPP = 4;
-const GemmTileInfo& gemm_tile_info_pp(int cfg);
-hipError_t launch_conv_gemm_bf16p(const ConvGemm& p, int tile_cfg, hipStream_t stream);
-// bf16 large tiles as one list: 100 + [0, kNumGemmTilesX) = k_gemm_bf16x.hip, then k_gemm_bf16p.hip
-constexpr int kNumGemmTilesXB = kNumGemmTilesX + kNumGemmTilesPP;
-inline const GemmTileInfo& gemm_tile_info_xb(int c) { return c < kNumGemmTilesX ? gemm_tile_info_x(c) : gemm_tile_info_pp(c - kNumGemmTilesX); }
-inline hipError_t launch_conv_gemm_bf16_large(const ConvGemm& p, int c, hipStream_t stream) {
-    return c < kNumGemmTilesX ? launch_conv_gemm_bf16x(p, c, stream) : launch_conv_gemm_bf16p(p, c - kNumGemmTilesX, stream);
-}
 // the same structure for fp32 storage (k_gemm2x.hip; Cin % 32 == 0, fp32 output); same tile list
 hipError_t launch_conv_gemm2x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 // fp32 on the bf16 matrix pipe: operands as exact sums of three bf16 terms, six partial products (k_gemm3x.hip); its own tile

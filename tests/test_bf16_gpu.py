@@ -98,12 +98,11 @@ XCASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [100, 101, 102, 103, 104, 105, 106, 107])
+@pytest.mark.parametrize("tile", [100, 101, 102, 103])
 @pytest.mark.parametrize("splitk", [1, 3])
 @pytest.mark.parametrize("case", XCASES)
 def test_conv2d_bf16_large_tiles(ops16, tile, splitk, case):
-    """k_gemm_bf16x.hip: 256-row, 8-wave tiles staged by LDS-DMA (tile 100 + x), incl. residual + time-embedding epilogue; 104 / 105: the
-    ping-pong form of the 256 x 320 / 256 x 256 tile (k_gemm_bf16p.hip)."""
+    """k_gemm_bf16x.hip: 256-row, 8-wave tiles staged by LDS-DMA (tile 100 + x), incl. residual + time-embedding epilogue."""
     n, cin, h, w, cout, k, stride, ups = case
     g = np.random.default_rng(3000 + tile + 7 * splitk + cin + cout)
     x = bf16_round(g.standard_normal((n, cin, h, w)))
@@ -127,10 +126,10 @@ XCASES_SHORT_K = [
 ]
 
 
-@pytest.mark.parametrize("tile", [100, 104, 105, 106, 107])
+@pytest.mark.parametrize("tile", [100, 101])
 @pytest.mark.parametrize("case", XCASES_SHORT_K)
 def test_conv2d_bf16_large_tiles_short_k(ops16, tile, case):
-    """one to three k tiles per k slice: the slab ring of k_gemm_bf16p.hip never fills (prologue + tail waits only)"""
+    """one to three k tiles per k slice"""
     n, cin, h, w, cout, k, splitk = case
     g = np.random.default_rng(3100 + tile + cin + cout + splitk)
     x = bf16_round(g.standard_normal((n, cin, h, w)))
@@ -147,7 +146,7 @@ def test_conv2d_bf16_large_tiles_short_k(ops16, tile, case):
     _check(got, ref, f"conv bf16 large tile={tile} short K {case}", 2 ** -8)
 
 
-@pytest.mark.parametrize("tile", [100, 103, 104, 105, 106, 107])
+@pytest.mark.parametrize("tile", [100, 103])
 def test_linear_bf16_large_tiles(ops16, tile):
     g = np.random.default_rng(tile)
     rows, cin, cout = 700, 320, 960
