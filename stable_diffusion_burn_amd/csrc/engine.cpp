@@ -385,6 +385,9 @@ void Engine::build_model() {
             }
         }
         lin(m.q, path + "/query", c, c, false);
+        // precision >= 1: the bf16 attention kernel takes q in log2 units -- d_head^-0.5 log2(e) is folded into the query weight here, in
+        // fp32, before its only rounding (attention.rs:15-26 applies d_head^-0.25 to q and to k)
+        if (m.q.dt) entries_[entry_index_.at(path + "/query/weight")].pre_scale = attn_bf16_q_scale(c / cfg_.n_head);
         lin(m.k, path + "/key", cctx, c, false);
         lin(m.v, path + "/value", cctx, c, false);
         lin(m.out, path + "/out", c, c, true);
@@ -690,6 +693,7 @@ void Engine::stage_commit(WeightEntry& e, size_t offset, int half) {
         size_t n_stage = count;
         if (e.kind == 0 && e.dims[1] == 3) n_stage = count / 3 * 4;   // padded on the host by the caller of stage_commit
         SDMI_HIP(hipMemcpyAsync(stage, host, n_stage * sizeof(float), hipMemcpyHostToDevice, stream_));
+        if (e.pre_scale != 1.f) SDMI_HIP(launch_scale_f32(stage, (long long)n_stage, e.pre_scale, stream_));
         hipError_t err;
         if (e.kind == 0) {
             const int cout = (int)e.dims[0], cin = e.dims[1] == 3 ? 4 : (int)e.dims[1], k = (int)e.dims[2];
@@ -1468,7 +1472,10 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
     if (dt < 0) dt = edt();
     if (nq <= 0 || nk <= 0) throw Error(SDMI_ERR_INVALID, "attention: empty sequence");
     if (o3 && (dt || !attn_supported_head_dim(d_head) || (n_head * d_head) % 32)) throw Error(SDMI_ERR_STATE, "attention: plane output needs a fused fp32 kernel");
-    const float scale = (float)std::pow((double)d_head, -0.25);
+    // bf16 tensors at the UNet's head dims: q arrives in log2 units (attn_bf16_q_scale: folded into the query weights at load, applied by
+    // qkv_attention_dev's conversion); the bf16 kernel needs no scale, the widened fp32 kernel (attn_bf16=0) gets scale^2 = ln 2
+    const bool q_log2 = dt && (d_head == 40 || d_head == 80 || d_head == 160);
+    const float scale = q_log2 ? 0.83255461115769775635f : (float)std::pow((double)d_head, -0.25);
     if (attn_supported_head_dim(d_head)) {
         AttnParams p{};
         p.q = q; p.k = k; p.v = v; p.o = o; p.kv_len = kv_len_dev; p.mask = mask; p.mask_ld = mask_ld;
@@ -2197,7 +2204,9 @@ void Engine::qkv_attention_dev(const float* q, const float* k, const float* v, c
     const long long qe = (long long)n * nq * n_state, ke = (long long)n * nk * n_state;
     if (bf16_ && !mask) {  // precision = 1: the boundary is fp32, the kernel sees bf16 tensors
         Buf qh(this, qe * 2), kh(this, ke * 2), vh(this, ke * 2), oh(this, qe * 2);
-        SDMI_HIP(launch_f32_to_bf16(q, qh.p, qe, stream_));
+        const int dh = n_state / n_head;
+        if (dh == 40 || dh == 80 || dh == 160) SDMI_HIP(launch_f32_to_bf16_scaled(q, qh.p, qe, attn_bf16_q_scale(dh), stream_));   // Engine::attention's q convention
+        else SDMI_HIP(launch_f32_to_bf16(q, qh.p, qe, stream_));
         SDMI_HIP(launch_f32_to_bf16(k, kh.p, ke, stream_));
         SDMI_HIP(launch_f32_to_bf16(v, vh.p, ke, stream_));
         attention(qh.f(), n_state, (long long)nq * n_state, kh.f(), n_state, (long long)nk * n_state, vh.f(), n_state,
@@ -2565,7 +2574,8 @@ double Engine::bench_attention(int n, int nq, int nk, int n_state, int n_head, i
     const int dt = edt();
     Buf qh(this, dt ? qe * 2 : 256), kh(this, dt ? ke * 2 : 256), vh(this, dt ? ke * 2 : 256);
     if (dt) {
-        SDMI_HIP(launch_f32_to_bf16(q.f(), qh.p, qe, stream_));
+        const int dh = n_state / n_head;
+        SDMI_HIP(launch_f32_to_bf16_scaled(q.f(), qh.p, qe, (dh == 40 || dh == 80 || dh == 160) ? attn_bf16_q_scale(dh) : 1.f, stream_));
         SDMI_HIP(launch_f32_to_bf16(k.f(), kh.p, ke, stream_));
         SDMI_HIP(launch_f32_to_bf16(v.f(), vh.p, ke, stream_));
     }

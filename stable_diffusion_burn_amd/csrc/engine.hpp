@@ -118,6 +118,7 @@ struct WeightEntry {
     int group = 0;  // 0: hot path (required); 1: CLIP text encoder, 2: VAE encoder (each optional as a whole)
     float** dst8 = nullptr;   // precision = 2: where the MXFP8 copy of a conv weight and its scales go (null: none)
     float** dsts = nullptr;
+    float pre_scale = 1.f;    // the tensor is multiplied by this in fp32 before it is packed (bf16 / MXFP8 query projections: attn_bf16_q_scale)
     bool set = false;
 };
 

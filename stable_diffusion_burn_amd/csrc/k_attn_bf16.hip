@@ -20,8 +20,17 @@
 // 16 different rows at one chunk column fall in 16 different 16-byte bank slots; V rows at a
 // stride = 64 (mod 256) bytes with 64-byte row segments, so the 4 rows x 64 B a half-wave
 // transpose-read touches tile the 256-byte bank row exactly.
-// The scale d^-0.5 (q and k each carry d^-0.25, attention.rs:15-26) is applied to the fp32
-// scores inside the exponent's fma, not to the bf16 operands.
+// Softmax work per score is ONE v_exp_f32, half a v_max3 and half a v_cvt_pk (round 4; the matrix pipe was 24 % busy at d = 40 because
+// the softmax's VALU work was of the order of the matrix work):
+//   * q arrives PRE-SCALED by d^-0.5 log2(e) (the scale of attention.rs:15-26 -- q and k each carry d^-0.25 there -- times log2 e): the engine
+//     folds it into the query projection's weight at load, before that weight's only bf16 rounding, so the scores leave the matrix pipe in
+//     log2 units and the kernel never multiplies them;
+//   * the running row maximum m enters as the ACCUMULATOR INPUT of the first K Q^T instruction (a 16-register vector holding -m), so the
+//     pipe returns s - m and the probabilities are exp2 of that, no subtraction;
+//   * m is only raised when a tile's maximum exceeds it by more than 2^8 (deferred rescale: probabilities up to 256 are as exact in
+//     bf16 / fp32 as those below 1): the rescale of O, m and the scores is a wave-uniform slow path;
+//   * the row sum is a column of ones appended to V (d = 40 / 80: the 32-row tiles of O^T have spare rows), i.e. it is accumulated by the
+//     P V instructions themselves, from the same bf16-rounded probabilities as the numerator.
 #include "kernels.hpp"
 
 #include <hip/hip_runtime.h>
@@ -81,7 +90,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) 
     constexpr int NT = Cfg::NT, BKV = Cfg::BKV, KS = Cfg::KS, NDT = Cfg::NDT, RSK = Cfg::RSK, RSV = Cfg::RSV, NLD = Cfg::NLD;
     constexpr int KT = Cfg::KT, ST = Cfg::ST;
     constexpr int CPR = D / 8;  // chunks per HBM row
-    constexpr float kLog2e = 1.4426950408889634f;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_bf[];
     unsigned char* Ks = smem_bf;
@@ -106,7 +114,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) 
     const int nk = p.kv_len ? p.kv_len[b] : p.nk;
     const int n_tiles = (nk + BKV - 1) / BKV;
     const int n_full = nk / BKV;
-    const float cs = p.scale * p.scale * kLog2e;  // scores -> log2 units
+    constexpr bool SUMCOL = (NDT * 32 > D);       // a spare row of O^T holds the row sum (V gets a column of ones)
+    constexpr int SUM_DT = D / 32, SUM_R = ((D % 32) >> 3) * 4;   // ... row D: tile D / 32, register 4 (D % 32 / 8) of the lanes with hi = 0
+    static_assert(!SUMCOL || (D % 8 == 0 && (D % 32) % 8 == 0), "row D of O^T must sit in a lane with hi = 0");
+    constexpr float kDefer = 8.0f;                // raise the running maximum only past 2^8
+
+    if constexpr (SUMCOL) {   // V[key][D] = 1, V[key][D + 1 .. D + 7] = 0 in both buffers, once (the staging never touches that chunk)
+        for (int i = tid; i < 2 * BKV; i += NT)
+            *reinterpret_cast<u32x4*>(Vs + (i / BKV) * Cfg::V_BYTES + (i % BKV) * RSV + CPR * 16) = u32x4{0x3F80u, 0u, 0u, 0u};
+    }
 
     if constexpr (Cfg::DK > D) {  // zero the K columns D..DK-1 once (the staging never touches them)
         for (int i = tid; i < 2 * BKV; i += NT)
@@ -159,8 +175,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) 
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-    float m_run = -INFINITY;  // running row max, raw score units
-    float l_run = 0.f;        // this lane's share of the row sum
+    f32x16 negm;              // -m in every register: the accumulator input of K Q^T (m = the row's reference maximum, log2 units; 0 before the first tile)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+    float l_run = 0.f;        // d = 160 (no spare row): this lane's share of the row sum
 
     // per-lane LDS offsets: K fragment row c, chunk hi; V transpose-read row 4 hi + (i >> 2), columns 16 (G & 1) + 4 (i & 3)
     const int k_off = c * RSK + hi * 16;
@@ -202,10 +220,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) 
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) kf[0][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Kt + kt * 32 * RSK + ks * 32));
             }
+            s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PF ? (kt & 1) : 0][0], qf[0], negm, 0, 0, 0);     // s - m
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PF ? (kt & 1) : 0][ks], qf[ks], s[kt], 0, 0, 0);
+            for (int ks = 1; ks < KS; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PF ? (kt & 1) : 0][ks], qf[ks], s[kt], 0, 0, 0);
             if constexpr (PF) __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -228,11 +245,22 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) 
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kt][r]);
-        mt = partner_max(mt);
-        const float m_new = fmaxf(m_run, mt);
-        const float mc = m_new * cs;
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
-        m_run = m_new;
+        mt = partner_max(mt);         // the tile's maximum relative to m
+        float alpha = 1.0f;
+        if (tile == 0 || __any(mt > kDefer)) {   // wave-uniform: the reference maximum moves (always on the first tile, where it is still 0)
+            const float delta = tile == 0 ? mt : fmaxf(mt, 0.f);
+            if (tile != 0) {
+                alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] -= delta;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kt][r] -= delta;
+        }
 
         unsigned pb[ST][4];  // [16-key step][4 dwords = 8 bf16]
         float psum = 0.f;
@@ -240,17 +268,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) 
         for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], cs, -mc));
-                const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r + 1], cs, -mc));
-                psum += e0 + e1;
+                const float e0 = __builtin_amdgcn_exp2f(s[kt][r]);
+                const float e1 = __builtin_amdgcn_exp2f(s[kt][r + 1]);
+                if constexpr (!SUMCOL) psum += e0 + e1;
                 pb[kt * 2 + (r >> 3)][(r & 7) >> 1] = pack_bf16(e0, e1);
             }
         }
-        l_run = l_run * alpha + psum;
-        if (__any(alpha != 1.0f)) {  // the running max moved somewhere in the wave
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
-        }
+        if constexpr (!SUMCOL) l_run = l_run * alpha + psum;
 
         // O^T += V^T P^T, 16 keys at a time; the V^T fragments of step st + 1 are read before the MFMAs of step st (fenced, as above)
         auto read_vf = [&](bf16x8 (&vf)[NDT], int st) {
@@ -283,7 +307,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) 
         __syncthreads();
     }
 
-    const float inv = 1.0f / partner_sum(l_run);
+    float l_own = l_run;
+    if constexpr (SUMCOL) l_own = hi ? 0.f : o[SUM_DT][SUM_R];     // row D of O^T = sum of the probabilities
+    const float inv = 1.0f / partner_sum(l_own);
     if (q_ok) {
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
@@ -319,7 +345,8 @@ static hipError_t launch_attn_bf16_any(const AttnParams& p, hipStream_t stream) 
     return launch_attn_bf16_d<D, 2>(p, stream);
 }
 
-// bf16 matrix-core attention; p.bf16 must be set, no additive mask (the masked CLIP path is fp32)
+// bf16 matrix-core attention; p.bf16 must be set, no additive mask (the masked CLIP path is fp32).  q must arrive multiplied by
+// d_head^-0.5 log2(e) (kernel header); p.scale is not used.
 hipError_t launch_attention_bf16(const AttnParams& p, hipStream_t stream) {
     if (!p.bf16 || p.mask) return hipErrorInvalidValue;
     if ((p.ldq | p.ldk | p.ldv | p.ldo) & 7) return hipErrorInvalidValue;  // 16-byte row alignment

@@ -272,6 +272,12 @@ __global__ void geglu_bf16_kernel(const unsigned short* __restrict__ proj, unsig
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long n) {
     GRID_STRIDE(i, n) dst[i] = (unsigned short)bf16_bits(src[i]);
 }
+__global__ void f32_to_bf16_scaled_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long n, float scale) {
+    GRID_STRIDE(i, n) dst[i] = (unsigned short)bf16_bits(src[i] * scale);
+}
+__global__ void scale_f32_kernel(float* __restrict__ x, long long n, float scale) {
+    GRID_STRIDE(i, n) x[i] *= scale;
+}
 
 __global__ void nhwc_bf16_to_nchw_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int n, int c, int h, int w) {
     const long long hw = (long long)h * w, total = (long long)n * c * hw;
@@ -345,6 +351,14 @@ hipError_t launch_geglu_bf16(const void* proj, void* out, long long rows, int hi
 }
 hipError_t launch_f32_to_bf16(const float* src, void* dst, long long n, hipStream_t s) {
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks_for(n)), dim3(256), 0, s, src, reinterpret_cast<unsigned short*>(dst), n);
+    return hipGetLastError();
+}
+hipError_t launch_f32_to_bf16_scaled(const float* src, void* dst, long long n, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(f32_to_bf16_scaled_kernel, dim3(blocks_for(n)), dim3(256), 0, s, src, reinterpret_cast<unsigned short*>(dst), n, scale);
+    return hipGetLastError();
+}
+hipError_t launch_scale_f32(float* x, long long n, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(scale_f32_kernel, dim3(blocks_for(n)), dim3(256), 0, s, x, n, scale);
     return hipGetLastError();
 }
 hipError_t launch_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int n, int c, int h, int w, hipStream_t s) {

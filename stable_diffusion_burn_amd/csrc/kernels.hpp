@@ -133,7 +133,9 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 // fp32 q/k/v/o on the bf16 matrix pipe, three-way split operands (k_attn_split.hip): d_head 40 / 80, no additive mask
 bool attn_split_supported(const AttnParams& p);
 hipError_t launch_attention_split(const AttnParams& p, hipStream_t stream);
-// bf16 matrix-core kernel (k_attn_bf16.hip): p.bf16 set, no additive mask
+// bf16 matrix-core kernel (k_attn_bf16.hip): p.bf16 set, no additive mask; q must arrive multiplied by attn_bf16_q_scale(d_head)
+// (the engine folds it into the query projection's weight at load); p.scale is not used
+inline float attn_bf16_q_scale(int d_head) { return (float)(1.4426950408889634 / __builtin_sqrt((double)d_head)); }
 hipError_t launch_attention_bf16(const AttnParams& p, hipStream_t stream);
 // row softmax (in place) for the unfused single-head VAE attention: x[rows][cols] *= scale first
 hipError_t launch_softmax_rows(float* x, int rows, int cols, float scale, hipStream_t stream);
@@ -195,6 +197,8 @@ hipError_t launch_layer_norm_bf16(const void* x, void* y, const float* gamma, co
                                   hipStream_t stream);
 hipError_t launch_geglu_bf16(const void* proj, void* out, long long rows, int hidden, hipStream_t s);
 hipError_t launch_f32_to_bf16(const float* src, void* dst, long long n, hipStream_t s);
+hipError_t launch_f32_to_bf16_scaled(const float* src, void* dst, long long n, float scale, hipStream_t s);   // dst = bf16(src * scale)
+hipError_t launch_scale_f32(float* x, long long n, float scale, hipStream_t s);                                // in place
 hipError_t launch_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int n, int c, int h, int w, hipStream_t s);
 hipError_t launch_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, int c, int h, int w, float scale, hipStream_t s);
 hipError_t launch_transpose2d_bf16(const void* src, void* dst, int rows, int cols, int src_ld, hipStream_t s);
