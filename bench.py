@@ -91,16 +91,19 @@ def cpu_baseline(weights, ddim_steps: int) -> dict:
     x = torch.from_numpy(syn.initial_latent(0))[None]
     ctx = torch.from_numpy(syn.cond_context(0))[None]
     unc = torch.from_numpy(syn.uncond_context())
-    sd.unet.forward(x, 999, ctx)  # untimed: first touch converts the cached synthetic weights to torch
-    t0 = time.perf_counter()
-    sd.forward_diffuser(x, 999, ctx, unc, 7.5)
-    t_step = time.perf_counter() - t0
+    sd.forward_diffuser(x, 999, ctx, unc, 7.5)  # untimed warm-up step: first touch converts the cached synthetic weights to torch, the thread pool spins up
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        sd.forward_diffuser(x, 999, ctx, unc, 7.5)
+        ts.append(time.perf_counter() - t0)
+    t_step = sorted(ts)[1]
     t0 = time.perf_counter()
     sd.decode_float(x)
     t_vae = time.perf_counter() - t0
     t_img = ddim_steps * t_step + t_vae
     return {"value": 1.0 / t_img, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 CFG step (2 UNet fwd, {t_step:.2f} s) + 1 VAE decode ({t_vae:.2f} s) of the fp32 torch-CPU "
+            "sample": f"median of 3 CFG steps after one warm-up (2 UNet fwd each; {', '.join(f'{t:.2f}' for t in ts)} s) + 1 VAE decode ({t_vae:.2f} s) of the fp32 torch-CPU "
                       f"oracle on {cores} threads, extrapolated to {ddim_steps} steps ({t_img:.1f} s/image)"}
 
 
@@ -185,6 +188,7 @@ class Runner:
         roof = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": None, "traffic_from_profiles": from_profiles,
                 "event_pair_overhead_us_subtracted": sd.profile_overhead_us(),
+                "achieved_without_event_calibration": g["flops"] / ((g["ms"] + g["launches"] * sd.profile_overhead_us() * 1e-3) * 1e-3) / 1e12,
                 "launches_per_image": g["launches"] / self.B, "avg_launch_us": g["ms"] * 1e3 / g["launches"],
                 "flop_per_launch": g["flops"] / g["launches"],
                 "share_of_gpu_time": g["ms"] / max(1e-9, sum(v["ms"] for v in prof.values()))}
@@ -203,7 +207,10 @@ class Runner:
         return roof, prof
 
     def class_summary(self, prof):
-        out = {"kernel_classes_ms_per_image": {k: round(v["ms"] / self.B, 3) for k, v in prof.items()}}
+        out = {"kernel_classes_ms_per_image": {k: round(v["ms"] / self.B, 3) for k, v in prof.items()},
+               "kernel_classes_launches_per_image": {k: v["launches"] / self.B for k, v in prof.items()},
+               # every launch of the path is in a class ("other" is measured, not a remainder): launches the profiler saw vs launches the call counted
+               "launches_profiled_vs_counted": [sum(v["launches"] for v in prof.values()), self.sd.last_call_stats()["kernels"]]}
         gn = prof["group_norm"]
         if gn["ms"] > 0:
             out["group_norm_algorithmic_GBps"] = gn["bytes"] / (gn["ms"] * 1e-3) / 1e9
@@ -222,8 +229,8 @@ ARITHMETIC = {
             "error <= 2^-23 worst case / 2^-28 on average (tests/test_split_oracle_cpu.py), measured against the fp64 oracle: not larger than the fp32 matrix instruction's -- tests/test_ops_gpu.py); "
             "attention, norms and the remaining GEMMs in plain fp32",
     "bf16": "bf16 storage, fp32 accumulation and statistics",
-    "fp8": "bf16 storage, fp32 accumulation; on MXFP8 operands (e4m3, E8M0 scale per 32 channels): the ResBlock / ResnetBlock 3x3 convolutions and (option "
-           "fp8_linear, default) the UNet's transformer-block Linear layers and 1x1 / up / down convolutions; attention in bf16",
+    "fp8": "bf16 storage, fp32 accumulation; on MXFP8 operands (e4m3, E8M0 scale per 32 channels): the ResBlock / ResnetBlock 3x3 convolutions (default; accuracy budget 6e-2 on the "
+           "20-step latent) and, with option fp8_linear=1, the UNet's transformer-block Linear layers and 1x1 / up / down convolutions; attention in bf16",
 }
 
 # What the reduced precisions cost, measured on MI355X against the fp64 oracle's golden vectors at the FULL model size (tests/test_golden_gpu.py
@@ -231,8 +238,8 @@ ARITHMETIC = {
 ACCURACY = {
     ("bf16", 50): {"latent_rel_rms_vs_fp64": 5.5e-3, "rgb_rel_rms_vs_fp64": 8.7e-3, "case": "batch 16, 50 steps, samples 0-1 (test_config3_bf16_batch16_50_steps)"},
     ("bf16", 20): {"latent_rel_rms_vs_fp64": 9e-3, "rgb_rel_rms_vs_fp64": 9e-3, "case": "batch 1, 20 steps (test_golden_gpu.py, bf16 cases)"},
-    ("fp8", 20): {"latent_rel_rms_vs_fp64": 8.1e-2, "rgb_rel_rms_vs_fp64": 2.1e-2, "unet_forward_rel_rms_vs_fp64": 1.2e-1,
-                  "with_fp8_linear_0": {"latent_rel_rms_vs_fp64": 5.2e-2, "unet_forward_rel_rms_vs_fp64": 8.5e-2},
+    ("fp8", 20): {"latent_rel_rms_vs_fp64": 5.2e-2, "rgb_rel_rms_vs_fp64": 2.1e-2, "unet_forward_rel_rms_vs_fp64": 8.5e-2,
+                  "with_fp8_linear_1": {"latent_rel_rms_vs_fp64": 8.1e-2, "unet_forward_rel_rms_vs_fp64": 1.2e-1},
                   "format_cost_in_fp64": "the same quantisation applied to the fp64 oracle: 5.1e-2 (fp8_linear=0 set, 20-step latent), 1.25e-1 / 9.1e-2 (one UNet forward, wide / narrow set)",
                   "case": "batch 16, 20 steps, samples 0-1 (test_config5_mxfp8_batch16_20_steps); UNet forward: tests/test_fp8_gpu.py"},
 }
@@ -243,8 +250,7 @@ def workload_name(precision, B, ddim_steps, scale):
              ("bf16", 8, 20): "the per-GPU shard of BASELINE.json configs[3] (64 images over 8 GPUs)",
              ("fp8", 16, 20): "the per-GPU shard of BASELINE.json configs[4] (128 images over 8 GPUs)"}.get((precision, B, ddim_steps), "not a BASELINE.json configuration")
     arith = {"fp32": "fp32", "bf16": "bf16 storage / fp32 accumulate",
-             "fp8": "bf16 storage / fp32 accumulate + MXFP8 (e4m3, E8M0 scales per 32 channels) on the ResBlock 3x3 convs, the transformer blocks' Linear layers "
-                    "and the UNet's 1x1 / up / down convs"}[precision]
+             "fp8": "bf16 storage / fp32 accumulate + MXFP8 (e4m3, E8M0 scales per 32 channels) on the ResBlock / ResnetBlock 3x3 convs"}[precision]
     return f"SD v1.4 512x512, {ddim_steps}-step DDIM, CFG={scale}, batch={B} per GPU, {arith} ({which})"
 
 
@@ -276,11 +282,19 @@ def main():
     B = args.batch_per_gpu
     ctx_dim = ModelConfig().ctx_dim
     weights = syn.SyntheticWeights(cache=(rank == 0 and world == 1 and not args.no_cpu_baseline))
-    # the flat fp32 image of the hot-path weights (untimed: numpy RNG, ~3.6 GB); both precisions load the same image
+    # the flat fp32 image of the hot-path weights (untimed: numpy RNG, ~3.6 GB); every precision loads the same image.  N > 1: rank 0 generates it
+    # once into /dev/shm and the other ranks map it (sharding.share_flat_array) instead of N ranks running the RNG on the same host cores
     t0 = time.perf_counter()
-    probe = StableDiffusion(ModelConfig(), device=local_rank)
-    flat = probe.pack_weights(weights, groups=1)
-    probe.close()
+
+    def make_flat():
+        probe = StableDiffusion(ModelConfig(), device=local_rank)
+        try:
+            return probe.pack_weights(weights, groups=1)
+        finally:
+            probe.close()
+
+    flat = sharding.share_flat_array(make_flat, rank, world, (lambda: dist.barrier()) if world > 1 else (lambda: None),
+                                     f"weights_{os.environ.get('MASTER_PORT', '0')}")
     t_gen = time.perf_counter() - t0
 
     # ---- inputs: rank 0 owns the prompt embedding; ONE RCCL broadcast ------------------
@@ -317,19 +331,19 @@ def main():
     # ---- secondary: the reduced-precision configurations BASELINE.json names, witnessed by the same run ----------
     secondary = []
     if rank == 0 and world == 1 and not args.no_secondary and not bf16 and B == 1 and args.ddim_steps == 20:
-        for (prec2, b2, s2, k2) in (("fp32", 1, 20, 3), ("bf16", 16, 50, 2), ("bf16", 8, 20, 3), ("fp8", 16, 20, 2)):
+        for (prec2, b2, s2, k2, extra) in (("fp32", 1, 20, 5, []), ("bf16", 16, 50, 5, []), ("bf16", 8, 20, 5, []), ("fp8", 16, 20, 5, []), ("fp8", 16, 20, 5, ["fp8_linear=1"])):
             idx = list(range(b2))
             # the headline configuration once more with every GEMM on the fp32 matrix instruction (the split kernel off)
             # (with the tile table that was tuned for those kernels: tuning/gfx950_fp32_mfma.txt)
-            opts2, tune2 = (["gemm_f32s=0", "attn_split=0"], str(ROOT / "stable_diffusion_burn_amd" / "tuning" / "gfx950_fp32_mfma.txt")) if prec2 == "fp32" else ([], None)
+            opts2, tune2 = (["gemm_f32s=0", "attn_split=0"], str(ROOT / "stable_diffusion_burn_amd" / "tuning" / "gfx950_fp32_mfma.txt")) if prec2 == "fp32" else (extra, None)
             r2 = Runner(torch, np, dev, local_rank, prec2, b2, s2, args.scale, cond, uncond, idx, flat, opts2, tune2)
-            e2 = r2.timed(k2, 1, barrier)
+            e2 = r2.timed(k2, 2, barrier)
             roof2, prof2 = r2.roofline()
             fpi = 2 * s2 * F_UNET + F_VAE
             v2 = k2 * b2 / e2
             entry = {"config": {"workload": workload_name(prec2, b2, s2, args.scale), "global_batch": b2, "ddim_steps": s2,
                                 "cfg_scale": args.scale, "context_len": T_CTX},
-                     "dtype": "f32" if prec2 == "fp32" else "bf16" if prec2 == "bf16" else "fp8(e4m3, MX)+bf16", "value": v2, "unit": "images/sec", "steps": k2, "warmup": 1, "ms_per_step": e2 / k2 * 1e3,
+                     "dtype": "f32" if prec2 == "fp32" else "bf16" if prec2 == "bf16" else "fp8(e4m3, MX)+bf16", "value": v2, "unit": "images/sec", "steps": k2, "warmup": 2, "ms_per_step": e2 / k2 * 1e3,
                      "algorithmic_tflop_per_image": fpi / 1e12, "whole_path_tflops_per_gpu": v2 * fpi / 1e12,
                      "whole_path_frac_of_bf16_mfma_peak": v2 * fpi / 1e12 / BF16_MFMA_PEAK_TFLOPS, "roofline": roof2,
                      "kernels_per_image": r2.sd.last_call_stats()["kernels"] / b2,
@@ -337,8 +351,11 @@ def main():
             if prec2 == "fp32":
                 entry["config"]["workload"] += "; every GEMM and attention on v_mfma_f32_16x16x4_f32 (options gemm_f32s=0, attn_split=0)"
                 entry["whole_path_frac_of_fp32_mfma_peak"] = entry.pop("whole_path_frac_of_bf16_mfma_peak") * BF16_MFMA_PEAK_TFLOPS / FP32_MFMA_PEAK_TFLOPS
+            if extra:
+                entry["config"]["workload"] += "; option " + ", ".join(extra) + " (MXFP8 also on the transformer blocks' Linear layers and the 1x1 / up / down convs: outside the 6e-2 accuracy budget, 8.1e-2)"
+                entry["options"] = extra
             if (prec2, s2) in ACCURACY:
-                entry["accuracy_measured_on_mi355x"] = ACCURACY[(prec2, s2)]
+                entry["accuracy_reference_from_tests"] = dict(ACCURACY[(prec2, s2)], note="static: measured on MI355X by the named tests (they assert 1.5 x these), not in this run")
             entry.update(r2.class_summary(prof2))
             secondary.append(entry)
             r2.close()
@@ -375,7 +392,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if (args.precision, args.ddim_steps) in ACCURACY:
-            out["accuracy_measured_on_mi355x"] = ACCURACY[(args.precision, args.ddim_steps)]
+            out["accuracy_reference_from_tests"] = dict(ACCURACY[(args.precision, args.ddim_steps)], note="static: measured on MI355X by the named tests (they assert 1.5 x these), not in this run")
         out.update(classes)
         if secondary:
             out["secondary"] = secondary

@@ -67,8 +67,8 @@ typedef struct sdmi_config {
     int32_t latent_w;        /* 64                                              */
     int32_t vae_ch;          /* 128  (decoder channels 4c,4c,2c,c)              */
     int32_t max_batch;       /* largest n a call may pass; 0 = no limit          */
-    int32_t precision;       /* 0 = fp32; 1 = bf16 storage, fp32 accumulate; 2 = 1 + MXFP8 operands for the ResBlock convolutions, the transformer
-                              * blocks' Linear layers and the 1x1 / up / down convolutions (option "fp8_linear=0": the ResBlock 3x3 convolutions only) */
+    int32_t precision;       /* 0 = fp32; 1 = bf16 storage, fp32 accumulate; 2 = 1 + MXFP8 operands for the ResBlock / ResnetBlock 3x3 convolutions (20-step latent 5.2e-2 relative RMS
+                              * of the exact one; option "fp8_linear=1": also the transformer blocks' Linear layers and the 1x1 / up / down convolutions, 8.1e-2 for +7 %) */
     /* CLIP text encoder, CLIPConfig::new(49408, 768, 12, 77, 12) stablediffusion/mod.rs:29;
      * its width is ctx_dim.  clip_layers = 0 builds a context without it.              */
     int32_t clip_layers;     /* 12                                              */
@@ -307,6 +307,8 @@ int sdmi_op_timestep_embedding(sdmi_ctx* ctx, int32_t t, int32_t dim, float* out
  *     partial products contain 0 * inf);
  *   - |x| < 2^-109: the low-order terms of x fall below bf16's normal range and are dropped (absolute error < 2^-118 |w| per term);
  *   - which kernel a layer runs on is a function of its shape and options only, never of the data.
+ * Size limit of the plane form: a tensor kept as planes must stay below 4 GiB (6 bytes per element, 32-bit offsets); past it a call fails with
+ * SDMI_ERR_UNSUPPORTED naming the limit (64x64x960 concat: CFG batch 2n <= 182, i.e. n <= 91 images per call; "gemm_planes=0" lifts it to the fp32 tensors' 273).
  * A caller that needs IEEE behaviour on infinities sets gemm_f32s = 0 / attn_split = 0.
  * precision = 2 selectors: "fp8_convs" (0: the fp8-capable layers on the bf16 kernels), "fp8_linear" (see sdmi_config.precision),
  * "fp8_min_rows" (GEMMs with fewer output rows stay bf16), "fp8_tile". */
@@ -319,7 +321,9 @@ int sdmi_last_call_stats(sdmi_ctx* ctx, double* gpu_ms, int64_t* n_kernels, doub
  * 2 attention, 3 group_norm(+silu), 4 layer_norm, 5 conv_gemm_fp8 (the MXFP8 convs of precision = 2),
  * 6 conv_gemm_split (precision = 0: the conv/linear launches that run on the bf16 matrix pipe with three-way split fp32
  * operands, k_gemm3x.hip / k_gemm3p.hip; class 0 then holds the launches left on the fp32 matrix instruction), 7 split_rows (fp32 tensors
- * converted to bf16 planes for a plane GEMM outside their producer), 8 other.  flops / bytes are the ALGORITHMIC work of
+ * converted to bf16 planes for a plane GEMM outside their producer), 8 other (every launch of the path that is in no other class: layout converters, the
+ * CFG + DDIM update, timestep embedding, SiLU of the embedding, row softmax / transposes of the unfused VAE attention, u8 conversion), 9 geglu (the GEGLU gate kernels
+ * where the gate is not fused into its GEMM; the quantising gate of precision = 2 included).  flops / bytes are the ALGORITHMIC work of
  * those launches (2*M*N*K; one read + one write of the tensor).  "profile_reset" clears. */
 int sdmi_profile_stats(sdmi_ctx* ctx, int32_t cls, double* ms, int64_t* launches, double* flops, double* bytes);
 /* What an empty HIP-event pair reads on the context stream (ms): calibrated when "profile" is switched on and already subtracted from

@@ -1229,7 +1229,11 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     const bool p_ok = s_ok && (unsigned long long)p.NB * p.Hs * p.Ws * (unsigned long long)(p.A3 ? p.a3_ld : p.Cin * 6) < 0xFFFFFF00ull;
     // the activations arrive as planes (their producer wrote them): the GEMM runs on a plane tile -- from the plane table or the cost model
     const bool from_planes = !in_dt && p.A3 != nullptr;
-    if (from_planes && !p_ok) throw Error(SDMI_ERR_STATE, "gemm: activation planes given for a layer the plane kernel does not take");
+    if (from_planes && !p_ok)
+        throw Error(s_ok ? SDMI_ERR_UNSUPPORTED : SDMI_ERR_STATE,
+                    s_ok ? "fp32 GEMM: an activation tensor stored as bf16 planes (6 bytes per element) reaches 4 GiB (32-bit piece offsets): lower the batch (at 64x64x960 the CFG "
+                           "batch 2n must stay <= 182) or set option gemm_planes=0"
+                         : "gemm: activation planes given for a layer the plane kernel does not take");
     if (!from_planes && !p.A) throw Error(SDMI_ERR_STATE, "gemm: no activations");
     auto usable = [&](int cfg) { return cfg < 100 || (in_dt ? opt_gemm_bf16x_ != 0 : (cfg >= 300 ? p_ok : cfg >= 200 ? (opt_gemm_f32s_ != 0 && s_ok) : (opt_gemm_x32_ != 0 && x32_ok))); };
     const auto it2 = in_dt ? tuned_mfma_.end() : tuned_mfma_.find(key);   // the table measured without the split kernels
@@ -1392,8 +1396,11 @@ void Engine::gemm_geglu(const float* x, long long rows, const float* bt, const f
     if (x3 || out3) {   // plane form: projection on a plane tile, gate kernel writing planes (the MLP's second Linear reads them)
         Buf proj(this, (size_t)rows * 2 * hidden * 4);
         gemm(x, (int)rows, bt, bias, cin, 2 * hidden, proj.f(), 2 * hidden, nullptr, 0, dt, 0, x3, nullptr);
-        if (out3) SDMI_HIP(launch_geglu_planes(proj.f(), out3, rows, hidden, stream_));
-        else SDMI_HIP(launch_geglu(proj.f(), out, rows, hidden, stream_));
+        {
+            ProfScope ps(this, PC_GEGLU, 0, (double)rows * hidden * (8.0 + (out3 ? 6.0 : 4.0)));
+            if (out3) SDMI_HIP(launch_geglu_planes(proj.f(), out3, rows, hidden, stream_));
+            else SDMI_HIP(launch_geglu(proj.f(), out, rows, hidden, stream_));
+        }
         count_kernel();
         return;
     }
@@ -1430,8 +1437,11 @@ void Engine::gemm_geglu(const float* x, long long rows, const float* bt, const f
     }
     Buf proj(this, (size_t)rows * 2 * hidden * es);
     gemm(x, (int)rows, bt, bias, cin, 2 * hidden, proj.f(), 2 * hidden, nullptr, 0, dt);
-    if (dt) SDMI_HIP(launch_geglu_bf16(proj.p, out, rows, hidden, stream_));
-    else SDMI_HIP(launch_geglu(proj.f(), out, rows, hidden, stream_));
+    {
+        ProfScope ps(this, PC_GEGLU, 0, (double)rows * hidden * (dt ? 6.0 : 12.0));
+        if (dt) SDMI_HIP(launch_geglu_bf16(proj.p, out, rows, hidden, stream_));
+        else SDMI_HIP(launch_geglu(proj.f(), out, rows, hidden, stream_));
+    }
     count_kernel();
 }
 
@@ -1513,11 +1523,11 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
             g.KH = g.KW = 1; g.stride = 1; g.ldc = nkb; g.ldr = nkb; g.a_ld = ldq; g.b_ld = ldk; g.CS = 32;
             g.out_mode = dt ? 1 : 0;
             launch_gemm(g, dt);
-            if (dt) SDMI_HIP(launch_softmax_rows_f32_to_bf16(s.f(), pb.p, nq, nkb, scale * scale, stream_));
-            else SDMI_HIP(launch_softmax_rows(s.f(), nq, nkb, scale * scale, stream_));
+            if (dt) { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_softmax_rows_f32_to_bf16(s.f(), pb.p, nq, nkb, scale * scale, stream_)); }
+            else { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_softmax_rows(s.f(), nq, nkb, scale * scale, stream_)); }
             count_kernel();
-            if (dt) SDMI_HIP(launch_transpose2d_bf16(vb, vt.p, nkb, d_head, ldv, stream_));
-            else SDMI_HIP(launch_transpose2d(vb, vt.f(), nkb, d_head, ldv, stream_));
+            if (dt) { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_transpose2d_bf16(vb, vt.p, nkb, d_head, ldv, stream_)); }
+            else { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_transpose2d(vb, vt.f(), nkb, d_head, ldv, stream_)); }
             count_kernel();
             ConvGemm g2{};
             g2.A = dt ? pb.f() : s.f(); g2.Bt = vt.f(); g2.C = ob;
@@ -1762,7 +1772,7 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
                 gemm_fp8(lnq, w.geglu_proj, 8 * C, proj.p, 8 * C, nullptr, 0);
                 ActQ uq = new_rowsq(M, 4 * C);
                 {
-                    ProfScope ps(this, PC_OTHER, 0, (double)M * (8.0 * C * 2.0 + 4.0 * C * 1.03));
+                    ProfScope ps(this, PC_GEGLU, 0, (double)M * (8.0 * C * 2.0 + 4.0 * C * 1.03));
                     SDMI_HIP(launch_geglu_fp8(proj.p, uq.q, uq.s, M, 4 * C, stream_));
                     count_kernel();
                 }
@@ -1872,13 +1882,13 @@ void Engine::unet_prepare(const float* ctx_packed, int nb, int t_max, const int*
     SDMI_HIP(hipStreamSynchronize(stream_));  // host vectors may go away; once per call, outside the step loop
 
     Buf te(this, (size_t)S * mc * 4), e1(this, (size_t)S * ed * 4), e2(this, (size_t)S * ed * 4);
-    SDMI_HIP(launch_timestep_embedding(t_dev, S, mc, te.f(), stream_));
+    { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_timestep_embedding(t_dev, S, mc, te.f(), stream_)); }
     count_kernel();
     gemm(te.f(), S, lin1_time_.bt, lin1_time_.bias, mc, ed, e1.f(), ed, nullptr, 0, /*dt=*/0);
-    SDMI_HIP(launch_silu(e1.f(), e1.f(), (long long)S * ed, stream_));
+    { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_silu(e1.f(), e1.f(), (long long)S * ed, stream_)); }
     count_kernel();
     gemm(e1.f(), S, lin2_time_.bt, lin2_time_.bias, ed, ed, e2.f(), ed, nullptr, 0, /*dt=*/0);
-    SDMI_HIP(launch_silu(e2.f(), e2.f(), (long long)S * ed, stream_));  // SiLU(emb), shared by all ResBlocks
+    { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_silu(e2.f(), e2.f(), (long long)S * ed, stream_)); }  // SiLU(emb), shared by all ResBlocks
     count_kernel();
     us_.temb.resize(res_list_.size());
     for (size_t i = 0; i < res_list_.size(); ++i) {
@@ -1891,7 +1901,7 @@ void Engine::unet_prepare(const float* ctx_packed, int nb, int t_max, const int*
     const float* ctx_e = ctx_packed;  // text context in the engine's storage type
     Buf ctx_h(this, bf16_ ? (size_t)nb * t_max * cd * 2 : 256);
     if (bf16_) {
-        SDMI_HIP(launch_f32_to_bf16(ctx_packed, ctx_h.p, (long long)nb * t_max * cd, stream_));
+        { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_f32_to_bf16(ctx_packed, ctx_h.p, (long long)nb * t_max * cd, stream_)); }
         count_kernel();
         ctx_e = ctx_h.f();
     }
@@ -1998,8 +2008,8 @@ void Engine::clip_forward_dev(const int32_t* tokens, int n, int T, float* out) {
     const long long M = (long long)n * T;
     Buf x(this, (size_t)M * C * 4), h(this, (size_t)M * C * 4), qkv(this, (size_t)M * 3 * C * 4), a(this, (size_t)M * C * 4);
     Buf f(this, (size_t)M * 4 * C * 4), mask(this, (size_t)T * T * 4);
-    SDMI_HIP(launch_clip_embed(tokens, clip_tok_, clip_pos_, x.f(), n, T, C, stream_));
-    SDMI_HIP(launch_causal_mask(mask.f(), T, stream_));
+    { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_clip_embed(tokens, clip_tok_, clip_pos_, x.f(), n, T, C, stream_)); }
+    { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_causal_mask(mask.f(), T, stream_)); }
     count_kernel(); count_kernel();
     for (const ClipBlockW& b : clip_blocks_) {
         layer_norm(b.attn_ln, x.f(), M, h.f(), 0);
@@ -2009,7 +2019,7 @@ void Engine::clip_forward_dev(const int32_t* tokens, int n, int T, float* out) {
         gemm(a.f(), (int)M, b.out.bt, b.out.bias, C, C, x.f(), C, x.f(), C, 0);               // x += out(attn)
         layer_norm(b.mlp_ln, x.f(), M, h.f(), 0);
         gemm(h.f(), (int)M, b.fc1.bt, b.fc1.bias, C, 4 * C, f.f(), 4 * C, nullptr, 0, 0);
-        SDMI_HIP(launch_quick_gelu(f.f(), M * 4 * C, stream_));
+        { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_quick_gelu(f.f(), M * 4 * C, stream_)); }
         count_kernel();
         gemm(f.f(), (int)M, b.fc2.bt, b.fc2.bias, 4 * C, C, x.f(), C, x.f(), C, 0);           // x += fc2(gelu(fc1))
     }
@@ -2024,10 +2034,10 @@ void Engine::unet_forward_dev(const float* x_nchw, int t, const float* context, 
     std::vector<int> kv(n, T), ts(1, t);
     unet_prepare(context, n, T, kv.data(), ts);
     Buf xin(this, (size_t)n * H * W * 4 * 4), xout(this, (size_t)n * H * W * 4 * 4);
-    SDMI_HIP(launch_nchw_to_nhwc(x_nchw, xin.f(), n, 4, H, W, 1.0f, stream_));
+    { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_nchw_to_nhwc(x_nchw, xin.f(), n, 4, H, W, 1.0f, stream_)); }
     count_kernel();
     unet_run(xin.f(), n, 0, xout.f());
-    SDMI_HIP(launch_nhwc_to_nchw(xout.f(), out_nchw, n, 4, H, W, stream_));
+    { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_nhwc_to_nchw(xout.f(), out_nchw, n, 4, H, W, stream_)); }
     count_kernel();
     unet_release();
 }
@@ -2061,7 +2071,7 @@ void Engine::sample_latent_dev(const float* context, int n, int T, const float* 
     const long long per_half = (long long)n * H * W * 4;
     Buf latent(this, per_half * 4), unet_in(this, 2 * per_half * 4), eps(this, 2 * per_half * 4);
     SDMI_HIP(launch_nchw_to_nhwc(init_latent, latent.f(), n, 4, H, W, 1.0f, stream_));
-    SDMI_HIP(launch_dup_latent(latent.f(), unet_in.f(), per_half, stream_));
+    { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_dup_latent(latent.f(), unet_in.f(), per_half, stream_)); }
     count_kernel(); count_kernel();
     for (size_t s = 0; s < ts.size(); ++s) {
         const size_t t = (size_t)ts[s];
@@ -2074,10 +2084,10 @@ void Engine::sample_latent_dev(const float* context, int n, int T, const float* 
         c.sqrt_prev = (float)std::sqrt(prev);
         c.dir_coef = (float)std::sqrt(1.0 - prev - 0.0);                                 // :153 (sigma = 0)
         unet_run(unet_in.f(), nb, (int)s, eps.f());
-        SDMI_HIP(launch_cfg_ddim(eps.f(), latent.f(), unet_in.f(), per_half, c, stream_));
+        { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_cfg_ddim(eps.f(), latent.f(), unet_in.f(), per_half, c, stream_)); }
         count_kernel();
     }
-    SDMI_HIP(launch_nhwc_to_nchw(latent.f(), latent_out, n, 4, H, W, stream_));
+    { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_nhwc_to_nchw(latent.f(), latent_out, n, 4, H, W, stream_)); }
     count_kernel();
     unet_release();
 }
@@ -2134,7 +2144,7 @@ void Engine::encode_image_dev(const float* img_nchw, int n, float* latent_nchw) 
     const size_t img_elems = (size_t)3 * H * W, lat_elems = (size_t)4 * cfg_.latent_h * cfg_.latent_w;
     for (int i = 0; i < n; ++i) {
         Act rgb = new_act(1, H, W, 4, /*dt=*/0);
-        SDMI_HIP(launch_nchw3_to_nhwc4(img_nchw + i * img_elems, rgb.p, 1, H, W, stream_));
+        { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_nchw3_to_nhwc4(img_nchw + i * img_elems, rgb.p, 1, H, W, stream_)); }
         count_kernel();
         Act x = new_act(1, H, W, enc_conv_in_.cout);
         conv(enc_conv_in_, rgb, x, 1, 0, nullptr, 0, nullptr);
@@ -2170,7 +2180,7 @@ void Engine::encode_image_dev(const float* img_nchw, int n, float* latent_nchw) 
         conv(quant_conv_, m8, q8, 1, 0, nullptr, 0, nullptr);
         release(m8);
         // latent.slice([0..n, 0..4]): the first 4 of the 8 channels, NHWC8 -> NCHW4
-        SDMI_HIP(launch_nhwc_to_nchw_slice(q8.p, latent_nchw + i * lat_elems, 1, 8, 4, q8.h, q8.w, stream_));
+        { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_nhwc_to_nchw_slice(q8.p, latent_nchw + i * lat_elems, 1, 8, 4, q8.h, q8.w, stream_)); }
         count_kernel();
         release(q8);
     }
@@ -2186,12 +2196,12 @@ void Engine::decode_latent_dev(const float* latent_nchw, int n, float in_scale, 
     const size_t lat_elems = (size_t)4 * H * W, img_elems = (size_t)3 * 64 * H * W;
     for (int i = 0; i < n; ++i) {  // one image at a time: peak activations are ~1 GB per image at 512x512
         Buf z(this, lat_elems * 4);
-        SDMI_HIP(launch_nchw_to_nhwc(latent_nchw + i * lat_elems, z.f(), 1, 4, H, W, in_scale, stream_));
+        { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_nchw_to_nhwc(latent_nchw + i * lat_elems, z.f(), 1, 4, H, W, in_scale, stream_)); }
         count_kernel();
         Act img = new_act(1, 8 * H, 8 * W, 3, /*dt=*/0);  // RGB stays fp32 (conv_out writes fp32 in both precisions)
         decode_one(z.f(), 1, img);
-        if (rgb_u8) SDMI_HIP(launch_image_to_u8(img.p, rgb_u8 + i * img_elems, (long long)img_elems, stream_));
-        else SDMI_HIP(launch_nhwc_to_nchw(img.p, img_nchw + i * img_elems, 1, 3, 8 * H, 8 * W, stream_));
+        if (rgb_u8) { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_image_to_u8(img.p, rgb_u8 + i * img_elems, (long long)img_elems, stream_)); }
+        else { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_nhwc_to_nchw(img.p, img_nchw + i * img_elems, 1, 3, 8 * H, 8 * W, stream_)); }
         count_kernel();
         release(img);
     }
@@ -2419,7 +2429,7 @@ void Engine::op_timestep_embedding(int t, int dim, float* out) {
     Buf td(this, sizeof(int));
     SDMI_HIP(hipMemcpyAsync(td.p, &t, sizeof(int), hipMemcpyHostToDevice, stream_));
     SDMI_HIP(hipStreamSynchronize(stream_));
-    SDMI_HIP(launch_timestep_embedding((const int*)td.p, 1, dim, out, stream_));
+    { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_timestep_embedding((const int*)td.p, 1, dim, out, stream_)); }
     SDMI_HIP(hipStreamSynchronize(stream_));
 }
 
@@ -2540,7 +2550,7 @@ double Engine::bench_conv(int n, int cin, int h, int w, int cout, int k, int str
         }
         if (opt_gemm_probe_ && a.p3) {
             // diagnostic: one more launch in which every workgroup of the plane GEMM stamps its phases (ConvGemm::probe; 100 MHz clock)
-            constexpr size_t kMaxBlocks = 1 << 13;
+            constexpr size_t kMaxBlocks = kGemmProbeBlocks;
             Buf pb(this, kMaxBlocks * 24 * sizeof(unsigned long long));
             SDMI_HIP(hipMemsetAsync(pb.p, 0, kMaxBlocks * 24 * sizeof(unsigned long long), stream_));
             if (opt_bench_cold_) {

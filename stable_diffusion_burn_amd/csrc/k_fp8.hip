@@ -486,9 +486,9 @@ __global__ void gn_apply_fp8_kernel(const unsigned short* __restrict__ x, unsign
         o[1] = cvt4_e4m3(v.v[4] * inv, v.v[5] * inv, v.v[6] * inv, v.v[7] * inv);
         *reinterpret_cast<u32x2*>(y + ybase + (long long)row * Cp + c8 * 8) = o;
         if ((c8 & 3) == 0) ys[sbase + (long long)row * (Cp >> 5) + (c8 >> 2)] = (unsigned char)sb;
-        if (c8 < pad8) {
-            *reinterpret_cast<u32x2*>(y + ybase + (long long)row * Cp + C + c8 * 8) = u32x2{0u, 0u};
-            if ((c8 & 3) == 0) ys[sbase + (long long)row * (Cp >> 5) + ((C + c8 * 8) >> 5)] = (unsigned char)127;
+        for (int g = c8; g < pad8; g += cq) {     // (C = 32: four threads per row write twelve pad groups)
+            *reinterpret_cast<u32x2*>(y + ybase + (long long)row * Cp + C + g * 8) = u32x2{0u, 0u};
+            if ((g & 3) == 0) ys[sbase + (long long)row * (Cp >> 5) + ((C + g * 8) >> 5)] = (unsigned char)127;
         }
     }
 }
@@ -556,9 +556,9 @@ __device__ __forceinline__ void mx_store8(const Q8& v, unsigned char* yrow, unsi
     *reinterpret_cast<u32x2*>(yrow + c8 * 8) = o;
     if ((c8 & 3) == 0) srow[c8 >> 2] = (unsigned char)sb;
     const int pad8 = (Cp - C) >> 3;
-    if (c8 < pad8) {
-        *reinterpret_cast<u32x2*>(yrow + C + c8 * 8) = u32x2{0u, 0u};
-        if ((c8 & 3) == 0) srow[(C + c8 * 8) >> 5] = (unsigned char)127;
+    for (int g = c8; g < pad8; g += (C >> 3)) {     // every pad group is written, also when the row has fewer threads than pad groups (C = 32)
+        *reinterpret_cast<u32x2*>(yrow + C + g * 8) = u32x2{0u, 0u};
+        if ((g & 3) == 0) srow[(C + g * 8) >> 5] = (unsigned char)127;
     }
 }
 
@@ -653,9 +653,9 @@ __global__ __launch_bounds__(256) void layer_norm_fp8_kernel(const unsigned shor
                 *reinterpret_cast<u32x2*>(yrow + f * 8) = w;
                 if ((f & 3) == 0) srow[f >> 2] = (unsigned char)sb;
                 const int pad8 = (Cp - C) >> 3;
-                if (f < pad8) {
-                    *reinterpret_cast<u32x2*>(yrow + C + f * 8) = u32x2{0u, 0u};
-                    if ((f & 3) == 0) srow[(C + f * 8) >> 5] = (unsigned char)127;
+                for (int g = f; g < pad8; g += cq) {
+                    *reinterpret_cast<u32x2*>(yrow + C + g * 8) = u32x2{0u, 0u};
+                    if ((g & 3) == 0) srow[(C + g * 8) >> 5] = (unsigned char)127;
                 }
             }
         }

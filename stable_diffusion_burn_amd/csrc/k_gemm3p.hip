@@ -355,6 +355,7 @@ hipError_t launch_conv_gemm3p(const ConvGemm& p, int cfg, hipStream_t stream) {
     const int MT = (p.M + bm - 1) / bm, NT = (p.N + bno - 1) / bno;
     const dim3 grid = gemm_grid(p, MT * NT);
     if (p.probe) {   // diagnostic instantiations (option gemm_probe): the three 8-wave tiles the batch-1 model uses most
+        if ((unsigned long long)grid.x * grid.z > (unsigned long long)kGemmProbeBlocks) return hipErrorInvalidValue;   // the stamps would run past the buffer
         switch (cfg) {
             case 0: return launch_cfg_3p<4, 5, 4, 2, 2, true>(p, grid, stream);
             case 3: return launch_cfg_3p<2, 5, 4, 2, 2, true>(p, grid, stream);

@@ -22,8 +22,8 @@ __host__ __device__ constexpr int s3_plane_pos(int j) { return ((j & 15) >> 2) *
 __host__ __device__ constexpr long long s3_plane_byte(int c, int pl) { return (long long)(c >> 5) * 192 + pl * 64 + s3_plane_pos(c & 31) * 2; }
 
 // x -> (h, m, l) bf16 bit patterns with x = h + m + l exactly, and fp32 semantics at the edges of the range (unlike the in-loop
-// S3SplitT, which assumes finite operands well inside it): NaN / +-inf stay in h with m = l = 0 (so inf * w = inf, inf * 0 = NaN,
-// as in fp32), and a finite x that round-to-nearest would carry to inf (|x| >= 0x7F7F8000) takes the TRUNCATED h, which is finite and
+// S3SplitT, which assumes finite operands well inside it): NaN / +-inf stay in h with m = l = 0 (the operand itself is represented as fp32 has it; the PRODUCT inf * w may
+// still come out NaN where fp32 gives +-inf, because w's low-order planes can be zero: sdmi.h, "fp32 semantics"), and a finite x that round-to-nearest would carry to inf (|x| >= 0x7F7F8000) takes the TRUNCATED h, which is finite and
 // leaves r = x - h exact.  |x| < 2^-109: m / l fall below bf16's normal range and are flushed, i.e. the tail of a tiny value is dropped
 // (absolute error < 2^-118 per product operand: sdmi.h, "fp32 semantics").
 __device__ __forceinline__ void s3_split1(float x, unsigned& h, unsigned& m, unsigned& l) {

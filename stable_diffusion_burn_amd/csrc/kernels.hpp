@@ -55,6 +55,9 @@ struct ConvGemm {
                                 // stores 24 words per workgroup (see conv_gemm3p_kernel)
 };
 
+// capacity of ConvGemm::probe in workgroups (24 words each); launch_conv_gemm3p refuses a probe launch with a larger grid
+constexpr int kGemmProbeBlocks = 1 << 13;
+
 // launch grid of a GEMM kernel: (tiles rounded up to the 8 XCDs) x slices
 inline dim3 gemm_grid(const ConvGemm& p, int tiles) {
     return dim3((unsigned)(((tiles + 7) / 8) * 8), 1, (unsigned)p.splits);

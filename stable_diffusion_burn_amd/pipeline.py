@@ -313,7 +313,7 @@ class StableDiffusion:
         check(self._lib.sdmi_last_call_stats(self._ctx, C.byref(ms), C.byref(nk), C.byref(fl)))
         return {"gpu_ms": ms.value, "kernels": nk.value, "flops": fl.value}
 
-    PROFILE_CLASSES = ("conv_gemm", "splitk_reduce", "attention", "group_norm", "layer_norm", "conv_gemm_fp8", "conv_gemm_split", "split_rows", "other")
+    PROFILE_CLASSES = ("conv_gemm", "splitk_reduce", "attention", "group_norm", "layer_norm", "conv_gemm_fp8", "conv_gemm_split", "split_rows", "other", "geglu")
 
     def profile_overhead_us(self) -> float:
         """what an empty HIP-event pair reads on the engine's stream (calibrated when profiling was switched on; subtracted from every sample)"""

@@ -46,3 +46,32 @@ def unpack_prompt(packed, t: int, tu: int, ctx_dim: int):
     cond = packed[: t * ctx_dim].reshape(t, ctx_dim)
     uncond = packed[t * ctx_dim: (t + tu) * ctx_dim].reshape(tu, ctx_dim)
     return cond, uncond
+
+
+def share_flat_array(make, rank: int, world: int, barrier, tag: str, directory: str = "/dev/shm"):
+    """One host copy of a large read-only float32 array for all ranks of a node (bench.py: the 3.6 GB synthetic weight image, which costs
+    seconds of numpy RNG per rank on shared cores).  Rank 0 calls `make()` and writes the result to `directory/sdmi_<tag>.f32`; after
+    `barrier()` the other ranks map the file read-only (np.memmap: the page cache holds ONE copy); after a second barrier rank 0 unlinks
+    the name (the mappings stay valid).  world == 1: returns make().  Not part of the data path: no collective, only two barriers."""
+    import os
+    import numpy as np
+    if world == 1:
+        return np.ascontiguousarray(make(), dtype=np.float32)
+    path = os.path.join(directory, f"sdmi_{tag}.f32")
+    arr = None
+    if rank == 0:
+        arr = np.ascontiguousarray(make(), dtype=np.float32)
+        tmp = path + ".tmp"
+        with open(tmp, "wb") as f:
+            arr.tofile(f)
+        os.replace(tmp, path)          # the name appears only once the file is complete
+    barrier()
+    if rank != 0:
+        arr = np.memmap(path, dtype=np.float32, mode="r")
+    barrier()
+    if rank == 0:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    return arr

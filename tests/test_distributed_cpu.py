@@ -62,6 +62,42 @@ def test_broadcast_and_sharding_world2():
     assert covered == list(range(global_batch))
 
 
+def _share_worker(rank, world, port, tag, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def make():
+        calls.append(rank)
+        return np.random.default_rng(7).standard_normal(100_003).astype(np.float32)
+
+    arr = sharding.share_flat_array(make, rank, world, dist.barrier, tag)
+    dist.barrier()
+    q.put((rank, len(calls), float(np.asarray(arr, np.float64).sum()), arr.shape, os.path.exists(f"/dev/shm/sdmi_{tag}.f32")))
+    dist.destroy_process_group()
+
+
+def test_weight_image_is_generated_once_and_mapped_by_the_other_ranks():
+    """bench.py --gpus N: rank 0 generates the synthetic weight image, the others map it (sharding.share_flat_array)"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    tag = f"test_{os.getpid()}"
+    port = _free_port()
+    procs = [ctx.Process(target=_share_worker, args=(r, world, port, tag, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = float(np.random.default_rng(7).standard_normal(100_003).astype(np.float32).astype(np.float64).sum())
+    assert [g[1] for g in got] == [1, 0]                    # generated on rank 0 only
+    assert all(g[2] == want and g[3] == (100_003,) for g in got)
+    assert not any(g[4] for g in got)                       # the name is gone once everybody has mapped it
+
+
 def test_single_process_broadcast_is_noop():
     p = torch.arange(6, dtype=torch.float32)
     assert sharding.broadcast_prompt(p) is p

@@ -108,6 +108,42 @@ def test_config2_20_steps_cfg(sd_full):
     assert diff.max() <= 1
 
 
+# ---- the reference's real prompt shape: unpadded contexts, Tc != Tu (stablediffusion/mod.rs:198-210) ----------------------
+def _q2():
+    path = GOLD / "sd14_synth_q2.npz"
+    if not path.exists():
+        pytest.skip("tests/golden/sd14_synth_q2.npz not generated yet (tests/golden/gen_golden_q2.py)")
+    return np.load(path), syn.initial_latent(0)[None], syn.cond_context(0, 77)[None], syn.uncond_context(2)
+
+
+def test_unpadded_contexts_full_size_fp32(sd_full):
+    """Tc = 77, Tu = 2 at the full model size, 20 steps, CFG 7.5, fp32: the two halves of the CFG batch attend over different key counts
+    (per-row key count of the batch-2n forward).  Same bars as configs[1]."""
+    g, lat, ctx, unc = _q2()
+    got = sd_full.sample_latent(ctx, unc, 7.5, 20, init_latent=lat)[0].astype(np.float64)
+    e32, e64 = np.abs(got - g["latent32"]).max(), np.abs(got - g["latent64"]).max()
+    gap = np.abs(g["latent32"].astype(np.float64) - g["latent64"]).max()
+    print(f"Tc=77 Tu=2 final latent: |gpu-f32|={e32:.2e} |gpu-f64|={e64:.2e} |f32-f64|={gap:.2e} absmax={np.abs(g['latent64']).max():.1f}")
+    assert e32 < 1e-3 and e64 <= max(1e-3, 2 * gap)
+
+
+@pytest.mark.parametrize("precision", [1, 2])
+def test_unpadded_contexts_full_size_reduced_precision(precision):
+    """the same call in bf16 and in precision 2 (defaults): relative RMS of the final latent against the fp64 fixture under the bars of the
+    T = Tu = 77 cases (bf16: BF16_BAR_LATENT20; precision 2: MX_BAR_LATENT20 of the default set)"""
+    from stable_diffusion_burn_amd import ModelConfig, StableDiffusion
+    g, lat, ctx, unc = _q2()
+    sd = StableDiffusion(ModelConfig(precision=precision))
+    try:
+        sd.load_weights(syn.SyntheticWeights(), clip=False, vae_encoder=False)
+        got = sd.sample_latent(ctx, unc, 7.5, 20, init_latent=lat)[0]
+        r = _rel_rms(got, g["latent64"])
+        print(f"Tc=77 Tu=2, precision {precision}: rel-RMS of the 20-step latent vs fp64 = {r:.3e}")
+        assert np.isfinite(got).all() and r < (BF16_BAR_LATENT20 if precision == 1 else MX_BAR_LATENT20[MX_DEFAULT_WIDE])
+    finally:
+        sd.close()
+
+
 def test_per_step_drift(sd_full):
     """Latent after each of the first 3 steps stays within the oracle's own f32/f64 gap (x4)."""
     g = np.load(GOLD / "sd14_synth_cfg2.npz")
@@ -209,6 +245,7 @@ def test_config3_bf16_batch16_50_steps():
 #                              (the quantisation of fp8_linear = 0 alone, fp64 vs fp64: 5.09e-2 / 5.08e-2 -- the GPU pays what the format costs)
 #                              decode of the exact latent (both modes: the decoder's fp8 set does not depend on fp8_linear): RGB 2.05e-2
 MX_BAR_LATENT20 = {0: 7.8e-2, 1: 1.21e-1}      # vs the exact fp64 network, by fp8_linear
+MX_DEFAULT_WIDE = 0                             # the engine's default fp8_linear (accuracy budget: 6e-2 on this latent; measured 5.2e-2 / 8.1e-2)
 MX_BAR_LATENT20_SAMEQ = 9.8e-2                  # fp8_linear = 0 vs the fp64 network with the same quantisation
 MX_BAR_RGB = {0: 3.1e-2, 1: 3.1e-2}
 
@@ -216,8 +253,8 @@ MX_BAR_RGB = {0: 3.1e-2, 1: 3.1e-2}
 @pytest.mark.parametrize("wide", [1, 0])
 def test_config5_mxfp8_batch16_20_steps(wide):
     """configs[4] as BASELINE.json states it for one GPU: batch 16, 20 DDIM steps, CFG 7.5, precision = 2 (reference arithmetic:
-    stablediffusion/mod.rs:102-160 in f32).  wide = 1: the default -- bf16 + MXFP8 on the ResBlock convolutions, the transformer blocks'
-    Linear layers and the UNet's 1x1 / up / down convolutions; wide = 0: option fp8_linear = 0, the ResBlock 3x3 convolutions only.  Samples 0 and 1
+    stablediffusion/mod.rs:102-160 in f32).  wide = 0: the default -- bf16 + MXFP8 on the ResBlock / ResnetBlock 3x3 convolutions; wide = 1: option fp8_linear = 1, also the transformer blocks'
+    Linear layers and the UNet's 1x1 / up / down convolutions.  Samples 0 and 1
     against the fp64 fixtures of tests/golden/gen_golden_cfg5.py: the exact network (what the format costs end to end, 20 chained CFG steps
     at the real model size) and -- for wide = 0, whose quantisation the fixture reproduces -- the fp64 network with the same MXFP8
     quantisation.  Every sample finite; a sample's result does not depend on its batch position (bit-exact)."""
