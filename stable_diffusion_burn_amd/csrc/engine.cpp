@@ -98,7 +98,7 @@ hipEvent_t Engine::prof_event() {
     return e;
 }
 
-Engine::ProfScope::ProfScope(Engine* e_, int cls_, double flops_, double bytes_, int n_launch_) : e(e_), cls(cls_), flops(flops_), bytes(bytes_), n_launch(n_launch_) {
+Engine::ProfScope::ProfScope(Engine* e_, int cls_, double flops_, double bytes_) : e(e_), cls(cls_), flops(flops_), bytes(bytes_) {
     if (!e->profiling_) return;
     a = e->prof_event();
     b = e->prof_event();
@@ -108,7 +108,7 @@ Engine::ProfScope::ProfScope(Engine* e_, int cls_, double flops_, double bytes_,
 Engine::ProfScope::~ProfScope() {
     if (!a) return;
     (void)hipEventRecord(b, e->stream_);
-    e->prof_pending_.push_back({cls, a, b, flops, bytes, n_launch});
+    e->prof_pending_.push_back({cls, a, b, flops, bytes});
     if (e->prof_pending_.size() >= 2048) {
         try { e->prof_flush(); } catch (...) {}
     }
@@ -145,7 +145,7 @@ void Engine::prof_flush() {
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             ms = (float)std::max(0.0, (double)ms - prof_overhead_ms_);
             prof_[p.cls].ms += ms;
-            prof_[p.cls].launches += p.n_launch;
+            prof_[p.cls].launches += 1;
             prof_[p.cls].flops += p.flops;
             prof_[p.cls].bytes += p.bytes;
         }
@@ -978,9 +978,8 @@ void Engine::release(Act& a) {
     if (!a.view) {
         if (a.p) pool_.free(a.p);
         if (a.p3) pool_.free(a.p3);
-        if (a.gn_part) pool_.free(a.gn_part);
     }
-    a.p = nullptr; a.p3 = nullptr; a.gn_part = nullptr;
+    a.p = nullptr; a.p3 = nullptr;
 }
 
 Act Engine::slice(const Act& parent, int c_off, int c) {
@@ -992,7 +991,6 @@ Act Engine::slice(const Act& parent, int c_off, int c) {
         a.p3 = (char*)parent.p3 + (size_t)(c_off / 32) * 192;
     }
     a.c = c; a.ld = parent.stride(); a.view = true;
-    a.gn_part = nullptr;      // (statistics belong to the whole tensor)
     return a;
 }
 
@@ -1049,7 +1047,6 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "gemm_f32s") opt_gemm_f32s_ = std::stoi(value);
     else if (key == "bench_cold") opt_bench_cold_ = std::stoi(value);
     else if (key == "gemm_probe") opt_gemm_probe_ = std::stoi(value);
-    else if (key == "gn_from_reduce") opt_gn_from_reduce_ = std::stoi(value);
     else if (key == "gemm_planes") opt_gemm_planes_ = (value == "default") ? kGemmPlanesDefault : std::stoi(value);
     else if (key == "gemm3x_variant") opt_gemm3x_variant_ = std::stoi(value);
     else if (key == "geglu_fuse") opt_geglu_fuse_ = std::stoi(value);
@@ -1336,10 +1333,6 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         {
             ProfScope ps(this, PC_SPLITK_REDUCE, 0, (double)(splits + 1) * p.slab_stride * 4.0);
             if (in_dt) SDMI_HIP(launch_splitk_reduce_bf16(p, stream_));
-            else if (p.gn_part && splitk_reduce_stats_supported(p, p.NB, p.Ho * p.Wo, 32)) {
-                SDMI_HIP(launch_splitk_reduce_stats(p, p.NB, p.Ho * p.Wo, 32, p.gn_part, stream_));
-                p.gn_done = 1;
-            }
             else SDMI_HIP(launch_splitk_reduce(p, stream_));
             count_kernel();
         }
@@ -1352,7 +1345,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
 }
 
 void Engine::conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, const float* rowvec, int rowvec_stride,
-                  const Act* resid, bool pad_br, bool want_gn) {
+                  const Act* resid, bool pad_br) {
     if (x.c != w.cin) throw Error(SDMI_ERR_INVALID, "conv: input channels mismatch");
     // pad_br: rows / columns past the bottom / right edge read as zero through the kernels' range check, so the
     // asymmetric padding is pad = 0 plus one more output row / column than a symmetric pad-0 conv has
@@ -1377,14 +1370,6 @@ void Engine::conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, con
     if (x.dt != w.dt) throw Error(SDMI_ERR_STATE, "conv: activation / weight storage types disagree");
     p.out_mode = x.dt ? (y.dt ? 0 : 1) : (y.dt ? 2 : 0);
     if (resid && !x.dt && y.dt) throw Error(SDMI_ERR_STATE, "conv: residual not supported on the fp32->bf16 layers");
-    if (want_gn && opt_gn_from_reduce_ && !x.dt && !y.dt && !y.view && !y.gn_part && y.c % 32 == 0) {
-        // the statistics of the output, if this layer turns out to run split-K: produced by its combine launch (k_norm.hip)
-        p.gn_part = pool_.alloc(gn_partials_bytes(y.n, y.h * y.w, y.c));
-        try { launch_gemm(p, x.dt); } catch (...) { pool_.free(p.gn_part); throw; }
-        if (p.gn_done) y.gn_part = p.gn_part;
-        else pool_.free(p.gn_part);
-        return;
-    }
     launch_gemm(p, x.dt);
 }
 
@@ -1463,15 +1448,8 @@ void Engine::gemm_geglu(const float* x, long long rows, const float* bt, const f
 void Engine::group_norm(const NormW& w, const Act& x, Act& y, bool silu) {
     const int hw = x.h * x.w;
     if (x.dt != y.dt) throw Error(SDMI_ERR_STATE, "group_norm: in/out storage types disagree");
-    if (x.gn_part && !x.dt && x.p && !y.view) {   // the split-K combine that wrote x left its statistics: the apply pass alone
-        ProfScope ps(this, PC_GROUP_NORM, 0, 2.0 * (double)x.bytes(), 1);
-        const bool planes = y.p3 && !y.p;
-        SDMI_HIP(launch_group_norm_apply(x.p, planes ? y.p3 : (void*)y.p, planes, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, x.gn_part, stream_));
-        count_kernel();
-        return;
-    }
     Buf part(this, x.dt ? gn_partials_bytes_bf16(x.n, hw, x.c) : gn_partials_bytes(x.n, hw, x.c));
-    ProfScope ps(this, PC_GROUP_NORM, 0, 2.0 * (double)x.bytes(), 2);  // algorithmic: one read + one write; two launches (statistics, apply)
+    ProfScope ps(this, PC_GROUP_NORM, 0, 2.0 * (double)x.bytes());  // algorithmic: one read + one write
     if (y.view) throw Error(SDMI_ERR_STATE, "group_norm: output must be dense");
     if (!x.p) throw Error(SDMI_ERR_STATE, "group_norm: the input must exist as fp32");
     if (y.p3 && !y.p) {   // the consumer is a plane GEMM: the normalised tensor is written as three bf16 planes only
@@ -1578,7 +1556,7 @@ void Engine::res_block(const ResW& w, const Act& x, Act& y, int step) {
         // the normalised tensors have one consumer, a 3x3 convolution: on the fp32 engine they exist only as bf16 planes (k_gemm3p.hip)
         Act h1 = plane_gemm(x.c, w.cout) ? new_act3(x.n, x.h, x.w, x.c, 2) : new_act(x.n, x.h, x.w, x.c);
         group_norm(w.norm_in, x, h1, true);
-        conv(w.conv_in, h1, h2, 1, 0, rowvec, 0, nullptr, false, /*want_gn=*/true);     // h2 feeds norm_out
+        conv(w.conv_in, h1, h2, 1, 0, rowvec, 0, nullptr);
         release(h1);
     }
     // the shortcut's result is the residual of conv_out: it goes through y's fp32 buffer, or through a temporary when y exists as planes only
@@ -1633,7 +1611,7 @@ void Engine::group_norm_fp8(const NormW& w, const Act& x, ActQ& y, bool silu) {
     const int hw = x.h * x.w;
     if (x.dt != 1 || y.c != x.c) throw Error(SDMI_ERR_STATE, "group_norm_fp8: bf16 input of matching width expected");
     Buf part(this, gn_partials_bytes_bf16(x.n, hw, x.c));
-    ProfScope ps(this, PC_GROUP_NORM, 0, (double)x.bytes() + (double)x.rows() * (y.cp + y.cp / 32), 2);
+    ProfScope ps(this, PC_GROUP_NORM, 0, (double)x.bytes() + (double)x.rows() * (y.cp + y.cp / 32));
     SDMI_HIP(launch_group_norm_fp8(x.p, y.q, y.s, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_));
     count_kernel(); count_kernel();
 }

@@ -72,8 +72,6 @@ struct Act {
     bool view = false;
     void* p3 = nullptr;
     int ld3 = 0;       // bytes between pixels of p3
-    void* gn_part = nullptr;   // not null: the GroupNorm statistics (32 groups) of this tensor, left by the split-K combine that produced it (k_norm.hip
-                               // splitk_reduce_stats_kernel; layout gn_partials_bytes) -- Engine::group_norm then launches its apply pass only
     size_t bytes3() const { return (size_t)rows() * (size_t)(c / 32) * 192; }
     long long rows() const { return (long long)n * h * w; }
     int stride() const { return ld ? ld : c; }
@@ -261,9 +259,8 @@ private:
     void release(Act& a);
     // pad_br: zero padding on the bottom / right only (PaddingCfg::new(0, 1, 0, 1), the VAE encoder's downsampler)
     void probe_report(void* pb_dev, size_t max_blocks, int n, int cin, int h, int w, int cout, int k, int tile_cfg, int splitk);
-    // want_gn: the output feeds a GroupNorm over exactly this tensor -- if the layer runs split-K (fp32), its combine leaves the statistics in y.gn_part
     void conv(const ConvW& w, const Act& x, Act& y, int stride, int ups, const float* rowvec, int rowvec_stride,
-              const Act* resid, bool pad_br = false, bool want_gn = false);
+              const Act* resid, bool pad_br = false);
     static Act slice(const Act& parent, int c_off, int c);   // channel-slice view
     // A3 / C3: the input / output as three bf16 planes (dense rows: 192 bytes per 32 channels); A and / or C may then be null
     void gemm(const float* A, int a_rows, const float* bt, const float* bias, int cin, int cout, float* C, int ldc,
@@ -345,11 +342,11 @@ public:
 
 private:
     struct ProfScope {
-        Engine* e; int cls; double flops, bytes; int n_launch; hipEvent_t a = nullptr, b = nullptr;
-        ProfScope(Engine* e_, int cls_, double flops_ = 0, double bytes_ = 0, int n_launch_ = 1);    // n_launch: kernels inside the scope (GroupNorm: statistics + apply)
+        Engine* e; int cls; double flops, bytes; hipEvent_t a = nullptr, b = nullptr;
+        ProfScope(Engine* e_, int cls_, double flops_ = 0, double bytes_ = 0);
         ~ProfScope();
     };
-    struct ProfPending { int cls; hipEvent_t a, b; double flops, bytes; int n_launch; };
+    struct ProfPending { int cls; hipEvent_t a, b; double flops, bytes; };
     hipEvent_t prof_event();
     bool profiling_ = false;
     std::vector<hipEvent_t> prof_free_;
@@ -429,7 +426,6 @@ private:
     static constexpr int kGemmPlanesDefault = 1;
     int opt_gemm_planes_ = kGemmPlanesDefault;   // precision = 0: k_gemm3p.hip (activations as bf16 planes too, no split in the k loop): 0 never, 1 every launch that would take a k_gemm3x.hip tile,
                                 // 2 = A/B switch (tests): every launch that chose a k_gemm3x.hip tile runs on the nearest k_gemm3p.hip tile, its fp32 input converted by split3_rows_kernel in front of it
-    int opt_gn_from_reduce_ = 1;   // fp32: 1 = split-K combines whose output feeds a GroupNorm also produce its statistics (one launch less per GroupNorm); 0 = never (A/B)
     int opt_gemm_probe_ = 0;    // bench_conv: 1 = one extra launch with per-workgroup phase stamps (ConvGemm::probe), summary on stderr
     unsigned long long* probe_buf_ = nullptr;
     int opt_bench_cold_ = 0;    // bench_conv: 1 = evict the weights from the Infinity Cache between timed launches (what a layer sees inside the model)

@@ -190,121 +190,6 @@ static hipError_t launch_group_norm_any(const float* x, void* y, bool planes, co
     return hipGetLastError();
 }
 
-// ---- split-K combine that also produces the GroupNorm statistics of its output (round 4) ---------------------------------------------
-// A convolution whose k slices went to fp32 slabs is finished by a reduce launch (k_gemm.hip), and where its output feeds a GroupNorm the
-// statistics pass then re-reads the tensor just written (fp32 batch 1: 1 220 gn_stats launches x 5.6 us per image).  Here the reduce runs in
-// the GEOMETRY of gn_stats_kernel -- block = cq x R threads on one (sample, row chunk), a thread owns one float4 column -- sums the slabs
-// in slice order, applies the epilogue (bias, time-embedding row, residual), stores the result (fp32 and / or planes) and accumulates the
-// same shifted sums from the values it holds: pivot = the thread's own first value (any sample of the data keeps |x - p| = O(sigma)); the
-// R thread rows of a channel are merged in fp64 in fixed order with the pairwise (Chan) update, the tail is gn_stats_kernel's.  The partials
-// have the layout gn_apply_kernel reads, so the GroupNorm is one launch.
-__global__ void splitk_reduce_stats_kernel(const ConvGemm p, int hw, int G, int rows_per_chunk, double* __restrict__ part) {
-    extern __shared__ float sh[];  // [3][R][C] floats (pivot, sum, square sum), then [2][C] doubles
-    const int C = p.N;
-    const int cq = C >> 2;
-    const int R = blockDim.x / cq;
-    const int tid = threadIdx.x;
-    const int c4 = tid % cq;
-    const int r0 = tid / cq;
-    const int chunk = blockIdx.x, chunks = gridDim.x, smp = blockIdx.y;
-    const int row_begin = chunk * rows_per_chunk;
-    const int row_end = min(row_begin + rows_per_chunk, hw);
-    const int n = c4 * 4;
-    f32x4 add = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) add += *reinterpret_cast<const f32x4*>(p.bias + n);
-    if (p.rowvec) add += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)smp * p.rowvec_stride + n);
-    f32x4 pv = {0.f, 0.f, 0.f, 0.f}, s0 = pv, q0 = pv;
-    int cnt = 0;
-    for (int row = row_begin + r0; row < row_end; row += R) {
-        const long long m = (long long)smp * hw + row;
-        const float* sl = p.slabs + m * p.N + n;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        int s = 0;
-        for (; s + 3 < p.splits; s += 4) {          // four loads in flight, summed in slice order
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(sl + (long long)s * p.slab_stride);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(sl + (long long)(s + 1) * p.slab_stride);
-            const f32x4 a2 = *reinterpret_cast<const f32x4*>(sl + (long long)(s + 2) * p.slab_stride);
-            const f32x4 a3 = *reinterpret_cast<const f32x4*>(sl + (long long)(s + 3) * p.slab_stride);
-            v += a0; v += a1; v += a2; v += a3;
-        }
-        for (; s < p.splits; ++s) v += *reinterpret_cast<const f32x4*>(sl + (long long)s * p.slab_stride);
-        v += add;
-        if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + m * p.ldr + n);
-        if (p.C) *reinterpret_cast<f32x4*>(p.C + m * p.ldc + n) = v;
-        if (p.C3) s3_store4(reinterpret_cast<unsigned char*>(p.C3) + m * p.ldc3, n, v);
-        if (cnt == 0) pv = v;
-        const f32x4 d = v - pv;
-        s0 += d; q0 += d * d;
-        ++cnt;
-    }
-    float* shp = sh;
-    float* shs = sh + R * C;
-    float* shq = sh + 2 * R * C;
-    double* chm = reinterpret_cast<double*>(sh + 3 * R * C);
-    double* chq = chm + C;
-    *reinterpret_cast<f32x4*>(shp + r0 * C + n) = pv;
-    *reinterpret_cast<f32x4*>(shs + r0 * C + n) = s0;
-    *reinterpret_cast<f32x4*>(shq + r0 * C + n) = q0;
-    __syncthreads();
-    const int n_rows = row_end - row_begin;
-    for (int ch = tid; ch < C; ch += blockDim.x) {  // per channel: the R thread rows in fixed order (thread row r holds rows r, r + R, ..)
-        double mean = 0.0, m2 = 0.0, na = 0.0;
-        for (int r = 0; r < R; ++r) {
-            const int c_r = n_rows > r ? (n_rows - r + R - 1) / R : 0;
-            if (!c_r) continue;
-            const double nb = (double)c_r, sb = (double)shs[r * C + ch], qb = (double)shq[r * C + ch];
-            const double mean_b = (double)shp[r * C + ch] + sb / nb;
-            double m2_b = qb - sb * sb / nb;
-            if (m2_b < 0.0) m2_b = 0.0;
-            const double dlt = mean_b - mean, nt = na + nb;
-            mean += dlt * nb / nt;
-            m2 += m2_b + dlt * dlt * na * nb / nt;
-            na = nt;
-        }
-        chm[ch] = mean;
-        chq[ch] = m2;
-    }
-    __syncthreads();
-    gn_merge_group_channels(chm, chq, C, G, (double)n_rows, part + (long long)(smp * chunks + chunk) * G * 2);
-}
-
-bool splitk_reduce_stats_supported(const ConvGemm& p, int n_samples, int hw, int n_group) {
-    const int c = p.N;
-    if (p.splits < 2 || !p.slabs || (long long)n_samples * hw != p.M) return false;
-    if ((c & 3) || (p.C && (p.ldc & 3)) || (p.resid && (p.ldr & 3)) || (p.C3 && (c & 31)) || c / 4 > 1024 || n_group > 64 || c % n_group) return false;
-    if (!p.C && !p.C3) return false;
-    const GnGeom g = gn_geom(hw, c);
-    return (size_t)3 * g.R * c * sizeof(float) + (size_t)2 * c * sizeof(double) <= 64 * 1024;
-}
-
-// the split-K combine of launch_splitk_reduce + the statistics pass of launch_group_norm over its output [n_samples][hw][p.N]; `partials` as for
-// launch_group_norm (gn_partials_bytes).  Follow with launch_group_norm_apply.
-hipError_t launch_splitk_reduce_stats(const ConvGemm& p, int n_samples, int hw, int n_group, void* partials, hipStream_t stream) {
-    if (!splitk_reduce_stats_supported(p, n_samples, hw, n_group)) return hipErrorInvalidValue;
-    const GnGeom g = gn_geom(hw, p.N);
-    const size_t lds = (size_t)3 * g.R * p.N * sizeof(float) + (size_t)2 * p.N * sizeof(double);
-    hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3(g.chunks, n_samples), dim3(g.threads), lds, stream, p, hw, n_group, g.rows_per_chunk,
-                       reinterpret_cast<double*>(partials));
-    return hipGetLastError();
-}
-
-// the apply half of launch_group_norm / launch_group_norm_planes alone, on statistics some producer left in `partials`
-hipError_t launch_group_norm_apply(const float* x, void* y, bool planes, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
-                                   int n_group, float eps, bool silu, const void* partials, hipStream_t stream) {
-    if ((c & 3) || (ldx & 3) || ldx < c || n_group > 64 || c % n_group) return hipErrorInvalidValue;
-    if (c / 4 > 1024 || (planes && (c & 31))) return hipErrorInvalidValue;
-    const GnGeom g = gn_geom(hw, c);
-    const double* part = reinterpret_cast<const double*>(partials);
-    float* yf = reinterpret_cast<float*>(y);
-#define SDMI_GN_APPLY(S, P)                                                                                                        \
-    hipLaunchKernelGGL((gn_apply_kernel<S, P>), dim3(g.chunks, n), dim3(g.threads), 0, stream, x, yf, gamma, beta, hw, c, ldx, n_group, \
-                       eps, g.chunks, g.rows_per_chunk, part, g.rows_per_chunk)
-    if (planes) { if (silu) SDMI_GN_APPLY(true, true); else SDMI_GN_APPLY(false, true); }
-    else { if (silu) SDMI_GN_APPLY(true, false); else SDMI_GN_APPLY(false, false); }
-#undef SDMI_GN_APPLY
-    return hipGetLastError();
-}
-
 hipError_t launch_group_norm(const float* x, float* y, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
                              int n_group, float eps, bool silu, void* partials, hipStream_t stream) {
     return launch_group_norm_any(x, y, false, gamma, beta, n, hw, c, ldx, n_group, eps, silu, partials, stream);

@@ -51,8 +51,6 @@ struct ConvGemm {
                                 // 2 two LDS stages on the 128-row tiles, 4 s_setprio 1 for waves 4-7
     int geglu;                  // large-tile kernels: Bt holds 2 N rows (N value rows, then N gate rows; bias likewise) and the
                                 // epilogue writes value * gelu_erf(gate) -- GEGLU::forward (unet/mod.rs:579-591) without the [M, 2N] tensor
-    void* gn_part;              // in: not null -> the caller wants the GroupNorm statistics of the output (n_group 32) in this buffer (gn_partials_bytes);
-    int gn_done;                // out (Engine::launch_gemm): 1 = they were written (a split-K launch whose combine produced them), 0 = the consumer runs its statistics pass
     unsigned long long* probe;  // diagnostic (option gemm_probe; k_gemm3p.hip tiles 300 / 303 / 304 only): when non-null the PROBE instantiation runs and
                                 // stores 24 words per workgroup (see conv_gemm3p_kernel)
 };
@@ -153,12 +151,6 @@ size_t gn_partials_bytes(int n, int hw, int c);
 hipError_t launch_group_norm(const float* x, float* y, const float* gamma, const float* beta,
                              int n, int hw, int c, int ldx, int n_group, float eps, bool silu,
                              void* partials, hipStream_t stream);
-// split-K combine (fp32 slabs of `p`, as launch_splitk_reduce) that also leaves the GroupNorm statistics of its output [n_samples][hw][p.N] in
-// `partials` (gn_partials_bytes), and the apply half of the GroupNorm on such statistics (k_norm.hip)
-bool splitk_reduce_stats_supported(const ConvGemm& p, int n_samples, int hw, int n_group);
-hipError_t launch_splitk_reduce_stats(const ConvGemm& p, int n_samples, int hw, int n_group, void* partials, hipStream_t stream);
-hipError_t launch_group_norm_apply(const float* x, void* y, bool planes, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
-                                   int n_group, float eps, bool silu, const void* partials, hipStream_t stream);
 hipError_t launch_layer_norm(const float* x, float* y, const float* gamma, const float* beta,
                              int rows, int c, float eps, hipStream_t stream);
 // the same normalisations with the result written as three bf16 planes (k_split3.hpp; y3 dense: (c / 32) * 192 bytes per pixel / row),

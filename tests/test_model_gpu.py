@@ -181,30 +181,6 @@ def test_run_to_run_bit_reproducible(sd_tiny, tiny_dims):
     assert np.array_equal(a, b)
 
 
-def test_group_norm_statistics_from_the_splitk_combine(sd_tiny, tiny_dims):
-    """fp32: where a ResBlock's first convolution runs split-K, its combine launch (k_norm.hip splitk_reduce_stats_kernel) also produces the statistics of
-    the GroupNorm that follows (groupnorm/mod.rs:53-82), and that GroupNorm is its apply pass alone.  A/B against option gn_from_reduce = 0 with split-K
-    forced on every layer: fewer launches, the same UNet output to fp32 rounding (the slab sum is taken in a different association), bit-reproducible."""
-    d = tiny_dims
-    lat, ctx, _ = _inputs(d, 2, 7, 2)
-    try:
-        sd_tiny.set_option("splitk", 3)
-        sd_tiny.set_option("gn_from_reduce", 0)
-        base = sd_tiny.unet.forward(lat, [999], ctx)
-        k0 = sd_tiny.last_call_stats()["kernels"]
-        sd_tiny.set_option("gn_from_reduce", 1)
-        got = sd_tiny.unet.forward(lat, [999], ctx)
-        k1 = sd_tiny.last_call_stats()["kernels"]
-        again = sd_tiny.unet.forward(lat, [999], ctx)
-    finally:
-        sd_tiny.set_option("splitk", 0)
-        sd_tiny.set_option("gn_from_reduce", 1)
-    print(f"kernels per forward: {k0} without, {k1} with the statistics from the combine; max|d| = {np.abs(got - base).max():.2e} (absmax {np.abs(base).max():.2f})")
-    assert k1 < k0
-    assert np.array_equal(got, again)
-    assert np.abs(got - base).max() <= 2e-5 * max(1.0, np.abs(base).max())
-
-
 def test_shape_errors_raise(sd_tiny, tiny_dims):
     d = tiny_dims
     lat, ctx, unc = _inputs(d, 1, 7, 2)
