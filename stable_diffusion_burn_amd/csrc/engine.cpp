@@ -98,7 +98,7 @@ hipEvent_t Engine::prof_event() {
     return e;
 }
 
-Engine::ProfScope::ProfScope(Engine* e_, int cls_, double flops_, double bytes_) : e(e_), cls(cls_), flops(flops_), bytes(bytes_) {
+Engine::ProfScope::ProfScope(Engine* e_, int cls_, double flops_, double bytes_, int n_launch_) : e(e_), cls(cls_), flops(flops_), bytes(bytes_), n_launch(n_launch_) {
     if (!e->profiling_) return;
     a = e->prof_event();
     b = e->prof_event();
@@ -108,7 +108,7 @@ Engine::ProfScope::ProfScope(Engine* e_, int cls_, double flops_, double bytes_)
 Engine::ProfScope::~ProfScope() {
     if (!a) return;
     (void)hipEventRecord(b, e->stream_);
-    e->prof_pending_.push_back({cls, a, b, flops, bytes});
+    e->prof_pending_.push_back({cls, a, b, flops, bytes, n_launch});
     if (e->prof_pending_.size() >= 2048) {
         try { e->prof_flush(); } catch (...) {}
     }
@@ -145,7 +145,7 @@ void Engine::prof_flush() {
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             ms = (float)std::max(0.0, (double)ms - prof_overhead_ms_);
             prof_[p.cls].ms += ms;
-            prof_[p.cls].launches += 1;
+            prof_[p.cls].launches += p.n_launch;
             prof_[p.cls].flops += p.flops;
             prof_[p.cls].bytes += p.bytes;
         }
@@ -1449,7 +1449,7 @@ void Engine::group_norm(const NormW& w, const Act& x, Act& y, bool silu) {
     const int hw = x.h * x.w;
     if (x.dt != y.dt) throw Error(SDMI_ERR_STATE, "group_norm: in/out storage types disagree");
     Buf part(this, x.dt ? gn_partials_bytes_bf16(x.n, hw, x.c) : gn_partials_bytes(x.n, hw, x.c));
-    ProfScope ps(this, PC_GROUP_NORM, 0, 2.0 * (double)x.bytes());  // algorithmic: one read + one write
+    ProfScope ps(this, PC_GROUP_NORM, 0, 2.0 * (double)x.bytes(), 2);  // algorithmic: one read + one write; two launches (statistics, apply)
     if (y.view) throw Error(SDMI_ERR_STATE, "group_norm: output must be dense");
     if (!x.p) throw Error(SDMI_ERR_STATE, "group_norm: the input must exist as fp32");
     if (y.p3 && !y.p) {   // the consumer is a plane GEMM: the normalised tensor is written as three bf16 planes only
@@ -1611,7 +1611,7 @@ void Engine::group_norm_fp8(const NormW& w, const Act& x, ActQ& y, bool silu) {
     const int hw = x.h * x.w;
     if (x.dt != 1 || y.c != x.c) throw Error(SDMI_ERR_STATE, "group_norm_fp8: bf16 input of matching width expected");
     Buf part(this, gn_partials_bytes_bf16(x.n, hw, x.c));
-    ProfScope ps(this, PC_GROUP_NORM, 0, (double)x.bytes() + (double)x.rows() * (y.cp + y.cp / 32));
+    ProfScope ps(this, PC_GROUP_NORM, 0, (double)x.bytes() + (double)x.rows() * (y.cp + y.cp / 32), 2);
     SDMI_HIP(launch_group_norm_fp8(x.p, y.q, y.s, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_));
     count_kernel(); count_kernel();
 }

@@ -342,11 +342,11 @@ public:
 
 private:
     struct ProfScope {
-        Engine* e; int cls; double flops, bytes; hipEvent_t a = nullptr, b = nullptr;
-        ProfScope(Engine* e_, int cls_, double flops_ = 0, double bytes_ = 0);
+        Engine* e; int cls; double flops, bytes; int n_launch; hipEvent_t a = nullptr, b = nullptr;
+        ProfScope(Engine* e_, int cls_, double flops_ = 0, double bytes_ = 0, int n_launch_ = 1);    // n_launch: kernels inside the scope (GroupNorm: statistics + apply)
         ~ProfScope();
     };
-    struct ProfPending { int cls; hipEvent_t a, b; double flops, bytes; };
+    struct ProfPending { int cls; hipEvent_t a, b; double flops, bytes; int n_launch; };
     hipEvent_t prof_event();
     bool profiling_ = false;
     std::vector<hipEvent_t> prof_free_;
