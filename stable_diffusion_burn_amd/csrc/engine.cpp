@@ -387,7 +387,7 @@ void Engine::build_model() {
         lin(m.q, path + "/query", c, c, false);
         // precision >= 1: the bf16 attention kernel takes q in log2 units -- d_head^-0.5 log2(e) is folded into the query weight here, in
         // fp32, before its only rounding (attention.rs:15-26 applies d_head^-0.25 to q and to k)
-        if (m.q.dt) entries_[entry_index_.at(path + "/query/weight")].pre_scale = attn_bf16_q_scale(c / cfg_.n_head);
+        if (m.q.dt && attn_bf16_q_is_log2(c / cfg_.n_head)) entries_[entry_index_.at(path + "/query/weight")].pre_scale = attn_bf16_q_scale(c / cfg_.n_head);
         lin(m.k, path + "/key", cctx, c, false);
         lin(m.v, path + "/value", cctx, c, false);
         lin(m.out, path + "/out", c, c, true);
@@ -1484,7 +1484,7 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
     if (o3 && (dt || !attn_supported_head_dim(d_head) || (n_head * d_head) % 32)) throw Error(SDMI_ERR_STATE, "attention: plane output needs a fused fp32 kernel");
     // bf16 tensors at the UNet's head dims: q arrives in log2 units (attn_bf16_q_scale: folded into the query weights at load, applied by
     // qkv_attention_dev's conversion); the bf16 kernel needs no scale, the widened fp32 kernel (attn_bf16=0) gets scale^2 = ln 2
-    const bool q_log2 = dt && (d_head == 40 || d_head == 80 || d_head == 160);
+    const bool q_log2 = dt && attn_bf16_q_is_log2(d_head);
     const float scale = q_log2 ? 0.83255461115769775635f : (float)std::pow((double)d_head, -0.25);
     if (attn_supported_head_dim(d_head)) {
         AttnParams p{};
@@ -2215,7 +2215,7 @@ void Engine::qkv_attention_dev(const float* q, const float* k, const float* v, c
     if (bf16_ && !mask) {  // precision = 1: the boundary is fp32, the kernel sees bf16 tensors
         Buf qh(this, qe * 2), kh(this, ke * 2), vh(this, ke * 2), oh(this, qe * 2);
         const int dh = n_state / n_head;
-        if (dh == 40 || dh == 80 || dh == 160) SDMI_HIP(launch_f32_to_bf16_scaled(q, qh.p, qe, attn_bf16_q_scale(dh), stream_));   // Engine::attention's q convention
+        if (attn_bf16_q_is_log2(dh)) SDMI_HIP(launch_f32_to_bf16_scaled(q, qh.p, qe, attn_bf16_q_scale(dh), stream_));   // Engine::attention's q convention
         else SDMI_HIP(launch_f32_to_bf16(q, qh.p, qe, stream_));
         SDMI_HIP(launch_f32_to_bf16(k, kh.p, ke, stream_));
         SDMI_HIP(launch_f32_to_bf16(v, vh.p, ke, stream_));
@@ -2585,7 +2585,7 @@ double Engine::bench_attention(int n, int nq, int nk, int n_state, int n_head, i
     Buf qh(this, dt ? qe * 2 : 256), kh(this, dt ? ke * 2 : 256), vh(this, dt ? ke * 2 : 256);
     if (dt) {
         const int dh = n_state / n_head;
-        SDMI_HIP(launch_f32_to_bf16_scaled(q.f(), qh.p, qe, (dh == 40 || dh == 80 || dh == 160) ? attn_bf16_q_scale(dh) : 1.f, stream_));
+        SDMI_HIP(launch_f32_to_bf16_scaled(q.f(), qh.p, qe, attn_bf16_q_is_log2(dh) ? attn_bf16_q_scale(dh) : 1.f, stream_));
         SDMI_HIP(launch_f32_to_bf16(k.f(), kh.p, ke, stream_));
         SDMI_HIP(launch_f32_to_bf16(v.f(), vh.p, ke, stream_));
     }

@@ -139,6 +139,8 @@ hipError_t launch_attention_split(const AttnParams& p, hipStream_t stream);
 // bf16 matrix-core kernel (k_attn_bf16.hip): p.bf16 set, no additive mask; q must arrive multiplied by attn_bf16_q_scale(d_head)
 // (the engine folds it into the query projection's weight at load); p.scale is not used
 inline float attn_bf16_q_scale(int d_head) { return (float)(1.4426950408889634 / __builtin_sqrt((double)d_head)); }
+// the head dims whose bf16 q tensors follow that convention (the fused bf16 kernel's; every other head dim keeps the reference's scale in the kernel)
+inline bool attn_bf16_q_is_log2(int d_head) { return d_head == 40 || d_head == 80 || d_head == 160; }
 hipError_t launch_attention_bf16(const AttnParams& p, hipStream_t stream);
 // row softmax (in place) for the unfused single-head VAE attention: x[rows][cols] *= scale first
 hipError_t launch_softmax_rows(float* x, int rows, int cols, float scale, hipStream_t stream);
