@@ -1047,6 +1047,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "gemm_f32s") opt_gemm_f32s_ = std::stoi(value);
     else if (key == "bench_cold") opt_bench_cold_ = std::stoi(value);
     else if (key == "gemm_probe") opt_gemm_probe_ = std::stoi(value);
+    else if (key == "conv3_reuse") opt_conv3_reuse_ = std::stoi(value);
     else if (key == "gemm_planes") opt_gemm_planes_ = (value == "default") ? kGemmPlanesDefault : std::stoi(value);
     else if (key == "gemm3x_variant") opt_gemm3x_variant_ = std::stoi(value);
     else if (key == "geglu_fuse") opt_geglu_fuse_ = std::stoi(value);
@@ -1070,7 +1071,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
         const bool b16 = key == "tune_bf16";
         TileChoice tc{0, 1};
         if (std::sscanf(value.c_str() + eq + 1, "%d,%d", &tc.cfg, &tc.splits) != 2 || tc.cfg < 0 || tc.splits < 1 ||
-            !(tc.cfg < kNumGemmTiles || (tc.cfg >= 100 && tc.cfg < 100 + kNumGemmTilesX) || (!b16 && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS) ||
+            !(tc.cfg < kNumGemmTiles || (tc.cfg >= 100 && tc.cfg < 100 + (b16 ? kNumGemmTilesXB : kNumGemmTilesX)) || (!b16 && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS) ||
               (!b16 && tc.cfg >= 300 && tc.cfg < 300 + kNumGemmTilesP)))
             throw Error(SDMI_ERR_INVALID, "tune: bad value");
         (b16 ? tuned_bf16_ : (tc.cfg >= 300 ? tuned_p_ : tuned_))[value.substr(0, eq)] = tc;   // plane tiles (300 + x) have their own table: what a GEMM whose input arrives as planes chooses from
@@ -1210,7 +1211,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         ++shape_counts_[sk];
     }
     auto tile_info = [&](int cfg) -> const GemmTileInfo& {
-        if (in_dt) return cfg >= 100 ? gemm_tile_info_x(cfg - 100) : gemm_tile_info(cfg);
+        if (in_dt) return cfg >= 100 ? gemm_tile_info_xb(cfg - 100) : gemm_tile_info(cfg);
         return cfg >= 300 ? gemm_tile_info_p(cfg - 300) : cfg >= 200 ? gemm_tile_info_s(cfg - 200) : cfg >= 100 ? gemm_tile_info_x(cfg - 100) : gemm_tile_info(cfg);
     };
     TileChoice tc;
@@ -1257,11 +1258,6 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         if (!p.geglu || c == 301 || c == 302 || c == 304) tc.cfg = c;   // (even fragment counts only for the GEGLU epilogue)
     }
     if (from_planes && tc.cfg < 300) throw Error(SDMI_ERR_STATE, "gemm: activation planes need a plane tile (300 + x)");
-    if (record_shapes_) {   // which kernel / tile / split-K each (M, N, K) got: option dump_choices
-        char ck[96];
-        std::snprintf(ck, sizeof ck, "%d,%d,%d cfg=%d splits=%d%s", p.M, p.N, p.K, tc.cfg, tc.splits, p.Bt3 ? "" : " (no planes)");
-        ++choice_counts_[ck];
-    }
     if (force_splits > 0) tc.splits = force_splits;
     if (!in_dt && p.out_mode == 2) tc.splits = 1;  // fp32 kernel emitting bf16: no split-K path
     int splits = std::max(1, std::min(tc.splits, p.kt_total));
@@ -1274,8 +1270,15 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     const unsigned long long a_ext = ((unsigned long long)p.NB * p.Hs * p.Ws - 1) * (unsigned long long)p.a_ld * es + (unsigned long long)p.Cin * es;
     const unsigned long long b_ext = ((unsigned long long)p.N * (p.geglu ? 2 : 1) - 1) * (unsigned long long)p.b_ld * es + (unsigned long long)p.K * es;
     p.zero_page = zero_page_;
+    // bf16 3x3 / stride-1 convolutions on the 256 x 320 / 256 x 256 tiles: the form that stages a kernel row's activations once for its three taps (k_gemm_bf16t.hip)
+    if (in_dt && opt_conv3_reuse_ && (tc.cfg == 100 || tc.cfg == 101) && conv_gemm_bf16t_supported(p)) tc.cfg += kNumGemmTilesX;
+    if (record_shapes_) {   // which kernel / tile / split-K each (M, N, K) got: option dump_choices
+        char ck[128];
+        std::snprintf(ck, sizeof ck, "%d,%d,%d k%d s%d u%d W%d cfg=%d splits=%d%s", p.M, p.N, p.K, p.KH, p.stride, p.ups, p.Ws, tc.cfg, splits, p.Bt3 || in_dt ? "" : " (no planes)");
+        ++choice_counts_[ck];
+    }
     if (tc.cfg >= 300 ? (in_dt || tc.cfg - 300 >= kNumGemmTilesP || !p_ok)
-        : tc.cfg >= 200 ? (in_dt || tc.cfg - 200 >= kNumGemmTilesS || !s_ok) : (tc.cfg >= 100 && (tc.cfg - 100 >= kNumGemmTilesX || (!in_dt && !x32_ok))))
+        : tc.cfg >= 200 ? (in_dt || tc.cfg - 200 >= kNumGemmTilesS || !s_ok) : (tc.cfg >= 100 && (tc.cfg - 100 >= (in_dt ? kNumGemmTilesXB : kNumGemmTilesX) || (!in_dt && !x32_ok))))
         throw Error(SDMI_ERR_INVALID, "gemm: large-tile kernel index out of range or not applicable to this layer");
     if (a_ext >= 0xFFFFFFE0ull || b_ext >= 0xFFFFFFE0ull) throw Error(SDMI_ERR_UNSUPPORTED, "GEMM: operand larger than 4 GiB (the buffer-load range check needs 32-bit extents)");
     p.a_bytes = (unsigned)a_ext;
@@ -1308,7 +1311,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     p.probe = probe_buf_;
     auto launch = [&](const ConvGemm& q) {
         if (tc.cfg >= 300) return launch_conv_gemm3p(q, tc.cfg - 300, stream_);
-        if (in_dt && tc.cfg >= 100) return launch_conv_gemm_bf16x(q, tc.cfg - 100, stream_);
+        if (in_dt && tc.cfg >= 100) return launch_conv_gemm_bf16_large(q, tc.cfg - 100, stream_);
         if (tc.cfg >= 200) return launch_conv_gemm3x(q, tc.cfg - 200, stream_);
         if (tc.cfg >= 100) return launch_conv_gemm2x(q, tc.cfg - 100, stream_);
         if (in_dt) return launch_conv_gemm_bf16(q, tc.cfg, stream_);

@@ -76,6 +76,18 @@ hipError_t launch_splitk_reduce_bf16(const ConvGemm& p, hipStream_t stream);
 constexpr int kNumGemmTilesX = 4;
 const GemmTileInfo& gemm_tile_info_x(int cfg);
 hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
+// the 256 x 320 / 256 x 256 tiles for 3x3 / stride-1 / pad-1 convolutions with the three taps of a kernel row read from one staged activation tile
+// (k_gemm_bf16t.hip); bf16 tile_cfg 100 + kNumGemmTilesX + x.  launch_conv_gemm_bf16t fails (hipErrorInvalidValue) unless conv_gemm_bf16t_supported(p).
+constexpr int kNumGemmTilesT = 2;
+const GemmTileInfo& gemm_tile_info_t(int cfg);
+bool conv_gemm_bf16t_supported(const ConvGemm& p);          // needs p.kt_per_split
+hipError_t launch_conv_gemm_bf16t(const ConvGemm& p, int tile_cfg, hipStream_t stream);
+// bf16 large tiles as one list: 100 + [0, kNumGemmTilesX) = k_gemm_bf16x.hip, then k_gemm_bf16t.hip
+constexpr int kNumGemmTilesXB = kNumGemmTilesX + kNumGemmTilesT;
+inline const GemmTileInfo& gemm_tile_info_xb(int c) { return c < kNumGemmTilesX ? gemm_tile_info_x(c) : gemm_tile_info_t(c - kNumGemmTilesX); }
+inline hipError_t launch_conv_gemm_bf16_large(const ConvGemm& p, int c, hipStream_t stream) {
+    return c < kNumGemmTilesX ? launch_conv_gemm_bf16x(p, c, stream) : launch_conv_gemm_bf16t(p, c - kNumGemmTilesX, stream);
+}
 // the same structure for fp32 storage (k_gemm2x.hip; Cin % 32 == 0, fp32 output); same tile list
 hipError_t launch_conv_gemm2x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 // fp32 on the bf16 matrix pipe: operands as exact sums of three bf16 terms, six partial products (k_gemm3x.hip); its own tile

@@ -146,6 +146,49 @@ def test_conv2d_bf16_large_tiles_short_k(ops16, tile, case):
     _check(got, ref, f"conv bf16 large tile={tile} short K {case}", 2 ** -8)
 
 
+TCASES = [
+    # (n, cin, h, w, cout, splitk): 3x3 / stride 1 / pad 1, widths 16 ... 128, pixel counts that are multiples of the 256-row tile, k slices of whole kernel rows
+    (2, 128, 16, 16, 320, 1), (1, 64, 32, 32, 256, 1), (1, 64, 64, 64, 96, 1), (1, 64, 16, 128, 64, 1), (3, 192, 16, 16, 328, 3), (2, 128, 32, 32, 640, 2),
+    (1, 64, 32, 16, 48, 3), (1, 320, 64, 64, 320, 1),
+]
+
+
+@pytest.mark.parametrize("tile", [104, 105])
+@pytest.mark.parametrize("case", TCASES)
+def test_conv2d_bf16_kernel_row_tiles(ops16, tile, case):
+    """k_gemm_bf16t.hip: the three taps of a kernel row read from one staged activation tile (borders by lane masks)"""
+    n, cin, h, w, cout, splitk = case
+    g = np.random.default_rng(3300 + tile + cin + cout + splitk + w)
+    x = bf16_round(g.standard_normal((n, cin, h, w)))
+    wt = bf16_round(g.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9))
+    b = g.standard_normal(cout).astype(np.float32)
+    try:
+        ops16.set_option("gemm_tile", tile)
+        ops16.set_option("splitk", splitk)
+        got = ops16.op_conv2d(x, wt, b)
+        ops16.set_option("gemm_tile", tile - 4)
+        same = ops16.op_conv2d(x, wt, b)
+    finally:
+        ops16.set_option("gemm_tile", "auto")
+        ops16.set_option("splitk", 0)
+    ref = O.conv2d(_t(x), (_t(wt), _t(b)), padding=1).numpy()
+    _check(got, ref, f"conv bf16 kernel-row tile={tile} {case}", 2 ** -8)
+    # the same products in the same order as the tile it replaces: bit-identical
+    np.testing.assert_array_equal(got, same)
+
+
+def test_conv2d_bf16_kernel_row_tiles_refuse_other_layers(ops16):
+    g = np.random.default_rng(5)
+    x = bf16_round(g.standard_normal((1, 64, 8, 8)))
+    wt = bf16_round(g.standard_normal((64, 64, 3, 3)) / 24.0)
+    try:
+        ops16.set_option("gemm_tile", 104)
+        with pytest.raises(Exception):
+            ops16.op_conv2d(x, wt, None)
+    finally:
+        ops16.set_option("gemm_tile", "auto")
+
+
 @pytest.mark.parametrize("tile", [100, 103])
 def test_linear_bf16_large_tiles(ops16, tile):
     g = np.random.default_rng(tile)

@@ -189,6 +189,31 @@ def test_bf16_full_size_against_the_fp64_fixtures():
         sd.close()
 
 
+def test_bf16_kernel_row_tiles_in_the_model_are_bit_identical(tmp_path):
+    """option conv3_reuse (default 1): the 3x3 convolutions that choose the 256 x 320 / 256 x 256 tile run on k_gemm_bf16t.hip (one staged activation tile per
+    kernel row).  Same products in the same order: one batch-32 UNet forward (the batch of BASELINE.json configs[2]'s CFG step) is bit-identical either way, and the
+    choice dump shows the tiles were taken -- concat inputs, residual / time-embedding epilogues included."""
+    from stable_diffusion_burn_amd import ModelConfig, StableDiffusion
+    sd = StableDiffusion(ModelConfig(precision=1))
+    try:
+        sd.load_weights(syn.SyntheticWeights(), clip=False, vae_encoder=False)
+        n = 32
+        lat = np.stack([syn.initial_latent(i % 4) for i in range(n)])
+        ctx = np.stack([syn.cond_context(i % 4) for i in range(n)])
+        sd.set_option("record_shapes", 1)
+        on = sd.unet.forward(lat, [500], ctx)
+        sd.set_option("dump_choices", str(tmp_path / "choices.txt"))
+        sd.set_option("record_shapes", 0)
+        taken = [ln for ln in (tmp_path / "choices.txt").read_text().splitlines() if "cfg=104" in ln or "cfg=105" in ln]
+        sd.set_option("conv3_reuse", 0)
+        off = sd.unet.forward(lat, [500], ctx)
+        print(f"kernel-row tiles: {len(taken)} GEMM shapes of the batch-{n} forward")
+        assert len(taken) >= 6 and np.isfinite(on).all()
+        np.testing.assert_array_equal(on, off)
+    finally:
+        sd.close()
+
+
 # ---- BASELINE.json configs[2]: 50 steps, batch 16, bf16 ------------------------------------------------------------
 def _cfg3_inputs(n):
     lat = np.stack([syn.initial_latent(i) for i in range(n)])
