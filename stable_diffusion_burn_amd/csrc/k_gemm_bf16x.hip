@@ -63,7 +63,6 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     const int NT = (p.N + BNO - 1) / BNO;
     const GemmWork gw = gemm_work_of_block(p, MT, NT);
     if (!gw.live) return;
-    const int lid = gw.lid;
     const int tm = gw.tm;
     const int tn = gw.tn;
     const int m0 = tm * BM;
