@@ -22,6 +22,8 @@ __device__ __forceinline__ F8 unpack8(u32x4 w) {
     }
     return r;
 }
+typedef float h_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 h_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned bf16_bits(float f) {
     unsigned u = __float_as_uint(f);
     u += 0x7FFFu + ((u >> 16) & 1u);
@@ -30,7 +32,10 @@ __device__ __forceinline__ unsigned bf16_bits(float f) {
 __device__ __forceinline__ u32x4 pack8(const F8& f) {
     u32x4 w;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = bf16_bits(f.v[2 * i]) | (bf16_bits(f.v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) {   // one v_cvt_pk_bf16_f32 per pair (round to nearest even, as bf16_bits)
+        const h_f32x2 p2 = {f.v[2 * i], f.v[2 * i + 1]};
+        w[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(p2, h_bf16x2));
+    }
     return w;
 }
 

@@ -21,6 +21,7 @@
 // 4-byte LDS-DMA (one 64-row piece per wave), and read back one byte per fragment (ds_read_u8).
 #include "kernels.hpp"
 #include "k_common.hpp"
+#include "k_gemm_bf16_epi.hpp"
 
 namespace sdmi {
 
@@ -38,7 +39,7 @@ __device__ __forceinline__ unsigned qbf16_bits(float f) {
     u += 0x7FFFu + ((u >> 16) & 1u);
     return u >> 16;
 }
-__device__ __forceinline__ unsigned qpack_bf16x2(float a, float b) { return qbf16_bits(a) | (qbf16_bits(b) << 16); }
+__device__ __forceinline__ unsigned qpack_bf16x2(float a, float b) { return xpack_bf16x2(a, b); }   // one v_cvt_pk_bf16_f32 (k_gemm_bf16_epi.hpp)
 
 // E8M0 scale byte of a block whose largest magnitude is amax: 2^(floor(log2 amax) - 8) (e4m3 emax = 8), so the scaled
 // block lies in [256, 512) at its maximum and is clamped to 448 (the OCP MX rule).  Returns the byte and 1 / scale.
@@ -131,7 +132,6 @@ __global__ __launch_bounds__(512) void conv_gemm_fp8x_kernel(const ConvGemm p) {
     const int NT = (p.N + BN - 1) / BN;
     const GemmWork gw = gemm_work_of_block(p, MT, NT);
     if (!gw.live) return;
-    const int lid = gw.lid;
     const int tm = gw.tm;
     const int tn = gw.tn;
     const int m0 = tm * BM;
@@ -279,76 +279,9 @@ __global__ __launch_bounds__(512) void conv_gemm_fp8x_kernel(const ConvGemm p) {
         if constexpr (NH == 2) mx_columns<MI, NI, NI0, NI - NI0>(stage, acc, a_base, b_base, as_base, bs_base, fr_off0, fr_off1);
     }
 
-    // ---- epilogue: fp32 bias + time-embedding row + (bf16) residual -> bf16 (or fp32 slab / fp32 output) -----------------
-    // the LDS-transposed, row-coalesced store of k_gemm_bf16x.hip (N % 8 == 0, ldc % 8 == 0 checked by the launcher)
-    constexpr int WNC = 16 * NI;
-    constexpr int LDSW = WNC + 4;
-    const bool split = p.splits > 1;
-    const bool out_f32 = split || p.out_mode == 1;
-    float* Cf = split ? (p.slabs + (long long)z * p.slab_stride) : p.C;
-    unsigned short* Ch = reinterpret_cast<unsigned short*>(p.C);
-    const unsigned short* Rh = reinterpret_cast<const unsigned short*>(p.resid);
-    const int ldc = split ? p.N : p.ldc;
-    const bool has_resid = !split && p.resid;
-    __syncthreads();
-    float* scr = reinterpret_cast<float*>(smem_q + wave * (16 * LDSW * 4));
-    const int nw0 = n0 + wn * WNC;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int mrow0 = m0 + (wm * MI + mi) * 16;
-        {
-            const int m = mrow0 + c15;
-            const int smp = (m < p.M ? m : 0) / HoWo;
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int n = nw0 + ni * 16 + g4 * 4;
-                f32x4 v = acc[mi][ni];
-                if (!split && n < p.N) {
-                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                    if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)smp * p.rowvec_stride + n);
-                }
-                *reinterpret_cast<f32x4*>(scr + c15 * LDSW + ni * 16 + g4 * 4) = v;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (!out_f32) {
-            constexpr int CH = WNC / 8;
-#pragma unroll
-            for (int q0 = 0; q0 < 16 * CH; q0 += 64) {
-                const int q = q0 + lane;
-                const int row = q / CH, c8 = q - row * CH;
-                const int m = mrow0 + row, n = nw0 + c8 * 8;
-                if (q < 16 * CH && m < p.M && n < p.N) {
-                    f32x4 lo = *reinterpret_cast<const f32x4*>(scr + row * LDSW + c8 * 8);
-                    f32x4 hi = *reinterpret_cast<const f32x4*>(scr + row * LDSW + c8 * 8 + 4);
-                    if (has_resid) {
-                        const u32x4 r = *reinterpret_cast<const u32x4*>(Rh + (long long)m * p.ldr + n);
-                        lo[0] += qbf16_lo(r[0]); lo[1] += qbf16_hi(r[0]); lo[2] += qbf16_lo(r[1]); lo[3] += qbf16_hi(r[1]);
-                        hi[0] += qbf16_lo(r[2]); hi[1] += qbf16_hi(r[2]); hi[2] += qbf16_lo(r[3]); hi[3] += qbf16_hi(r[3]);
-                    }
-                    const u32x4 o = {qpack_bf16x2(lo[0], lo[1]), qpack_bf16x2(lo[2], lo[3]), qpack_bf16x2(hi[0], hi[1]), qpack_bf16x2(hi[2], hi[3])};
-                    *reinterpret_cast<u32x4*>(Ch + (long long)m * ldc + n) = o;
-                }
-            }
-        } else {
-            constexpr int CH = WNC / 4;
-#pragma unroll
-            for (int q0 = 0; q0 < 16 * CH; q0 += 64) {
-                const int q = q0 + lane;
-                const int row = q / CH, c4 = q - row * CH;
-                const int m = mrow0 + row, n = nw0 + c4 * 4;
-                if (q < 16 * CH && m < p.M && n < p.N) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * LDSW + c4 * 4);
-                    if (has_resid) {
-                        const u32x2 r = *reinterpret_cast<const u32x2*>(Rh + (long long)m * p.ldr + n);
-                        v[0] += qbf16_lo(r[0]); v[1] += qbf16_hi(r[0]); v[2] += qbf16_lo(r[1]); v[3] += qbf16_hi(r[1]);
-                    }
-                    *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
+    // ---- epilogue: fp32 bias + time-embedding row + (bf16) residual -> bf16 (or fp32 slab / fp32 output): the LDS-transposed, row-coalesced store shared
+    // with k_gemm_bf16x.hip (N % 8 == 0, ldc % 8 == 0 checked by the launcher; no GEGLU pairing on this kernel)
+    gemm_epilogue_bf16<MI, NI, WM, WN>(p, acc, smem_q, m0, n0, z, wave, lane, HoWo);
 }
 
 static const GemmTileInfo kTilesQ[kNumGemmTilesQ] = {{256, 320, "256x320q"}, {256, 256, "256x256q"}, {256, 128, "256x128q"}};

@@ -32,7 +32,12 @@ __device__ __forceinline__ unsigned f32_to_bf16_bits(float f) {
     u += 0x7FFFu + ((u >> 16) & 1u);
     return u >> 16;
 }
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) { return f32_to_bf16_bits(a) | (f32_to_bf16_bits(b) << 16); }
+typedef float g16_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 g16_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {   // one v_cvt_pk_bf16_f32 (round to nearest even, as f32_to_bf16_bits)
+    const g16_f32x2 f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, g16_bf16x2));
+}
 
 template <int MI, int NI, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const ConvGemm p) {

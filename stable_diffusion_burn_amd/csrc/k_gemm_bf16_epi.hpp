@@ -19,7 +19,14 @@ __device__ __forceinline__ unsigned xf32_to_bf16_bits(float f) {
     u += 0x7FFFu + ((u >> 16) & 1u);
     return u >> 16;
 }
-__device__ __forceinline__ unsigned xpack_bf16x2(float a, float b) { return xf32_to_bf16_bits(a) | (xf32_to_bf16_bits(b) << 16); }
+typedef float bepi_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bepi_bf16x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> one dword of bf16 (a low, b high), round to nearest even: ONE v_cvt_pk_bf16_f32 (the integer form above is 4 instructions per value; the epilogue of a
+// 256 x 320 tile packs 81 920 values -- profiles/r04ad_*: 8 of a short-K launch's 27 us per tile were this epilogue's instructions, not its stores)
+__device__ __forceinline__ unsigned xpack_bf16x2(float a, float b) {
+    const bepi_f32x2 f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bepi_bf16x2));
+}
 
 template <int MI, int NI, int WM, int WN>
 __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4 (&acc)[MI][NI], unsigned char* smem_x, const int m0, const int n0,
@@ -53,42 +60,76 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4
             __syncthreads();
             float* scr = reinterpret_cast<float*>(smem_x + wave * (16 * LDSW2 * 4));
             const int nw0 = n0 + wn * WNO;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int mrow0 = m0 + (wm * MI + mi) * 16;
-#pragma unroll
-                for (int j = 0; j < NI / 2; ++j) {
-                    const int n = nw0 + j * 16 + g4 * 4;
-                    f32x4 v = acc[mi][2 * j], g = acc[mi][2 * j + 1];
-                    if (p.bias && n < p.N) {
-                        v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                        g += *reinterpret_cast<const f32x4*>(p.bias + p.N + n);
-                    }
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = v[e] * (0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752440f)));
-                    *reinterpret_cast<f32x4*>(scr + c15 * LDSW2 + j * 16 + g4 * 4) = o;
+            auto gate = [&](int mi, int j) {
+                const int n = nw0 + j * 16 + g4 * 4;
+                f32x4 v = acc[mi][2 * j], g = acc[mi][2 * j + 1];
+                if (p.bias && n < p.N) {
+                    v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    g += *reinterpret_cast<const f32x4*>(p.bias + p.N + n);
                 }
-                __builtin_amdgcn_wave_barrier();
-                constexpr int CH = WNO / 8;
+                f32x4 o;
 #pragma unroll
-                for (int q0 = 0; q0 < 16 * CH; q0 += 64) {
-                    const int q = q0 + lane;
-                    const int row = q / CH, c8 = q - row * CH;
-                    const int m = mrow0 + row, n = nw0 + c8 * 8;
-                    if (q < 16 * CH && m < p.M && n < p.N) {
-                        const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + row * LDSW2 + c8 * 8);
-                        const f32x4 hi = *reinterpret_cast<const f32x4*>(scr + row * LDSW2 + c8 * 8 + 4);
-                        if (p.out_mode == 1) {
+                for (int e = 0; e < 4; ++e) o[e] = v[e] * (0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752440f)));
+                return o;
+            };
+            constexpr int CH = WNO / 8;
+            if (p.out_mode != 1) {
+                // bf16 output: rounded before the transpose, 2-byte scratch (see the main path below), the gate of group mi + 1 behind the stores of group mi
+                constexpr int RSB = WNO * 2 + 16;
+                static_assert(((RSB / 16) & 1) == 1, "scratch rows must start on distinct 16-byte bank slots");
+                constexpr int NR = (16 * CH + 63) / 64;
+                unsigned char* sb = smem_x + wave * (16 * LDSW2 * 4);
+                auto stage_b = [&](int mi) {
+#pragma unroll
+                    for (int j = 0; j < NI / 2; ++j) {
+                        const f32x4 o = gate(mi, j);
+                        const u32x2 w = {xpack_bf16x2(o[0], o[1]), xpack_bf16x2(o[2], o[3])};
+                        *reinterpret_cast<u32x2*>(sb + c15 * RSB + j * 32 + g4 * 8) = w;
+                    }
+                };
+                stage_b(0);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int mrow0 = m0 + (wm * MI + mi) * 16;
+                    u32x4 o[NR];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const int q = r * 64 + lane;
+                        const int row = q / CH, c8 = q - row * CH;
+                        if (q < 16 * CH) o[r] = *reinterpret_cast<const u32x4*>(sb + row * RSB + c8 * 16);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (mi + 1 < MI) stage_b(mi + 1);
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const int q = r * 64 + lane;
+                        const int row = q / CH, c8 = q - row * CH;
+                        const int m = mrow0 + row, n = nw0 + c8 * 8;
+                        if (q < 16 * CH && m < p.M && n < p.N) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.C) + (long long)m * p.ldc + n) = o[r];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int mrow0 = m0 + (wm * MI + mi) * 16;
+#pragma unroll
+                    for (int j = 0; j < NI / 2; ++j) *reinterpret_cast<f32x4*>(scr + c15 * LDSW2 + j * 16 + g4 * 4) = gate(mi, j);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int q0 = 0; q0 < 16 * CH; q0 += 64) {
+                        const int q = q0 + lane;
+                        const int row = q / CH, c8 = q - row * CH;
+                        const int m = mrow0 + row, n = nw0 + c8 * 8;
+                        if (q < 16 * CH && m < p.M && n < p.N) {
+                            const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + row * LDSW2 + c8 * 8);
+                            const f32x4 hi = *reinterpret_cast<const f32x4*>(scr + row * LDSW2 + c8 * 8 + 4);
                             *reinterpret_cast<f32x4*>(p.C + (long long)m * p.ldc + n) = lo;
                             *reinterpret_cast<f32x4*>(p.C + (long long)m * p.ldc + n + 4) = hi;
-                        } else {
-                            const u32x4 o = {xpack_bf16x2(lo[0], lo[1]), xpack_bf16x2(lo[2], lo[3]), xpack_bf16x2(hi[0], hi[1]), xpack_bf16x2(hi[2], hi[3])};
-                            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.C) + (long long)m * p.ldc + n) = o;
                         }
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_wave_barrier();
             }
         }
         return;
@@ -97,44 +138,113 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4
         __syncthreads();                // every wave is done with the last k tile
         float* scr = reinterpret_cast<float*>(smem_x + wave * (16 * LDSW * 4));
         const int nw0 = n0 + wn * WNC;
+        // fragment group mi (16 rows x WNC columns of this wave) -> scratch, with the per-column / per-sample terms
+        auto stage = [&](int mi) {
+            const int m = m0 + (wm * MI + mi) * 16 + c15;
+            const int smp = (m < p.M ? m : 0) / HoWo;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int mrow0 = m0 + (wm * MI + mi) * 16;
-            {
-                const int m = mrow0 + c15;
+            for (int ni = 0; ni < NI; ++ni) {
+                const int n = nw0 + ni * 16 + g4 * 4;
+                f32x4 v = acc[mi][ni];
+                if (!split && n < p.N) {
+                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)smp * p.rowvec_stride + n);
+                }
+                *reinterpret_cast<f32x4*>(scr + c15 * LDSW + ni * 16 + g4 * 4) = v;
+            }
+        };
+        if (!out_f32 && !has_resid) {
+            // bf16 output without a residual: the values are rounded to bf16 BEFORE the transpose (the same single rounding), so the scratch holds 2 bytes per
+            // element -- 5 ds_write_b64 + 3 ds_read_b128 per fragment group where the fp32 scratch below takes 5 ds_write_b128 + 6 ds_read_b128 whose 32-byte lane
+            // stride uses half the banks.  Row stride WNC 2 + 16 bytes = 4 x odd dwords: the 16 rows of a half-wave's ds_write_b64 tile the 64 banks.
+            constexpr int RSB = WNC * 2 + 16;
+            static_assert(((RSB / 16) & 1) == 1, "scratch rows must start on distinct 16-byte bank slots");
+            constexpr int CH = WNC / 8;   // 16-byte bf16 chunks per row
+            constexpr int NR = (16 * CH + 63) / 64;
+            unsigned char* sb = smem_x + wave * (16 * LDSW * 4);
+            auto stage_b = [&](int mi) {
+                const int m = m0 + (wm * MI + mi) * 16 + c15;
                 const int smp = (m < p.M ? m : 0) / HoWo;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const int n = nw0 + ni * 16 + g4 * 4;
                     f32x4 v = acc[mi][ni];
-                    if (!split && n < p.N) {
+                    if (n < p.N) {
                         if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
                         if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)smp * p.rowvec_stride + n);
                     }
-                    *reinterpret_cast<f32x4*>(scr + c15 * LDSW + ni * 16 + g4 * 4) = v;
+                    const u32x2 w = {xpack_bf16x2(v[0], v[1]), xpack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(sb + c15 * RSB + ni * 32 + g4 * 8) = w;
+                }
+            };
+            stage_b(0);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int mrow0 = m0 + (wm * MI + mi) * 16;
+                u32x4 o[NR];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int q = r * 64 + lane;
+                    const int row = q / CH, c8 = q - row * CH;
+                    if (q < 16 * CH) o[r] = *reinterpret_cast<const u32x4*>(sb + row * RSB + c8 * 16);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (mi + 1 < MI) stage_b(mi + 1);    // (in-order LDS: lands behind the reads above)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int q = r * 64 + lane;
+                    const int row = q / CH, c8 = q - row * CH;
+                    const int m = mrow0 + row, n = nw0 + c8 * 8;
+                    if (q < 16 * CH && m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Ch + (long long)m * ldc + n) = o[r];
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            if (!out_f32) {
-                constexpr int CH = WNC / 8;   // 16-byte bf16 chunks per row
+        } else if (!out_f32) {
+            // bf16 output.  Software-pipelined over the fragment groups: group mi is read back row-coalesced into registers, group mi + 1 is staged into the SAME
+            // scratch right behind those reads (the LDS executes one wave's instructions in order, so the writes land after them), and only then are the rows of
+            // group mi converted and stored -- the LDS round trip of the next group hides behind the conversion and the store issue of this one
+            constexpr int CH = WNC / 8;   // 16-byte bf16 chunks per row
+            constexpr int NR = (16 * CH + 63) / 64;
+            stage(0);
 #pragma unroll
-                for (int q0 = 0; q0 < 16 * CH; q0 += 64) {
-                    const int q = q0 + lane;
+            for (int mi = 0; mi < MI; ++mi) {
+                const int mrow0 = m0 + (wm * MI + mi) * 16;
+                f32x4 lo[NR], hi[NR];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int q = r * 64 + lane;
+                    const int row = q / CH, c8 = q - row * CH;
+                    if (q < 16 * CH) {
+                        lo[r] = *reinterpret_cast<const f32x4*>(scr + row * LDSW + c8 * 8);
+                        hi[r] = *reinterpret_cast<const f32x4*>(scr + row * LDSW + c8 * 8 + 4);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (mi + 1 < MI) stage(mi + 1);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int q = r * 64 + lane;
                     const int row = q / CH, c8 = q - row * CH;
                     const int m = mrow0 + row, n = nw0 + c8 * 8;
                     if (q < 16 * CH && m < p.M && n < p.N) {
-                        f32x4 lo = *reinterpret_cast<const f32x4*>(scr + row * LDSW + c8 * 8);
-                        f32x4 hi = *reinterpret_cast<const f32x4*>(scr + row * LDSW + c8 * 8 + 4);
+                        f32x4 l = lo[r], h = hi[r];
                         if (has_resid) {
-                            const u32x4 r = *reinterpret_cast<const u32x4*>(Rh + (long long)m * p.ldr + n);
-                            lo[0] += xbf16_lo(r[0]); lo[1] += xbf16_hi(r[0]); lo[2] += xbf16_lo(r[1]); lo[3] += xbf16_hi(r[1]);
-                            hi[0] += xbf16_lo(r[2]); hi[1] += xbf16_hi(r[2]); hi[2] += xbf16_lo(r[3]); hi[3] += xbf16_hi(r[3]);
+                            const u32x4 rr = *reinterpret_cast<const u32x4*>(Rh + (long long)m * p.ldr + n);
+                            l[0] += xbf16_lo(rr[0]); l[1] += xbf16_hi(rr[0]); l[2] += xbf16_lo(rr[1]); l[3] += xbf16_hi(rr[1]);
+                            h[0] += xbf16_lo(rr[2]); h[1] += xbf16_hi(rr[2]); h[2] += xbf16_lo(rr[3]); h[3] += xbf16_hi(rr[3]);
                         }
-                        const u32x4 o = {xpack_bf16x2(lo[0], lo[1]), xpack_bf16x2(lo[2], lo[3]), xpack_bf16x2(hi[0], hi[1]), xpack_bf16x2(hi[2], hi[3])};
+                        const u32x4 o = {xpack_bf16x2(l[0], l[1]), xpack_bf16x2(l[2], l[3]), xpack_bf16x2(h[0], h[1]), xpack_bf16x2(h[2], h[3])};
                         *reinterpret_cast<u32x4*>(Ch + (long long)m * ldc + n) = o;
                     }
                 }
-            } else {
+            }
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int mrow0 = m0 + (wm * MI + mi) * 16;
+                stage(mi);
+                __builtin_amdgcn_wave_barrier();
                 constexpr int CH = WNC / 4;   // 16-byte fp32 chunks per row
 #pragma unroll
                 for (int q0 = 0; q0 < 16 * CH; q0 += 64) {
@@ -150,8 +260,8 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4
                         *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;     // (split-K: Cf = this k slice's fp32 slab)
                     }
                 }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
         }
     } else {
     // odd strides / N not a multiple of 8: element-wise stores straight from the accumulators
