@@ -1048,7 +1048,6 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "bench_cold") opt_bench_cold_ = std::stoi(value);
     else if (key == "gemm_probe") opt_gemm_probe_ = std::stoi(value);
     else if (key == "conv3_reuse") opt_conv3_reuse_ = std::stoi(value);
-    else if (key == "slab_native") opt_slab_native_ = std::stoi(value);
     else if (key == "gemm_planes") opt_gemm_planes_ = (value == "default") ? kGemmPlanesDefault : std::stoi(value);
     else if (key == "gemm3x_variant") opt_gemm3x_variant_ = std::stoi(value);
     else if (key == "geglu_fuse") opt_geglu_fuse_ = std::stoi(value);
@@ -1327,14 +1326,6 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         count_kernel(flops);
     } else {
         p.slab_stride = (long long)p.M * p.N;
-        p.slab_native = 0;
-        if (!in_dt && tc.cfg >= 300 && opt_slab_native_ && !p.probe && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (!p.resid || (p.ldr & 3) == 0)) {
-            // plane GEMM: slabs in accumulator order, padded to whole tiles (k_gemm_epi.hpp, splitk_reduce_native_kernel)
-            gemm_tile_shape_p(tc.cfg - 300, &p.t_mi, &p.t_ni, &p.t_wm, &p.t_wn);
-            const long long bm = 16 * p.t_mi * p.t_wm, bn = 16 * p.t_ni * p.t_wn;
-            p.slab_stride = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * bm * bn;
-            p.slab_native = 1;
-        }
         Buf slab(this, (size_t)splits * p.slab_stride * sizeof(float));
         p.slabs = slab.f();
         {

@@ -426,7 +426,6 @@ private:
     static constexpr int kGemmPlanesDefault = 1;
     int opt_gemm_planes_ = kGemmPlanesDefault;   // precision = 0: k_gemm3p.hip (activations as bf16 planes too, no split in the k loop): 0 never, 1 every launch that would take a k_gemm3x.hip tile,
                                 // 2 = A/B switch (tests): every launch that chose a k_gemm3x.hip tile runs on the nearest k_gemm3p.hip tile, its fp32 input converted by split3_rows_kernel in front of it
-    int opt_slab_native_ = 1;   // precision = 0: 1 = split-K launches of k_gemm3p.hip store their slabs in accumulator order (ConvGemm::slab_native), the combine kernel transposes
     int opt_conv3_reuse_ = 1;   // precision >= 1: 1 = 3x3 / stride-1 convolutions that chose the 256 x 320 / 256 x 256 tile run on k_gemm_bf16t.hip (one staged activation tile per kernel row)
     int opt_gemm_probe_ = 0;    // bench_conv: 1 = one extra launch with per-workgroup phase stamps (ConvGemm::probe), summary on stderr
     unsigned long long* probe_buf_ = nullptr;

@@ -118,63 +118,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvGemm p) {
     }
 }
 
-// The same combine for slabs stored in the accumulators' own order (ConvGemm::slab_native; k_gemm_epi.hpp): slot i (one float4) of a slab is
-// [tile][wave][fragment][lane]; the thread that sums slot i over the slices finds its (m, n) from the tile shape and does the epilogue and the row-major
-// store (a wave writes 16 rows x 64 B per fragment).  Slices are summed in the order of splitk_reduce_kernel (same G): bit-identical results.
-template <int G>
-__global__ __launch_bounds__(256) void splitk_reduce_native_kernel(const ConvGemm p) {
-    const float* slabs = p.slabs;
-    float* C = p.C;
-    const int HoWo = p.Ho * p.Wo;
-    const int MI = p.t_mi, NI = p.t_ni, WM = p.t_wm, WN = p.t_wn;
-    const int BM = 16 * MI * WM, BN = 16 * NI * WN;
-    const int NT = (p.N + BN - 1) / BN, MT = (p.M + BM - 1) / BM;
-    const int frags = MI * NI, waves = WM * WN;
-    const long long total = (long long)MT * NT * waves * frags * 64;   // 16-byte slots (those of rows >= M / columns >= N are dead)
-    const long long rounded = (total * G + 255) / 256 * 256;            // whole workgroups take part in the shuffles
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < rounded; t += (long long)gridDim.x * blockDim.x) {
-        const long long i = t / G;
-        const int g = (int)(t - i * G);
-        const bool in_slab = i < total;
-        const long long ii = in_slab ? i : 0;
-        const int lane = (int)(ii & 63);
-        // a wave's 64 threads hold 64 / G consecutive slots of ONE fragment (t is a multiple of 64 at lane 0): everything but the lane is wave-uniform, 32-bit
-        // (launcher: slots < 2^31) -- the first version decoded per thread with 64-bit divisions and gave back in this kernel what the GEMM had saved
-        unsigned r = (unsigned)__builtin_amdgcn_readfirstlane((int)(ii >> 6));
-        const int frag = (int)(r % (unsigned)frags); r /= (unsigned)frags;
-        const int wave = (int)(r % (unsigned)waves);
-        const int tile = (int)(r / (unsigned)waves);
-        const int tm = tile / NT, tn = tile - tm * NT;
-        const int mi = frag / NI, ni = frag - mi * NI;
-        const int wm = wave / WN, wn = wave - wm * WN;
-        const int m = tm * BM + (wm * MI + mi) * 16 + (lane & 15);
-        const int n = tn * BN + (wn * NI + ni) * 16 + (lane >> 4) * 4;
-        const long long off = ii * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        int s = g;
-        for (; s + 3 * G < p.splits; s += 4 * G) {      // four loads in flight, summed in slice order
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(slabs + (long long)s * p.slab_stride + off);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(slabs + (long long)(s + G) * p.slab_stride + off);
-            const f32x4 a2 = *reinterpret_cast<const f32x4*>(slabs + (long long)(s + 2 * G) * p.slab_stride + off);
-            const f32x4 a3 = *reinterpret_cast<const f32x4*>(slabs + (long long)(s + 3 * G) * p.slab_stride + off);
-            v += a0; v += a1; v += a2; v += a3;
-        }
-        for (; s < p.splits; s += G) v += *reinterpret_cast<const f32x4*>(slabs + (long long)s * p.slab_stride + off);
-#pragma unroll
-        for (int o = 1; o < G; o <<= 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], o, 64);
-        }
-        if (in_slab && g == 0 && m < p.M && n < p.N) {
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)(m / HoWo) * p.rowvec_stride + n);
-            if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (long long)m * p.ldr + n);
-            if (C) *reinterpret_cast<f32x4*>(C + (long long)m * p.ldc + n) = v;
-            if (p.C3) s3_store4(reinterpret_cast<unsigned char*>(p.C3) + (long long)m * p.ldc3, n, v);
-        }
-    }
-}
-
 // ---- weight packing ------------------------------------------------------------------
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ bt, int cout, int cin,
                                         int kh, int kw) {
@@ -235,22 +178,6 @@ hipError_t launch_splitk_reduce(const ConvGemm& p, hipStream_t stream) {
     int g = 1;
     if (vec)
         while (g < 8 && work * g < 262144 && 4 * g <= p.splits) g *= 2;
-    if (p.slab_native) {   // slabs in accumulator order (k_gemm3p.hip): same G, i.e. the same summation order, over the padded slot count
-        if (!vec || p.t_mi <= 0 || p.t_ni <= 0 || p.t_wm <= 0 || p.t_wn <= 0) return hipErrorInvalidValue;
-        const int bm = 16 * p.t_mi * p.t_wm, bn = 16 * p.t_ni * p.t_wn;
-        const long long slots = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * bm * bn / 4;
-        if (p.slab_stride != slots * 4 || slots >= (1ll << 31)) return hipErrorInvalidValue;
-        long long nb = (slots * g + 255) / 256;
-        if (nb > 4096) nb = 4096;
-        if (nb < 1) nb = 1;
-        switch (g) {
-            case 1: hipLaunchKernelGGL(splitk_reduce_native_kernel<1>, dim3((unsigned)nb), dim3(256), 0, stream, p); break;
-            case 2: hipLaunchKernelGGL(splitk_reduce_native_kernel<2>, dim3((unsigned)nb), dim3(256), 0, stream, p); break;
-            case 4: hipLaunchKernelGGL(splitk_reduce_native_kernel<4>, dim3((unsigned)nb), dim3(256), 0, stream, p); break;
-            default: hipLaunchKernelGGL(splitk_reduce_native_kernel<8>, dim3((unsigned)nb), dim3(256), 0, stream, p); break;
-        }
-        return hipGetLastError();
-    }
     long long blocks = (work * g + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;

@@ -343,12 +343,6 @@ static hipError_t launch_cfg_3p(const ConvGemm& p, dim3 grid, hipStream_t stream
     return hipGetLastError();
 }
 
-// (MI, NI, WM, WN) of tile cfg: must mirror the switch in launch_conv_gemm3p below (checked there)
-static const int kShapeP[kNumGemmTilesP][4] = {{4, 5, 4, 2}, {4, 4, 4, 2}, {4, 4, 2, 4}, {2, 5, 4, 2}, {2, 4, 4, 2}, {2, 2, 2, 2}, {2, 4, 2, 2}, {4, 5, 1, 4}, {2, 4, 4, 1}};
-void gemm_tile_shape_p(int cfg, int* mi, int* ni, int* wm, int* wn) {
-    *mi = kShapeP[cfg][0]; *ni = kShapeP[cfg][1]; *wm = kShapeP[cfg][2]; *wn = kShapeP[cfg][3];
-}
-
 hipError_t launch_conv_gemm3p(const ConvGemm& p, int cfg, hipStream_t stream) {
     if (cfg < 0 || cfg >= kNumGemmTilesP) return hipErrorInvalidValue;
     if ((p.Cin % 32) || p.CS != 32 || !p.zero_page || !p.Bt3 || !p.A3 || p.a3_ld <= 0 || (p.a3_ld % 192) || p.out_mode != 0) return hipErrorInvalidValue;
@@ -360,10 +354,6 @@ hipError_t launch_conv_gemm3p(const ConvGemm& p, int cfg, hipStream_t stream) {
     const int bno = p.geglu ? bn / 2 : bn;
     const int MT = (p.M + bm - 1) / bm, NT = (p.N + bno - 1) / bno;
     const dim3 grid = gemm_grid(p, MT * NT);
-    if (16 * kShapeP[cfg][0] * kShapeP[cfg][2] != bm || 16 * kShapeP[cfg][1] * kShapeP[cfg][3] != bn) return hipErrorInvalidValue;
-    if (p.slab_native && (p.splits <= 1 || p.t_mi != kShapeP[cfg][0] || p.t_ni != kShapeP[cfg][1] || p.t_wm != kShapeP[cfg][2] || p.t_wn != kShapeP[cfg][3] ||
-                          p.slab_stride != (long long)MT * NT * bm * bn))
-        return hipErrorInvalidValue;
     if (p.probe) {   // diagnostic instantiations (option gemm_probe): the three 8-wave tiles the batch-1 model uses most
         if ((unsigned long long)grid.x * grid.z > (unsigned long long)kGemmProbeBlocks) return hipErrorInvalidValue;   // the stamps would run past the buffer
         switch (cfg) {

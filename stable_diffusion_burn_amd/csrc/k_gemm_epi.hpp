@@ -35,18 +35,6 @@ __device__ __forceinline__ void gemm_epilogue_f32(const ConvGemm& p, epi_f32x4 (
     const bool has_resid = !split && p.resid;
     const bool vec_ok = ((p.N & 3) == 0) && ((ldc & 3) == 0) && ((p.ldr & 3) == 0 || !has_resid);
     constexpr int LDSW = WNC + 4;       // scratch row stride in floats
-    if (split && p.slab_native) {
-        // split-K slab in the accumulators' own order (ConvGemm::slab_native): fragment (mi, ni) of this wave is one 1 KiB store, lane-linear -- no LDS, no index
-        // arithmetic; the combine kernel (splitk_reduce_native_kernel) owns the transposition.  (Measured before: 4.9 of a 66.7 us launch were the transposed store.)
-        const int NT = (p.N + BN - 1) / BN;
-        const long long tile = (long long)(m0 / BM) * NT + n0 / BN;
-        f32x4* dst = reinterpret_cast<f32x4*>(p.slabs + (long long)z * p.slab_stride) + (tile * (WM * WN) + wave) * (MI * NI * 64) + lane;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) dst[(mi * NI + ni) * 64] = acc[mi][ni];
-        return;
-    }
     if (geglu) {   // launch-side guarantees: NI even, no split-K, N % 8 == 0, ldc % 8 == 0, no rowvec / residual
         if constexpr (NI % 2 == 0) {
             constexpr int WNO = WNC / 2;     // output columns of a wave tile

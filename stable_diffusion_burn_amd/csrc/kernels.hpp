@@ -51,10 +51,6 @@ struct ConvGemm {
                                 // 2 two LDS stages on the 128-row tiles, 4 s_setprio 1 for waves 4-7
     int geglu;                  // large-tile kernels: Bt holds 2 N rows (N value rows, then N gate rows; bias likewise) and the
                                 // epilogue writes value * gelu_erf(gate) -- GEGLU::forward (unet/mod.rs:579-591) without the [M, 2N] tensor
-    int slab_native;            // k_gemm3p.hip with splits > 1 (option slab_native, default 1): every wave stores its accumulators in their own order -- slab of slice z =
-                                // [tile = tm NT + tn][wave][fragment mi NI + ni][lane] float4, slab_stride = MT NT BM BN floats -- 1 KiB per store instruction, no LDS transpose
-                                // in the GEMM; launch_splitk_reduce finds (m, n) of a slot from the tile shape below and does the row-major store (profiles/r04ag_*)
-    int t_mi, t_ni, t_wm, t_wn; // ... the tile's fragments per wave (MI x NI of 16 x 16) and waves (WM x WN): gemm_tile_shape_p()
     unsigned long long* probe;  // diagnostic (option gemm_probe; k_gemm3p.hip tiles 300 / 303 / 304 only): when non-null the PROBE instantiation runs and
                                 // stores 24 words per workgroup (see conv_gemm3p_kernel)
 };
@@ -103,7 +99,6 @@ hipError_t launch_pack_split3(const float* bt, void* w3, long long rows, int K, 
 // the same arithmetic with the ACTIVATIONS as planes too, written once by their producer (k_gemm3p.hip; tile_cfg 300 + x; needs p.A3)
 constexpr int kNumGemmTilesP = 9;
 const GemmTileInfo& gemm_tile_info_p(int cfg);
-void gemm_tile_shape_p(int cfg, int* mi, int* ni, int* wm, int* wn);   // the template arguments launch_conv_gemm3p instantiates for tile cfg
 hipError_t launch_conv_gemm3p(const ConvGemm& p, int tile_cfg, hipStream_t stream);
 // fp32 rows [rows][ld] (c channels, c % 32 == 0) -> planes [rows][ld3_bytes / 192 slices][3][32] bf16 (slices [0, c / 32) written)
 hipError_t launch_split3_rows(const float* x, void* y3, long long rows, int c, long long ld, long long ld3_bytes, hipStream_t s);
