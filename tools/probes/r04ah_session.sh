@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a measured-and-removed lever: the option slab_native and its code are in the history -- commit "fp32 plane GEMM: split-K slabs stored in accumulator order" -- not in the tree)
 # round 4, call ah: the whole GPU suite and the headline line on the tree with slab_native (second form: wave-uniform slot decode in the combine kernel)
 out=gpurun_out/r04ah; mkdir -p $out
 timeout 1000 python -m pytest tests -m gpu -x -q -p no:cacheprovider > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -n "passed\|failed\|error" $out/pytest_gpu.log | tail -3
