@@ -311,7 +311,9 @@ int sdmi_op_timestep_embedding(sdmi_ctx* ctx, int32_t t, int32_t dim, float* out
  * SDMI_ERR_UNSUPPORTED naming the limit (64x64x960 concat: CFG batch 2n <= 182, i.e. n <= 91 images per call; "gemm_planes=0" lifts it to the fp32 tensors' 273).
  * A caller that needs IEEE behaviour on infinities sets gemm_f32s = 0 / attn_split = 0.
  * precision = 2 selectors: "fp8_convs" (0: the fp8-capable layers on the bf16 kernels), "fp8_linear" (see sdmi_config.precision),
- * "fp8_min_rows" (GEMMs with fewer output rows stay bf16), "fp8_tile". */
+ * "fp8_min_rows" (GEMMs with fewer output rows stay bf16), "fp8_tile".
+ * precision >= 1: "conv3_reuse" (default 1: 3x3 / stride-1 convolutions that chose the 256 x 320 / 256 x 256 bf16 tile run on k_gemm_bf16t.hip, which stages a kernel
+ * row's activations once for its three taps; results are bit-identical to "0"). */
 int sdmi_set_option(sdmi_ctx* ctx, const char* key, const char* value);
 /* time (ms, HIP events on the context stream) and kernel count of the last
  * hot-path call; flops = algorithmic FLOPs it executed (2*MAC of conv/GEMM/attention). */
