@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record only: the temporary switches / variant this call measured are not in the tree; see profiles/README.md, "Round 4")
 # round 4, call aa: the erf-GELU of the reduced-precision paths by A&S 7.1.26 (13 instructions) instead of erff (~30): parity of the bf16 / precision-2 suites, then the models
 out=gpurun_out/r04aa; mkdir -p $out
 timeout 1500 python -m pytest tests/test_bf16_gpu.py tests/test_fp8_gpu.py -q -p no:cacheprovider -x > $out/pytest_bf16_fp8.log 2>&1; echo "bf16+fp8 tests rc=$?"; tail -3 $out/pytest_bf16_fp8.log | cut -c1-200

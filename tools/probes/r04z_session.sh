@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record only: the temporary switches / variant this call measured are not in the tree; see profiles/README.md, "Round 4")
 # round 4, call z: what the bf16 attention's tile time is made of -- timing-only ablations of attn_bf16_kernel<40, 8> (SDMI_ATTN_ABL bits: 1 no exp / cvt, 2 no maxima,
 # 4 no global loads / LDS stores, 8 no barrier, 16 no V fragment reads, 32 no K fragment reads); results of ablated runs are wrong by construction
 out=gpurun_out/r04z; mkdir -p $out
