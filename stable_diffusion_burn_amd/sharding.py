@@ -48,30 +48,53 @@ def unpack_prompt(packed, t: int, tu: int, ctx_dim: int):
     return cond, uncond
 
 
-def share_flat_array(make, rank: int, world: int, barrier, tag: str, directory: str = "/dev/shm"):
+def share_flat_array(make, rank: int, world: int, barrier, tag: str, directory: str = "/dev/shm", fallback_dirs=None):
     """One host copy of a large read-only float32 array for all ranks of a node (bench.py: the 3.6 GB synthetic weight image, which costs
-    seconds of numpy RNG per rank on shared cores).  Rank 0 calls `make()` and writes the result to `directory/sdmi_<tag>.f32`; after
-    `barrier()` the other ranks map the file read-only (np.memmap: the page cache holds ONE copy); after a second barrier rank 0 unlinks
-    the name (the mappings stay valid).  world == 1: returns make().  Not part of the data path: no collective, only two barriers."""
+    seconds of numpy RNG per rank on shared cores).  Rank 0 calls `make()` and writes the result to `<dir>/sdmi_<tag>.f32` in the first of
+    `directory`, then `fallback_dirs` (default: the temporary directory), that exists, is writable and has room; after `barrier()` the other
+    ranks map the file read-only (np.memmap: the page cache holds ONE copy); after a second barrier rank 0 unlinks the name (the mappings stay
+    valid).  If NO candidate takes the file (a container with a 64 MB /dev/shm and a read-only /tmp), every rank finds no file behind the
+    barrier and calls `make()` itself -- slower, never wrong, and no rank is left waiting.  world == 1: returns make().  Not part of the data
+    path: no collective, only two barriers."""
     import os
+    import shutil
+    import tempfile
     import numpy as np
     if world == 1:
         return np.ascontiguousarray(make(), dtype=np.float32)
-    path = os.path.join(directory, f"sdmi_{tag}.f32")
+    dirs = [directory] + list(fallback_dirs if fallback_dirs is not None else [tempfile.gettempdir()])
+    paths = [os.path.join(d, f"sdmi_{tag}.f32") for d in dirs]
     arr = None
+    written = None
     if rank == 0:
         arr = np.ascontiguousarray(make(), dtype=np.float32)
-        tmp = path + ".tmp"
-        with open(tmp, "wb") as f:
-            arr.tofile(f)
-        os.replace(tmp, path)          # the name appears only once the file is complete
+        for path in paths:
+            tmp = path + ".tmp"
+            try:
+                if shutil.disk_usage(os.path.dirname(path)).free < arr.nbytes + (64 << 20):
+                    continue
+                with open(tmp, "wb") as f:
+                    arr.tofile(f)
+                os.replace(tmp, path)          # the name appears only once the file is complete
+                written = path
+                break
+            except OSError:
+                try:
+                    os.unlink(tmp)
+                except OSError:
+                    pass
     barrier()
     if rank != 0:
-        arr = np.memmap(path, dtype=np.float32, mode="r")
+        for path in paths:
+            if os.path.exists(path):
+                arr = np.memmap(path, dtype=np.float32, mode="r")
+                break
+        else:
+            arr = np.ascontiguousarray(make(), dtype=np.float32)     # rank 0 found no place for the file
     barrier()
-    if rank == 0:
+    if rank == 0 and written is not None:
         try:
-            os.unlink(path)
+            os.unlink(written)
         except OSError:
             pass
     return arr

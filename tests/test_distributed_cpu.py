@@ -62,7 +62,7 @@ def test_broadcast_and_sharding_world2():
     assert covered == list(range(global_batch))
 
 
-def _share_worker(rank, world, port, tag, q):
+def _share_worker(rank, world, port, tag, q, directory="/dev/shm", fallback_dirs=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -72,10 +72,42 @@ def _share_worker(rank, world, port, tag, q):
         calls.append(rank)
         return np.random.default_rng(7).standard_normal(100_003).astype(np.float32)
 
-    arr = sharding.share_flat_array(make, rank, world, dist.barrier, tag)
+    arr = sharding.share_flat_array(make, rank, world, dist.barrier, tag, directory, fallback_dirs)
     dist.barrier()
-    q.put((rank, len(calls), float(np.asarray(arr, np.float64).sum()), arr.shape, os.path.exists(f"/dev/shm/sdmi_{tag}.f32")))
+    left = [d for d in [directory] + list(fallback_dirs or []) if os.path.exists(os.path.join(d, f"sdmi_{tag}.f32"))]
+    q.put((rank, len(calls), float(np.asarray(arr, np.float64).sum()), arr.shape, bool(left), type(arr).__name__))
     dist.destroy_process_group()
+
+
+def _run_share(directory, fallback_dirs):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    tag = f"test_{os.getpid()}_{abs(hash((directory, tuple(fallback_dirs or ())))) % 10 ** 6}"
+    port = _free_port()
+    procs = [ctx.Process(target=_share_worker, args=(r, world, port, tag, q, directory, fallback_dirs)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = float(np.random.default_rng(7).standard_normal(100_003).astype(np.float32).astype(np.float64).sum())
+    assert all(g[2] == want and g[3] == (100_003,) for g in got)
+    assert not any(g[4] for g in got)                       # no file is left behind
+    return got
+
+
+def test_weight_image_falls_back_to_the_next_directory(tmp_path):
+    """the first directory does not exist (or is full: same branch): rank 0 writes to the fallback, rank 1 maps it"""
+    got = _run_share(str(tmp_path / "no_such_dir"), [str(tmp_path)])
+    assert [g[1] for g in got] == [1, 0] and got[1][5] == "memmap"
+
+
+def test_weight_image_is_generated_per_rank_when_no_directory_takes_it(tmp_path):
+    """a container whose /dev/shm is too small and whose temporary directory is read-only: nobody waits, every rank generates its own copy"""
+    got = _run_share(str(tmp_path / "no_such_dir"), [str(tmp_path / "nor_this")])
+    assert [g[1] for g in got] == [1, 1] and got[1][5] == "ndarray"
 
 
 def test_weight_image_is_generated_once_and_mapped_by_the_other_ranks():
@@ -96,6 +128,7 @@ def test_weight_image_is_generated_once_and_mapped_by_the_other_ranks():
     assert [g[1] for g in got] == [1, 0]                    # generated on rank 0 only
     assert all(g[2] == want and g[3] == (100_003,) for g in got)
     assert not any(g[4] for g in got)                       # the name is gone once everybody has mapped it
+    assert got[1][5] == "memmap"
 
 
 def test_single_process_broadcast_is_noop():
