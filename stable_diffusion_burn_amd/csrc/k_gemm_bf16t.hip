@@ -14,7 +14,7 @@
 //     DMA is lane-linear), one precomputed offset per piece.
 // Per kernel row a wave issues 4-5 activation pieces instead of 12, i.e. (33 ... 36) + 3 x 40 = 153 ... 156 pieces per CU instead of 216 (-29 %).  LDS: two
 // activation buffers of 264 ... 288 rows (one kernel row ahead, its pieces spread over the three taps of the current one) + two weight buffers (one tap ahead)
-// <= 152 KB.  Everything else -- weight packing (k = (cs T + tap) 64 + ci), tile map, epilogue, the order of the products (results are bit-identical to tiles
+// = 149.5 ... 155.6 KB.  Everything else -- weight packing (k = (cs T + tap) 64 + ci), tile map, epilogue, the order of the products (results are bit-identical to tiles
 // 100 / 101) -- is k_gemm_bf16x.hip's; split-K slices must hold whole kernel rows.
 //
 // (First form, measured in profiles/r04u: consecutive pixels staged unpadded and the border fixed by zeroing lane c = 0 / 15 of the fragments that start / end
