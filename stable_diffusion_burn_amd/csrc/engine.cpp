@@ -1039,6 +1039,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "fp8_min_rows") opt_fp8_min_rows_ = std::stoi(value);
     else if (key == "fp8_linear") opt_fp8_linear_ = std::stoi(value);
     else if (key == "fp8_ops") opt_fp8_ops_ = std::stoi(value);
+    else if (key == "op_resid") opt_op_resid_ = std::stoi(value);
     else if (key == "fp8_tile") opt_fp8_tile_ = (value == "auto") ? -1 : std::stoi(value);
     else if (key == "attn_bf16") opt_attn_bf16_ = std::stoi(value);
     else if (key == "attn_split") opt_attn_split_ = std::stoi(value);
@@ -1050,6 +1051,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "conv3_reuse") opt_conv3_reuse_ = std::stoi(value);
     else if (key == "gemm_planes") opt_gemm_planes_ = (value == "default") ? kGemmPlanesDefault : std::stoi(value);
     else if (key == "gemm3x_variant") opt_gemm3x_variant_ = std::stoi(value);
+    else if (key == "gemm_bf16x_variant") opt_gemm_bf16x_variant_ = (value == "default") ? kGemmBf16xVariantDefault : std::stoi(value);
     else if (key == "geglu_fuse") opt_geglu_fuse_ = std::stoi(value);
     else if (key == "record_shapes") { record_shapes_ = std::stoi(value) != 0; if (record_shapes_) { shape_counts_.clear(); choice_counts_.clear(); } }
     else if (key == "dump_shapes") {
@@ -1221,7 +1223,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     auto it = table.find(key);
     const bool x32_ok = !in_dt && p.CS == 32 && p.Cin % 32 == 0 && p.out_mode == 0;   // what k_gemm2x.hip handles
     p.Bt3 = in_dt ? nullptr : split_planes(p.Bt);
-    p.variant = in_dt ? 0 : opt_gemm3x_variant_;
+    p.variant = in_dt ? opt_gemm_bf16x_variant_ : opt_gemm3x_variant_;
     // k_gemm3x.hip: the same layers, when the weight has its bf16 planes (weights in the arenas; not e.g. the K / V operands of
     // the unfused VAE attention) and the 32-bit piece offsets reach
     const bool s_ok = x32_ok && p.Bt3 && (unsigned long long)p.N * (p.geglu ? 2 : 1) * (unsigned long long)p.kt_total * 192ull < 0xFFFFFF00ull;
@@ -1247,9 +1249,10 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     else if (it != table.end() && usable(it->second.cfg)) tc = it->second;
     else if (it2 != tuned_mfma_.end() && usable(it2->second.cfg)) tc = it2->second;
     else tc = in_dt ? choose_tile_bf16(p.M, p.N, p.kt_total) : choose_tile(p.M, p.N, p.kt_total, x32_ok, s_ok);
-    if (opt_force_tile_ >= 0 && (from_planes ? opt_force_tile_ >= 300 : (opt_force_tile_ < 100 || in_dt || (opt_force_tile_ >= 300 ? p_ok : opt_force_tile_ >= 200 ? s_ok : x32_ok)))) tc.cfg = opt_force_tile_;  // 100+ / 200+: large-tile kernels, where applicable
+    bool tile_forced = false;   // by option gemm_tile or by the caller: the launch then runs exactly that tile (no upgrade to the kernel-row form below)
+    if (opt_force_tile_ >= 0 && (from_planes ? opt_force_tile_ >= 300 : (opt_force_tile_ < 100 || in_dt || (opt_force_tile_ >= 300 ? p_ok : opt_force_tile_ >= 200 ? s_ok : x32_ok)))) { tc.cfg = opt_force_tile_; tile_forced = true; }  // 100+ / 200+: large-tile kernels, where applicable
     if (opt_force_splits_ > 0) tc.splits = opt_force_splits_;
-    if (force_cfg >= 0) tc.cfg = force_cfg;
+    if (force_cfg >= 0) { tc.cfg = force_cfg; tile_forced = true; }
     // gemm_planes = 2 (A/B switch, tests): every launch that chose a k_gemm3x.hip tile runs on the k_gemm3p.hip tile nearest in shape, its
     // fp32 activations converted by split3_rows_kernel in front of it
     if (!in_dt && !from_planes && p_ok && opt_gemm_planes_ == 2 && tc.cfg >= 200 && tc.cfg < 200 + kNumGemmTilesS) {
@@ -1271,7 +1274,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     const unsigned long long b_ext = ((unsigned long long)p.N * (p.geglu ? 2 : 1) - 1) * (unsigned long long)p.b_ld * es + (unsigned long long)p.K * es;
     p.zero_page = zero_page_;
     // bf16 3x3 / stride-1 convolutions on the 256 x 320 / 256 x 256 tiles: the form that stages a kernel row's activations once for its three taps (k_gemm_bf16t.hip)
-    if (in_dt && opt_conv3_reuse_ && (tc.cfg == 100 || tc.cfg == 101) && conv_gemm_bf16t_supported(p)) tc.cfg += kNumGemmTilesX;
+    if (in_dt && opt_conv3_reuse_ && !tile_forced && (tc.cfg == 100 || tc.cfg == 101) && conv_gemm_bf16t_supported(p)) tc.cfg += kNumGemmTilesX;
     if (record_shapes_) {   // which kernel / tile / split-K each (M, N, K) got: option dump_choices
         char ck[128];
         std::snprintf(ck, sizeof ck, "%d,%d,%d k%d s%d u%d W%d cfg=%d splits=%d%s", p.M, p.N, p.K, p.KH, p.stride, p.ups, p.Ws, tc.cfg, splits, p.Bt3 || in_dt ? "" : " (no planes)");
@@ -1651,6 +1654,7 @@ void Engine::gemm_fp8(const ActQ& x, const LinW& w, int n_rows_w, void* C, int l
 
 void Engine::launch_fp8(ConvGemm& p, double flops) {
     p.out_mode = 0;
+    p.variant = opt_gemm_bf16x_variant_;
     p.zero_page = zero_page_;
     p.kt_total = p.K / 128;
     if ((unsigned long long)p.NB * p.Hs * p.Ws * (unsigned long long)p.a_ld >= 0xFFFFFFE0ull || (unsigned long long)p.N * p.K >= 0xFFFFFFE0ull) throw Error(SDMI_ERR_UNSUPPORTED, "fp8 GEMM: operand larger than 4 GiB");
@@ -2352,7 +2356,9 @@ void Engine::op_conv2d(const float* x, const float* wt, const float* bias, int n
     const int hin = h << ups, win = wd << ups;
     const int ho = (hin + 2 * pad - k) / stride + 1, wo = (win + 2 * pad - k) / stride + 1;
     Act y = new_act(n, ho, wo, cout, (bf16_ && cout > 4) ? 1 : 0);
-    conv(w, a, y, stride, ups, nullptr, 0, nullptr);
+    // option op_resid (tests): out = conv(x) + x through the GEMM's residual epilogue, where the shapes allow it
+    const bool with_resid = opt_op_resid_ && cin == cout && stride == 1 && !ups && a.dt == y.dt;
+    conv(w, a, y, stride, ups, nullptr, 0, with_resid ? &a : nullptr);
     if (y.dt) SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(y.p, out, n, cout, ho, wo, stream_));
     else SDMI_HIP(launch_nhwc_to_nchw(y.p, out, n, cout, ho, wo, stream_));
     release(a); release(y);
@@ -2378,13 +2384,15 @@ void Engine::op_linear(const float* x, const float* wt, const float* bias, int r
         Buf xh(this, (size_t)rows * cin * 2), yh(this, (size_t)rows * cout * 2);
         SDMI_HIP(launch_pack_linear_weight_bf16(wt, bt.p, cin, cout, stream_));
         SDMI_HIP(launch_f32_to_bf16(x, xh.p, (long long)rows * cin, stream_));
-        gemm(xh.f(), rows, bt.f(), bias, cin, cout, yh.f(), cout, nullptr, 0, 1);
+        const bool with_resid = opt_op_resid_ && cin == cout;   // option op_resid (tests): out = x W + b + x through the residual epilogue
+        gemm(xh.f(), rows, bt.f(), bias, cin, cout, yh.f(), cout, with_resid ? xh.f() : nullptr, with_resid ? cin : 0, 1);
         SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(yh.p, out, rows, cout, 1, 1, stream_));
         return;
     }
     SDMI_HIP(launch_pack_linear_weight(wt, bt.f(), cin, cout, stream_));
     TempSplit planes(this, bt.f(), cout, cin);
-    gemm(x, rows, bt.f(), bias, cin, cout, out, cout, nullptr, 0, 0);
+    const bool with_resid = opt_op_resid_ && cin == cout;
+    gemm(x, rows, bt.f(), bias, cin, cout, out, cout, with_resid ? x : nullptr, with_resid ? cin : 0, 0);
 }
 
 void Engine::op_geglu_forward(const float* x, const float* wt, const float* bias, int rows, int cin, int hidden, float* out) {

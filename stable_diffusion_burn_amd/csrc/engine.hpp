@@ -358,6 +358,7 @@ private:
     int opt_fp8_convs_ = 1;          // 0: run the fp8-capable convs on the bf16 kernels (A/B, accuracy comparison)
     int opt_fp8_min_rows_ = 1024;    // GEMMs with fewer output rows stay bf16 (256-row tiles need rows to fill the chip)
     int opt_fp8_tile_ = -1;
+    int opt_op_resid_ = 0;           // tests: op_conv2d / op_linear add their input as the residual (cin == cout) through the GEMM epilogue
     int opt_fp8_ops_ = 0;            // tests: op_linear / op_layer_norm / op_geglu run the fp8_linear path's kernels (outputs dequantised)
     int opt_fp8_linear_ = 0;         // precision = 2: 0 (default: the accuracy budget of 6e-2 final-latent relative RMS) = MXFP8 on the ResBlock / ResnetBlock 3x3
                                      // convolutions only; 1 = also the transformer blocks' Linear layers and the 1x1 / up / down convolutions (8.1e-2)
@@ -431,6 +432,9 @@ private:
     unsigned long long* probe_buf_ = nullptr;
     int opt_bench_cold_ = 0;    // bench_conv: 1 = evict the weights from the Infinity Cache between timed launches (what a layer sees inside the model)
     int opt_gemm_x32_ = 1;      // precision = 0: 1 = large-tile LDS-DMA fp32 GEMM (k_gemm2x.hip) where measured / modelled faster
+    static constexpr int kGemmBf16xVariantDefault = 0;
+    int opt_gemm_bf16x_variant_ = kGemmBf16xVariantDefault; // precision >= 1, the large-tile kernels (k_gemm_bf16x.hip, k_gemm_bf16t.hip, k_fp8.hip): bit 0 = persistent tile loop (k_gemm_bf16x.hip launches without split-K
+                                     // and with more tiles than CUs), bit 1 = bf16 epilogue without the LDS transpose (k_gemm_bf16_epi.hpp "direct")
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
     void* zero_page_ = nullptr;
     TileChoice choose_tile_p(int M, int N, int kt_total, bool even_ni_only) const;   // k_gemm3p.hip tiles (300 + x)

@@ -36,8 +36,18 @@ static const GemmTileInfo kTilesX[kNumGemmTilesX] = {
     {256, 320, "256x320x"}, {256, 256, "256x256x"}, {256, 128, "256x128x"}, {128, 320, "128x320x"}};
 const GemmTileInfo& gemm_tile_info_x(int cfg) { return kTilesX[cfg]; }
 
-template <int MI, int NI, int WM, int WN>
+// PERSIST (round 5; ConvGemm::variant bit 0, launches without split-K and with more tiles than workgroups): the grid is one workgroup per CU and every workgroup
+// walks the tiles vb = blockIdx.x, blockIdx.x + gridDim.x, ... of the same XCD-aware order.  Behind the last k tile of a tile: workgroup barrier (every wave is done
+// with stage L) -> the FIRST k tile of the next tile is DMA'd into stage L -> epilogue with its LDS scratch in stage L ^ 1 (free since the top of the last k
+// iteration) -> the next tile's k loop starts on stage L.  What a tile's launch + prologue cost (profiles/r04ad: 2.2 us of a short-K tile's 11 us of fixed cost) hides
+// behind the epilogue, and the epilogue's stores drain behind the next tile's k loop instead of in front of the next workgroup's start.  Same products in the same
+// order: bit-identical to the one-tile-per-workgroup form.
+// PM: -1 = one tile per workgroup; 0 / 1 / 2 = persistent, with the epilogue's mode fixed at compile time (k_gemm_bf16_epi.hpp: plain / residual / GEGLU gate; bf16 out).
+// In the tile loop hipcc hoists every lane-derived invariant of the per-tile code (piece rows, scratch offsets, ...) in front of the loop, where it lives through the k
+// loop beside 160 accumulators and 52 fragment registers -- 30 to 200 spilled registers; the per-tile code therefore derives them from an opaque copy of the lane index.
+template <int MI, int NI, int WM, int WN, int PM>
 __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) {
+    constexpr bool PERSIST = PM >= 0;
     constexpr int BM = 16 * MI * WM;
     constexpr int BN = 16 * NI * WN;
     static_assert(WM * WN == 8, "8 waves per workgroup");
@@ -57,18 +67,27 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     // GEGLU mode: a tile pairs BN/2 value columns with their BN/2 gate columns (fragment ni even = values, odd = gates of
     // the same outputs), so a lane holds both and the epilogue emits value * gelu(gate)
     constexpr int WNC = 16 * NI;        // columns of a wave tile
-    const bool geglu = p.geglu != 0;
+    const bool geglu = PERSIST ? PM == 2 : p.geglu != 0;
     const int BNO = geglu ? BN / 2 : BN;   // output columns per tile
     const int MT = (p.M + BM - 1) / BM;
     const int NT = (p.N + BNO - 1) / BNO;
-    const GemmWork gw = gemm_work_of_block(p, MT, NT);
-    if (!gw.live) return;
-    const int tm = gw.tm;
-    const int tn = gw.tn;
-    const int m0 = tm * BM;
-    const int n0 = tn * BNO;
+    // tile vb of the XCD-aware order (gemm_work_of_block with the grid's x extent spelled out, so that it also holds for vb >= gridDim.x)
+    const int tiles = MT * NT;
+    const int tpx = (tiles + 7) >> 3;
+    int vb = blockIdx.x;
+    auto tile_of = [&](int b, int& tm_, int& tn_) {
+        const int j = b >> 3;
+        const int lid = (b & 7) * tpx + j;
+        tm_ = lid / NT;
+        tn_ = lid - tm_ * NT;
+        return j < tpx && lid < tiles;
+    };
+    int tm, tn;
+    if (!tile_of(vb, tm, tn)) return;
+    int m0 = tm * BM;
+    int n0 = tn * BNO;
 
-    const int z = gw.z;
+    const int z = PERSIST ? 0 : (int)blockIdx.z;
     const int kt_begin = z * p.kt_per_split;
     const int kt_end = min(kt_begin + p.kt_per_split, p.kt_total);
     const int n_t = kt_end - kt_begin;
@@ -77,7 +96,6 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     const int HoWo = p.Ho * p.Wo;
     f32x4 acc[MI][NI];
     const int c15 = lane & 15, g4 = lane >> 4;
-    {
     const int Hin = p.Hs << p.ups;
     const int Win = p.Ws << p.ups;
     const long long pix_bytes = (long long)p.a_ld * 2;
@@ -85,46 +103,61 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     const char* Bbase = reinterpret_cast<const char*>(p.Bt);
     const char* zero = reinterpret_cast<const char*>(p.zero_page);
 
-    // DMA piece j of a wave covers tile rows (wave + 8 j) * 8 .. + 7; lane -> row + (lane >> 3), LDS slot lane & 7,
+    // DMA piece j of a wave covers tile rows (wave + 8 j) * 8 .. + 7; lane -> row + (lane >> 3) =: sub, LDS slot lane & 7,
     // which receives global chunk (lane & 7) ^ (row & 7) = (lane & 7) ^ (lane >> 3)
-    const int sub = lane >> 3;
-    const int chunk = (lane & 7) ^ sub;
-
     int a_iy0[NA], a_ix0[NA];
     long long a_nboff[NA];
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-        const int m = m0 + (wave + 8 * j) * 8 + sub;
-        const bool ok = m < p.M;
-        const int mm = ok ? m : 0;
-        const int nb = mm / HoWo;
-        const int rem = mm - nb * HoWo;
-        const int oy = rem / p.Wo;
-        const int ox = rem - oy * p.Wo;
-        a_nboff[j] = (long long)nb * (p.Hs * p.Ws) * pix_bytes + chunk * 16;
-        a_iy0[j] = ok ? oy * p.stride - p.pad : -(1 << 28);   // rows past M: never in range -> zero page
-        a_ix0[j] = ox * p.stride - p.pad;
-    }
     const char* b_src[NB];
+    int cs, ky, kx, kt_next;
+    auto opaque_lane = [&]() {
+        int l = lane;
+        if constexpr (PERSIST) asm volatile("" : "+v"(l));
+        return l;
+    };
+    auto setup = [&]() {   // source addresses of tile (m0, n0); rewinds the k walk
+        const int lane_o = opaque_lane();
+        const int sub = lane_o >> 3;
+        const int chunk = (lane_o & 7) ^ sub;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int r0 = (wave + 8 * j) * 8 + sub;   // tile row of operand B
-        int n = n0 + r0;
-        long long wrow = n;
-        if (geglu) {
-            const int f = r0 >> 4, fw = f / NI, ni = f - fw * NI;
-            n = n0 + fw * (WNC / 2) + (ni >> 1) * 16 + (r0 & 15);
-            wrow = (long long)n + ((ni & 1) ? p.N : 0);
+        for (int j = 0; j < NA; ++j) {
+            const int m = m0 + (wave + 8 * j) * 8 + sub;
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0;
+            const int nb = mm / HoWo;
+            const int rem = mm - nb * HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            a_nboff[j] = (long long)nb * (p.Hs * p.Ws) * pix_bytes + chunk * 16;
+            a_iy0[j] = ok ? oy * p.stride - p.pad : -(1 << 28);   // rows past M: never in range -> zero page
+            a_ix0[j] = ox * p.stride - p.pad;
         }
-        b_src[j] = (n < p.N) ? Bbase + wrow * p.b_ld * 2 + chunk * 16 : nullptr;
-    }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int r0 = (wave + 8 * j) * 8 + sub;   // tile row of operand B
+            int n = n0 + r0;
+            long long wrow = n;
+            if (geglu) {
+                const int f = r0 >> 4, fw = f / NI, ni = f - fw * NI;
+                n = n0 + fw * (WNC / 2) + (ni >> 1) * 16 + (r0 & 15);
+                wrow = (long long)n + ((ni & 1) ? p.N : 0);
+            }
+            b_src[j] = (n < p.N) ? Bbase + wrow * p.b_ld * 2 + chunk * 16 : nullptr;
+        }
+        cs = kt_begin / T;
+        const int tap0 = kt_begin - cs * T;
+        ky = tap0 / p.KW;
+        kx = tap0 - ky * p.KW;
+        kt_next = kt_begin;
+    };
 
-    int cs = kt_begin / T;
-    int tap0 = kt_begin - cs * T;
-    int ky = tap0 / p.KW;
-    int kx = tap0 - ky * p.KW;
-    int kt_next = kt_begin;
-
+    auto advance_k = [&]() {
+        const bool wrap_x = (kx + 1 == p.KW);
+        const bool wrap_y = wrap_x && (ky + 1 == p.KH);
+        kx = wrap_x ? 0 : kx + 1;
+        ky = wrap_x ? (wrap_y ? 0 : ky + 1) : ky;
+        cs = wrap_y ? cs + 1 : cs;
+        ++kt_next;
+    };
     auto issue = [&](int buf) {   // DMA of k tile kt_next into LDS stage buf; advances (cs, ky, kx)
         unsigned char* stage = smem_x + buf * STAGE;
         const long long c0b = (long long)cs * 128;
@@ -143,12 +176,43 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
             const char* src = b_src[j] ? b_src[j] + k0b : zero;
             __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(stage + BM * 128 + (wave + 8 * j) * 1024), 16, 0, 0);
         }
-        const bool wrap_x = (kx + 1 == p.KW);
-        const bool wrap_y = wrap_x && (ky + 1 == p.KH);
-        kx = wrap_x ? 0 : kx + 1;
-        ky = wrap_x ? (wrap_y ? 0 : ky + 1) : ky;
-        cs = wrap_y ? cs + 1 : cs;
-        ++kt_next;
+        advance_k();
+    };
+
+    // persistent form: the first k tile (channel slice 0, tap 0) of tile (m0n, n0n) into stage buf, every piece's address computed right in front of its DMA and not
+    // kept -- this runs between a tile's k loop and its epilogue, beside 160 live accumulators
+    auto issue_first = [&](int buf, int m0n, int n0n) {
+        unsigned char* stage = smem_x + buf * STAGE;
+        const int lane_o = opaque_lane();
+        const int sub = lane_o >> 3;
+        const int chunk = (lane_o & 7) ^ sub;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int m = m0n + (wave + 8 * j) * 8 + sub;
+            const int mm = m < p.M ? m : 0;
+            const int nb = mm / HoWo;
+            const int rem = mm - nb * HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            const int iy = oy * p.stride - p.pad, ix = ox * p.stride - p.pad;
+            const bool ok = (m < p.M) & ((unsigned)iy < (unsigned)Hin) & ((unsigned)ix < (unsigned)Win);
+            const long long pix = (long long)((iy >> p.ups) * p.Ws + (ix >> p.ups));
+            const char* src = ok ? Abase + (long long)nb * (p.Hs * p.Ws) * pix_bytes + chunk * 16 + pix * pix_bytes : zero;
+            __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(stage + (wave + 8 * j) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int r0 = (wave + 8 * j) * 8 + sub;
+            int n = n0n + r0;
+            long long wrow = n;
+            if (geglu) {
+                const int f = r0 >> 4, fw = f / NI, ni = f - fw * NI;
+                n = n0n + fw * (WNC / 2) + (ni >> 1) * 16 + (r0 & 15);
+                wrow = (long long)n + ((ni & 1) ? p.N : 0);
+            }
+            const char* src = (n < p.N) ? Bbase + wrow * p.b_ld * 2 + chunk * 16 : zero;
+            __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(stage + BM * 128 + (wave + 8 * j) * 1024), 16, 0, 0);
+        }
     };
 
     // fragment reads: lane (c = lane & 15, g = lane >> 4) reads row base + c, chunk (4 kk + g) ^ (c & 7)
@@ -157,14 +221,17 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     const int a_base = wm * 16 * MI * 128;
     const int b_base = BM * 128 + wn * 16 * NI * 128;
 
+    setup();
+    int s0 = 0;      // LDS stage of the tile's first k tile
+    issue(0);
+    for (;;) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    issue(0);
     for (int t = 0; t < n_t; ++t) {
-        const int cur = t & 1;
+        const int cur = (s0 + t) & 1;
         __syncthreads();                    // k tile t is in LDS; every wave is done with stage cur ^ 1
         if (t + 1 < n_t) issue(cur ^ 1);
         const unsigned char* stage = smem_x + cur * STAGE;
@@ -209,18 +276,74 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
                 }
         }
     }
-    }   // plain k loop
 
-    gemm_epilogue_bf16<MI, NI, WM, WN>(p, acc, smem_x, m0, n0, z, wave, lane, HoWo);
+    const bool direct = (p.variant & 2) != 0;
+    if constexpr (!PERSIST) {
+        gemm_epilogue_bf16<MI, NI, WM, WN>(p, acc, smem_x, m0, n0, z, wave, lane, HoWo, false, direct);
+        break;
+    } else {
+        const int L = (s0 + n_t - 1) & 1;     // stage of the last k tile
+        const int m0c = m0, n0c = n0;
+        vb += gridDim.x;
+        const bool more = tile_of(vb, tm, tn);
+        __syncthreads();                      // every wave is done with stage L (and, since the top of the last k iteration, with stage L ^ 1)
+        if (more) {
+            m0 = tm * BM;
+            n0 = tn * BNO;
+            issue_first(L, m0, n0);
+        }
+        // (the lane index is made opaque per tile: the epilogue's lane-derived offsets are then recomputed here instead of being hoisted out of the tile loop, where
+        // they would live through the k loop beside the accumulators)
+        gemm_epilogue_bf16<MI, NI, WM, WN, PM>(p, acc, smem_x + (L ^ 1) * STAGE, m0c, n0c, 0, wave, opaque_lane(), HoWo, true, direct);
+        if (!more) break;
+        s0 = L;
+        setup();          // (the addresses issue_first computed were not kept: 26 registers that would live through the epilogue)
+        advance_k();      // (k tile 0 is on its way)
+    }
+    }
 }
 
-template <int MI, int NI, int WM, int WN>
+template <int MI, int NI, int WM, int WN, int PM>
 static hipError_t launch_cfg_bf16x(const ConvGemm& p, dim3 grid, hipStream_t stream) {
-    auto k = conv_gemm_bf16x_kernel<MI, NI, WM, WN>;
+    auto k = conv_gemm_bf16x_kernel<MI, NI, WM, WN, PM>;
     constexpr size_t lds = 2 * (size_t)(16 * MI * WM + 16 * NI * WN) * 128;
     if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, dim3(512), lds, stream, p);
     return hipGetLastError();
+}
+template <int MI, int NI, int WM, int WN>
+static hipError_t launch_persist_bf16x(const ConvGemm& p, int mode, dim3 grid, hipStream_t stream) {
+    if (mode == 0) return launch_cfg_bf16x<MI, NI, WM, WN, 0>(p, grid, stream);
+    if (mode == 1) return launch_cfg_bf16x<MI, NI, WM, WN, 1>(p, grid, stream);
+    if constexpr (NI % 2 == 0) { if (mode == 2) return launch_cfg_bf16x<MI, NI, WM, WN, 2>(p, grid, stream); }
+    return hipErrorInvalidValue;
+}
+
+// workgroups of a persistent launch: one per CU of the device the stream belongs to (these tiles take the whole LDS, so more would only queue)
+static int persistent_workgroups() {
+    static int n_cu[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!n_cu[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n_cu[dev] = (v / 8) * 8 > 0 ? (v / 8) * 8 : 8;    // a multiple of the 8 XCDs: workgroup b stays on XCD b % 8 for every tile it walks
+    }
+    return n_cu[dev];
+}
+
+// the persistent kernel's epilogue mode for this launch, or -1: ConvGemm::variant bit 0, no split-K, more tiles than workgroups, and the conditions under which
+// gemm_epilogue_bf16 takes its 16-byte bf16 paths (checked here, compiled in there); a residual needs the direct epilogue (variant bit 1: the LDS form of that path
+// spills inside the tile loop)
+int conv_gemm_bf16x_persistent_mode(const ConvGemm& p, int cfg) {
+    if (!(p.variant & 1) || p.splits != 1 || cfg < 0 || cfg >= kNumGemmTilesX || p.out_mode == 1) return -1;
+    if ((p.N & 7) || (p.ldc & 7) || (p.resid && (p.ldr & 7))) return -1;
+    if (p.resid && !(p.variant & 2)) return -1;
+    const int bm = kTilesX[cfg].bm, bn = kTilesX[cfg].bn;
+    const int bno = p.geglu ? bn / 2 : bn;
+    const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bno - 1) / bno);
+    if (tiles <= persistent_workgroups()) return -1;
+    return p.geglu ? 2 : p.resid ? 1 : 0;
 }
 
 hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int cfg, hipStream_t stream) {
@@ -231,12 +354,21 @@ hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int cfg, hipStream_t stream
     const int bno = p.geglu ? bn / 2 : bn;
     const int MT = (p.M + bm - 1) / bm, NT = (p.N + bno - 1) / bno;
     const int tiles = MT * NT;
+    if (const int mode = conv_gemm_bf16x_persistent_mode(p, cfg); mode >= 0) {
+        const dim3 grid((unsigned)persistent_workgroups(), 1, 1);
+        switch (cfg) {
+            case 0: return launch_persist_bf16x<8, 5, 2, 4>(p, mode, grid, stream);
+            case 1: return launch_persist_bf16x<8, 4, 2, 4>(p, mode, grid, stream);
+            case 2: return launch_persist_bf16x<4, 4, 4, 2>(p, mode, grid, stream);
+            case 3: return launch_persist_bf16x<4, 5, 2, 4>(p, mode, grid, stream);
+        }
+    }
     const dim3 grid = gemm_grid(p, tiles);
     switch (cfg) {
-        case 0: return launch_cfg_bf16x<8, 5, 2, 4>(p, grid, stream);
-        case 1: return launch_cfg_bf16x<8, 4, 2, 4>(p, grid, stream);
-        case 2: return launch_cfg_bf16x<4, 4, 4, 2>(p, grid, stream);
-        case 3: return launch_cfg_bf16x<4, 5, 2, 4>(p, grid, stream);
+        case 0: return launch_cfg_bf16x<8, 5, 2, 4, -1>(p, grid, stream);
+        case 1: return launch_cfg_bf16x<8, 4, 2, 4, -1>(p, grid, stream);
+        case 2: return launch_cfg_bf16x<4, 4, 4, 2, -1>(p, grid, stream);
+        case 3: return launch_cfg_bf16x<4, 5, 2, 4, -1>(p, grid, stream);
     }
     return hipErrorInvalidValue;
 }

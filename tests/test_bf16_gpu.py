@@ -156,7 +156,8 @@ TCASES = [
 @pytest.mark.parametrize("tile", [104, 105])
 @pytest.mark.parametrize("case", TCASES)
 def test_conv2d_bf16_kernel_row_tiles(ops16, tile, case):
-    """k_gemm_bf16t.hip: the three taps of a kernel row read from one staged activation tile (borders by lane masks)"""
+    """k_gemm_bf16t.hip: the three taps of a kernel row read from one staged activation tile (image rows padded in LDS, border columns from the zero page);
+    the reference launch is the forced plain tile 100 / 101 -- a forced tile is not upgraded to the kernel-row form"""
     n, cin, h, w, cout, splitk = case
     g = np.random.default_rng(3300 + tile + cin + cout + splitk + w)
     x = bf16_round(g.standard_normal((n, cin, h, w)))
@@ -302,6 +303,86 @@ def test_geglu_forward_bf16(ops16, rows, cin, hidden, fuse):
     ref = (proj[:, :hidden] * O.gelu_erf(proj[:, hidden:])).numpy()
     # unfused: the projection is rounded to bf16 before the gate (one more rounding than the fused form)
     _check(got, ref, f"geglu_forward bf16 ({rows},{cin},{hidden}) fuse={fuse}", 2 ** -8 if fuse else 2 ** -7)
+
+
+# ---- round 5: the persistent tile loop (gemm_bf16x_variant bit 0) and the epilogue without the LDS transpose (bit 1) --------------------------------------------
+# Both keep every product, its order and the single rounding: results must be BIT-IDENTICAL to variant 0, which the tests above hold against the oracle.  The shapes
+# have more tiles than the chip has CUs (the persistent form's condition), ragged M, N tails, one to nine k tiles, padding taps in a tile's FIRST k tile (issue_first).
+def _variants(ops16, fn, what, variants=(1, 2, 3)):
+    try:
+        ops16.set_option("gemm_bf16x_variant", 0)
+        base = fn()
+        for v in variants:
+            ops16.set_option("gemm_bf16x_variant", v)
+            got = fn()
+            assert np.isfinite(got).all(), f"{what} variant {v}"
+            np.testing.assert_array_equal(got, base, err_msg=f"{what}: gemm_bf16x_variant={v} differs from 0")
+    finally:
+        ops16.set_option("gemm_bf16x_variant", "default")
+    return base
+
+
+PERSIST_LINEAR = [(70001, 64, 1000), (70001, 320, 960), (33000, 128, 2560), (66000, 1280, 320), (140000, 320, 320)]
+
+
+@pytest.mark.parametrize("tile", [100, 101, 102, 103])
+@pytest.mark.parametrize("rows,cin,cout", PERSIST_LINEAR)
+@pytest.mark.parametrize("resid", [0, 1])
+def test_linear_bf16_persistent_and_direct_epilogue(ops16, tile, rows, cin, cout, resid):
+    if resid and cin != cout:
+        pytest.skip("the residual test form needs cin == cout")
+    g = np.random.default_rng(5000 + tile + rows + cin + cout)
+    x = bf16_round(g.standard_normal((rows, cin)))
+    wt = bf16_round(g.standard_normal((cin, cout)) / math.sqrt(cin))
+    b = g.standard_normal(cout).astype(np.float32)
+    try:
+        ops16.set_option("gemm_tile", tile)
+        ops16.set_option("op_resid", resid)
+        base = _variants(ops16, lambda: ops16.op_linear(x, wt, b), f"linear ({rows},{cin},{cout}) tile={tile} resid={resid}")
+    finally:
+        ops16.set_option("gemm_tile", "auto")
+        ops16.set_option("op_resid", 0)
+    rs = np.r_[0:300, rows // 2:rows // 2 + 300, rows - 300:rows]     # oracle on the first / middle / last rows (a full fp64 product would take longer than the rest of the file)
+    ref = O.linear(_t(x[rs]), _t(wt), _t(b)).numpy() + (x[rs] if resid else 0.0)
+    _check(base[rs], ref, f"linear bf16 persistent shapes ({rows},{cin},{cout}) tile={tile} resid={resid}", 2 ** -8)
+
+
+@pytest.mark.parametrize("case", [(8, 64, 97, 97, 320, 3, 1, 0), (8, 64, 49, 48, 200, 3, 1, 1), (8, 128, 96, 96, 64, 1, 1, 0), (8, 64, 96, 96, 64, 3, 1, 0)])
+@pytest.mark.parametrize("tile", [100, 102])
+def test_conv2d_bf16_persistent_and_direct_epilogue(ops16, tile, case):
+    n, cin, h, w, cout, k, stride, ups = case
+    g = np.random.default_rng(5100 + tile + cin + cout + h)
+    x = bf16_round(g.standard_normal((n, cin, h, w)))
+    wt = bf16_round(g.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k))
+    b = g.standard_normal(cout).astype(np.float32)
+    resid = int(cin == cout)
+    try:
+        ops16.set_option("gemm_tile", tile)
+        ops16.set_option("op_resid", resid)
+        base = _variants(ops16, lambda: ops16.op_conv2d(x, wt, b, stride=stride, upsample2x=bool(ups)), f"conv {case} tile={tile}")
+    finally:
+        ops16.set_option("gemm_tile", "auto")
+        ops16.set_option("op_resid", 0)
+    xin = O.upsample2x(_t(x[:1])) if ups else _t(x[:1])               # oracle on the first sample
+    ref = O.conv2d(xin, (_t(wt), _t(b)), stride=stride, padding=1 if k == 3 else 0).numpy() + (x[:1] if resid else 0.0)
+    _check(base[:1], ref, f"conv bf16 persistent shapes {case} tile={tile}", 2 ** -8)
+
+
+@pytest.mark.parametrize("rows,cin,hidden", [(40000, 320, 1280), (70001, 64, 328)])
+@pytest.mark.parametrize("fuse", [2, 3])
+def test_geglu_forward_bf16_persistent_and_direct_epilogue(ops16, rows, cin, hidden, fuse):
+    g = np.random.default_rng(5200 + rows + hidden + fuse)
+    x = bf16_round(g.standard_normal((rows, cin)))
+    w = bf16_round(g.standard_normal((cin, 2 * hidden)) / math.sqrt(cin))
+    b = g.standard_normal(2 * hidden).astype(np.float32)
+    try:
+        ops16.set_option("geglu_fuse", fuse)
+        base = _variants(ops16, lambda: ops16.op_geglu_forward(x, w, b, hidden), f"geglu_forward ({rows},{cin},{hidden}) fuse={fuse}")
+    finally:
+        ops16.set_option("geglu_fuse", 1)
+    rs = np.r_[0:300, rows - 300:rows]
+    proj = _t(x[rs]) @ _t(w) + _t(b)
+    _check(base[rs], (proj[:, :hidden] * O.gelu_erf(proj[:, hidden:])).numpy(), f"geglu_forward bf16 persistent shapes ({rows},{cin},{hidden}) fuse={fuse}", 2 ** -8)
 
 
 # ---- model level: full-width UNet / decoder at an 8x8 latent -----------------------------------------------------
