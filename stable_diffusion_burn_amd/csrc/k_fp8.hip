@@ -281,7 +281,7 @@ __global__ __launch_bounds__(512) void conv_gemm_fp8x_kernel(const ConvGemm p) {
 
     // ---- epilogue: fp32 bias + time-embedding row + (bf16) residual -> bf16 (or fp32 slab / fp32 output): the LDS-transposed, row-coalesced store shared
     // with k_gemm_bf16x.hip (N % 8 == 0, ldc % 8 == 0 checked by the launcher; no GEGLU pairing on this kernel)
-    gemm_epilogue_bf16<MI, NI, WM, WN>(p, acc, smem_q, m0, n0, z, wave, lane, HoWo, false, (p.variant & 2) != 0);
+    gemm_epilogue_bf16<MI, NI, WM, WN>(p, acc, smem_q, m0, n0, z, wave, lane, HoWo);
 }
 
 static const GemmTileInfo kTilesQ[kNumGemmTilesQ] = {{256, 320, "256x320q"}, {256, 256, "256x256q"}, {256, 128, "256x128q"}};

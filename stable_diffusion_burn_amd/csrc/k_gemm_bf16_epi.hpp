@@ -28,29 +28,14 @@ __device__ __forceinline__ unsigned xpack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bepi_bf16x2));
 }
 
-// v_permlane16_swap_b32: the odd 16-lane rows of a swap with the even rows of b (a = [a.r0, b.r0, a.r2, b.r2], b = [a.r1, b.r1, a.r3, b.r3]).  Inline asm with its
-// own wait states (a VALU write of either operand needs two before the swap reads it; hipcc pads nothing inside an asm string).
-__device__ __forceinline__ void xswap16(unsigned& a, unsigned& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-// two packed fragments a, b (two dwords each) -> the 16 bytes this lane stores: {a.x, a.y, b.x, b.y} after both dwords were exchanged
-__device__ __forceinline__ bepi_u32x4 xswap16_pair(bepi_u32x2 a, bepi_u32x2 b) {
-    unsigned a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
-    xswap16(a0, b0);
-    xswap16(a1, b1);
-    return bepi_u32x4{a0, a1, b0, b1};
-}
-
 // pre_synced: the caller has already passed a workgroup barrier behind the last k tile (the persistent kernel, which issues the next tile's first DMA between that
 //             barrier and this epilogue) -- smem_x is then the stage the next tile does NOT land in.
-// direct:     bf16 output without a residual leaves WITHOUT the LDS transpose (round 5): the packed fragments of two neighbouring column groups are exchanged between the
-//             wave's 16-lane rows (two v_permlane16_swap per pair), after which every lane holds 8 consecutive channels of one row = one 16-byte store; a row receives
-//             64-byte pieces instead of whole 160-byte segments, the values and their single rounding are the same.
-// MODE: -1 = every decision below is taken at run time from p (the one-tile-per-workgroup kernels); 0 / 1 / 2 = bf16 output through the 16-byte paths, known at compile
-//             time to be plain / with a residual / the GEGLU gate (the persistent kernel: inside its tile loop the run-time form with all its paths costs 200 spilled
-//             registers) -- the launcher checks what the run-time form checks.
+// MODE: -1 = every decision below is taken at run time from p (the one-tile-per-workgroup kernels); 0 / 2 = bf16 output through the 16-byte paths, known at compile
+//             time to be plain (no residual) / the GEGLU gate (the persistent kernel: inside its tile loop the run-time form with all its paths costs 200 spilled
+//             registers, the residual path alone 49) -- the launcher checks what the run-time form checks.
 template <int MI, int NI, int WM, int WN, int MODE = -1>
 __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4 (&acc)[MI][NI], unsigned char* smem_x, const int m0, const int n0,
-                                                   const int z, const int wave, const int lane, const int HoWo, const bool pre_synced = false,
-                                                   const bool direct = false) {
+                                                   const int z, const int wave, const int lane, const int HoWo, const bool pre_synced = false) {
     typedef bepi_f32x4 f32x4;
     typedef bepi_u32x4 u32x4;
     typedef bepi_u32x2 u32x2;
@@ -70,7 +55,7 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4
     unsigned short* Ch = reinterpret_cast<unsigned short*>(p.C);
     const unsigned short* Rh = reinterpret_cast<const unsigned short*>(p.resid);
     const int ldc = split ? p.N : p.ldc;
-    const bool has_resid = MODE < 0 ? (!split && p.resid) : MODE == 1;
+    const bool has_resid = MODE < 0 ? (!split && p.resid) : false;
     const bool vec_ok = MODE < 0 ? (((p.N & 7) == 0) && ((ldc & 7) == 0) && ((p.ldr & 7) == 0 || !has_resid)) : true;
     constexpr int LDSW = WNC + 4;       // scratch row stride in floats (336 B for NI = 5: 16-byte aligned, rows on distinct banks)
     if (geglu) {   // launch-side guarantees: NI even, no split-K, N % 8 == 0, ldc % 8 == 0, no rowvec / residual
@@ -93,33 +78,7 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4
                 return o;
             };
             constexpr int CH = WNO / 8;
-            if (direct && (MODE >= 0 || p.out_mode != 1)) {
-                constexpr int NJ = NI / 2;
-                static_assert(NJ % 2 == 0 || MI % 2 == 0, "an odd fragment column pairs with the next row group");
-                const int gl = g4 & 1, gh = g4 >> 1;
-                unsigned short* Cg = reinterpret_cast<unsigned short*>(p.C);
-                auto packed = [&](int mi, int j) {
-                    const f32x4 o = gate(mi, j);
-                    return u32x2{xpack_bf16x2(o[0], o[1]), xpack_bf16x2(o[2], o[3])};
-                };
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const int m = m0 + (wm * MI + mi) * 16 + c15;
-#pragma unroll
-                    for (int j = 0; j + 1 < NJ; j += 2) {
-                        const u32x2 a = packed(mi, j), b = packed(mi, j + 1);
-                        const u32x4 o4 = xswap16_pair(a, b);
-                        const int n = nw0 + (j + gl) * 16 + gh * 8;
-                        if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Cg + (long long)m * p.ldc + n) = o4;
-                    }
-                    if ((NJ & 1) && !(mi & 1)) {
-                        const u32x2 a = packed(mi, NJ - 1), b = packed(mi + 1, NJ - 1);
-                        const u32x4 o4 = xswap16_pair(a, b);
-                        const int mm = m + gl * 16, n = nw0 + (NJ - 1) * 16 + gh * 8;
-                        if (mm < p.M && n < p.N) *reinterpret_cast<u32x4*>(Cg + (long long)mm * p.ldc + n) = o4;
-                    }
-                }
-            } else if (MODE >= 0 || p.out_mode != 1) {
+            if (MODE >= 0 || p.out_mode != 1) {
                 // bf16 output: rounded before the transpose, 2-byte scratch (see the main path below), the gate of group mi + 1 behind the stores of group mi
                 constexpr int RSB = WNO * 2 + 16;
                 static_assert(((RSB / 16) & 1) == 1, "scratch rows must start on distinct 16-byte bank slots");
@@ -180,77 +139,7 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4
         }
         return;
     }
-    if (vec_ok && direct && !out_f32 && !has_resid) {
-        static_assert(NI % 2 == 0 || MI % 2 == 0, "an odd fragment column pairs with the next row group");
-        const int nw0 = n0 + wn * WNC;
-        const int gl = g4 & 1, gh = g4 >> 1;
-        auto packed = [&](int mi, int ni) {
-            const int m = m0 + (wm * MI + mi) * 16 + c15;
-            const int smp = (m < p.M ? m : 0) / HoWo;
-            const int n = nw0 + ni * 16 + g4 * 4;
-            f32x4 v = acc[mi][ni];
-            if (n < p.N) {
-                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)smp * p.rowvec_stride + n);
-            }
-            return u32x2{xpack_bf16x2(v[0], v[1]), xpack_bf16x2(v[2], v[3])};
-        };
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int m = m0 + (wm * MI + mi) * 16 + c15;
-#pragma unroll
-            for (int j = 0; j + 1 < NI; j += 2) {
-                // lane rows after the exchange: r0 = (ni j, columns 0..7), r1 = (ni j + 1, 0..7), r2 = (ni j, 8..15), r3 = (ni j + 1, 8..15) of tile row c15
-                const u32x2 a = packed(mi, j), b = packed(mi, j + 1);
-                const u32x4 o4 = xswap16_pair(a, b);
-                const int n = nw0 + (j + gl) * 16 + gh * 8;
-                if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Ch + (long long)m * ldc + n) = o4;
-            }
-            if ((NI & 1) && !(mi & 1)) {   // the odd column group of row groups mi and mi + 1 share their stores
-                const u32x2 a = packed(mi, NI - 1), b = packed(mi + 1, NI - 1);
-                const u32x4 o4 = xswap16_pair(a, b);
-                const int mm = m + gl * 16, n = nw0 + (NI - 1) * 16 + gh * 8;
-                if (mm < p.M && n < p.N) *reinterpret_cast<u32x4*>(Ch + (long long)mm * ldc + n) = o4;
-            }
-        }
-    } else if (vec_ok && direct && !out_f32) {
-        // ... with a residual: the add precedes the only rounding, so the fp32 values are exchanged (four swaps per fragment pair), after which a lane holds 8 consecutive
-        // channels of one row, reads the residual's 16 bytes there, adds, rounds and stores
-        static_assert(NI % 2 == 0 || MI % 2 == 0, "an odd fragment column pairs with the next row group");
-        const int nw0 = n0 + wn * WNC;
-        const int gl = g4 & 1, gh = g4 >> 1;
-        auto biased = [&](int mi, int ni) {
-            const int m = m0 + (wm * MI + mi) * 16 + c15;
-            const int smp = (m < p.M ? m : 0) / HoWo;
-            const int n = nw0 + ni * 16 + g4 * 4;
-            f32x4 v = acc[mi][ni];
-            if (n < p.N) {
-                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)smp * p.rowvec_stride + n);
-            }
-            return v;
-        };
-        auto emit = [&](f32x4 a, f32x4 b, int m, int n) {
-            unsigned a0 = __float_as_uint(a[0]), a1 = __float_as_uint(a[1]), a2 = __float_as_uint(a[2]), a3 = __float_as_uint(a[3]);
-            unsigned b0 = __float_as_uint(b[0]), b1 = __float_as_uint(b[1]), b2 = __float_as_uint(b[2]), b3 = __float_as_uint(b[3]);
-            xswap16(a0, b0); xswap16(a1, b1); xswap16(a2, b2); xswap16(a3, b3);
-            if (m < p.M && n < p.N) {
-                const u32x4 rr = *reinterpret_cast<const u32x4*>(Rh + (long long)m * p.ldr + n);
-                const u32x4 o = {xpack_bf16x2(__uint_as_float(a0) + xbf16_lo(rr[0]), __uint_as_float(a1) + xbf16_hi(rr[0])),
-                                 xpack_bf16x2(__uint_as_float(a2) + xbf16_lo(rr[1]), __uint_as_float(a3) + xbf16_hi(rr[1])),
-                                 xpack_bf16x2(__uint_as_float(b0) + xbf16_lo(rr[2]), __uint_as_float(b1) + xbf16_hi(rr[2])),
-                                 xpack_bf16x2(__uint_as_float(b2) + xbf16_lo(rr[3]), __uint_as_float(b3) + xbf16_hi(rr[3]))};
-                *reinterpret_cast<u32x4*>(Ch + (long long)m * ldc + n) = o;
-            }
-        };
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int m = m0 + (wm * MI + mi) * 16 + c15;
-#pragma unroll
-            for (int j = 0; j + 1 < NI; j += 2) emit(biased(mi, j), biased(mi, j + 1), m, nw0 + (j + gl) * 16 + gh * 8);
-            if ((NI & 1) && !(mi & 1)) emit(biased(mi, NI - 1), biased(mi + 1, NI - 1), m + gl * 16, nw0 + (NI - 1) * 16 + gh * 8);
-        }
-    } else if (vec_ok) {
+    if (vec_ok) {
         if (!pre_synced) __syncthreads();                // every wave is done with the last k tile
         float* scr = reinterpret_cast<float*>(smem_x + wave * (16 * LDSW * 4));
         const int nw0 = n0 + wn * WNC;

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512) void conv3_gemm_bf16t_kernel(const ConvGemm p)
         }
     }
 
-    gemm_epilogue_bf16<MI, NI, WM, WN>(p, acc, smem_t, m0, n0, z, wave, lane, HoWo, false, (p.variant & 2) != 0);
+    gemm_epilogue_bf16<MI, NI, WM, WN>(p, acc, smem_t, m0, n0, z, wave, lane, HoWo);
 }
 
 template <int NI, int WF>

@@ -42,7 +42,7 @@ const GemmTileInfo& gemm_tile_info_x(int cfg) { return kTilesX[cfg]; }
 // iteration) -> the next tile's k loop starts on stage L.  What a tile's launch + prologue cost (profiles/r04ad: 2.2 us of a short-K tile's 11 us of fixed cost) hides
 // behind the epilogue, and the epilogue's stores drain behind the next tile's k loop instead of in front of the next workgroup's start.  Same products in the same
 // order: bit-identical to the one-tile-per-workgroup form.
-// PM: -1 = one tile per workgroup; 0 / 1 / 2 = persistent, with the epilogue's mode fixed at compile time (k_gemm_bf16_epi.hpp: plain / residual / GEGLU gate; bf16 out).
+// PM: -1 = one tile per workgroup; 0 / 2 = persistent, with the epilogue's mode fixed at compile time (k_gemm_bf16_epi.hpp: plain / GEGLU gate; bf16 out, no residual).
 // In the tile loop hipcc hoists every lane-derived invariant of the per-tile code (piece rows, scratch offsets, ...) in front of the loop, where it lives through the k
 // loop beside 160 accumulators and 52 fragment registers -- 30 to 200 spilled registers; the per-tile code therefore derives them from an opaque copy of the lane index.
 template <int MI, int NI, int WM, int WN, int PM>
@@ -277,9 +277,8 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
         }
     }
 
-    const bool direct = (p.variant & 2) != 0;
     if constexpr (!PERSIST) {
-        gemm_epilogue_bf16<MI, NI, WM, WN>(p, acc, smem_x, m0, n0, z, wave, lane, HoWo, false, direct);
+        gemm_epilogue_bf16<MI, NI, WM, WN>(p, acc, smem_x, m0, n0, z, wave, lane, HoWo);
         break;
     } else {
         const int L = (s0 + n_t - 1) & 1;     // stage of the last k tile
@@ -294,7 +293,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
         }
         // (the lane index is made opaque per tile: the epilogue's lane-derived offsets are then recomputed here instead of being hoisted out of the tile loop, where
         // they would live through the k loop beside the accumulators)
-        gemm_epilogue_bf16<MI, NI, WM, WN, PM>(p, acc, smem_x + (L ^ 1) * STAGE, m0c, n0c, 0, wave, opaque_lane(), HoWo, true, direct);
+        gemm_epilogue_bf16<MI, NI, WM, WN, PM>(p, acc, smem_x + (L ^ 1) * STAGE, m0c, n0c, 0, wave, opaque_lane(), HoWo, true);
         if (!more) break;
         s0 = L;
         setup();          // (the addresses issue_first computed were not kept: 26 registers that would live through the epilogue)
@@ -314,7 +313,6 @@ static hipError_t launch_cfg_bf16x(const ConvGemm& p, dim3 grid, hipStream_t str
 template <int MI, int NI, int WM, int WN>
 static hipError_t launch_persist_bf16x(const ConvGemm& p, int mode, dim3 grid, hipStream_t stream) {
     if (mode == 0) return launch_cfg_bf16x<MI, NI, WM, WN, 0>(p, grid, stream);
-    if (mode == 1) return launch_cfg_bf16x<MI, NI, WM, WN, 1>(p, grid, stream);
     if constexpr (NI % 2 == 0) { if (mode == 2) return launch_cfg_bf16x<MI, NI, WM, WN, 2>(p, grid, stream); }
     return hipErrorInvalidValue;
 }
@@ -332,18 +330,16 @@ static int persistent_workgroups() {
     return n_cu[dev];
 }
 
-// the persistent kernel's epilogue mode for this launch, or -1: ConvGemm::variant bit 0, no split-K, more tiles than workgroups, and the conditions under which
-// gemm_epilogue_bf16 takes its 16-byte bf16 paths (checked here, compiled in there); a residual needs the direct epilogue (variant bit 1: the LDS form of that path
-// spills inside the tile loop)
+// the persistent kernel's epilogue mode for this launch, or -1: ConvGemm::variant bit 0, no split-K, more tiles than workgroups, no residual (that path of the
+// epilogue spills inside the tile loop) and the conditions under which gemm_epilogue_bf16 takes its 16-byte bf16 paths (checked here, compiled in there)
 int conv_gemm_bf16x_persistent_mode(const ConvGemm& p, int cfg) {
     if (!(p.variant & 1) || p.splits != 1 || cfg < 0 || cfg >= kNumGemmTilesX || p.out_mode == 1) return -1;
-    if ((p.N & 7) || (p.ldc & 7) || (p.resid && (p.ldr & 7))) return -1;
-    if (p.resid && !(p.variant & 2)) return -1;
+    if ((p.N & 7) || (p.ldc & 7) || p.resid) return -1;
     const int bm = kTilesX[cfg].bm, bn = kTilesX[cfg].bn;
     const int bno = p.geglu ? bn / 2 : bn;
     const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bno - 1) / bno);
     if (tiles <= persistent_workgroups()) return -1;
-    return p.geglu ? 2 : p.resid ? 1 : 0;
+    return p.geglu ? 2 : 0;
 }
 
 hipError_t launch_conv_gemm_bf16x(const ConvGemm& p, int cfg, hipStream_t stream) {

@@ -48,8 +48,7 @@ struct ConvGemm {
     const void* a_scale;        // fp8 kernel: E8M0 scales of A, [pixels][a_ld / 32] bytes (a_ld = padded channel count = bytes per pixel)
     const void* b_scale;        // fp8 kernel: E8M0 scales of Bt, [N][b_ld / 32] bytes
     int variant;                // k_gemm3x.hip A/B switches (option gemm3x_variant): bit 0 DMA issued in one block per k tile, 1 scalar residual subtractions,
-                                // 2 two LDS stages on the 128-row tiles, 4 s_setprio 1 for waves 4-7; the bf16 / fp8 large-tile kernels (option gemm_bf16x_variant):
-                                // bit 0 persistent tile loop (k_gemm_bf16x.hip), bit 1 bf16 epilogue without the LDS transpose
+                                // 2 two LDS stages on the 128-row tiles, 4 s_setprio 1 for waves 4-7; k_gemm_bf16x.hip (option gemm_bf16x_variant): bit 0 persistent tile loop
     int geglu;                  // large-tile kernels: Bt holds 2 N rows (N value rows, then N gate rows; bias likewise) and the
                                 // epilogue writes value * gelu_erf(gate) -- GEGLU::forward (unet/mod.rs:579-591) without the [M, 2N] tensor
     unsigned long long* probe;  // diagnostic (option gemm_probe; k_gemm3p.hip tiles 300 / 303 / 304 only): when non-null the PROBE instantiation runs and

@@ -305,10 +305,12 @@ def test_geglu_forward_bf16(ops16, rows, cin, hidden, fuse):
     _check(got, ref, f"geglu_forward bf16 ({rows},{cin},{hidden}) fuse={fuse}", 2 ** -8 if fuse else 2 ** -7)
 
 
-# ---- round 5: the persistent tile loop (gemm_bf16x_variant bit 0) and the epilogue without the LDS transpose (bit 1) --------------------------------------------
-# Both keep every product, its order and the single rounding: results must be BIT-IDENTICAL to variant 0, which the tests above hold against the oracle.  The shapes
-# have more tiles than the chip has CUs (the persistent form's condition), ragged M, N tails, one to nine k tiles, padding taps in a tile's FIRST k tile (issue_first).
-def _variants(ops16, fn, what, variants=(1, 2, 3)):
+# ---- round 5: the persistent tile loop (gemm_bf16x_variant bit 0, the default) ------------------------------------------------------------------------------------
+# It keeps every product, its order and the single rounding: results must be BIT-IDENTICAL to variant 0 (one tile per workgroup), which the tests above hold against
+# the oracle.  The shapes have more tiles than the chip has CUs (the persistent form's condition), ragged M, N tails, one to twenty k tiles, padding taps in a tile's
+# FIRST k tile (issue_first); with a residual the launch stays on the one-tile form (checked to be a no-op here).  (Round 5 also measured an epilogue without the LDS
+# transpose -- v_permlane16_swap pairs, 64-byte row pieces -- bit-identical and 4 ... 7 % slower per launch: removed, profiles/r05a_*.)
+def _variants(ops16, fn, what, variants=(1,)):
     try:
         ops16.set_option("gemm_bf16x_variant", 0)
         base = fn()

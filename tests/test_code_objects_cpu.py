@@ -54,16 +54,12 @@ def test_large_tile_bf16_epilogue_form(tmp_path):
     funcs = _functions("k_gemm_bf16x", tmp_path)
     inst = {k: v for k, v in funcs.items() if "conv_gemm_bf16x_kernel" in k}
     one_tile = {k: v for k, v in inst.items() if k.endswith("ELin1EEEvNS_8ConvGemmE")}      # PM = -1: one tile per workgroup, every epilogue decision at run time
-    persistent = {k: v for k, v in inst.items() if k not in one_tile}                         # PM = 0 / 1 / 2: the tile loop with its epilogue mode compiled in (round 5)
-    assert len(one_tile) == 4 and len(persistent) == 10, sorted(inst)                         # 4 tiles x {plain, residual} + the two even-NI tiles' GEGLU form
+    persistent = {k: v for k, v in inst.items() if k not in one_tile}                         # PM = 0 / 2: the tile loop with its epilogue mode compiled in (round 5)
+    assert len(one_tile) == 4 and len(persistent) == 6, sorted(inst)                          # 4 tiles plain + the two even-NI tiles' GEGLU form
     for name, body in inst.items():
         tail = body.rsplit("v_mfma_f32_16x16x32_bf16", 1)[1]               # everything behind the last matrix instruction: the epilogue
-        assert "v_cvt_pk_bf16_f32" in tail, name
+        assert "v_cvt_pk_bf16_f32" in tail and "ds_write_b64" in tail and "ds_read_b128" in tail, name
         assert tail.count("v_cvt_pk_bf16_f32") >= 16, name               # (the integer round-to-nearest-even survives only in the odd-stride fallback's scalar stores)
-        assert "v_permlane16_swap_b32" in tail, name                     # the epilogue without the LDS transpose (ConvGemm::variant bit 1)
-    for name, body in one_tile.items():
-        tail = body.rsplit("v_mfma_f32_16x16x32_bf16", 1)[1]
-        assert "ds_write_b64" in tail and "ds_read_b128" in tail, name  # the 2-byte LDS transpose (variant bit 1 clear)
     for name, body in persistent.items():
         # the tile loop keeps the k loop free of spill traffic: no SGPR-spill lane moves between the first and the last matrix instruction of the body
         loop = body.split("v_mfma_f32_16x16x32_bf16", 1)[1].rsplit("v_mfma_f32_16x16x32_bf16", 1)[0]
