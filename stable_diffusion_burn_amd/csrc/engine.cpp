@@ -387,7 +387,7 @@ void Engine::build_model() {
         lin(m.q, path + "/query", c, c, false);
         // precision >= 1: the bf16 attention kernel takes q in log2 units -- d_head^-0.5 log2(e) is folded into the query weight here, in
         // fp32, before its only rounding (attention.rs:15-26 applies d_head^-0.25 to q and to k)
-        if (m.q.dt && attn_bf16_q_is_log2(c / cfg_.n_head)) entries_[entry_index_.at(path + "/query/weight")].pre_scale = attn_bf16_q_scale(c / cfg_.n_head);
+        if (q_prescaled(m.q.dt, c / cfg_.n_head)) entries_[entry_index_.at(path + "/query/weight")].pre_scale = attn_bf16_q_scale(c / cfg_.n_head);
         lin(m.k, path + "/key", cctx, c, false);
         lin(m.v, path + "/value", cctx, c, false);
         lin(m.out, path + "/out", c, c, true);
@@ -1322,9 +1322,14 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     };
     p.slabs = nullptr;
     const int pc = (!in_dt && tc.cfg >= 200) ? PC_CONV_SPLIT : PC_CONV_GEMM;   // k_gemm3x.hip launches are timed as their own class
+    // ALGORITHMIC bytes of the launch in the formats the tensors are stored in: the source activations once, the weights once, the result once (bf16 2 B, fp32 4 B,
+    // planes 6 B per element; split-K slabs and im2col / tile re-reads are not algorithmic) -- what the PMC byte counters of profiles/pmc_summary.json are held against
+    const double a_es = in_dt ? 2.0 : (tc.cfg >= 300 ? 6.0 : 4.0), w_es = in_dt ? 2.0 : (tc.cfg >= 200 ? 6.0 : 4.0);
+    const double c_es = in_dt ? (p.out_mode == 1 ? 4.0 : 2.0) : (p.out_mode == 2 ? 2.0 : ((p.C ? 4.0 : 0.0) + (c3_native ? 6.0 : 0.0)));
+    const double gemm_bytes = (double)p.NB * p.Hs * p.Ws * p.Cin * a_es + (double)p.N * (p.geglu ? 2.0 : 1.0) * p.K * w_es + (double)p.M * p.N * c_es;
     if (splits == 1) {
         p.slab_stride = 0;
-        ProfScope ps(this, pc, flops);
+        ProfScope ps(this, pc, flops, gemm_bytes);
         SDMI_HIP(launch(p));
         count_kernel(flops);
     } else {
@@ -1332,7 +1337,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         Buf slab(this, (size_t)splits * p.slab_stride * sizeof(float));
         p.slabs = slab.f();
         {
-            ProfScope ps(this, pc, flops);
+            ProfScope ps(this, pc, flops, gemm_bytes);
             SDMI_HIP(launch(p));
         }
         count_kernel(flops);
@@ -1484,13 +1489,13 @@ void Engine::layer_norm(const NormW& w, const float* x, long long rows, float* y
 void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, int ldk, long long k_bs,
                        const float* v, int ldv, long long v_bs, float* o, int ldo, long long o_bs, int n, int nq,
                        int nk, int n_head, int d_head, const int* kv_len_dev, const int* kv_len_host,
-                       const float* mask, int mask_ld, int dt, void* o3) {
+                       const float* mask, int mask_ld, int dt, void* o3, bool q_log2) {
     if (dt < 0) dt = edt();
     if (nq <= 0 || nk <= 0) throw Error(SDMI_ERR_INVALID, "attention: empty sequence");
     if (o3 && (dt || !attn_supported_head_dim(d_head) || (n_head * d_head) % 32)) throw Error(SDMI_ERR_STATE, "attention: plane output needs a fused fp32 kernel");
-    // bf16 tensors at the UNet's head dims: q arrives in log2 units (attn_bf16_q_scale: folded into the query weights at load, applied by
+    // q_log2 (stated by the caller, Engine::q_prescaled): q arrives in log2 units (attn_bf16_q_scale: folded into the query weights at load, applied by
     // qkv_attention_dev's conversion); the bf16 kernel needs no scale, the widened fp32 kernel (attn_bf16=0) gets scale^2 = ln 2
-    const bool q_log2 = dt && attn_bf16_q_is_log2(d_head);
+    if (q_log2 != q_prescaled(dt, d_head)) throw Error(SDMI_ERR_STATE, "attention: the caller's statement about the query's scale does not match the storage type / head dim");
     const float scale = q_log2 ? 0.83255461115769775635f : (float)std::pow((double)d_head, -0.25);
     if (attn_supported_head_dim(d_head)) {
         AttnParams p{};
@@ -1499,6 +1504,7 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
         p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
         p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs; p.scale = scale;
         p.bf16 = dt;
+        p.q_log2 = q_log2 ? 1 : 0;
         p.o3 = o3; p.ldo3 = (n_head * d_head / 32) * 192;
         if (dt && mask) throw Error(SDMI_ERR_UNSUPPORTED, "attention: additive mask is fp32-only");
         const double fl = 4.0 * n * n_head * (double)nq * nk * d_head;
@@ -1688,8 +1694,15 @@ void Engine::launch_fp8(ConvGemm& p, double flops) {
     p.kt_per_split = (p.kt_total + splits - 1) / splits;
     splits = (p.kt_total + p.kt_per_split - 1) / p.kt_per_split;
     p.splits = splits;
+    if (record_shapes_) {   // option dump_choices: the MXFP8 launches are listed with their own tag, so a test can pin WHICH layers run on fp8 operands
+        char ck[128];
+        std::snprintf(ck, sizeof ck, "%d,%d,%d k%d s%d u%d W%d fp8 cfg=%d splits=%d", p.M, p.N, p.K, p.KH, p.stride, p.ups, p.Ws, cfg, splits);
+        ++choice_counts_[ck];
+    }
+    // algorithmic bytes: e4m3 operands + one E8M0 scale byte per 32 elements, bf16 result
+    const double fp8_bytes = ((double)p.NB * p.Hs * p.Ws * p.a_ld + (double)p.N * p.K) * (1.0 + 1.0 / 32.0) + (double)p.M * p.N * 2.0;
     if (splits == 1) {
-        ProfScope ps(this, PC_CONV_FP8, flops);
+        ProfScope ps(this, PC_CONV_FP8, flops, fp8_bytes);
         SDMI_HIP(launch_conv_gemm_fp8x(p, cfg, stream_));
         count_kernel(flops);
     } else {
@@ -1697,7 +1710,7 @@ void Engine::launch_fp8(ConvGemm& p, double flops) {
         Buf slab(this, (size_t)splits * p.slab_stride * sizeof(float));
         p.slabs = slab.f();
         {
-            ProfScope ps(this, PC_CONV_FP8, flops);
+            ProfScope ps(this, PC_CONV_FP8, flops, fp8_bytes);
             SDMI_HIP(launch_conv_gemm_fp8x(p, cfg, stream_));
         }
         count_kernel(flops);
@@ -1762,7 +1775,7 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
                 gemm_fp8(lnq, w.attn1.q, 3 * C, qkv.p, 3 * C, nullptr, 0);      // q | k | v: the packed [3C][Kp] weight
                 const long long bs3 = (long long)hw * 3 * C;
                 attention(qkv.f(), 3 * C, bs3, adv(qkv.f(), C, 1), 3 * C, bs3, adv(qkv.f(), 2 * C, 1), 3 * C, bs3, a.f(), C,
-                          (long long)hw * C, nb, hw, hw, heads, d, nullptr, nullptr, nullptr, 0);
+                          (long long)hw * C, nb, hw, hw, heads, d, nullptr, nullptr, nullptr, 0, -1, nullptr, q_prescaled(edt(), d));
             }
             quantize(av, aq);
             gemm_fp8(aq, w.attn1.out, C, h.p, C, h.p, C);
@@ -1770,7 +1783,7 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
             gemm_fp8(lnq, w.attn2.q, C, q.p, C, nullptr, 0);
             const long long cbs = (long long)us_.t_max * C;
             attention(q.f(), C, (long long)hw * C, us_.kc.at(w.ctx_index), C, cbs, us_.vc.at(w.ctx_index), C, cbs, a.f(),
-                      C, (long long)hw * C, nb, hw, us_.t_max, heads, d, us_.kv_len_dev, us_.kv_len_host.data(), nullptr, 0);
+                      C, (long long)hw * C, nb, hw, us_.t_max, heads, d, us_.kv_len_dev, us_.kv_len_host.data(), nullptr, 0, -1, nullptr, q_prescaled(edt(), d));
             quantize(av, aq);
             gemm_fp8(aq, w.attn2.out, C, h.p, C, h.p, C);
             layer_norm_fp8(w.ln3, h.p, M, lnq);
@@ -1819,7 +1832,7 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
             gemm(lnf, (int)M, w.attn1.q.bt, nullptr, C, 3 * C, qkv.f(), 3 * C, nullptr, 0, -1, 0, ln3);
             const long long bs3 = (long long)hw * 3 * C;
             attention(qkv.f(), 3 * C, bs3, adv(qkv.f(), C, edt()), 3 * C, bs3, adv(qkv.f(), 2 * C, edt()), 3 * C, bs3, af, C,
-                      (long long)hw * C, nb, hw, hw, heads, d, nullptr, nullptr, nullptr, 0, -1, a3);
+                      (long long)hw * C, nb, hw, hw, heads, d, nullptr, nullptr, nullptr, 0, -1, a3, q_prescaled(edt(), d));
         }
         gemm(af, (int)M, w.attn1.out.bt, w.attn1.out.bias, C, C, h.p, C, h.p, C, -1, 0, a3);
         // cross attention against the hoisted K/V of the text context
@@ -1827,7 +1840,7 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
         gemm(lnf, (int)M, w.attn2.q.bt, nullptr, C, C, q.f(), C, nullptr, 0, -1, 0, ln3);
         const long long cbs = (long long)us_.t_max * C;
         attention(q.f(), C, (long long)hw * C, us_.kc.at(w.ctx_index), C, cbs, us_.vc.at(w.ctx_index), C, cbs, af,
-                  C, (long long)hw * C, nb, hw, us_.t_max, heads, d, us_.kv_len_dev, us_.kv_len_host.data(), nullptr, 0, -1, a3);
+                  C, (long long)hw * C, nb, hw, us_.t_max, heads, d, us_.kv_len_dev, us_.kv_len_host.data(), nullptr, 0, -1, a3, q_prescaled(edt(), d));
         gemm(af, (int)M, w.attn2.out.bt, w.attn2.out.bias, C, C, h.p, C, h.p, C, -1, 0, a3);
         // GEGLU MLP
         layer_norm(w.ln3, h.p, M, lnf, -1, ln3);
@@ -2222,13 +2235,13 @@ void Engine::qkv_attention_dev(const float* q, const float* k, const float* v, c
     if (bf16_ && !mask) {  // precision = 1: the boundary is fp32, the kernel sees bf16 tensors
         Buf qh(this, qe * 2), kh(this, ke * 2), vh(this, ke * 2), oh(this, qe * 2);
         const int dh = n_state / n_head;
-        if (attn_bf16_q_is_log2(dh)) SDMI_HIP(launch_f32_to_bf16_scaled(q, qh.p, qe, attn_bf16_q_scale(dh), stream_));   // Engine::attention's q convention
+        if (q_prescaled(1, dh)) SDMI_HIP(launch_f32_to_bf16_scaled(q, qh.p, qe, attn_bf16_q_scale(dh), stream_));   // Engine::attention's q convention
         else SDMI_HIP(launch_f32_to_bf16(q, qh.p, qe, stream_));
         SDMI_HIP(launch_f32_to_bf16(k, kh.p, ke, stream_));
         SDMI_HIP(launch_f32_to_bf16(v, vh.p, ke, stream_));
         attention(qh.f(), n_state, (long long)nq * n_state, kh.f(), n_state, (long long)nk * n_state, vh.f(), n_state,
                   (long long)nk * n_state, oh.f(), n_state, (long long)nq * n_state, n, nq, nk, n_head, n_state / n_head,
-                  nullptr, nullptr, nullptr, 0, 1);
+                  nullptr, nullptr, nullptr, 0, 1, nullptr, q_prescaled(1, dh));
         SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(oh.p, out, (int)((long long)n * nq), n_state, 1, 1, stream_));
         return;
     }
@@ -2596,14 +2609,14 @@ double Engine::bench_attention(int n, int nq, int nk, int n_state, int n_head, i
     Buf qh(this, dt ? qe * 2 : 256), kh(this, dt ? ke * 2 : 256), vh(this, dt ? ke * 2 : 256);
     if (dt) {
         const int dh = n_state / n_head;
-        SDMI_HIP(launch_f32_to_bf16_scaled(q.f(), qh.p, qe, attn_bf16_q_is_log2(dh) ? attn_bf16_q_scale(dh) : 1.f, stream_));
+        SDMI_HIP(launch_f32_to_bf16_scaled(q.f(), qh.p, qe, q_prescaled(dt, dh) ? attn_bf16_q_scale(dh) : 1.f, stream_));
         SDMI_HIP(launch_f32_to_bf16(k.f(), kh.p, ke, stream_));
         SDMI_HIP(launch_f32_to_bf16(v.f(), vh.p, ke, stream_));
     }
     const float* qp = dt ? qh.f() : q.f(); const float* kp = dt ? kh.f() : k.f(); const float* vp = dt ? vh.f() : v.f();
     auto run = [&] {
         attention(qp, n_state, (long long)nq * n_state, kp, n_state, (long long)nk * n_state, vp, n_state, (long long)nk * n_state,
-                  o.f(), n_state, (long long)nq * n_state, n, nq, nk, n_head, n_state / n_head, nullptr, nullptr, nullptr, 0, dt);
+                  o.f(), n_state, (long long)nq * n_state, n, nq, nk, n_head, n_state / n_head, nullptr, nullptr, nullptr, 0, dt, nullptr, q_prescaled(dt, n_state / n_head));
     };
     run();
     float ms = 0;

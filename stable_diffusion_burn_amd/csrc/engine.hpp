@@ -296,7 +296,11 @@ private:
                     const void* x3 = nullptr, void* out3 = nullptr);
     void attention(const float* q, int ldq, long long q_bs, const float* k, int ldk, long long k_bs, const float* v,
                    int ldv, long long v_bs, float* o, int ldo, long long o_bs, int n, int nq, int nk, int n_head,
-                   int d_head, const int* kv_len_dev, const int* kv_len_host, const float* mask, int mask_ld, int dt = -1, void* o3 = nullptr);
+                   int d_head, const int* kv_len_dev, const int* kv_len_host, const float* mask, int mask_ld, int dt = -1, void* o3 = nullptr, bool q_log2 = false);
+    // ONE rule for "the query arrives multiplied by attn_bf16_q_scale(d_head)": bf16 storage at the head dims the fused bf16 kernel serves.  The weight loader
+    // folds the factor into the query projection by it, the fp32 -> bf16 conversions of the operator entry points apply it by it, and every attention() call
+    // passes it as q_log2 -- the kernel launcher refuses a bf16 call that does not state it.
+    static bool q_prescaled(int dt, int d_head) { return dt != 0 && attn_bf16_q_is_log2(d_head); }
 
     // composite blocks
     void res_block(const ResW& w, const Act& x, Act& y, int step);

@@ -349,6 +349,7 @@ static hipError_t launch_attn_bf16_any(const AttnParams& p, hipStream_t stream) 
 // d_head^-0.5 log2(e) (kernel header); p.scale is not used.
 hipError_t launch_attention_bf16(const AttnParams& p, hipStream_t stream) {
     if (!p.bf16 || p.mask) return hipErrorInvalidValue;
+    if (!p.q_log2) return hipErrorInvalidValue;   // the kernel applies no scale: a q without attn_bf16_q_scale folded in would give a silently wrong softmax
     if ((p.ldq | p.ldk | p.ldv | p.ldo) & 7) return hipErrorInvalidValue;  // 16-byte row alignment
     switch (p.d_head) {
         case 40: return launch_attn_bf16_any<40>(p, stream);

@@ -140,6 +140,8 @@ struct AttnParams {
     long long q_bs, k_bs, v_bs, o_bs;   // batch strides in floats
     float scale;                        // d_head^-0.25 applied to q and to k (attention.rs:15-26)
     int bf16;                           // q/k/v/o are bf16 in HBM (strides in elements)
+    int q_log2;                         // the CALLER states that q already carries d_head^-0.5 log2(e) (attn_bf16_q_scale: folded into the query weight at load, or applied by
+                                        // the fp32 -> bf16 conversion): launch_attention_bf16 ignores `scale` and refuses the call without it
     void* o3;                           // fp32 kernels: not null -> the output is written as three bf16 planes instead of fp32 ([n * nq][ldo3 / 192 slices][3][32],
     int ldo3;                           // channel = head * d_head + column; bytes between rows), what the out-projection's k_gemm3p.hip launch reads
 };
@@ -149,7 +151,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 bool attn_split_supported(const AttnParams& p);
 hipError_t launch_attention_split(const AttnParams& p, hipStream_t stream);
 // bf16 matrix-core kernel (k_attn_bf16.hip): p.bf16 set, no additive mask; q must arrive multiplied by attn_bf16_q_scale(d_head)
-// (the engine folds it into the query projection's weight at load); p.scale is not used
+// (the engine folds it into the query projection's weight at load) and the caller must say so (p.q_log2, else hipErrorInvalidValue); p.scale is not used
 inline float attn_bf16_q_scale(int d_head) { return (float)(1.4426950408889634 / __builtin_sqrt((double)d_head)); }
 // the head dims whose bf16 q tensors follow that convention (the fused bf16 kernel's; every other head dim keeps the reference's scale in the kernel)
 inline bool attn_bf16_q_is_log2(int d_head) { return d_head == 40 || d_head == 80 || d_head == 160; }

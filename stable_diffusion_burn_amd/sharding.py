@@ -52,8 +52,9 @@ def share_flat_array(make, rank: int, world: int, barrier, tag: str, directory: 
     """One host copy of a large read-only float32 array for all ranks of a node (bench.py: the 3.6 GB synthetic weight image, which costs
     seconds of numpy RNG per rank on shared cores).  Rank 0 calls `make()` and writes the result to `<dir>/sdmi_<tag>.f32` in the first of
     `directory`, then `fallback_dirs` (default: the temporary directory), that exists, is writable and has room; after `barrier()` the other
-    ranks map the file read-only (np.memmap: the page cache holds ONE copy); after a second barrier rank 0 unlinks the name (the mappings stay
-    valid).  If NO candidate takes the file (a container with a 64 MB /dev/shm and a read-only /tmp), every rank finds no file behind the
+    ranks map the file rank 0 wrote -- named by its sidecar `<file>.len` (the byte count; leftovers of a crashed run with the same tag are removed by
+    rank 0 before it writes, so a stale file is never mapped) -- read-only (np.memmap: the page cache holds ONE copy); after a second barrier rank 0 unlinks the
+    names (the mappings stay valid).  If NO candidate takes the file (a container with a 64 MB /dev/shm and a read-only /tmp), every rank finds no file behind the
     barrier and calls `make()` itself -- slower, never wrong, and no rank is left waiting.  world == 1: returns make().  Not part of the data
     path: no collective, only two barriers."""
     import os
@@ -67,15 +68,26 @@ def share_flat_array(make, rank: int, world: int, barrier, tag: str, directory: 
     arr = None
     written = None
     if rank == 0:
+        # names left behind by a crashed earlier run (same tag = same MASTER_PORT) are removed FIRST: behind the barrier a rank maps only what this call wrote --
+        # the sidecar `<path>.len` names the byte count, and a mapping of any other size is refused
+        for path in paths:
+            for leftover in (path, path + ".len", path + ".tmp"):
+                try:
+                    os.unlink(leftover)
+                except OSError:
+                    pass
         arr = np.ascontiguousarray(make(), dtype=np.float32)
         for path in paths:
             tmp = path + ".tmp"
             try:
                 if shutil.disk_usage(os.path.dirname(path)).free < arr.nbytes + (64 << 20):
                     continue
-                with open(tmp, "wb") as f:
+                fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)   # a fresh file of our own, never through a planted link
+                with os.fdopen(fd, "wb") as f:
                     arr.tofile(f)
                 os.replace(tmp, path)          # the name appears only once the file is complete
+                with open(path + ".len", "w") as f:
+                    f.write(str(arr.nbytes))
                 written = path
                 break
             except OSError:
@@ -86,15 +98,22 @@ def share_flat_array(make, rank: int, world: int, barrier, tag: str, directory: 
     barrier()
     if rank != 0:
         for path in paths:
-            if os.path.exists(path):
-                arr = np.memmap(path, dtype=np.float32, mode="r")
-                break
+            try:
+                with open(path + ".len") as f:
+                    nbytes = int(f.read().strip())
+            except (OSError, ValueError):
+                continue
+            if os.path.getsize(path) != nbytes:
+                raise RuntimeError(f"share_flat_array: {path} has {os.path.getsize(path)} bytes, rank 0 wrote {nbytes}")
+            arr = np.memmap(path, dtype=np.float32, mode="r")
+            break
         else:
             arr = np.ascontiguousarray(make(), dtype=np.float32)     # rank 0 found no place for the file
     barrier()
     if rank == 0 and written is not None:
-        try:
-            os.unlink(written)
-        except OSError:
-            pass
+        for name in (written, written + ".len"):
+            try:
+                os.unlink(name)
+            except OSError:
+                pass
     return arr

@@ -104,6 +104,31 @@ def test_weight_image_falls_back_to_the_next_directory(tmp_path):
     assert [g[1] for g in got] == [1, 0] and got[1][5] == "memmap"
 
 
+def test_a_stale_weight_image_of_a_crashed_run_is_never_mapped(tmp_path):
+    """round 4's advice: a leftover `sdmi_<tag>.f32` (a crashed earlier run with the same MASTER_PORT; wrong size, wrong content) sits in the first directory.
+    Rank 0 removes leftovers before it writes and names what it wrote in a sidecar with the byte count; the other ranks map only that -- every rank ends up with
+    THIS run's array and no name is left behind."""
+    first, second = tmp_path / "first", tmp_path / "second"
+    first.mkdir(); second.mkdir()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    tag = f"stale_{os.getpid()}"
+    stale = first / f"sdmi_{tag}.f32"
+    np.full(17, 123.0, dtype=np.float32).tofile(stale)            # wrong size, wrong content
+    port = _free_port()
+    procs = [ctx.Process(target=_share_worker, args=(r, world, port, tag, q, str(first), [str(second)])) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = float(np.random.default_rng(7).standard_normal(100_003).astype(np.float32).astype(np.float64).sum())
+    assert all(g[2] == want and g[3] == (100_003,) for g in got)   # every rank holds THIS run's array
+    assert not stale.exists() and not any(g[4] for g in got)       # the leftover was removed, nothing new is left behind
+
+
 def test_weight_image_is_generated_per_rank_when_no_directory_takes_it(tmp_path):
     """a container whose /dev/shm is too small and whose temporary directory is read-only: nobody waits, every rank generates its own copy"""
     got = _run_share(str(tmp_path / "no_such_dir"), [str(tmp_path / "nor_this")])

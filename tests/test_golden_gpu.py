@@ -233,31 +233,73 @@ def test_config3_50_steps_fp32(sd_full):
         assert e < 1e-3
 
 
+def _more():
+    """samples 7 and 15 of the batched configurations (tests/golden/gen_golden_more_samples.py): index -> position in the fixture's arrays"""
+    m = np.load(GOLD / "sd14_synth_more.npz")
+    return m, {int(i): j for j, i in enumerate(m["index"].tolist())}
+
+
 def test_config3_bf16_batch16_50_steps():
-    """configs[2] as BASELINE.json states it: batch 16, 50 DDIM steps, CFG 7.5, bf16 on one GPU.  Samples 0 and 1 are
+    """configs[2] as BASELINE.json states it: batch 16, 50 DDIM steps, CFG 7.5, bf16 on one GPU.  Samples 0, 1, 7 and 15 (round 5: four, not two) are
     compared with the fp64 oracle's batch-1 runs (the reference defines batch > 1 as independent samples, SURVEY Q1);
-    the bars are 1.5x the values measured on MI355X (printed).  Samples 2..15 must be finite and must not depend on the
-    batch position: sample 0's latent is reproduced bit-exactly when it is also placed at position 15."""
+    the bars are 1.5x the values measured on MI355X (printed).  Every sample must be finite and must not depend on the
+    batch position: sample 0's latent is reproduced bit-exactly when it is also placed at position 14."""
     from stable_diffusion_burn_amd import ModelConfig, StableDiffusion
     g = np.load(GOLD / "sd14_synth_cfg3.npz")
+    m, at = _more()
+    ref = {0: g["latent64"][0], 1: g["latent64"][1], 7: m["latent64_s50"][at[7]], 15: m["latent64_s50"][at[15]]}
+    ref_rgb = {0: g["rgb64_s4"][0], 1: g["rgb64_s4"][1], 7: m["rgb64_s50_s4"][at[7]], 15: m["rgb64_s50_s4"][at[15]]}
     sd = StableDiffusion(ModelConfig(precision=1))
     try:
         sd.load_weights(syn.SyntheticWeights(), clip=False, vae_encoder=False)
         lat, ctx, unc = _cfg3_inputs(16)
-        lat[15] = lat[0]
+        lat[14] = lat[0]
         got = sd.sample_latent(ctx, unc, 7.5, 50, init_latent=lat)
         assert np.isfinite(got).all()
-        assert np.array_equal(got[0], got[15])
-        for i in range(2):
-            r = _rel_rms(got[i], g["latent64"][i])
-            steps = []
+        assert np.array_equal(got[0], got[14])
+        for i in sorted(ref):
+            r = _rel_rms(got[i], ref[i])
             print(f"bf16 B=16 S=50, sample {i}: rel-RMS of the final latent vs fp64 = {r:.3e}")
             assert r < BF16_BAR_LATENT50
-        rgb = sd.autoencoder.decode_latent((g["latent64"][:2] * (1.0 / 0.18215)).astype(np.float32))
-        for i in range(2):
-            r = _rel_rms(rgb[i][:, ::4, ::4], g["rgb64_s4"][i])
+        rgb = sd.autoencoder.decode_latent((np.stack([ref[i] for i in sorted(ref)]) * (1.0 / 0.18215)).astype(np.float32))
+        for k, i in enumerate(sorted(ref)):
+            r = _rel_rms(rgb[k][:, ::4, ::4], ref_rgb[i])
             print(f"bf16 decode of the fp64 latent, sample {i}: rel-RMS RGB = {r:.3e}")
             assert r < BF16_BAR_RGB
+    finally:
+        sd.close()
+
+
+# ---- configs[3]: bf16, 64 images over 8 GPUs = batch 8 per GPU, 20 steps: the per-GPU shard, its own golden test (round 5) ---------------
+def test_config4_shard_bf16_batch8_20_steps():
+    """The shard one GPU of BASELINE.json configs[3] runs (and `bench.py --config 3` times): batch 8, 20 DDIM steps, CFG 7.5, bf16.  Samples 0, 1 (fixture
+    sd14_synth_cfg5.npz, exact network) and 7 -- the shard's last image -- (sd14_synth_more.npz) against the fp64 oracle's batch-1 runs; the u8 image of sample 7
+    against the oracle's decode of ITS latent; every sample finite and position-independent (sample 0 again at position 6, bit-exact)."""
+    from stable_diffusion_burn_amd import ModelConfig, StableDiffusion
+    g = np.load(GOLD / "sd14_synth_cfg5.npz")
+    m, at = _more()
+    ref = {0: g["latent64"][0], 1: g["latent64"][1], 7: m["latent64_s20"][at[7]]}
+    sd = StableDiffusion(ModelConfig(precision=1))
+    try:
+        sd.load_weights(syn.SyntheticWeights(), clip=False, vae_encoder=False)
+        lat, ctx, unc = _cfg3_inputs(8)
+        lat[6] = lat[0]
+        got = sd.sample_latent(ctx, unc, 7.5, 20, init_latent=lat)
+        assert np.isfinite(got).all()
+        assert np.array_equal(got[0], got[6])
+        for i in sorted(ref):
+            r = _rel_rms(got[i], ref[i])
+            print(f"bf16 B=8 S=20, sample {i}: rel-RMS of the final latent vs fp64 = {r:.3e}")
+            assert r < BF16_BAR_LATENT20
+        rgb = sd.autoencoder.decode_latent((ref[7][None] * (1.0 / 0.18215)).astype(np.float32))[0]
+        r = _rel_rms(rgb[:, ::4, ::4], m["rgb64_s20_s4"][at[7]])
+        print(f"bf16 decode of the fp64 latent, sample 7: rel-RMS RGB = {r:.3e}")
+        assert r < BF16_BAR_RGB
+        img = sd.latent_to_image(ref[7][None].astype(np.float32))[0].astype(np.float64)      # truncating u8 of the bf16 decode: within a few LSB of the exact decode on the grid
+        exact = np.clip((m["rgb64_s20_s4"][at[7]] + 1.0) * 127.5, 0, 255).transpose(1, 2, 0)
+        d = np.abs(img[::4, ::4] - exact)
+        print(f"bf16 u8 image of sample 7 vs the exact decode: mean |d| = {d.mean():.2f} LSB, max {d.max():.1f}")
+        assert d.mean() < 2.5
     finally:
         sd.close()
 
@@ -279,8 +321,8 @@ MX_BAR_RGB = {0: 3.1e-2, 1: 3.1e-2}
 def test_config5_mxfp8_batch16_20_steps(wide):
     """configs[4] as BASELINE.json states it for one GPU: batch 16, 20 DDIM steps, CFG 7.5, precision = 2 (reference arithmetic:
     stablediffusion/mod.rs:102-160 in f32).  wide = 0: the default -- bf16 + MXFP8 on the ResBlock / ResnetBlock 3x3 convolutions; wide = 1: option fp8_linear = 1, also the transformer blocks'
-    Linear layers and the UNet's 1x1 / up / down convolutions.  Samples 0 and 1
-    against the fp64 fixtures of tests/golden/gen_golden_cfg5.py: the exact network (what the format costs end to end, 20 chained CFG steps
+    Linear layers and the UNet's 1x1 / up / down convolutions.  Samples 0, 1, 7 and 15
+    against the fp64 fixtures of tests/golden/gen_golden_cfg5.py / gen_golden_more_samples.py: the exact network (what the format costs end to end, 20 chained CFG steps
     at the real model size) and -- for wide = 0, whose quantisation the fixture reproduces -- the fp64 network with the same MXFP8
     quantisation.  Every sample finite; a sample's result does not depend on its batch position (bit-exact)."""
     from stable_diffusion_burn_amd import ModelConfig, StableDiffusion
@@ -292,16 +334,18 @@ def test_config5_mxfp8_batch16_20_steps(wide):
     try:
         sd.load_weights(syn.SyntheticWeights(), clip=False, vae_encoder=False)
         sd.set_option("fp8_linear", wide)
+        m, at = _more()
+        exact = {0: g["latent64"][0], 1: g["latent64"][1], 7: m["latent64_s20"][at[7]], 15: m["latent64_s20"][at[15]]}
+        sameq = {0: g["latent64_mx"][0], 1: g["latent64_mx"][1], 7: m["latent64_mx_s20"][at[7]], 15: m["latent64_mx_s20"][at[15]]}
         lat, ctx, unc = _cfg3_inputs(16)
-        lat[15] = lat[0]
+        lat[14] = lat[0]
         got = sd.sample_latent(ctx, unc, 7.5, 20, init_latent=lat)
         assert np.isfinite(got).all()
-        assert np.array_equal(got[0], got[15])
-        fmt = [_rel_rms(g["latent64_mx"][i], g["latent64"][i]) for i in range(2)]
-        for i in range(2):
-            r_exact, r_same = _rel_rms(got[i], g["latent64"][i]), _rel_rms(got[i], g["latent64_mx"][i])
+        assert np.array_equal(got[0], got[14])
+        for i in sorted(exact):      # round 5: samples 0, 1, 7 and 15
+            r_exact, r_same, fmt = _rel_rms(got[i], exact[i]), _rel_rms(got[i], sameq[i]), _rel_rms(sameq[i], exact[i])
             print(f"precision 2 (fp8_linear={wide}), B=16 S=20, sample {i}: rel-RMS of the final latent vs exact fp64 = {r_exact:.3e}, vs fp64 with the "
-                  f"ResBlock-conv MXFP8 quantisation = {r_same:.3e} (that quantisation alone, quantised fp64 vs exact fp64: {fmt[i]:.3e})")
+                  f"ResBlock-conv MXFP8 quantisation = {r_same:.3e} (that quantisation alone, quantised fp64 vs exact fp64: {fmt:.3e})")
             assert r_exact < MX_BAR_LATENT20[wide]
             if not wide:
                 assert r_same < MX_BAR_LATENT20_SAMEQ
@@ -310,5 +354,39 @@ def test_config5_mxfp8_batch16_20_steps(wide):
             r = _rel_rms(rgb[i][:, ::4, ::4], g["rgb64_s4"][i])
             print(f"precision 2 (fp8_linear={wide}) decode of the exact fp64 latent, sample {i}: rel-RMS RGB = {r:.3e}")
             assert r < MX_BAR_RGB[wide]
+    finally:
+        sd.close()
+
+
+def test_precision2_runs_mxfp8_on_exactly_the_resblock_convolutions(tmp_path):
+    """Which layers precision = 2 puts on MXFP8 operands, pinned by the engine's choice dump (round 5: "fp8 conv" must not shrink silently): one batch-16 UNet
+    forward = the 44 ResBlock 3x3 convolutions (unet/mod.rs:716,729; every level has >= fp8_min_rows output rows at this batch) and nothing else; one decode = the
+    28 ResnetBlock 3x3 convolutions (autoencoder/mod.rs:516-523); with fp8_linear=1 the transformer blocks' Linear layers and the 1x1 / up / down convolutions join."""
+    from stable_diffusion_burn_amd import ModelConfig, StableDiffusion
+    sd = StableDiffusion(ModelConfig(precision=2))
+    try:
+        sd.load_weights(syn.SyntheticWeights(), clip=False, vae_encoder=False)
+        lat, ctx, _ = _cfg3_inputs(16)
+
+        def fp8_launches(fn, name):
+            sd.set_option("record_shapes", 1)
+            fn()
+            sd.set_option("dump_choices", str(tmp_path / name))
+            sd.set_option("record_shapes", 0)
+            rows = [ln.split() for ln in (tmp_path / name).read_text().splitlines()]
+            fp8 = [(r[0], r[1], int(r[-1][1:])) for r in rows if "fp8" in r]
+            rest = [(r[0], r[1], int(r[-1][1:])) for r in rows if "fp8" not in r]
+            return fp8, rest
+
+        fp8, rest = fp8_launches(lambda: sd.unet.forward(lat, [500], ctx), "unet.txt")
+        print(f"precision 2 UNet forward: {sum(c for *_, c in fp8)} MXFP8 launches over {len(fp8)} shapes, {sum(c for *_, c in rest)} bf16 / fp32 GEMM launches")
+        assert sum(c for *_, c in fp8) == 44 and all(k == "k3" for _, k, _ in fp8)
+        fp8d, _ = fp8_launches(lambda: sd.autoencoder.decode_latent(lat[:1]), "dec.txt")
+        print(f"precision 2 decode: {sum(c for *_, c in fp8d)} MXFP8 launches")
+        assert sum(c for *_, c in fp8d) == 28 and all(k == "k3" for _, k, _ in fp8d)
+        sd.set_option("fp8_linear", 1)
+        fp8w, _ = fp8_launches(lambda: sd.unet.forward(lat, [500], ctx), "unet_wide.txt")
+        print(f"precision 2, fp8_linear=1, UNet forward: {sum(c for *_, c in fp8w)} MXFP8 launches")
+        assert sum(c for *_, c in fp8w) > 44 + 100 and any(k == "k1" for _, k, _ in fp8w)
     finally:
         sd.close()
