@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the bf16 configs[2] / configs[3]-shard measurements after the headline")
+    ap.add_argument("--no-parity", action="store_true", help="skip parity_in_run (one more un-timed sample_latent call; the PMC passes count launches per image)")
+    ap.add_argument("--pmc-ddim-steps", type=int, default=0, help="PMC passes only: run this many DDIM steps instead of the configuration's (bytes PER LAUNCH do not depend "
+                    "on the step count; rocprofv3's counter collection segfaults on the 100 k dispatches of configs[2]'s 50 steps)")
     ap.add_argument("--tune-file", default=str(ROOT / "stable_diffusion_burn_amd" / "tuning" / "gfx950_fp32.txt"))
     ap.add_argument("--config", type=int, choices=[1, 2, 3, 4], default=None,
                     help="preset = BASELINE.json configs[i]: 1 fp32 B=1 S=20 (the default headline); 2 bf16 B=16 S=50; 3 bf16 B=8 per GPU S=20 "
@@ -69,6 +72,8 @@ def parse():
     a = ap.parse_args()
     if a.config is not None:
         a.precision, a.batch_per_gpu, a.ddim_steps = {1: ("fp32", 1, 20), 2: ("bf16", 16, 50), 3: ("bf16", 8, 20), 4: ("fp8", 16, 20)}[a.config]
+    if a.pmc_ddim_steps > 0:
+        a.ddim_steps, a.no_parity = a.pmc_ddim_steps, True
     return a
 
 
@@ -367,7 +372,7 @@ def main():
     stats = run.sd.last_call_stats()
 
     roofline, prof = (None, None)
-    parity = run.parity_in_run() if rank == 0 else None      # (after the timed region; reads the u8 image the last timed step left on the host)
+    parity = run.parity_in_run() if rank == 0 and not args.no_parity else None      # (after the timed region; reads the u8 image the last timed step left on the host)
     if rank == 0 and not args.no_roofline:
         roofline, prof = run.roofline()
     bf16 = args.precision in ("bf16", "fp8")

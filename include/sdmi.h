@@ -68,7 +68,10 @@ typedef struct sdmi_config {
     int32_t vae_ch;          /* 128  (decoder channels 4c,4c,2c,c)              */
     int32_t max_batch;       /* largest n a call may pass; 0 = no limit          */
     int32_t precision;       /* 0 = fp32; 1 = bf16 storage, fp32 accumulate; 2 = 1 + MXFP8 operands for the ResBlock / ResnetBlock 3x3 convolutions (20-step latent 5.2e-2 relative RMS
-                              * of the exact one; option "fp8_linear=1": also the transformer blocks' Linear layers and the 1x1 / up / down convolutions, 8.1e-2 for +7 %) */
+                              * of the exact one; option "fp8_linear=1": also the transformer blocks' Linear layers and the 1x1 / up / down convolutions, 8.1e-2 for +5 %).
+                              * ATTENTION IS NOT ON FP8 OPERANDS at any precision (BASELINE.json configs[4] names "fp8 conv+attn"): qkv_attention runs bf16 at precision 1 and 2 --
+                              * formally dropped, DESIGN.md section 8: Q K^T contracts over d_head = 40 (no gain on the K = 128 MX instruction), P V would return at most 2.5 % of an
+                              * image (measured ablation), at the price of an e4m3 P with block scales inside the softmax loop. */
     /* CLIP text encoder, CLIPConfig::new(49408, 768, 12, 77, 12) stablediffusion/mod.rs:29;
      * its width is ctx_dim.  clip_layers = 0 builds a context without it.              */
     int32_t clip_layers;     /* 12                                              */
@@ -313,7 +316,9 @@ int sdmi_op_timestep_embedding(sdmi_ctx* ctx, int32_t t, int32_t dim, float* out
  * precision = 2 selectors: "fp8_convs" (0: the fp8-capable layers on the bf16 kernels), "fp8_linear" (see sdmi_config.precision),
  * "fp8_min_rows" (GEMMs with fewer output rows stay bf16), "fp8_tile".
  * precision >= 1: "conv3_reuse" (default 1: 3x3 / stride-1 convolutions that chose the 256 x 320 / 256 x 256 bf16 tile run on k_gemm_bf16t.hip, which stages a kernel
- * row's activations once for its three taps; results are bit-identical to "0"). */
+ * row's activations once for its three taps; results are bit-identical to "0"); "gemm_bf16x_variant" (default 1: bit 0 = the large-tile bf16 GEMM as a persistent tile
+ * loop where a launch has no split-K, no residual and more tiles than CUs; bit-identical to "0"); "gn_target_wgs" / "gn_max_threads" / "gn_unroll" (launch geometry of
+ * the bf16 / MXFP8 GroupNorm passes: results equal to fp32 rounding, not bit-identical across settings -- the chunking orders the fp64 merges). */
 int sdmi_set_option(sdmi_ctx* ctx, const char* key, const char* value);
 /* time (ms, HIP events on the context stream) and kernel count of the last
  * hot-path call; flops = algorithmic FLOPs it executed (2*MAC of conv/GEMM/attention). */

@@ -1040,6 +1040,10 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "fp8_linear") opt_fp8_linear_ = std::stoi(value);
     else if (key == "fp8_ops") opt_fp8_ops_ = std::stoi(value);
     else if (key == "op_resid") opt_op_resid_ = std::stoi(value);
+    else if (key == "gn32_min_wgs") opt_gn32_min_wgs_ = std::stoi(value);
+    else if (key == "gn_target_wgs") gn_tune_.target_wgs = std::stoi(value);
+    else if (key == "gn_max_threads") gn_tune_.max_threads = std::stoi(value);
+    else if (key == "gn_unroll") gn_tune_.unroll = std::stoi(value);
     else if (key == "fp8_tile") opt_fp8_tile_ = (value == "auto") ? -1 : std::stoi(value);
     else if (key == "attn_bf16") opt_attn_bf16_ = std::stoi(value);
     else if (key == "attn_split") opt_attn_split_ = std::stoi(value);
@@ -1459,16 +1463,16 @@ void Engine::gemm_geglu(const float* x, long long rows, const float* bt, const f
 void Engine::group_norm(const NormW& w, const Act& x, Act& y, bool silu) {
     const int hw = x.h * x.w;
     if (x.dt != y.dt) throw Error(SDMI_ERR_STATE, "group_norm: in/out storage types disagree");
-    Buf part(this, x.dt ? gn_partials_bytes_bf16(x.n, hw, x.c) : gn_partials_bytes(x.n, hw, x.c));
+    Buf part(this, x.dt ? gn_partials_bytes_bf16(x.n, hw, x.c, gn_tune_) : gn_partials_bytes(x.n, hw, x.c, opt_gn32_min_wgs_));
     ProfScope ps(this, PC_GROUP_NORM, 0, 2.0 * (double)x.bytes(), 2);  // algorithmic: one read + one write; two launches (statistics, apply)
     if (y.view) throw Error(SDMI_ERR_STATE, "group_norm: output must be dense");
     if (!x.p) throw Error(SDMI_ERR_STATE, "group_norm: the input must exist as fp32");
     if (y.p3 && !y.p) {   // the consumer is a plane GEMM: the normalised tensor is written as three bf16 planes only
         if (x.dt) throw Error(SDMI_ERR_STATE, "group_norm: planes are an fp32-engine format");
-        SDMI_HIP(launch_group_norm_planes(x.p, y.p3, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_));
+        SDMI_HIP(launch_group_norm_planes(x.p, y.p3, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_, opt_gn32_min_wgs_));
     }
-    else if (x.dt) SDMI_HIP(launch_group_norm_bf16(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_));
-    else SDMI_HIP(launch_group_norm(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_));
+    else if (x.dt) SDMI_HIP(launch_group_norm_bf16(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_, gn_tune_));
+    else SDMI_HIP(launch_group_norm(x.p, y.p, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_, opt_gn32_min_wgs_));
     count_kernel(); count_kernel();
 }
 
@@ -1622,9 +1626,9 @@ void Engine::release(ActQ& a) {
 void Engine::group_norm_fp8(const NormW& w, const Act& x, ActQ& y, bool silu) {
     const int hw = x.h * x.w;
     if (x.dt != 1 || y.c != x.c) throw Error(SDMI_ERR_STATE, "group_norm_fp8: bf16 input of matching width expected");
-    Buf part(this, gn_partials_bytes_bf16(x.n, hw, x.c));
+    Buf part(this, gn_partials_bytes_bf16(x.n, hw, x.c, gn_tune_));
     ProfScope ps(this, PC_GROUP_NORM, 0, (double)x.bytes() + (double)x.rows() * (y.cp + y.cp / 32), 2);
-    SDMI_HIP(launch_group_norm_fp8(x.p, y.q, y.s, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_));
+    SDMI_HIP(launch_group_norm_fp8(x.p, y.q, y.s, w.gamma, w.beta, x.n, hw, x.c, x.stride(), 32, w.eps, silu, part.p, stream_, &gn_tune_));
     count_kernel(); count_kernel();
 }
 
@@ -2268,18 +2272,18 @@ void Engine::op_group_norm(const float* x, const float* gamma, const float* beta
     Act a = new_act(n, h, w, c, dt), b = new_act(n, h, w, c, dt);
     if (dt) {
         SDMI_HIP(launch_nchw_f32_to_nhwc_bf16(x, a.p, n, c, h, w, 1.0f, stream_));
-        Buf part(this, gn_partials_bytes_bf16(n, h * w, c));
-        SDMI_HIP(launch_group_norm_bf16(a.p, b.p, gamma, beta, n, h * w, c, c, groups, eps, silu, part.p, stream_));
+        Buf part(this, gn_partials_bytes_bf16(n, h * w, c, gn_tune_));
+        SDMI_HIP(launch_group_norm_bf16(a.p, b.p, gamma, beta, n, h * w, c, c, groups, eps, silu, part.p, stream_, gn_tune_));
         SDMI_HIP(launch_nhwc_bf16_to_nchw_f32(b.p, out, n, c, h, w, stream_));
     } else {
         SDMI_HIP(launch_nchw_to_nhwc(x, a.p, n, c, h, w, 1.0f, stream_));
-        Buf part(this, gn_partials_bytes(n, h * w, c));
+        Buf part(this, gn_partials_bytes(n, h * w, c, opt_gn32_min_wgs_));
         if (plane_gemm(c, c)) {   // option gemm_planes: the plane-writing form of the kernel, joined back to fp32 (exact)
             Buf y3(this, (size_t)n * h * w * (c / 32) * 192);
-            SDMI_HIP(launch_group_norm_planes(a.p, y3.p, gamma, beta, n, h * w, c, c, groups, eps, silu, part.p, stream_));
+            SDMI_HIP(launch_group_norm_planes(a.p, y3.p, gamma, beta, n, h * w, c, c, groups, eps, silu, part.p, stream_, opt_gn32_min_wgs_));
             SDMI_HIP(launch_join3_rows(y3.p, b.p, (long long)n * h * w, c, (long long)(c / 32) * 192, c, stream_));
         } else {
-            SDMI_HIP(launch_group_norm(a.p, b.p, gamma, beta, n, h * w, c, c, groups, eps, silu, part.p, stream_));
+            SDMI_HIP(launch_group_norm(a.p, b.p, gamma, beta, n, h * w, c, c, groups, eps, silu, part.p, stream_, opt_gn32_min_wgs_));
         }
         SDMI_HIP(launch_nhwc_to_nchw(b.p, out, n, c, h, w, stream_));
     }
@@ -2294,8 +2298,8 @@ void Engine::op_group_norm_fp8(const float* x, const float* gamma, const float* 
     Act a = new_act(n, h, w, c, 1);
     SDMI_HIP(launch_nchw_f32_to_nhwc_bf16(x, a.p, n, c, h, w, 1.0f, stream_));
     ActQ q = new_actq(n, h, w, c);
-    Buf part(this, gn_partials_bytes_bf16(n, h * w, c));
-    SDMI_HIP(launch_group_norm_fp8(a.p, q.q, q.s, gamma, beta, n, h * w, c, c, groups, eps, silu, part.p, stream_));
+    Buf part(this, gn_partials_bytes_bf16(n, h * w, c, gn_tune_));
+    SDMI_HIP(launch_group_norm_fp8(a.p, q.q, q.s, gamma, beta, n, h * w, c, c, groups, eps, silu, part.p, stream_, &gn_tune_));
     Act d = new_act(n, h, w, c, 0);
     SDMI_HIP(launch_dequant_fp8(q.q, q.s, d.p, d.rows(), c, stream_));
     SDMI_HIP(launch_nhwc_to_nchw(d.p, out, n, c, h, w, stream_));

@@ -50,17 +50,20 @@ static inline int blocks_for(long long work, int cap = 2048) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (total); i += (long long)gridDim.x * blockDim.x)
 
 // ---- GroupNorm (+SiLU) ------------------------------------------------------------------------------
-struct GnGeomH { int cq, R, threads, chunks, rows_per_chunk; };
-
-static inline GnGeomH gn_geom_h(int hw, int c) {
+GnGeomH gn_geom_bf16(int n, int hw, int c, GnTune t) {
     GnGeomH g;
+    const int maxt = t.max_threads >= 64 ? t.max_threads : 1024;
     g.cq = c / 8;
-    g.R = g.cq >= 1024 ? 1 : 1024 / g.cq;
+    g.R = g.cq >= maxt ? 1 : maxt / g.cq;
     if (g.R > 32) g.R = 32;
     if (g.R > hw) g.R = hw;
     g.threads = g.cq * g.R;
     const long long bytes = (long long)hw * c * 2;
     long long chunks = (bytes + 32767) / 32768;   // 32 KB of bf16 = as many rows (and workgroups) per chunk as the fp32 kernels' 64 KB
+    if (t.target_wgs > 0) {                       // ... but not more workgroups than one round of the chip needs (kernels.hpp, GnTune)
+        const long long per_sample = (t.target_wgs + (n > 0 ? n : 1) - 1) / (n > 0 ? n : 1);
+        if (chunks > per_sample) chunks = per_sample;
+    }
     if (chunks > 256) chunks = 256;
     if (chunks < 1) chunks = 1;
     int rpc = (int)((hw + chunks - 1) / chunks);
@@ -70,9 +73,11 @@ static inline GnGeomH gn_geom_h(int hw, int c) {
     return g;
 }
 
-size_t gn_partials_bytes_bf16(int n, int hw, int c) { return (size_t)n * gn_geom_h(hw, c).chunks * 64 * 2 * sizeof(double); }
+size_t gn_partials_bytes_bf16(int n, int hw, int c, GnTune t) { return (size_t)n * gn_geom_bf16(n, hw, c, t).chunks * 64 * 2 * sizeof(double); }
 
-// shifted statistics, partial format and merge order: k_norm.hip / k_common.hpp.  `ldx` = elements between pixels of x.
+// shifted statistics, partial format and merge order: k_norm.hip / k_common.hpp.  `ldx` = elements between pixels of x.  U independent loads per thread are in
+// flight; the values are consumed in row order, so a thread's sums do not depend on U.
+template <int U>
 __global__ void gn_stats_bf16_kernel(const unsigned short* __restrict__ x, int hw, int C, int ldx, int G, int rows_per_chunk,
                                      double* __restrict__ part) {
     extern __shared__ float sh[];  // [2][R][C] floats, [C] pivots, then [2][C] doubles
@@ -89,11 +94,22 @@ __global__ void gn_stats_bf16_kernel(const unsigned short* __restrict__ x, int h
     for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
     const unsigned short* xb = x + (long long)smp * hw * ldx + c8 * 8;
     const F8 pv = unpack8(*reinterpret_cast<const u32x4*>(xb + (long long)row_begin * ldx));
-    for (int row = row_begin + r0; row < row_end; row += R) {
-        const F8 v = unpack8(*reinterpret_cast<const u32x4*>(xb + (long long)row * ldx));
+    auto add = [&](const u32x4 w) {
+        const F8 v = unpack8(w);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { const float d = v.v[i] - pv.v[i]; s[i] += d; q[i] += d * d; }
+    };
+    int row = row_begin + r0;
+    if constexpr (U > 1) {
+        for (; row + (U - 1) * R < row_end; row += U * R) {
+            u32x4 w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) w[u] = *reinterpret_cast<const u32x4*>(xb + (long long)(row + u * R) * ldx);
+#pragma unroll
+            for (int u = 0; u < U; ++u) add(w[u]);
+        }
     }
+    for (; row < row_end; row += R) add(*reinterpret_cast<const u32x4*>(xb + (long long)row * ldx));
     float* shs = sh;
     float* shq = sh + R * C;
     float* shp = sh + 2 * R * C;
@@ -119,7 +135,7 @@ __global__ void gn_stats_bf16_kernel(const unsigned short* __restrict__ x, int h
     gn_merge_group_channels(chm, chq, C, G, n_rows, part + (long long)(smp * chunks + chunk) * G * 2);
 }
 
-template <bool SILU>
+template <bool SILU, int U>
 __global__ void gn_apply_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, int hw, int C, int ldx, int G,
                                      float eps, int stat_chunks, int stat_rows, const double* __restrict__ part, int rows_per_chunk) {
@@ -133,56 +149,77 @@ __global__ void gn_apply_bf16_kernel(const unsigned short* __restrict__ x, unsig
     gn_finalize(part, smp, G, cpg, hw, stat_chunks, stat_rows, eps, s_red, s_mean_hi, s_mean_lo, s_rstd);
     const int c8 = tid % cq;
     const int r0 = tid / cq;
-    float gm[8], bt[8], mean_hi[8], mean_lo[8], rstd[8];
+    float gr[8], bt[8], mean_hi[8], mean_lo[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int ch = c8 * 8 + i;
-        gm[i] = gamma[ch];
+        gr[i] = gamma[ch];
         bt[i] = beta[ch];
         mean_hi[i] = s_mean_hi[ch / cpg];
         mean_lo[i] = s_mean_lo[ch / cpg];
-        rstd[i] = s_rstd[ch / cpg];
     }
+    float rstd[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rstd[i] = s_rstd[(c8 * 8 + i) / cpg];
     const int row_begin = blockIdx.x * rows_per_chunk;
     const int row_end = min(row_begin + rows_per_chunk, hw);
     const long long xbase = (long long)smp * hw * ldx + c8 * 8;
     const long long ybase = (long long)smp * hw * C + c8 * 8;
-    for (int row = row_begin + r0; row < row_end; row += R) {
-        F8 v = unpack8(*reinterpret_cast<const u32x4*>(x + xbase + (long long)row * ldx));
+    auto norm = [&](const u32x4 w) {
+        F8 v = unpack8(w);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float t = ((v.v[i] - mean_hi[i]) - mean_lo[i]) * rstd[i];
-            t = t * gm[i] + bt[i];
+            t = t * gr[i] + bt[i];
             if (SILU) t = t / (1.0f + __expf(-t));
             v.v[i] = t;
         }
-        *reinterpret_cast<u32x4*>(y + ybase + (long long)row * C) = pack8(v);
+        return pack8(v);
+    };
+    int row = row_begin + r0;
+    if constexpr (U > 1) {
+        for (; row + (U - 1) * R < row_end; row += U * R) {
+            u32x4 w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) w[u] = *reinterpret_cast<const u32x4*>(x + xbase + (long long)(row + u * R) * ldx);
+#pragma unroll
+            for (int u = 0; u < U; ++u) *reinterpret_cast<u32x4*>(y + ybase + (long long)(row + u * R) * C) = norm(w[u]);
+        }
     }
+    for (; row < row_end; row += R) *reinterpret_cast<u32x4*>(y + ybase + (long long)row * C) = norm(*reinterpret_cast<const u32x4*>(x + xbase + (long long)row * ldx));
 }
 
-hipError_t launch_group_norm_bf16_stats(const void* x, int n, int hw, int c, int ldx, int n_group, void* partials, hipStream_t stream) {
+hipError_t launch_group_norm_bf16_stats(const void* x, int n, int hw, int c, int ldx, int n_group, void* partials, hipStream_t stream, GnTune t) {
     if ((c & 7) || (ldx & 7) || ldx < c || n_group > 64 || c % n_group || c / 8 > 1024) return hipErrorInvalidValue;
-    const GnGeomH g = gn_geom_h(hw, c);
+    const GnGeomH g = gn_geom_bf16(n, hw, c, t);
     const size_t lds = (size_t)(2 * g.R + 1) * c * sizeof(float) + (size_t)2 * c * sizeof(double);
-    hipLaunchKernelGGL(gn_stats_bf16_kernel, dim3(g.chunks, n), dim3(g.threads), lds, stream, reinterpret_cast<const unsigned short*>(x), hw, c,
-                       ldx, n_group, g.rows_per_chunk, reinterpret_cast<double*>(partials));
+    auto xs = reinterpret_cast<const unsigned short*>(x);
+    double* part = reinterpret_cast<double*>(partials);
+    if (t.unroll >= 4) hipLaunchKernelGGL(gn_stats_bf16_kernel<4>, dim3(g.chunks, n), dim3(g.threads), lds, stream, xs, hw, c, ldx, n_group, g.rows_per_chunk, part);
+    else if (t.unroll >= 2) hipLaunchKernelGGL(gn_stats_bf16_kernel<2>, dim3(g.chunks, n), dim3(g.threads), lds, stream, xs, hw, c, ldx, n_group, g.rows_per_chunk, part);
+    else hipLaunchKernelGGL(gn_stats_bf16_kernel<1>, dim3(g.chunks, n), dim3(g.threads), lds, stream, xs, hw, c, ldx, n_group, g.rows_per_chunk, part);
     return hipGetLastError();
 }
 
+template <bool SILU>
+static void launch_gn_apply_bf16(const GnGeomH& g, int unroll, int n, hipStream_t stream, const unsigned short* xs, unsigned short* ys, const float* gamma, const float* beta,
+                                 int hw, int c, int ldx, int n_group, float eps, const double* part) {
+    if (unroll >= 2) hipLaunchKernelGGL((gn_apply_bf16_kernel<SILU, 2>), dim3(g.chunks, n), dim3(g.threads), 0, stream, xs, ys, gamma, beta, hw, c, ldx, n_group, eps,
+                                        g.chunks, g.rows_per_chunk, part, g.rows_per_chunk);
+    else hipLaunchKernelGGL((gn_apply_bf16_kernel<SILU, 1>), dim3(g.chunks, n), dim3(g.threads), 0, stream, xs, ys, gamma, beta, hw, c, ldx, n_group, eps,
+                            g.chunks, g.rows_per_chunk, part, g.rows_per_chunk);
+}
+
 hipError_t launch_group_norm_bf16(const void* x, void* y, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
-                                  int n_group, float eps, bool silu, void* partials, hipStream_t stream) {
-    hipError_t e = launch_group_norm_bf16_stats(x, n, hw, c, ldx, n_group, partials, stream);
+                                  int n_group, float eps, bool silu, void* partials, hipStream_t stream, GnTune t) {
+    hipError_t e = launch_group_norm_bf16_stats(x, n, hw, c, ldx, n_group, partials, stream, t);
     if (e != hipSuccess) return e;
-    const GnGeomH g = gn_geom_h(hw, c);
-    double* part = reinterpret_cast<double*>(partials);
+    const GnGeomH g = gn_geom_bf16(n, hw, c, t);
+    const double* part = reinterpret_cast<const double*>(partials);
     auto xs = reinterpret_cast<const unsigned short*>(x);
     auto ys = reinterpret_cast<unsigned short*>(y);
-    if (silu)
-        hipLaunchKernelGGL(gn_apply_bf16_kernel<true>, dim3(g.chunks, n), dim3(g.threads), 0, stream, xs, ys, gamma, beta, hw, c, ldx, n_group,
-                           eps, g.chunks, g.rows_per_chunk, part, g.rows_per_chunk);
-    else
-        hipLaunchKernelGGL(gn_apply_bf16_kernel<false>, dim3(g.chunks, n), dim3(g.threads), 0, stream, xs, ys, gamma, beta, hw, c, ldx, n_group,
-                           eps, g.chunks, g.rows_per_chunk, part, g.rows_per_chunk);
+    if (silu) launch_gn_apply_bf16<true>(g, t.unroll, n, stream, xs, ys, gamma, beta, hw, c, ldx, n_group, eps, part);
+    else launch_gn_apply_bf16<false>(g, t.unroll, n, stream, xs, ys, gamma, beta, hw, c, ldx, n_group, eps, part);
     return hipGetLastError();
 }
 

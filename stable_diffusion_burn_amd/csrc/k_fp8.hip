@@ -426,32 +426,13 @@ __global__ void gn_apply_fp8_kernel(const unsigned short* __restrict__ x, unsign
     }
 }
 
-// geometry of the bf16 GroupNorm (k_bf16.hip): the statistics pass is launch_group_norm_bf16's first half
-struct GnGeomQ { int cq, R, threads, chunks, rows_per_chunk; };
-static inline GnGeomQ gn_geom_q(int hw, int c) {
-    GnGeomQ g;
-    g.cq = c / 8;
-    g.R = g.cq >= 1024 ? 1 : 1024 / g.cq;
-    if (g.R > 32) g.R = 32;
-    if (g.R > hw) g.R = hw;
-    g.threads = g.cq * g.R;
-    const long long bytes = (long long)hw * c * 2;
-    long long chunks = (bytes + 32767) / 32768;
-    if (chunks > 256) chunks = 256;
-    if (chunks < 1) chunks = 1;
-    int rpc = (int)((hw + chunks - 1) / chunks);
-    rpc = (rpc + g.R - 1) / g.R * g.R;
-    g.rows_per_chunk = rpc;
-    g.chunks = (hw + rpc - 1) / rpc;
-    return g;
-}
-
 hipError_t launch_group_norm_fp8(const void* x, void* y8, void* y_scale, const float* gamma, const float* beta, int n, int hw, int c,
-                                 int ldx, int n_group, float eps, bool silu, void* partials, hipStream_t stream) {
+                                 int ldx, int n_group, float eps, bool silu, void* partials, hipStream_t stream, const GnTune* tp) {
     if ((c & 31) || (ldx & 7) || ldx < c || n_group > 64 || c % n_group || c / 8 > 1024) return hipErrorInvalidValue;
-    hipError_t e = launch_group_norm_bf16_stats(x, n, hw, c, ldx, n_group, partials, stream);
+    const GnTune t = tp ? *tp : GnTune();
+    hipError_t e = launch_group_norm_bf16_stats(x, n, hw, c, ldx, n_group, partials, stream, t);
     if (e != hipSuccess) return e;
-    const GnGeomQ g = gn_geom_q(hw, c);
+    const GnGeomH g = gn_geom_bf16(n, hw, c, t);    // the geometry of the bf16 GroupNorm (k_bf16.hip): the statistics pass is launch_group_norm_bf16's first half
     const int cp = (c + 127) / 128 * 128;
     auto xs = reinterpret_cast<const unsigned short*>(x);
     auto yq = reinterpret_cast<unsigned char*>(y8);

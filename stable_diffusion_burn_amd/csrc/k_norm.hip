@@ -40,7 +40,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // the same cut for the stats and the apply pass.
 struct GnGeom { int cq, R, threads, chunks, rows_per_chunk; };
 
-static inline GnGeom gn_geom(int hw, int c) {
+// min_wgs > 0 (round 5, option gn32_min_wgs): at least that many workgroups over the n samples, where the tensor has the rows -- a batch-1 tensor cut by size alone
+// (80 chunks x 2 samples) leaves 96 CUs without a workgroup, and the apply pass is bound by the busy CUs' store path
+static inline GnGeom gn_geom(int hw, int c, int n = 1, int min_wgs = 0) {
     GnGeom g;
     g.cq = c / 4;
     g.R = g.cq >= 1024 ? 1 : 1024 / g.cq;
@@ -49,6 +51,7 @@ static inline GnGeom gn_geom(int hw, int c) {
     g.threads = g.cq * g.R;
     const long long bytes = (long long)hw * c * 4;
     long long chunks = (bytes + 65535) / 65536;
+    if (min_wgs > 0 && chunks * n < min_wgs) chunks = (min_wgs + n - 1) / n;
     if (chunks > 256) chunks = 256;
     if (chunks < 1) chunks = 1;
     int rpc = (int)((hw + chunks - 1) / chunks);
@@ -58,8 +61,8 @@ static inline GnGeom gn_geom(int hw, int c) {
     return g;
 }
 
-size_t gn_partials_bytes(int n, int hw, int c) {
-    return (size_t)n * gn_geom(hw, c).chunks * 64 * 2 * sizeof(double);
+size_t gn_partials_bytes(int n, int hw, int c, int min_wgs) {
+    return (size_t)n * gn_geom(hw, c, n, min_wgs).chunks * 64 * 2 * sizeof(double);
 }
 
 // Partial statistics of one (sample, chunk, group): part[((smp*chunks + chunk)*G + g)*2 + {0: mean, 1: M2}]
@@ -170,10 +173,10 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__
 }
 
 static hipError_t launch_group_norm_any(const float* x, void* y, bool planes, const float* gamma, const float* beta, int n, int hw, int c,
-                                        int ldx, int n_group, float eps, bool silu, void* partials, hipStream_t stream) {
+                                        int ldx, int n_group, float eps, bool silu, void* partials, hipStream_t stream, int min_wgs) {
     if ((c & 3) || (ldx & 3) || ldx < c || n_group > 64 || c % n_group) return hipErrorInvalidValue;
     if (c / 4 > 1024 || (planes && (c & 31))) return hipErrorInvalidValue;
-    const GnGeom g = gn_geom(hw, c);
+    const GnGeom g = gn_geom(hw, c, n, min_wgs);
     double* part = reinterpret_cast<double*>(partials);
     const size_t lds = (size_t)(2 * g.R + 1) * c * sizeof(float) + (size_t)2 * c * sizeof(double);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(g.chunks, n), dim3(g.threads), lds, stream, x, hw, c, ldx, n_group,
@@ -191,12 +194,12 @@ static hipError_t launch_group_norm_any(const float* x, void* y, bool planes, co
 }
 
 hipError_t launch_group_norm(const float* x, float* y, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
-                             int n_group, float eps, bool silu, void* partials, hipStream_t stream) {
-    return launch_group_norm_any(x, y, false, gamma, beta, n, hw, c, ldx, n_group, eps, silu, partials, stream);
+                             int n_group, float eps, bool silu, void* partials, hipStream_t stream, int min_wgs) {
+    return launch_group_norm_any(x, y, false, gamma, beta, n, hw, c, ldx, n_group, eps, silu, partials, stream, min_wgs);
 }
 hipError_t launch_group_norm_planes(const float* x, void* y3, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
-                                    int n_group, float eps, bool silu, void* partials, hipStream_t stream) {
-    return launch_group_norm_any(x, y3, true, gamma, beta, n, hw, c, ldx, n_group, eps, silu, partials, stream);
+                                    int n_group, float eps, bool silu, void* partials, hipStream_t stream, int min_wgs) {
+    return launch_group_norm_any(x, y3, true, gamma, beta, n, hw, c, ldx, n_group, eps, silu, partials, stream, min_wgs);
 }
 
 // ---- LayerNorm: L lanes per row ---------------------------------------------------------------

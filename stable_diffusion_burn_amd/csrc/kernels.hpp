@@ -112,8 +112,9 @@ hipError_t launch_conv_gemm_fp8x(const ConvGemm& p, int tile_cfg, hipStream_t st
 // fp32 OIHW -> e4m3 [Cout][Kp] + scales [Cout][Kp / 32], Kp = roundup(Cin, 128) * kh * kw, k = (slice * T + tap) * 128 + ci
 hipError_t launch_pack_conv_weight_fp8(const float* w_oihw, void* bt8, void* bs, int cout, int cin, int kh, int kw, hipStream_t s);
 // GroupNorm(+SiLU) of a bf16 tensor with MXFP8 output: y8 [n][hw][Cp] e4m3, y_scale [n][hw][Cp / 32], Cp = roundup(c, 128)
+struct GnTune;
 hipError_t launch_group_norm_fp8(const void* x, void* y8, void* y_scale, const float* gamma, const float* beta, int n, int hw, int c,
-                                 int ldx, int n_group, float eps, bool silu, void* partials, hipStream_t stream);
+                                 int ldx, int n_group, float eps, bool silu, void* partials, hipStream_t stream, const GnTune* t = nullptr);
 hipError_t launch_quantize_fp8(const float* x, void* q, void* s, long long rows, int c, hipStream_t stream);   // fp32 [rows][c] -> MXFP8
 // precision = 2 beyond the ResBlock convolutions (option fp8_linear; k_fp8.hip): quantising producers and the Linear weight packer
 hipError_t launch_quantize_bf16_fp8(const void* x, void* q, void* s, long long rows, int c, int ldx, hipStream_t stream);   // bf16 [rows][ldx] -> MXFP8 (c % 32 == 0)
@@ -162,17 +163,17 @@ hipError_t launch_softmax_rows(float* x, int rows, int cols, float scale, hipStr
 // ---- normalisation (HBM-bound class) --------------------------------------------
 // GroupNorm (+SiLU) over NHWC: stats pass (per-chunk partial sums) + apply pass.
 // `partials` needs gn_partials_bytes(n, hw, c) bytes of scratch.
-size_t gn_partials_bytes(int n, int hw, int c);
+size_t gn_partials_bytes(int n, int hw, int c, int min_wgs = 0);    // min_wgs: k_norm.hip gn_geom (option gn32_min_wgs)
 // ldx: elements between pixels of x (>= c; x may be a channel slice of a wider buffer); y is dense [n][hw][c]
 hipError_t launch_group_norm(const float* x, float* y, const float* gamma, const float* beta,
                              int n, int hw, int c, int ldx, int n_group, float eps, bool silu,
-                             void* partials, hipStream_t stream);
+                             void* partials, hipStream_t stream, int min_wgs = 0);
 hipError_t launch_layer_norm(const float* x, float* y, const float* gamma, const float* beta,
                              int rows, int c, float eps, hipStream_t stream);
 // the same normalisations with the result written as three bf16 planes (k_split3.hpp; y3 dense: (c / 32) * 192 bytes per pixel / row),
 // what the consuming k_gemm3p.hip launch reads.  c % 32 == 0.
 hipError_t launch_group_norm_planes(const float* x, void* y3, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
-                                    int n_group, float eps, bool silu, void* partials, hipStream_t stream);
+                                    int n_group, float eps, bool silu, void* partials, hipStream_t stream, int min_wgs = 0);
 hipError_t launch_layer_norm_planes(const float* x, void* y3, const float* gamma, const float* beta, int rows, int c, float eps,
                                     hipStream_t stream);
 
@@ -207,11 +208,18 @@ hipError_t launch_image_to_u8(const float* img_nhwc, uint8_t* out, long long n_e
 hipError_t launch_fill_normal(float* dst, long long n, uint64_t seed, hipStream_t s);
 
 // ---- bf16-storage variants (k_bf16.hip) ---------------------------------------------------------------
-size_t gn_partials_bytes_bf16(int n, int hw, int c);
+// Launch geometry of the bf16 GroupNorm passes (statistics, apply, the MXFP8 apply of k_fp8.hip): a sample's hw rows are cut into `chunks` ranges, one workgroup
+// of cq x R threads each (cq = c / 8 columns of 8 channels, R pixel rows per pass).  Round 4 cut by size alone (32 KB per chunk): at the batches of
+// BASELINE.json configs[2..4] that is 2 560 workgroups of 2-3 loads per thread for a 64 x 64 x 320 tensor, and every one pays the fixed tail (LDS reduction, the fp64
+// merges; the apply pass re-reads all chunk partials).  target_wgs > 0 (round 5) also bounds the chunks per sample by target_wgs / n: one round of larger chunks.
+struct GnTune { int target_wgs = 0; int max_threads = 1024; int unroll = 1; };   // unroll: independent 16-byte loads in flight per thread (1, 2 or 4)
+struct GnGeomH { int cq, R, threads, chunks, rows_per_chunk; };
+GnGeomH gn_geom_bf16(int n, int hw, int c, GnTune t);
+size_t gn_partials_bytes_bf16(int n, int hw, int c, GnTune t = GnTune());
 hipError_t launch_group_norm_bf16(const void* x, void* y, const float* gamma, const float* beta, int n, int hw, int c, int ldx,
-                                  int n_group, float eps, bool silu, void* partials, hipStream_t stream);
+                                  int n_group, float eps, bool silu, void* partials, hipStream_t stream, GnTune t = GnTune());
 // the statistics half of launch_group_norm_bf16 alone (shared with the fp8-output apply of k_fp8.hip)
-hipError_t launch_group_norm_bf16_stats(const void* x, int n, int hw, int c, int ldx, int n_group, void* partials, hipStream_t stream);
+hipError_t launch_group_norm_bf16_stats(const void* x, int n, int hw, int c, int ldx, int n_group, void* partials, hipStream_t stream, GnTune t = GnTune());
 hipError_t launch_layer_norm_bf16(const void* x, void* y, const float* gamma, const float* beta, int rows, int c, float eps,
                                   hipStream_t stream);
 hipError_t launch_geglu_bf16(const void* proj, void* out, long long rows, int hidden, hipStream_t s);

@@ -17,6 +17,7 @@ the C status) or ValueError (caught before the call).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -107,6 +108,10 @@ class StableDiffusion:
         cfg.clip_ctx = config.clip_ctx
         self._ctx = C.c_void_p()
         check(self._lib.sdmi_create(C.byref(self._ctx), C.byref(cfg)))
+        # SDMI_OPTS="key=value key=value": engine options applied to every context of the process (A/B runs of the test suite under another kernel setting)
+        for kv in os.environ.get("SDMI_OPTS", "").split():
+            k, _, v = kv.partition("=")
+            self.set_option(k, v)
         self.unet = UNet(self)
         self.autoencoder = Autoencoder(self)
         self.clip = CLIP(self)
