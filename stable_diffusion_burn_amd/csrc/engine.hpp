@@ -362,7 +362,8 @@ private:
     int opt_fp8_convs_ = 1;          // 0: run the fp8-capable convs on the bf16 kernels (A/B, accuracy comparison)
     int opt_fp8_min_rows_ = 1024;    // GEMMs with fewer output rows stay bf16 (256-row tiles need rows to fill the chip)
     int opt_fp8_tile_ = -1;
-    int opt_gn32_min_wgs_ = 0;       // precision = 0: at least this many workgroups per GroupNorm pass over the call's samples (k_norm.hip gn_geom)
+    int opt_gn32_min_wgs_ = 256;     // precision = 0: at least this many workgroups per GroupNorm pass over the call's samples (k_norm.hip gn_geom); 0 = round 4's cut by size
+                                     // alone; measured at batch 1: GroupNorm class 21.3 -> 19.8 ms per image (profiles/r05d_*)
     GnTune gn_tune_;                 // launch geometry of the bf16 / MXFP8 GroupNorm passes (kernels.hpp; options gn_target_wgs, gn_max_threads, gn_unroll)
     int opt_op_resid_ = 0;           // tests: op_conv2d / op_linear add their input as the residual (cin == cout) through the GEMM epilogue
     int opt_fp8_ops_ = 0;            // tests: op_linear / op_layer_norm / op_geglu run the fp8_linear path's kernels (outputs dequantised)

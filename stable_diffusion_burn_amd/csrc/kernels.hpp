@@ -212,7 +212,8 @@ hipError_t launch_fill_normal(float* dst, long long n, uint64_t seed, hipStream_
 // of cq x R threads each (cq = c / 8 columns of 8 channels, R pixel rows per pass).  Round 4 cut by size alone (32 KB per chunk): at the batches of
 // BASELINE.json configs[2..4] that is 2 560 workgroups of 2-3 loads per thread for a 64 x 64 x 320 tensor, and every one pays the fixed tail (LDS reduction, the fp64
 // merges; the apply pass re-reads all chunk partials).  target_wgs > 0 (round 5) also bounds the chunks per sample by target_wgs / n: one round of larger chunks.
-struct GnTune { int target_wgs = 0; int max_threads = 1024; int unroll = 1; };   // unroll: independent 16-byte loads in flight per thread (1, 2 or 4)
+// Defaults measured in round 5 (profiles/r05d_*): GroupNorm class -21 % (bf16 B = 16), -24 % (MXFP8), images/s +2.0 % / +2.6 %; {0, 1024, 1} is round 4's geometry.
+struct GnTune { int target_wgs = 512; int max_threads = 512; int unroll = 2; };   // unroll: independent 16-byte loads in flight per thread (1, 2 or 4)
 struct GnGeomH { int cq, R, threads, chunks, rows_per_chunk; };
 GnGeomH gn_geom_bf16(int n, int hw, int c, GnTune t);
 size_t gn_partials_bytes_bf16(int n, int hw, int c, GnTune t = GnTune());
