@@ -146,9 +146,22 @@ __global__ void gn_apply_bf16_kernel(const unsigned short* __restrict__ x, unsig
     const int tid = threadIdx.x;
     const int smp = blockIdx.y;
     const int cpg = C / G;
-    gn_finalize(part, smp, G, cpg, hw, stat_chunks, stat_rows, eps, s_red, s_mean_hi, s_mean_lo, s_rstd);
     const int c8 = tid % cq;
     const int r0 = tid / cq;
+    const int row_begin = blockIdx.x * rows_per_chunk;
+    const int row_end = min(row_begin + rows_per_chunk, hw);
+    const long long xbase = (long long)smp * hw * ldx + c8 * 8;
+    const long long ybase = (long long)smp * hw * C + c8 * 8;
+    // the thread's first rows are requested BEFORE the statistics are finalised (round 5): gn_finalize is a chain of latencies -- every workgroup reads its sample's
+    // chunk partials, merges them in fp64, crosses two barriers -- during which nothing of the tensor was in flight
+    int row = row_begin + r0;
+    u32x4 w0[U];
+    const bool head = row + (U - 1) * R < row_end;
+    if (head) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) w0[u] = *reinterpret_cast<const u32x4*>(x + xbase + (long long)(row + u * R) * ldx);
+    }
+    gn_finalize(part, smp, G, cpg, hw, stat_chunks, stat_rows, eps, s_red, s_mean_hi, s_mean_lo, s_rstd);
     float gr[8], bt[8], mean_hi[8], mean_lo[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -161,10 +174,6 @@ __global__ void gn_apply_bf16_kernel(const unsigned short* __restrict__ x, unsig
     float rstd[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) rstd[i] = s_rstd[(c8 * 8 + i) / cpg];
-    const int row_begin = blockIdx.x * rows_per_chunk;
-    const int row_end = min(row_begin + rows_per_chunk, hw);
-    const long long xbase = (long long)smp * hw * ldx + c8 * 8;
-    const long long ybase = (long long)smp * hw * C + c8 * 8;
     auto norm = [&](const u32x4 w) {
         F8 v = unpack8(w);
 #pragma unroll
@@ -176,7 +185,11 @@ __global__ void gn_apply_bf16_kernel(const unsigned short* __restrict__ x, unsig
         }
         return pack8(v);
     };
-    int row = row_begin + r0;
+    if (head) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) *reinterpret_cast<u32x4*>(y + ybase + (long long)(row + u * R) * C) = norm(w0[u]);
+        row += U * R;
+    }
     if constexpr (U > 1) {
         for (; row + (U - 1) * R < row_end; row += U * R) {
             u32x4 w[U];

@@ -379,9 +379,13 @@ __global__ void gn_apply_fp8_kernel(const unsigned short* __restrict__ x, unsign
     const int tid = threadIdx.x;
     const int smp = blockIdx.y;
     const int cpg = C / G;
-    gn_finalize(part, smp, G, cpg, hw, stat_chunks, stat_rows, eps, s_red, s_mean_hi, s_mean_lo, s_rstd);
     const int c8 = tid % cq;
     const int r0 = tid / cq;
+    // the thread's first row is requested before the statistics are finalised (as in gn_apply_bf16_kernel)
+    const int row_first = blockIdx.x * rows_per_chunk + r0;
+    u32x4 w_first = {0u, 0u, 0u, 0u};
+    if (row_first < min(blockIdx.x * rows_per_chunk + rows_per_chunk, hw)) w_first = *reinterpret_cast<const u32x4*>(x + (long long)smp * hw * ldx + c8 * 8 + (long long)row_first * ldx);
+    gn_finalize(part, smp, G, cpg, hw, stat_chunks, stat_rows, eps, s_red, s_mean_hi, s_mean_lo, s_rstd);
     float gm[8], bt[8], mean_hi[8], mean_lo[8], rstd[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -398,8 +402,8 @@ __global__ void gn_apply_fp8_kernel(const unsigned short* __restrict__ x, unsign
     const long long ybase = (long long)smp * hw * Cp;
     const long long sbase = (long long)smp * hw * (Cp >> 5);
     const int pad8 = (Cp - C) >> 3;    // 8-channel groups of zero padding per row (C = 320: 8)
-    for (int row = row_begin + r0; row < row_end; row += R) {
-        Q8 v = qunpack8(*reinterpret_cast<const u32x4*>(x + xbase + (long long)row * ldx));
+    auto emit = [&](const int row, const u32x4 w) {
+        Q8 v = qunpack8(w);
         float amax = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -422,6 +426,20 @@ __global__ void gn_apply_fp8_kernel(const unsigned short* __restrict__ x, unsign
         for (int g = c8; g < pad8; g += cq) {     // (C = 32: four threads per row write twelve pad groups)
             *reinterpret_cast<u32x2*>(y + ybase + (long long)row * Cp + C + g * 8) = u32x2{0u, 0u};
             if ((g & 3) == 0) ys[sbase + (long long)row * (Cp >> 5) + ((C + g * 8) >> 5)] = (unsigned char)127;
+        }
+    };
+    // one row ahead: the next row's load is in flight while this row is normalised and quantised (the first was requested in front of gn_finalize)
+    if (row_first < row_end) {
+        int row = row_first;
+        u32x4 w = w_first;
+        for (;;) {
+            const int nxt = row + R;
+            u32x4 wn = w;
+            if (nxt < row_end) wn = *reinterpret_cast<const u32x4*>(x + xbase + (long long)nxt * ldx);
+            emit(row, w);
+            if (nxt >= row_end) break;
+            row = nxt;
+            w = wn;
         }
     }
 }

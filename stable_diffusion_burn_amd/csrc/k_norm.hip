@@ -130,9 +130,22 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__
     const int tid = threadIdx.x;
     const int smp = blockIdx.y;
     const int cpg = C / G;
-    gn_finalize(part, smp, G, cpg, hw, stat_chunks, stat_rows, eps, s_red, s_mean_hi, s_mean_lo, s_rstd);
     const int c4 = tid % cq;
     const int r0 = tid / cq;
+    const int row_begin = blockIdx.x * rows_per_chunk;
+    const int row_end = min(row_begin + rows_per_chunk, hw);
+    const long long xbase = (long long)smp * hw * ldx + c4 * 4;
+    const long long ybase = (long long)smp * hw * C + c4 * 4;
+    // the thread's first two rows are requested BEFORE the statistics are finalised (round 5): gn_finalize is a chain of latencies (chunk partials from memory, fp64
+    // merges, two barriers) during which nothing of the tensor was in flight
+    int row = row_begin + r0;
+    const bool head = row + R < row_end;
+    f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;
+    if (head) {
+        h0 = *reinterpret_cast<const f32x4*>(x + xbase + (long long)row * ldx);
+        h1 = *reinterpret_cast<const f32x4*>(x + xbase + (long long)(row + R) * ldx);
+    }
+    gn_finalize(part, smp, G, cpg, hw, stat_chunks, stat_rows, eps, s_red, s_mean_hi, s_mean_lo, s_rstd);
     const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c4 * 4);
     const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c4 * 4);
     f32x4 mean_hi, mean_lo, rstd;
@@ -143,10 +156,6 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__
         mean_lo[i] = s_mean_lo[gi];
         rstd[i] = s_rstd[gi];
     }
-    const int row_begin = blockIdx.x * rows_per_chunk;
-    const int row_end = min(row_begin + rows_per_chunk, hw);
-    const long long xbase = (long long)smp * hw * ldx + c4 * 4;
-    const long long ybase = (long long)smp * hw * C + c4 * 4;
     auto norm = [&](f32x4 v) {
         v = ((v - mean_hi) - mean_lo) * rstd;
         v = v * gm + bt;
@@ -162,7 +171,11 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__
         if constexpr (P3) s3_store4(y3 + (long long)r * pix3, c4 * 4, v);
         else *reinterpret_cast<f32x4*>(y + ybase + (long long)r * C) = v;
     };
-    int row = row_begin + r0;
+    if (head) {
+        put(row, norm(h0));
+        put(row + R, norm(h1));
+        row += 2 * R;
+    }
     for (; row + R < row_end; row += 2 * R) {
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + xbase + (long long)row * ldx);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + xbase + (long long)(row + R) * ldx);
