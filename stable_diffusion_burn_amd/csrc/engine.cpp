@@ -1040,6 +1040,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "fp8_linear") opt_fp8_linear_ = std::stoi(value);
     else if (key == "fp8_ops") opt_fp8_ops_ = std::stoi(value);
     else if (key == "op_resid") opt_op_resid_ = std::stoi(value);
+    else if (key == "cfg_share") opt_cfg_share_ = std::stoi(value);
     else if (key == "gn32_min_wgs") opt_gn32_min_wgs_ = std::stoi(value);
     else if (key == "gn_target_wgs") gn_tune_.target_wgs = std::stoi(value);
     else if (key == "gn_max_threads") gn_tune_.max_threads = std::stoi(value);
@@ -1756,9 +1757,27 @@ void Engine::layer_norm_fp8(const NormW& w, const float* x, long long rows, ActQ
 // two NCHW<->token transposes disappear.
 void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
     Range rng(this, "SpatialTransformer");
-    const int C = w.c, nb = x.n, hw = x.h * x.w;
-    const long long M = x.rows();
+    // y.n == 2 x.n: the shared prefix of a CFG pair (unet_run): x holds ONE copy of the two halves' identical input; everything in front of the cross attention --
+    // the first place the text context enters -- is computed once and duplicated there
+    if (y.n != x.n && y.n != 2 * x.n) throw Error(SDMI_ERR_STATE, "spatial_transformer: batch mismatch");
+    auto duplicate = [&](const Act& src) {   // [n] -> [2n] (dense, same type): both halves = src
+        Act d2 = new_act(2 * src.n, src.h, src.w, src.c);
+        ProfScope ps_o(this, PC_OTHER, 0, 3.0 * (double)src.bytes());
+        SDMI_HIP(launch_repeat_rows(src.p, d2.p, 2, (long long)(src.bytes() / 4), stream_));
+        count_kernel();
+        return d2;
+    };
+    const int C = w.c, hw = x.h * x.w;
     const int heads = cfg_.n_head, d = C / heads;
+    if (y.n != x.n && use_fp8_wide(w.proj_in.bt8, y.rows()) && x.dt == 1 && y.dt == 1) {   // option fp8_linear: no shared form -- duplicate first
+        Act x2 = duplicate(x);
+        spatial_transformer(w, x2, y);
+        release(x2);
+        return;
+    }
+    const int nb = y.n, n1 = x.n;            // n1: samples of the part in front of the cross attention
+    const bool share = nb != n1;
+    const long long M = (long long)nb * hw, M1 = (long long)n1 * hw;
     if (use_fp8_wide(w.proj_in.bt8, M) && w.attn1.q.bt8 && w.attn1.out.bt8 && w.attn2.q.bt8 && w.attn2.out.bt8 && w.geglu_proj.bt8 && w.mlp_lin.bt8 &&
         w.proj_out.bt8 && x.dt == 1 && y.dt == 1) {
         // precision = 2, option fp8_linear: every GEMM of the block on MXFP8 operands.  Their inputs are quantised by the kernel that
@@ -1820,7 +1839,8 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
     Act h = new_act(x.n, x.h, x.w, C);
     conv(w.proj_in, g, h, 1, 0, nullptr, 0, nullptr);
     release(g);
-    Act hp = pl ? new_act3(x.n, x.h, x.w, C, 2) : Act{};      // the hidden state after the MLP: read by proj_out only
+    Act hp = pl ? new_act3(nb, x.h, x.w, C, 2) : Act{};      // the hidden state after the MLP: read by proj_out only
+    Act x2{};                                                 // shared prefix: the block input once per half (proj_out's residual)
     {
         const size_t es = esz();
         const size_t row3 = (size_t)(C / 32) * 192;
@@ -1830,15 +1850,21 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
         float* af = pl ? nullptr : a.f();
         void* a3 = pl ? a.p : nullptr;
         // self attention: q, k, v in one GEMM (N = 3C) on the packed [3C][C] weight
-        layer_norm(w.ln1, h.p, M, lnf, -1, ln3);
+        layer_norm(w.ln1, h.p, M1, lnf, -1, ln3);
         {
-            Buf qkv(this, (size_t)M * 3 * C * es);
-            gemm(lnf, (int)M, w.attn1.q.bt, nullptr, C, 3 * C, qkv.f(), 3 * C, nullptr, 0, -1, 0, ln3);
+            Buf qkv(this, (size_t)M1 * 3 * C * es);
+            gemm(lnf, (int)M1, w.attn1.q.bt, nullptr, C, 3 * C, qkv.f(), 3 * C, nullptr, 0, -1, 0, ln3);
             const long long bs3 = (long long)hw * 3 * C;
             attention(qkv.f(), 3 * C, bs3, adv(qkv.f(), C, edt()), 3 * C, bs3, adv(qkv.f(), 2 * C, edt()), 3 * C, bs3, af, C,
-                      (long long)hw * C, nb, hw, hw, heads, d, nullptr, nullptr, nullptr, 0, -1, a3, q_prescaled(edt(), d));
+                      (long long)hw * C, n1, hw, hw, heads, d, nullptr, nullptr, nullptr, 0, -1, a3, q_prescaled(edt(), d));
         }
-        gemm(af, (int)M, w.attn1.out.bt, w.attn1.out.bias, C, C, h.p, C, h.p, C, -1, 0, a3);
+        gemm(af, (int)M1, w.attn1.out.bt, w.attn1.out.bias, C, C, h.p, C, h.p, C, -1, 0, a3);
+        if (share) {   // from here on the halves differ: the hidden state and the block input, once per half
+            Act h2 = duplicate(h);
+            release(h);
+            h = h2;
+            x2 = duplicate(x);
+        }
         // cross attention against the hoisted K/V of the text context
         layer_norm(w.ln2, h.p, M, lnf, -1, ln3);
         gemm(lnf, (int)M, w.attn2.q.bt, nullptr, C, C, q.f(), C, nullptr, 0, -1, 0, ln3);
@@ -1855,9 +1881,11 @@ void Engine::spatial_transformer(const SpatialW& w, const Act& x, Act& y) {
             else gemm(u.f(), (int)M, w.mlp_lin.bt, w.mlp_lin.bias, 4 * C, C, h.p, C, h.p, C);
         }
     }
-    if (pl) { conv(w.proj_out, hp, y, 1, 0, nullptr, 0, &x); release(hp); }
-    else conv(w.proj_out, h, y, 1, 0, nullptr, 0, &x);
+    const Act& xr = share ? x2 : x;
+    if (pl) { conv(w.proj_out, hp, y, 1, 0, nullptr, 0, &xr); release(hp); }
+    else conv(w.proj_out, h, y, 1, 0, nullptr, 0, &xr);
     release(h);
+    if (share) release(x2);
 }
 
 // ConvSelfAttentionBlock::forward (autoencoder/mod.rs:563-607)
@@ -1943,7 +1971,7 @@ void Engine::unet_prepare(const float* ctx_packed, int nb, int t_max, const int*
 // output block i ([x channels | skip channels]) is allocated when its skip is produced on the way down; input block
 // 11 - i writes its result straight into the skip slice (the GEMM epilogue's row stride), output block i - 1 (or
 // the middle block) writes the x slice, and output block i reads the whole buffer.
-void Engine::unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc) {
+void Engine::unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc, bool cfg_pair) {
     Range rng(this, "UNet::forward step " + std::to_string(step));
     const int H = cfg_.latent_h, W = cfg_.latent_w;
     Act x; x.p = const_cast<float*>(x_nhwc); x.n = nb; x.h = H; x.w = W; x.c = 4; x.dt = 0;  // latents stay fp32
@@ -1987,7 +2015,20 @@ void Engine::unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc) {
         const bool catp = plane_gemm(ctot, out_blocks_[i].cout) && cx % 32 == 0 && cskip % 32 == 0;
         cats[i] = catp ? new_act3(nb, ho, wo, ctot, 3) : new_act(nb, ho, wo, ctot);
         Act y = slice(cats[i], cx, cskip);
-        run_block(b, x, y);
+        if (cfg_pair && j == 1 && b.kind == BK_RES_ST && nb % 2 == 0) {
+            // The two halves of a CFG step's batch -- uncond rows, then cond rows (stablediffusion/mod.rs:173-179: two forwards of the SAME x and t) -- are identical
+            // until the text context first enters: conv_in, this block's ResBlock and its transformer up to the cross attention.  That prefix is computed ONCE on
+            // the first half and duplicated in front of the cross attention (spatial_transformer): the same values the two forwards would produce, per sample
+            // (GroupNorm and attention are per sample), for half the 64x64-level ResBlock convolutions and one of its five self-attentions less.  Option cfg_share=0
+            // computes both halves.
+            Act xh = x; xh.n = nb / 2;
+            Act r = new_act(nb / 2, x.h, x.w, b.cout);
+            res_block(b.res, xh, r, step);
+            spatial_transformer(b.st, r, y);
+            release(r);
+        } else {
+            run_block(b, x, y);
+        }
         x = y;
     }
     {   // middle block: reads the last skip, writes the x slice of output block 0's input
@@ -2107,7 +2148,7 @@ void Engine::sample_latent_dev(const float* context, int n, int T, const float* 
         c.sqrt_cur = (float)std::sqrt(cur);
         c.sqrt_prev = (float)std::sqrt(prev);
         c.dir_coef = (float)std::sqrt(1.0 - prev - 0.0);                                 // :153 (sigma = 0)
-        unet_run(unet_in.f(), nb, (int)s, eps.f());
+        unet_run(unet_in.f(), nb, (int)s, eps.f(), opt_cfg_share_ != 0);   // unet_in = [latent | latent]: a CFG pair
         { ProfScope ps_o(this, PC_OTHER); SDMI_HIP(launch_cfg_ddim(eps.f(), latent.f(), unet_in.f(), per_half, c, stream_)); }
         count_kernel();
     }

@@ -310,7 +310,7 @@ private:
     // UNet driver
     void unet_prepare(const float* ctx_packed, int nb, int t_max, const int* kv_len_host, const std::vector<int>& ts);
     void unet_release();
-    void unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc);
+    void unet_run(const float* x_nhwc, int nb, int step, float* out_nhwc, bool cfg_pair = false);
     void decode_one(const float* z_nhwc, int n, Act& img);
 
     void count_kernel(double flops = 0) { ++n_kernels_; flops_ += flops; }
@@ -365,6 +365,7 @@ private:
     int opt_gn32_min_wgs_ = 256;     // precision = 0: at least this many workgroups per GroupNorm pass over the call's samples (k_norm.hip gn_geom); 0 = round 4's cut by size
                                      // alone; measured at batch 1: GroupNorm class 21.3 -> 19.8 ms per image (profiles/r05d_*)
     GnTune gn_tune_;                 // launch geometry of the bf16 / MXFP8 GroupNorm passes (kernels.hpp; options gn_target_wgs, gn_max_threads, gn_unroll)
+    int opt_cfg_share_ = 1;          // sample_latent: the part of the UNet in front of the first cross attention is computed once for the two identical halves of a CFG step (unet_run)
     int opt_op_resid_ = 0;           // tests: op_conv2d / op_linear add their input as the residual (cin == cout) through the GEMM epilogue
     int opt_fp8_ops_ = 0;            // tests: op_linear / op_layer_norm / op_geglu run the fp8_linear path's kernels (outputs dequantised)
     int opt_fp8_linear_ = 0;         // precision = 2: 0 (default: the accuracy budget of 6e-2 final-latent relative RMS) = MXFP8 on the ResBlock / ResnetBlock 3x3

@@ -131,6 +131,32 @@ def test_sample_latent_batch2_matches_single(sd_tiny, tiny_dims):
         assert np.abs(both[i:i + 1] - one).max() <= 2e-5 * scale, f"sample {i}"
 
 
+@pytest.mark.parametrize("precision", [0, 1, 2])
+def test_shared_cfg_prefix_equals_two_full_forwards(synth, tiny_dims, precision):
+    """Round 5, option cfg_share (default 1): the part of the UNet in front of the first cross attention (input block 1's ResBlock and its transformer up to the
+    cross attention) is computed ONCE for the two halves of a CFG step -- they are the reference's two forwards of the SAME x and t (stablediffusion/mod.rs:173-179)
+    and differ only in the context -- and duplicated there.  cfg_share=0 computes both halves.  Same values per sample; the GEMMs of the prefix run at half the rows, so
+    their tile / split-K choice (hence the summation order) may differ: fp32 to 2e-5 relative, reduced precisions to their operator bars over 3 chained steps."""
+    from stable_diffusion_burn_amd import ModelConfig, StableDiffusion
+    # fp32: the half-width model; bf16 / MXFP8 need channel counts that are multiples of 64: the full-width model at an 8x8 latent (as tests/test_bf16_gpu.py)
+    d = tiny_dims if precision == 0 else O.Dims(320, 8, 768, 8, 8, 64)
+    sd = StableDiffusion(ModelConfig(d.model_channels, d.n_head, d.ctx_dim, d.latent_h, d.latent_w, d.vae_ch, precision=precision))
+    try:
+        sd.load_weights(synth, clip=False, vae_encoder=False)
+        lat, ctx, unc = _inputs(d, 3, 7, 2)
+        shared = sd.sample_latent(ctx, unc, 7.5, 3, init_latent=lat)
+        ks = sd.last_call_stats()["kernels"]
+        sd.set_option("cfg_share", 0)
+        full = sd.sample_latent(ctx, unc, 7.5, 3, init_latent=lat)
+        kf = sd.last_call_stats()["kernels"]
+        scale = max(1.0, np.abs(full).max())
+        err = np.abs(shared - full).max() / scale
+        print(f"precision {precision}: shared prefix vs two full forwards, 3 steps: max|d| / absmax = {err:.2e}; kernels {ks} vs {kf}")
+        assert np.isfinite(shared).all() and err <= (2e-5 if precision == 0 else 2e-2)
+    finally:
+        sd.close()
+
+
 def test_decode_latent(sd_tiny, synth, tiny_dims):
     """Autoencoder::decode_latent (autoencoder/mod.rs:68-71, 205-217)."""
     d = tiny_dims
