@@ -1296,7 +1296,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     void* const c3_want = in_dt ? nullptr : p.C3;
     const int ldc3_want = p.ldc3;
     const bool vec_out = (p.N % 4 == 0) && (!p.C || p.ldc % 4 == 0) && (!p.resid || p.ldr % 4 == 0);
-    const bool c3_native = c3_want && tc.cfg >= 200 && vec_out && !p.geglu;
+    const bool c3_native = c3_want && tc.cfg >= 200 && vec_out && (!p.geglu || (p.geglu == 2 && tc.cfg >= 300));
     std::unique_ptr<Buf> c_tmp;
     if (!c3_native) {
         p.C3 = nullptr;
@@ -1409,6 +1409,31 @@ void Engine::gemm(const float* A, int a_rows, const float* bt, const float* bias
 void Engine::gemm_geglu(const float* x, long long rows, const float* bt, const float* bias, int cin, int hidden, float* out, int dt,
                         const void* x3, void* out3) {
     if (dt < 0) dt = edt();
+    if (x3 && (out3 || out) && !dt && opt_geglu_fuse_ && hidden % 32 == 0 && cin % 32 == 0 && split_planes(bt)) {
+        // round 5: the gate in the plane GEMM's epilogue -- value / gate rows split by WAVE column, so the tiles with an odd fragment count per wave (256 x 160:
+        // the batch-1 model's) qualify.  The tile is the one the unfused projection [rows, 2 hidden] would take (same tile count: 80 outputs = 160 weight rows per
+        // tile); it must run without split-K and have an even number of wave columns (not 128 x 64).
+        const int kt_total = (cin + 31) / 32;
+        char key[64];
+        std::snprintf(key, sizeof key, "%lld,%d,%d", rows, 2 * hidden, cin);
+        const auto itp = tuned_p_.find(key);
+        const TileChoice tc = itp != tuned_p_.end() ? itp->second : choose_tile_p((int)rows, 2 * hidden, kt_total, false);
+        const int force = opt_force_tile_ >= 300 ? opt_force_tile_ : tc.cfg;
+        if (force >= 300 && force != 308 && (tc.splits == 1 || opt_force_tile_ >= 300) && opt_force_splits_ <= 1) {
+            ConvGemm p{};
+            p.A = x; p.Bt = bt; p.C = out; p.bias = bias;
+            p.A3 = x3; p.a3_ld = (cin / 32) * 192;
+            p.C3 = out3; p.ldc3 = (hidden / 32) * 192;
+            p.M = (int)rows; p.N = hidden; p.K = cin;
+            p.NB = 1; p.Hs = 1; p.Ws = (int)rows; p.Cin = cin; p.Ho = 1; p.Wo = (int)rows;
+            p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.ups = 0;
+            p.ldc = hidden; p.ldr = hidden; p.a_ld = cin; p.b_ld = cin; p.rowvec_stride = 0; p.CS = 32;
+            p.out_mode = 0;
+            p.geglu = 2;
+            launch_gemm(p, 0, force, 1);
+            return;
+        }
+    }
     if (x3 || out3) {   // plane form: projection on a plane tile, gate kernel writing planes (the MLP's second Linear reads them)
         Buf proj(this, (size_t)rows * 2 * hidden * 4);
         gemm(x, (int)rows, bt, bias, cin, 2 * hidden, proj.f(), 2 * hidden, nullptr, 0, dt, 0, x3, nullptr);
@@ -2465,6 +2490,21 @@ void Engine::op_geglu_forward(const float* x, const float* wt, const float* bias
     }
     SDMI_HIP(launch_pack_linear_weight(wt, bt.f(), cin, 2 * hidden, stream_));
     TempSplit planes(this, bt.f(), 2 * hidden, cin);
+    if (opt_geglu_fuse_ >= 7 && plane_gemm(cin, hidden) && hidden % 32 == 0) {
+        // tests: the model's plane form -- x as planes in, the gated result as planes out (joined back exactly) -- through the plane GEMM's fused gate;
+        // geglu_fuse = 7: the tile the table / cost model picks, 8: also the fp32 result from the same launch (both outputs of the epilogue)
+        Buf x3(this, (size_t)rows * (cin / 32) * 192), o3(this, (size_t)rows * (hidden / 32) * 192);
+        SDMI_HIP(launch_split3_rows(x, x3.p, rows, cin, cin, (long long)(cin / 32) * 192, stream_));
+        if (opt_geglu_fuse_ == 8) {
+            Buf o32(this, (size_t)rows * hidden * 4);
+            gemm_geglu(nullptr, rows, bt.f(), bias, cin, hidden, o32.f(), 0, x3.p, o3.p);
+            SDMI_HIP(hipMemcpyAsync(out, o32.p, (size_t)rows * hidden * 4, hipMemcpyDeviceToDevice, stream_));   // the fp32 output of a launch that writes both
+        } else {
+            gemm_geglu(nullptr, rows, bt.f(), bias, cin, hidden, nullptr, 0, x3.p, o3.p);
+            SDMI_HIP(launch_join3_rows(o3.p, out, rows, hidden, (long long)(hidden / 32) * 192, hidden, stream_));
+        }
+        return;
+    }
     gemm_geglu(x, rows, bt.f(), bias, cin, hidden, out, 0);
 }
 

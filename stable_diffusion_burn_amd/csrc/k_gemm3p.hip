@@ -244,7 +244,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3p_kernel(const Conv
         const int f = q / 3, pl = q - 3 * f;
         int n = n0 + f * 16 + r16;
         long long wrow = n;
-        if (geglu) {
+        if (p.geglu == 2) {        // wave columns [0, WN / 2) hold the value rows of the tile's outputs, [WN / 2, WN) their gate rows (k_gemm_epi.hpp)
+            const int fw = f / NI, ni = f - fw * NI;
+            const int vg = fw / (WN / 2 > 0 ? WN / 2 : 1), col = fw - vg * (WN / 2);
+            n = n0 + col * WNC + ni * 16 + r16;
+            wrow = (long long)n + (vg ? p.N : 0);
+        } else if (geglu) {
             const int fw = f / NI, ni = f - fw * NI;
             n = n0 + fw * (WNC / 2) + (ni >> 1) * 16 + r16;
             wrow = (long long)n + ((ni & 1) ? p.N : 0);
@@ -347,7 +352,10 @@ hipError_t launch_conv_gemm3p(const ConvGemm& p, int cfg, hipStream_t stream) {
     if (cfg < 0 || cfg >= kNumGemmTilesP) return hipErrorInvalidValue;
     if ((p.Cin % 32) || p.CS != 32 || !p.zero_page || !p.Bt3 || !p.A3 || p.a3_ld <= 0 || (p.a3_ld % 192) || p.out_mode != 0) return hipErrorInvalidValue;
     const bool odd_ni = (cfg == 0 || cfg == 3 || cfg == 7);
-    if (p.geglu && (odd_ni || p.splits != 1 || (p.N & 7) || (p.ldc & 7) || p.rowvec || p.resid)) return hipErrorInvalidValue;
+    if (p.geglu == 1 && (odd_ni || p.splits != 1 || (p.N & 7) || (p.ldc & 7) || p.rowvec || p.resid)) return hipErrorInvalidValue;
+    // geglu = 2 (value / gate split by wave column, combined across the two waves in the epilogue): any tile with an even number of wave columns
+    if (p.geglu == 2 && (cfg == 8 || p.splits != 1 || (p.N & 3) || (p.C && (p.ldc & 3)) || (p.C3 && (p.N & 31)) || p.rowvec || p.resid || (!p.C && !p.C3))) return hipErrorInvalidValue;
+    if (p.geglu != 0 && p.geglu != 1 && p.geglu != 2) return hipErrorInvalidValue;
     if ((unsigned long long)p.N * (p.geglu ? 2 : 1) * (unsigned long long)p.kt_total * 192ull >= 0xFFFFFF00ull) return hipErrorInvalidValue;   // 32-bit piece offsets
     if ((unsigned long long)p.NB * p.Hs * p.Ws * (unsigned long long)p.a3_ld >= 0xFFFFFF00ull) return hipErrorInvalidValue;
     const int bm = kTilesP[cfg].bm, bn = kTilesP[cfg].bn;

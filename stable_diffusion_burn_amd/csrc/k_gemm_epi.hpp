@@ -35,6 +35,53 @@ __device__ __forceinline__ void gemm_epilogue_f32(const ConvGemm& p, epi_f32x4 (
     const bool has_resid = !split && p.resid;
     const bool vec_ok = ((p.N & 3) == 0) && ((ldc & 3) == 0) && ((p.ldr & 3) == 0 || !has_resid);
     constexpr int LDSW = WNC + 4;       // scratch row stride in floats
+    if (p.geglu == 2) {
+        // GEGLU with the value and gate columns in DIFFERENT waves (round 5; tiles with an odd fragment count per wave, e.g. 256 x 160: 80 outputs per tile): wave
+        // columns [0, WN / 2) computed x W_value, [WN / 2, WN) x W_gate for the same 16 NI outputs.  Per 16-row fragment group both waves of a pair put their
+        // fragments (+ bias) into their scratch, the workgroup meets at a barrier, and each wave of the pair gates 8 of the 16 rows -- value from one scratch, gate
+        // from the other -- and writes them as fp32 and / or planes.  Launch-side guarantees: no split-K, N % 4 == 0, no rowvec / residual.
+        if constexpr (WN % 2 == 0) {
+            constexpr int HWN = WN / 2;
+            const int vg = wn / HWN, col = wn - vg * HWN;
+            const int pw = wm * WN + (vg ? wn - HWN : wn + HWN);     // the partner wave
+            __syncthreads();                                        // every wave is done with the last k tile
+            float* scr = reinterpret_cast<float*>(smem_x32 + wave * (16 * LDSW * 4));
+            const float* scr_v = reinterpret_cast<const float*>(smem_x32 + (vg ? pw : wave) * (16 * LDSW * 4));
+            const float* scr_g = reinterpret_cast<const float*>(smem_x32 + (vg ? wave : pw) * (16 * LDSW * 4));
+            const int nw0 = n0 + col * WNC;
+            const float* bias = p.bias ? p.bias + (vg ? p.N : 0) : nullptr;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int mrow0 = m0 + (wm * MI + mi) * 16;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int n = nw0 + ni * 16 + g4 * 4;
+                    f32x4 v = acc[mi][ni];
+                    if (bias && n < p.N) v += *reinterpret_cast<const f32x4*>(bias + n);
+                    *reinterpret_cast<f32x4*>(scr + c15 * LDSW + ni * 16 + g4 * 4) = v;
+                }
+                __syncthreads();
+                constexpr int CH = WNC / 4;   // 16-byte chunks per row
+#pragma unroll
+                for (int q0 = 0; q0 < 8 * CH; q0 += 64) {
+                    const int q = q0 + lane;
+                    const int row = 8 * vg + q / CH, c4 = q - (q / CH) * CH;
+                    const int m = mrow0 + row, n = nw0 + c4 * 4;
+                    if (q < 8 * CH && m < p.M && n < p.N) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(scr_v + row * LDSW + c4 * 4);
+                        const f32x4 g = *reinterpret_cast<const f32x4*>(scr_g + row * LDSW + c4 * 4);
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = v[e] * (0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752440f)));
+                        if (p.C) *reinterpret_cast<f32x4*>(p.C + (long long)m * p.ldc + n) = o;
+                        if (p.C3) s3_store4(reinterpret_cast<unsigned char*>(p.C3) + (long long)m * p.ldc3, n, o);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        return;
+    }
     if (geglu) {   // launch-side guarantees: NI even, no split-K, N % 8 == 0, ldc % 8 == 0, no rowvec / residual
         if constexpr (NI % 2 == 0) {
             constexpr int WNO = WNC / 2;     // output columns of a wave tile

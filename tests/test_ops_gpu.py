@@ -473,3 +473,31 @@ def test_geglu_forward(sd_ops, rows, cin, hidden, fuse):
     proj = _t(x) @ _t(w) + _t(b)
     ref = (proj[:, :hidden] * O.gelu_erf(proj[:, hidden:])).numpy()
     _check(got, ref, f"geglu_forward ({rows},{cin},{hidden}) fuse={fuse}")
+
+
+# ---- round 5: the gate in the PLANE GEMM's epilogue, value / gate rows split by wave column (tiles with an odd fragment count per wave qualify) -----------
+@pytest.mark.parametrize("rows,cin,hidden", [(700, 320, 1280), (300, 64, 224), (2048, 320, 1280), (513, 128, 384), (8192, 320, 1280)])
+@pytest.mark.parametrize("tile", ["auto", 300, 301, 302, 303, 304, 305, 306, 307])
+def test_geglu_forward_plane_tiles_wave_column_pairs(sd_ops, rows, cin, hidden, tile):
+    """GEGLU::forward (unet/mod.rs:579-591) as the fp32 model runs it since round 5: x arrives as bf16 planes, the projection runs on a k_gemm3p.hip tile whose
+    wave columns [0, WN / 2) multiply by the value rows and [WN / 2, WN) by the gate rows of the SAME outputs, the two waves of a pair exchange their fragments
+    through LDS in the epilogue (k_gemm_epi.hpp, geglu = 2), and the gated result leaves as planes (geglu_fuse = 7, joined back exactly) and as fp32 (8) --
+    the [rows, 2 hidden] tensor and the gate kernel's launch are gone.  Same operator bar as every fp32 GEMM."""
+    g = _rng(rows + hidden + (0 if tile == "auto" else tile))
+    x = g.standard_normal((rows, cin)).astype(np.float32)
+    w = (g.standard_normal((cin, 2 * hidden)) / math.sqrt(cin)).astype(np.float32)
+    b = g.standard_normal(2 * hidden).astype(np.float32)
+    proj = _t(x) @ _t(w) + _t(b)
+    ref = (proj[:, :hidden] * O.gelu_erf(proj[:, hidden:])).numpy()
+    try:
+        sd_ops.set_option("gemm_tile", tile)
+        outs = []
+        for fuse in (7, 8):
+            sd_ops.set_option("geglu_fuse", fuse)
+            got = sd_ops.op_geglu_forward(x, w, b, hidden)
+            _check(got, ref, f"geglu_forward plane tile {tile} ({rows},{cin},{hidden}) fuse={fuse}")
+            outs.append(got)
+        np.testing.assert_array_equal(outs[0], outs[1])     # the planes ARE the fp32 result, split
+    finally:
+        sd_ops.set_option("geglu_fuse", 1)
+        sd_ops.set_option("gemm_tile", "auto")
