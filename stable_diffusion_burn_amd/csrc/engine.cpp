@@ -1041,6 +1041,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "fp8_ops") opt_fp8_ops_ = std::stoi(value);
     else if (key == "op_resid") opt_op_resid_ = std::stoi(value);
     else if (key == "cfg_share") opt_cfg_share_ = std::stoi(value);
+    else if (key == "attn_kv_splits") opt_attn_kv_splits_ = std::stoi(value);
     else if (key == "gn32_min_wgs") opt_gn32_min_wgs_ = std::stoi(value);
     else if (key == "gn_target_wgs") gn_tune_.target_wgs = std::stoi(value);
     else if (key == "gn_max_threads") gn_tune_.max_threads = std::stoi(value);
@@ -1538,11 +1539,33 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
         p.o3 = o3; p.ldo3 = (n_head * d_head / 32) * 192;
         if (dt && mask) throw Error(SDMI_ERR_UNSUPPORTED, "attention: additive mask is fp32-only");
         const double fl = 4.0 * n * n_head * (double)nq * nk * d_head;
-        ProfScope ps(this, PC_ATTENTION, fl);
+        const bool on_split = !dt && opt_attn_split_ && attn_split_supported(p);
+        // Key slices (round 5; fp32, no mask): at batch 1 the 32 x 32 level's self attention is 128 workgroups and the 16 x 16 level's 64 -- most CUs idle while each
+        // workgroup walks every key.  S slices of the keys run as S x the workgroups (blockIdx.z) and a merge launch combines them in slice order.  S = what fills
+        // 256 CUs, at least two K / V tiles per slice, at most 8; option attn_kv_splits: 0 = this rule, 1 = never, S = forced.
+        int kv_splits = 1;
+        if (!dt && !mask && opt_attn_kv_splits_ != 1) {
+            const long long wgs = (long long)((nq + (on_split ? 127 : 63)) / (on_split ? 128 : 64)) * n * n_head;   // the 4-wave workgroups these sizes get
+            const int tiles = (nk + attn_f32_kv_tile(p) - 1) / attn_f32_kv_tile(p);
+            long long s_auto = wgs > 0 && wgs <= 128 ? 256 / wgs : 1;
+            s_auto = std::min<long long>(std::min<long long>(s_auto, tiles / 2), 8);
+            kv_splits = opt_attn_kv_splits_ > 1 ? std::min(opt_attn_kv_splits_, std::max(1, tiles)) : (int)std::max<long long>(1, s_auto);
+        }
+        std::unique_ptr<Buf> part_o, part_ml;
+        if (kv_splits > 1) {
+            part_o.reset(new Buf(this, (size_t)kv_splits * n * nq * n_head * d_head * sizeof(float)));
+            part_ml.reset(new Buf(this, (size_t)kv_splits * n * n_head * nq * 2 * sizeof(float)));
+            p.kv_splits = kv_splits; p.part_o = part_o->f(); p.part_ml = part_ml->f();
+        }
+        ProfScope ps(this, PC_ATTENTION, fl, 0, kv_splits > 1 ? 2 : 1);
         if (dt && opt_attn_bf16_ && (d_head == 40 || d_head == 80 || d_head == 160)) SDMI_HIP(launch_attention_bf16(p, stream_));
-        else if (!dt && opt_attn_split_ && attn_split_supported(p)) SDMI_HIP(launch_attention_split(p, stream_));
+        else if (on_split) SDMI_HIP(launch_attention_split(p, stream_));
         else SDMI_HIP(launch_attention(p, stream_));
         count_kernel(fl);
+        if (kv_splits > 1) {
+            SDMI_HIP(launch_attention_combine(p, stream_));
+            count_kernel();
+        }
         return;
     }
     if (mask) throw Error(SDMI_ERR_UNSUPPORTED, "attention: additive mask is only supported for head dims 40/80/160");

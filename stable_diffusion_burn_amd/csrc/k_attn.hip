@@ -129,6 +129,10 @@ __global__ __launch_bounds__(NW * 64) void attn2_kernel(const AttnParams p) {
     const int nk = p.kv_len ? p.kv_len[b] : p.nk;
     const int n_tiles = (nk + BKV - 1) / BKV;
     const int n_full = nk / BKV;
+    // key slices (kv_splits > 1; fp32, no mask): this workgroup's tiles [t_begin, t_end)
+    const int n_split = (!H16 && !HAS_MASK && p.kv_splits > 1) ? p.kv_splits : 1;
+    const int tps = (n_tiles + n_split - 1) / n_split;
+    const int t_begin = min((int)blockIdx.z * tps, n_tiles), t_end = min(t_begin + tps, n_tiles);
 
     const float qscale = p.scale * p.scale * kLog2e;  // (q*s)(k*s) = q k s^2, in log2 units
     f32x2 qf[DC];
@@ -205,13 +209,15 @@ __global__ __launch_bounds__(NW * 64) void attn2_kernel(const AttnParams p) {
     float m_run = -INFINITY;
     float l_run = 0.f;
 
-    gload(0);
-    lstore(0);
+    if (t_begin < t_end) {
+        gload(t_begin);
+        lstore(0);
+    }
     __syncthreads();
 
-    for (int tile = 0; tile < n_tiles; ++tile) {
-        const int cur = tile & 1;
-        const bool more = (tile + 1) < n_tiles;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int cur = (tile - t_begin) & 1;
+        const bool more = (tile + 1) < t_end;
         if (more) gload(tile + 1);
 
         const float* Kt = Ks + cur * Cfg::TILE_FLOATS;
@@ -290,6 +296,21 @@ __global__ __launch_bounds__(NW * 64) void attn2_kernel(const AttnParams p) {
         __syncthreads();
     }
 
+    if constexpr (!H16 && !HAS_MASK) {
+        if (n_split > 1) {   // a key slice: unnormalised rows + (maximum in log2 units, row sum) for launch_attention_combine
+            const float l_tot = xlane_sum4(l_run);
+            if (q_ok) {
+                float* po = p.part_o + (((long long)blockIdx.z * p.n + b) * p.nq + qrow) * ((long long)p.n_head * D) + hh * D;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const int dcol = dt * 16 + g * 4;
+                    if (dcol < D) *reinterpret_cast<f32x4*>(po + dcol) = o[dt];
+                }
+                if (g == 0) *reinterpret_cast<f32x2*>(p.part_ml + ((((long long)blockIdx.z * p.n + b) * p.n_head + hh) * p.nq + qrow) * 2) = f32x2{m_run, l_tot};
+            }
+            return;
+        }
+    }
     const float inv = 1.0f / xlane_sum4(l_run);
     if (q_ok) {
 #pragma unroll
@@ -345,7 +366,7 @@ static hipError_t launch_attn2_d(const AttnParams& p, hipStream_t stream) {
     auto k = attn2_kernel<D, NW, HAS_MASK, H16>;
     const size_t lds = Attn2Cfg<D, NW, H16>::LDS_BYTES;
     if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds); e != hipSuccess) return e;
-    dim3 grid((p.nq + 16 * NW - 1) / (16 * NW), p.n * p.n_head);
+    dim3 grid((p.nq + 16 * NW - 1) / (16 * NW), p.n * p.n_head, (!H16 && !HAS_MASK && p.kv_splits > 1) ? p.kv_splits : 1);
     hipLaunchKernelGGL(k, grid, dim3(NW * 64), lds, stream, p);
     return hipGetLastError();
 }
@@ -363,7 +384,48 @@ static hipError_t launch_attn2_any(const AttnParams& p, hipStream_t stream) {
     return big ? launch_attn2_d<D, 8, false, false>(p, stream) : launch_attn2_d<D, 4, false, false>(p, stream);
 }
 
+// ---- merge of the key slices of a kv_splits > 1 launch (this file's fp32 kernel or k_attn_split.hip's) -----------------------------------------
+// One thread per (sample, query, head, 4 output channels): m = max_s m_s, w_s = 2^(m_s - m), out = sum_s w_s o_s / sum_s w_s l_s, slices in order (deterministic);
+// a slice without keys has m_s = -inf, l_s = 0 and drops out.  Writes fp32 rows or the three bf16 planes, like the kernels' own epilogues.
+__global__ __launch_bounds__(256) void attn_combine_kernel(const AttnParams p) {
+    const int D = p.d_head, d4 = D >> 2;
+    const long long total = (long long)p.n * p.nq * p.n_head * d4;
+    const long long row_elems = (long long)p.n_head * D;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % d4);
+        const int hh = (int)((i / d4) % p.n_head);
+        const long long bq = i / ((long long)d4 * p.n_head);
+        const int q = (int)(bq % p.nq), b = (int)(bq / p.nq);
+        float m = -INFINITY;
+        for (int s = 0; s < p.kv_splits; ++s) m = fmaxf(m, p.part_ml[((((long long)s * p.n + b) * p.n_head + hh) * p.nq + q) * 2]);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float l = 0.f;
+        for (int s = 0; s < p.kv_splits; ++s) {
+            const f32x2 ml = *reinterpret_cast<const f32x2*>(p.part_ml + ((((long long)s * p.n + b) * p.n_head + hh) * p.nq + q) * 2);
+            if (ml[0] == -INFINITY) continue;
+            const float w = __builtin_amdgcn_exp2f(ml[0] - m);
+            acc += *reinterpret_cast<const f32x4*>(p.part_o + (((long long)s * p.n + b) * p.nq + q) * row_elems + hh * D + c4 * 4) * w;
+            l += ml[1] * w;
+        }
+        const f32x4 r = acc * (1.0f / l);
+        if (p.o3) s3_store4(reinterpret_cast<unsigned char*>(p.o3) + ((long long)b * p.nq + q) * p.ldo3, hh * D + c4 * 4, r);
+        else *reinterpret_cast<f32x4*>(p.o + (long long)b * p.o_bs + (long long)q * p.ldo + hh * D + c4 * 4) = r;
+    }
+}
+
+hipError_t launch_attention_combine(const AttnParams& p, hipStream_t stream) {
+    if (p.kv_splits < 2 || !p.part_o || !p.part_ml || p.bf16 || (p.d_head & 3) || (!p.o3 && (p.ldo & 3))) return hipErrorInvalidValue;
+    const long long total = (long long)p.n * p.nq * p.n_head * (p.d_head >> 2);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+int attn_f32_kv_tile(const AttnParams& p) { return attn_split_supported(p) ? 64 : (p.d_head > 96 ? 32 : 64); }
+
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
+    if (p.kv_splits > 1 && (p.bf16 || p.mask || !p.part_o || !p.part_ml)) return hipErrorInvalidValue;
     switch (p.d_head) {
         case 40: return launch_attn2_any<40>(p, stream);
         case 64: return launch_attn2_any<64>(p, stream);

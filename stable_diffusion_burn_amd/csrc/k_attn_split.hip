@@ -121,6 +121,10 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
     const int n_tiles = (nk + BKV - 1) / BKV;
     const int n_full = nk / BKV;
     const float cs = p.scale * p.scale * kLog2e;  // scores -> log2 units
+    // key slices (kv_splits > 1): this workgroup's tiles [t_begin, t_end)
+    const int n_split = p.kv_splits > 1 ? p.kv_splits : 1;
+    const int tps = (n_tiles + n_split - 1) / n_split;
+    const int t_begin = min((int)blockIdx.z * tps, n_tiles), t_end = min(t_begin + tps, n_tiles);
 
     if constexpr (Cfg::DK > D) {  // zero the K columns D..DK-1 of every plane once (the staging never touches them)
         for (int i = tid; i < 6 * BKV; i += NT)
@@ -196,13 +200,15 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
     const int i16 = lane & 15;
     const int v_off = (4 * hi + (i16 >> 2)) * RSV + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
 
-    gload(0);
-    lstore(0);
+    if (t_begin < t_end) {
+        gload(t_begin);
+        lstore(0);
+    }
     __syncthreads();
 
-    for (int tile = 0; tile < n_tiles; ++tile) {
-        const int cur = tile & 1;
-        const bool more = (tile + 1) < n_tiles;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int cur = (tile - t_begin) & 1;
+        const bool more = (tile + 1) < t_end;
         if (more) gload(tile + 1);
 
         const unsigned char* Kt = Ks + cur * 3 * Cfg::K_BYTES + k_off;
@@ -313,6 +319,21 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
         __syncthreads();
     }
 
+    if (n_split > 1) {   // a key slice: unnormalised rows + (maximum in log2 units, row sum) for launch_attention_combine
+        const float l_tot = sp_partner_sum(l_run);
+        if (q_ok) {
+            float* po = p.part_o + (((long long)blockIdx.z * p.n + b) * p.nq + qrow) * ((long long)p.n_head * D) + hh * D;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int dcol = 32 * dt + 8 * rq + 4 * hi;
+                    if (dcol < D) *reinterpret_cast<f32x4*>(po + dcol) = f32x4{o[dt][4 * rq], o[dt][4 * rq + 1], o[dt][4 * rq + 2], o[dt][4 * rq + 3]};
+                }
+            if (hi == 0) *reinterpret_cast<f32x2*>(p.part_ml + ((((long long)blockIdx.z * p.n + b) * p.n_head + hh) * p.nq + qrow) * 2) = f32x2{m_run * cs, l_tot};
+        }
+        return;
+    }
     const float inv = 1.0f / sp_partner_sum(l_run);
     if (q_ok) {
 #pragma unroll
@@ -335,7 +356,7 @@ static hipError_t launch_attn_split_d(const AttnParams& p, hipStream_t stream) {
     auto k = attn_split_kernel<D, NW>;
     const size_t lds = AttnSpCfg<D, NW>::LDS_BYTES;
     if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds); e != hipSuccess) return e;
-    dim3 grid((p.nq + 32 * NW - 1) / (32 * NW), p.n * p.n_head);
+    dim3 grid((p.nq + 32 * NW - 1) / (32 * NW), p.n * p.n_head, p.kv_splits > 1 ? p.kv_splits : 1);
     hipLaunchKernelGGL(k, grid, dim3(NW * 64), lds, stream, p);
     return hipGetLastError();
 }
@@ -355,6 +376,7 @@ bool attn_split_supported(const AttnParams& p) {
 // fp32 q/k/v/o, no additive mask, d_head 40 or 80, 16-byte aligned rows (attn_split_supported)
 hipError_t launch_attention_split(const AttnParams& p, hipStream_t stream) {
     if (!attn_split_supported(p)) return hipErrorInvalidValue;
+    if (p.kv_splits > 1 && (!p.part_o || !p.part_ml)) return hipErrorInvalidValue;
     if (p.d_head == 40) return launch_attn_split_any<40>(p, stream);
     return launch_attn_split_any<80>(p, stream);
 }

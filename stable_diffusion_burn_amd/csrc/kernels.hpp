@@ -145,12 +145,22 @@ struct AttnParams {
                                         // the fp32 -> bf16 conversion): launch_attention_bf16 ignores `scale` and refuses the call without it
     void* o3;                           // fp32 kernels: not null -> the output is written as three bf16 planes instead of fp32 ([n * nq][ldo3 / 192 slices][3][32],
     int ldo3;                           // channel = head * d_head + column; bytes between rows), what the out-projection's k_gemm3p.hip launch reads
+    // fp32 kernels, no mask (round 5): kv_splits = S > 1 -> blockIdx.z = key slice: workgroup z walks K / V tiles [z T / S, (z + 1) T / S) and writes its
+    // UNNORMALISED output rows + (running maximum in log2 units, row sum) instead of o / o3; launch_attention_combine merges the S slices in slice order.  For the
+    // batch-1 levels whose (query tile x head) grid leaves most CUs without a workgroup (32 x 32: 128 workgroups, 16 x 16: 64).
+    int kv_splits;
+    float* part_o;                      // [S][n][nq][n_head * d_head]
+    float* part_ml;                     // [S][n][n_head][nq][2]
 };
 bool attn_supported_head_dim(int d);
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 // fp32 q/k/v/o on the bf16 matrix pipe, three-way split operands (k_attn_split.hip): d_head 40 / 80, no additive mask
 bool attn_split_supported(const AttnParams& p);
 hipError_t launch_attention_split(const AttnParams& p, hipStream_t stream);
+// merges the key slices of a kv_splits > 1 launch (either fp32 kernel) into p.o / p.o3
+hipError_t launch_attention_combine(const AttnParams& p, hipStream_t stream);
+// K / V tile (keys per loop iteration) of the fp32 kernel that would run p: the unit kv_splits cuts
+int attn_f32_kv_tile(const AttnParams& p);
 // bf16 matrix-core kernel (k_attn_bf16.hip): p.bf16 set, no additive mask; q must arrive multiplied by attn_bf16_q_scale(d_head)
 // (the engine folds it into the query projection's weight at load) and the caller must say so (p.q_log2, else hipErrorInvalidValue); p.scale is not used
 inline float attn_bf16_q_scale(int d_head) { return (float)(1.4426950408889634 / __builtin_sqrt((double)d_head)); }

@@ -501,3 +501,37 @@ def test_geglu_forward_plane_tiles_wave_column_pairs(sd_ops, rows, cin, hidden, 
     finally:
         sd_ops.set_option("geglu_fuse", 1)
         sd_ops.set_option("gemm_tile", "auto")
+
+
+# ---- round 5: key slices of the fp32 attention kernels + the merge launch (option attn_kv_splits; automatic where the query-tile grid leaves CUs idle) ----------
+KV_SPLIT_CASES = [
+    # (n, nq, nk, c, heads): d = 80 on k_attn_split.hip (the 32 x 32 level at batch 1), d = 160 on k_attn.hip (16 x 16), d = 40, ragged key counts, fewer tiles than slices
+    (2, 1024, 1024, 640, 8), (2, 256, 256, 1280, 8), (1, 300, 333, 640, 8), (1, 200, 700, 160, 4), (2, 64, 64, 1280, 8), (1, 128, 77, 320, 8), (1, 70, 100, 640, 4),
+]
+
+
+@pytest.mark.parametrize("case", KV_SPLIT_CASES)
+@pytest.mark.parametrize("splits", [0, 2, 3, 4, 8])
+def test_qkv_attention_key_slices(sd_ops, case, splits):
+    """qkv_attention (attention.rs:5-45) with the keys cut into S slices that run as S x the workgroups and are merged by a second launch:
+    out = sum_s 2^(m_s - m) O_s / sum_s 2^(m_s - m) l_s -- the online-softmax identity across workgroups instead of across a workgroup's tiles.  Same bar as the
+    unsliced kernels; a spiked key in a late slice exercises the merge's rescale; splits = 0 is the engine's own rule; with the plane output (gemm_planes, the model's form)
+    the result must EQUAL the fp32 output's planes."""
+    n, nq, nk, c, heads = case
+    g = _rng(7000 + nq + nk + c + splits)
+    q = g.standard_normal((n, nq, c)).astype(np.float32)
+    k = g.standard_normal((n, nk, c)).astype(np.float32)
+    v = (g.standard_normal((n, nk, c)) * np.exp2(g.integers(-3, 4, (1, 1, c)))).astype(np.float32)
+    k[0, nk - 5] = q[0, 7] * 5.0        # a dominating key in the LAST slice for query 7, and one in the first slice for query 9
+    k[0, 2] = q[0, 9] * 5.0
+    ref = O.qkv_attention(_t(q), _t(k), _t(v), None, heads).numpy()
+    try:
+        sd_ops.set_option("attn_kv_splits", splits)
+        got = sd_ops.qkv_attention(q, k, v, None, heads)
+        _check(got, ref, f"qkv_attention{case} attn_kv_splits={splits}")
+        sd_ops.set_option("gemm_planes", 0)
+        plain = sd_ops.qkv_attention(q, k, v, None, heads)     # fp32 rows instead of joined planes: the same values
+        np.testing.assert_array_equal(got, plain)
+    finally:
+        sd_ops.set_option("attn_kv_splits", 0)
+        sd_ops.set_option("gemm_planes", "default")
