@@ -1042,6 +1042,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "op_resid") opt_op_resid_ = std::stoi(value);
     else if (key == "cfg_share") opt_cfg_share_ = std::stoi(value);
     else if (key == "attn_kv_splits") opt_attn_kv_splits_ = std::stoi(value);
+    else if (key == "attn_kv_prefer8") opt_attn_kv_prefer8_ = std::stoi(value);
     else if (key == "gn32_min_wgs") opt_gn32_min_wgs_ = std::stoi(value);
     else if (key == "gn_target_wgs") gn_tune_.target_wgs = std::stoi(value);
     else if (key == "gn_max_threads") gn_tune_.max_threads = std::stoi(value);
@@ -1549,6 +1550,11 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
             const int tiles = (nk + attn_f32_kv_tile(p) - 1) / attn_f32_kv_tile(p);
             long long s_auto = wgs > 0 && wgs <= 128 ? 256 / wgs : 1;
             s_auto = std::min<long long>(std::min<long long>(s_auto, tiles / 2), 8);
+            if (on_split && opt_attn_kv_prefer8_) {   // k_attn_split.hip: enough slices that the 8-wave form fills the chip beat fewer slices of the 4-wave form
+                const long long wgs8 = (long long)((nq + 255) / 256) * n * n_head;
+                const long long s8 = std::min<long long>(std::min<long long>(wgs8 < 256 ? (256 + wgs8 - 1) / wgs8 : 1, tiles / 2), 8);
+                if (s8 >= 2 && wgs8 * s8 >= 256) s_auto = s8;
+            }
             kv_splits = opt_attn_kv_splits_ > 1 ? std::min(opt_attn_kv_splits_, std::max(1, tiles)) : (int)std::max<long long>(1, s_auto);
         }
         std::unique_ptr<Buf> part_o, part_ml;

@@ -365,6 +365,7 @@ private:
     int opt_gn32_min_wgs_ = 256;     // precision = 0: at least this many workgroups per GroupNorm pass over the call's samples (k_norm.hip gn_geom); 0 = round 4's cut by size
                                      // alone; measured at batch 1: GroupNorm class 21.3 -> 19.8 ms per image (profiles/r05d_*)
     GnTune gn_tune_;                 // launch geometry of the bf16 / MXFP8 GroupNorm passes (kernels.hpp; options gn_target_wgs, gn_max_threads, gn_unroll)
+    int opt_attn_kv_prefer8_ = 1;    // ... and, for k_attn_split.hip, as many slices as let its 8-wave form fill the chip (A/B switch)
     int opt_attn_kv_splits_ = 0;     // fp32 attention: key slices + merge launch where the query-tile grid leaves CUs idle (Engine::attention): 0 = automatic, 1 = never, S = forced
     int opt_cfg_share_ = 1;          // sample_latent: the part of the UNet in front of the first cross attention is computed once for the two identical halves of a CFG step (unet_run)
     int opt_op_resid_ = 0;           // tests: op_conv2d / op_linear add their input as the residual (cin == cout) through the GEMM epilogue

@@ -363,8 +363,10 @@ static hipError_t launch_attn_split_d(const AttnParams& p, hipStream_t stream) {
 
 template <int D>
 static hipError_t launch_attn_split_any(const AttnParams& p, hipStream_t stream) {
-    // widest workgroup that still gives every CU a workgroup (256 CUs)
-    const long long bh = (long long)p.n * p.n_head;
+    // widest workgroup that still gives every CU a workgroup (256 CUs), key slices included: the 8-wave form runs two waves per SIMD (the softmax of one beside
+    // the matrix instructions of the other) and splits a K / V tile with half the work per thread -- per unit of work it is 1.5 x the 4-wave form
+    // (profiles/r05l: 64 x 64, one sample: 185 us on 256 4-wave workgroups, two samples 142 us on 256 8-wave workgroups)
+    const long long bh = (long long)p.n * p.n_head * (p.kv_splits > 1 ? p.kv_splits : 1);
     if ((long long)((p.nq + 255) / 256) * bh >= 256) return launch_attn_split_d<D, 8>(p, stream);
     return launch_attn_split_d<D, 4>(p, stream);
 }
