@@ -20,12 +20,15 @@ the image batch is sharded by global image index with no other collective
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
 `roofline` for the dominant kernel (implicit-GEMM conv on fp32 MFMA) measured
-live with HIP events on the engine's stream, `cpu_baseline` (the fp32 oracle
-timed on the host cores, rank 0, N=1 only) and -- at N=1 -- `secondary`: the same
-measurement for the reduced-precision configurations BASELINE.json names next
-to the headline (configs[2]: bf16, batch 16, 50 steps; the per-GPU shards of
-configs[3]: bf16, batch 8, 20 steps, and configs[4]: MXFP8 convs, batch 16, 20 steps),
-run after the timed headline loop.
+live with HIP events on the engine's stream (its `traffic` from the committed
+rocprofv3 PMC passes, its `algorithmic_bytes_per_launch` from this run's shapes),
+`parity_in_run` (this run's own results against the golden vectors of tests/golden,
+after the timed loop), `cpu_baseline` (the fp32 oracle timed on the host cores, rank 0,
+N=1 only) and -- at N=1 -- `secondary`: the same measurement for the headline with
+every GEMM on the fp32 matrix instruction and for the reduced-precision configurations
+BASELINE.json names (the per-GPU shards of configs[4]: MXFP8 convs, batch 16, 20 steps,
+and configs[3]: bf16, batch 8, 20 steps; configs[2]: bf16, batch 16, 50 steps), run
+after the timed headline loop.
 """
 from __future__ import annotations
 
