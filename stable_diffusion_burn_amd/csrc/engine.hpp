@@ -362,8 +362,10 @@ private:
     int opt_fp8_convs_ = 1;          // 0: run the fp8-capable convs on the bf16 kernels (A/B, accuracy comparison)
     int opt_fp8_min_rows_ = 1024;    // GEMMs with fewer output rows stay bf16 (256-row tiles need rows to fill the chip)
     int opt_fp8_tile_ = -1;
-    int opt_gn32_min_wgs_ = 256;     // precision = 0: at least this many workgroups per GroupNorm pass over the call's samples (k_norm.hip gn_geom); 0 = round 4's cut by size
-                                     // alone; measured at batch 1: GroupNorm class 21.3 -> 19.8 ms per image (profiles/r05d_*)
+    int opt_gn32_min_wgs_ = 256 | ((64 + 1) << 16);   // precision = 0, GroupNorm launch geometry (k_norm.hip gn_geom): low 16 bits = at least this many workgroups in the APPLY pass over
+                                     // the call's samples (a batch-1 tensor cut by size alone leaves CUs without a workgroup); bits 16.. = 1 + the same for the STATISTICS pass, which
+                                     // is cut coarser (every apply workgroup merges all chunk partials).  Options gn32_min_wgs / gn32_stats_min_wgs / gn32_stats_chunk_kb;
+                                     // measured at batch 1: GroupNorm class 21.3 -> 17.3 ms per image (profiles/r05d, r05f, r05o, r05p)
     GnTune gn_tune_;                 // launch geometry of the bf16 / MXFP8 GroupNorm passes (kernels.hpp; options gn_target_wgs, gn_max_threads, gn_unroll)
     int opt_attn_kv_prefer8_ = 1;    // ... and, for k_attn_split.hip, as many slices as let its 8-wave form fill the chip (A/B switch)
     int opt_attn_kv_splits_ = 0;     // fp32 attention: key slices + merge launch where the query-tile grid leaves CUs idle (Engine::attention): 0 = automatic, 1 = never, S = forced

@@ -42,7 +42,11 @@ struct GnGeom { int cq, R, threads, chunks, rows_per_chunk; };
 
 // min_wgs > 0 (round 5, option gn32_min_wgs): at least that many workgroups over the n samples, where the tensor has the rows -- a batch-1 tensor cut by size alone
 // (80 chunks x 2 samples) leaves 96 CUs without a workgroup, and the apply pass is bound by the busy CUs' store path
-static inline GnGeom gn_geom(int hw, int c, int n = 1, int min_wgs = 0) {
+// bytes per chunk of the STATISTICS pass (option gn32_stats_chunk_kb; a process-wide A/B switch): larger than the apply pass's 64 KB -- every apply workgroup merges all
+// chunk partials of its sample, so fewer partials shorten the latency chain in front of its first store (profiles/r05o, r05p: 64 -> 128 KB, class -1.4 %)
+static int g_gn32_stats_chunk_kb = 128;
+void launch_group_norm_tune(int stats_chunk_kb) { g_gn32_stats_chunk_kb = stats_chunk_kb > 0 ? stats_chunk_kb : 128; }
+static inline GnGeom gn_geom(int hw, int c, int n = 1, int min_wgs = 0, int chunk_kb = 64) {
     GnGeom g;
     g.cq = c / 4;
     g.R = g.cq >= 1024 ? 1 : 1024 / g.cq;
@@ -50,7 +54,7 @@ static inline GnGeom gn_geom(int hw, int c, int n = 1, int min_wgs = 0) {
     if (g.R > hw) g.R = hw;
     g.threads = g.cq * g.R;
     const long long bytes = (long long)hw * c * 4;
-    long long chunks = (bytes + 65535) / 65536;
+    long long chunks = (bytes + chunk_kb * 1024LL - 1) / (chunk_kb * 1024LL);
     if (min_wgs > 0 && chunks * n < min_wgs) chunks = (min_wgs + n - 1) / n;
     if (chunks > 256) chunks = 256;
     if (chunks < 1) chunks = 1;
@@ -62,7 +66,8 @@ static inline GnGeom gn_geom(int hw, int c, int n = 1, int min_wgs = 0) {
 }
 
 size_t gn_partials_bytes(int n, int hw, int c, int min_wgs) {
-    return (size_t)n * gn_geom(hw, c, n, min_wgs).chunks * 64 * 2 * sizeof(double);
+    const int min_apply = min_wgs & 0xFFFF, min_stats = (min_wgs >> 16) ? (min_wgs >> 16) - 1 : min_apply;
+    return (size_t)n * gn_geom(hw, c, n, min_stats, 16).chunks * 64 * 2 * sizeof(double);   // (room for any statistics cut the probe switch can select)
 }
 
 // Partial statistics of one (sample, chunk, group): part[((smp*chunks + chunk)*G + g)*2 + {0: mean, 1: M2}]
@@ -161,7 +166,9 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__
         v = v * gm + bt;
         if (SILU) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.0f + __expf(-v[i]));
+            // x sigmoid(x) (silu.rs:14-16) with the hardware reciprocal (1 ulp) instead of the IEEE division's ten-instruction sequence: 88 of the unrolled body's
+            // instructions in a latency-bound launch; the result moves by <= 2 ulp, far inside every bar
+            for (int i = 0; i < 4; ++i) v[i] = v[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[i]));
         }
         return v;
     };
@@ -189,17 +196,20 @@ static hipError_t launch_group_norm_any(const float* x, void* y, bool planes, co
                                         int ldx, int n_group, float eps, bool silu, void* partials, hipStream_t stream, int min_wgs) {
     if ((c & 3) || (ldx & 3) || ldx < c || n_group > 64 || c % n_group) return hipErrorInvalidValue;
     if (c / 4 > 1024 || (planes && (c & 31))) return hipErrorInvalidValue;
-    const GnGeom g = gn_geom(hw, c, n, min_wgs);
+    // min_wgs: low 16 bits = the apply pass's minimum workgroup count, bits 16.. = the statistics pass's (0 = the same): the apply pass re-reads every chunk partial of
+    // its sample in every workgroup, so the two passes need not be cut alike
+    const int min_apply = min_wgs & 0xFFFF, min_stats = (min_wgs >> 16) ? (min_wgs >> 16) - 1 : min_apply;
+    const GnGeom gs = gn_geom(hw, c, n, min_stats, g_gn32_stats_chunk_kb), g = gn_geom(hw, c, n, min_apply);
     double* part = reinterpret_cast<double*>(partials);
-    const size_t lds = (size_t)(2 * g.R + 1) * c * sizeof(float) + (size_t)2 * c * sizeof(double);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(g.chunks, n), dim3(g.threads), lds, stream, x, hw, c, ldx, n_group,
-                       g.rows_per_chunk, part);
+    const size_t lds = (size_t)(2 * gs.R + 1) * c * sizeof(float) + (size_t)2 * c * sizeof(double);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(gs.chunks, n), dim3(gs.threads), lds, stream, x, hw, c, ldx, n_group,
+                       gs.rows_per_chunk, part);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     float* yf = reinterpret_cast<float*>(y);
 #define SDMI_GN_APPLY(S, P)                                                                                                        \
     hipLaunchKernelGGL((gn_apply_kernel<S, P>), dim3(g.chunks, n), dim3(g.threads), 0, stream, x, yf, gamma, beta, hw, c, ldx, n_group, \
-                       eps, g.chunks, g.rows_per_chunk, part, g.rows_per_chunk)
+                       eps, gs.chunks, gs.rows_per_chunk, part, g.rows_per_chunk)
     if (planes) { if (silu) SDMI_GN_APPLY(true, true); else SDMI_GN_APPLY(false, true); }
     else { if (silu) SDMI_GN_APPLY(true, false); else SDMI_GN_APPLY(false, false); }
 #undef SDMI_GN_APPLY

@@ -173,6 +173,7 @@ hipError_t launch_softmax_rows(float* x, int rows, int cols, float scale, hipStr
 // ---- normalisation (HBM-bound class) --------------------------------------------
 // GroupNorm (+SiLU) over NHWC: stats pass (per-chunk partial sums) + apply pass.
 // `partials` needs gn_partials_bytes(n, hw, c) bytes of scratch.
+void launch_group_norm_tune(int stats_chunk_kb);   // probe switch: bytes per statistics chunk (default 64 KB)
 size_t gn_partials_bytes(int n, int hw, int c, int min_wgs = 0);    // min_wgs: k_norm.hip gn_geom (option gn32_min_wgs)
 // ldx: elements between pixels of x (>= c; x may be a channel slice of a wider buffer); y is dense [n][hw][c]
 hipError_t launch_group_norm(const float* x, float* y, const float* gamma, const float* beta,
