@@ -180,7 +180,7 @@ __global__ void gn_apply_bf16_kernel(const unsigned short* __restrict__ x, unsig
         for (int i = 0; i < 8; ++i) {
             float t = ((v.v[i] - mean_hi[i]) - mean_lo[i]) * rstd[i];
             t = t * gr[i] + bt[i];
-            if (SILU) t = t / (1.0f + __expf(-t));
+            if (SILU) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));   // (hardware reciprocal, 1 ulp: at the batches of configs[2..4] the IEEE division made this pass VALU-bound)
             v.v[i] = t;
         }
         return pack8(v);
