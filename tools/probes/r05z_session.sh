@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, evidence call on the final tree: the whole GPU suite, the driver's bench command, the PMC byte passes of all four configurations
 # (profiles/pmc_summary.json -> roofline.traffic), and the rocprofv3 kernel traces of the headline and of --config 2 / 4
-out=gpurun_out/r05z; mkdir -p $out
+out=gpurun_out/${OUTDIR:-r05z}; mkdir -p $out
 R=$GRAFT_REPO_ROOT
 COMMIT=$1
 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -6 > $out/pytest_gpu_tail.txt; echo "pytest rc=${PIPESTATUS[0]}"; tail -3 $out/pytest_gpu_tail.txt
