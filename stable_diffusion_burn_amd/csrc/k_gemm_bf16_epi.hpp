@@ -201,12 +201,7 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4
                     const int q = r * 64 + lane;
                     const int row = q / CH, c8 = q - row * CH;
                     const int m = mrow0 + row, n = nw0 + c8 * 8;
-                    if (q < 16 * CH && m < p.M && n < p.N) {
-                        u32x4* dst = reinterpret_cast<u32x4*>(Ch + (long long)m * ldc + n);
-                        if (p.variant & 4) __builtin_nontemporal_store(o[r], dst);                                     // PROBE: nt
-                        else if (p.variant & 8) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(o[r]) : "memory");   // PROBE: write-through
-                        else *dst = o[r];
-                    }
+                    if (q < 16 * CH && m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Ch + (long long)m * ldc + n) = o[r];
                 }
             }
         } else if (!out_f32) {
