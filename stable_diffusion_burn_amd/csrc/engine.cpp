@@ -1043,6 +1043,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "cfg_share") opt_cfg_share_ = std::stoi(value);
     else if (key == "attn_kv_splits") opt_attn_kv_splits_ = std::stoi(value);
     else if (key == "attn_kv_prefer8") opt_attn_kv_prefer8_ = std::stoi(value);
+    else if (key == "attn_pack_tail") opt_attn_pack_tail_ = std::stoi(value);
     else if (key == "gn32_min_wgs") opt_gn32_min_wgs_ = (opt_gn32_min_wgs_ & ~0xFFFF) | (std::stoi(value) & 0xFFFF);
     else if (key == "gn32_stats_chunk_kb") launch_group_norm_tune(std::stoi(value));
     else if (key == "gn32_stats_min_wgs") opt_gn32_min_wgs_ = (opt_gn32_min_wgs_ & 0xFFFF) | ((std::stoi(value) + 1) << 16);   // the statistics pass cut differently from the apply pass (-1: the same)
@@ -1540,6 +1541,7 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
         p.bf16 = dt;
         p.q_log2 = q_log2 ? 1 : 0;
         p.o3 = o3; p.ldo3 = (n_head * d_head / 32) * 192;
+        p.pack_tail = opt_attn_pack_tail_;
         if (dt && mask) throw Error(SDMI_ERR_UNSUPPORTED, "attention: additive mask is fp32-only");
         const double fl = 4.0 * n * n_head * (double)nq * nk * d_head;
         const bool on_split = !dt && opt_attn_split_ && attn_split_supported(p);

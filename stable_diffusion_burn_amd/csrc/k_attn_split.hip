@@ -12,7 +12,13 @@
 //   * K / V tiles of 64 keys staged through registers: a thread splits the 8 floats it loaded and writes three 16-byte chunks,
 //     one per plane -- the LDS images are [buffer][plane][key][row stride] bf16, same strides as the bf16 kernel;
 //   * Q fragments split once per workgroup into registers; the probabilities split right after the exponentials, 32 keys at a time.
-// Measured (rocprofv3 --pmc, 2 x 8 heads x 4096^2, d = 40): matrix pipe 56 % busy, 138 TFLOP/s against 95 for k_attn.hip; 8.4 bf16
+// d = 40, round 5 -- the packed tail.  Columns 32..39 used to cost a whole 16-deep k step of K Q^T (8 of 16 slots zero) and a whole 32-row tile of O^T (8 of 32 rows used),
+// six instructions each.  Now (i) the tail k step pairs planes along k: K plane 0 holds [K_h | K_m] and K plane 1 [K_h | K_l] in slots 32..39 | 40..47, the query operand
+// holds the SAME eight columns in both lane halves, so [K_h | K_l] x [Q_l | Q_h], [K_h | K_m] x [Q_m | Q_m] and [K_h | K_m] x [Q_h | Q_h] are the six products in three
+// instructions; (ii) the tail tile of V^T stacks planes along its rows: V plane 0 holds [V_h | V_m | V_l | 0] in columns 32..63, so one instruction per probability plane
+// yields the rows V_h P, V_m P, V_l P -- all nine products (three more than before, each < 2^-16 of the product) in three instructions, summed per lane after the key loop.
+// 15 + 9 instead of 18 + 12 instructions per 32 keys (-20 %), 10 + 8 fragment reads instead of 18 + 12.
+// Measured (rocprofv3 --pmc, 2 x 8 heads x 4096^2, d = 40; before the packed tail): matrix pipe 56 % busy, 138 TFLOP/s against 95 for k_attn.hip; 8.4 bf16
 // flops are issued per fp32 flop (6 products x 1.4 for padding d = 40 to 48 in K Q^T and to 64 in V^T P^T).  A software-pipelined
 // variant (S(t+1) issued between the exponentials of tile t, staging between the MFMAs of V^T P^T) measured 3 % SLOWER and was
 // removed: the loop is bound by total issue slots of the two waves per SIMD, not by the order inside one wave.  Explicit, fenced
@@ -89,13 +95,17 @@ __device__ __forceinline__ void sp_split8(const f32x4 x0, const f32x4 x1, u32x4&
 }
 __device__ __forceinline__ bf16x8 sp_bf(const u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-template <int D, int NW>
+template <int D, int NW, bool PK = false>
 __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p) {
     using Cfg = AttnSpCfg<D, NW>;
     constexpr int NT = Cfg::NT, BKV = Cfg::BKV, KS = Cfg::KS, NDT = Cfg::NDT, RSK = Cfg::RSK, RSV = Cfg::RSV, NLD = Cfg::NLD;
     constexpr int KT = Cfg::KT;
     constexpr int CPR = D / 8;  // chunks per row
     constexpr float kLog2e = 1.4426950408889634f;
+    // d = 40 (round 5): the head's last 8 columns would occupy a 16-deep k step of K Q^T and a 32-row tile of O^T on their own, six matrix instructions each for
+    // 8 useful columns.  Both are PACKED instead (kernel header): 3 instructions per tail k step, 3 per tail tile -- 15 + 9 instead of 18 + 12 per 32 keys.
+    constexpr bool PACK = PK;
+    static_assert(!PK || D == 40, "the packed tail is the d = 40 form");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sp[];
     unsigned char* Ks = smem_sp;                            // [buffer][plane][key][RSK]
@@ -126,7 +136,10 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
     const int tps = (n_tiles + n_split - 1) / n_split;
     const int t_begin = min((int)blockIdx.z * tps, n_tiles), t_end = min(t_begin + tps, n_tiles);
 
-    if constexpr (Cfg::DK > D) {  // zero the K columns D..DK-1 of every plane once (the staging never touches them)
+    if constexpr (PACK) {         // V plane 0, columns 56..63 (rows 24..31 of the packed tail tile) = 0 in both buffers, once; every other byte that is read is staged per tile
+        for (int i = tid; i < 2 * BKV; i += NT)
+            *reinterpret_cast<u32x4*>(Vs + (i / BKV) * 3 * Cfg::V_BYTES + (i % BKV) * RSV + 7 * 16) = u32x4{0u, 0u, 0u, 0u};
+    } else if constexpr (Cfg::DK > D) {  // zero the K columns D..DK-1 of every plane once (the staging never touches them)
         for (int i = tid; i < 6 * BKV; i += NT)
             *reinterpret_cast<u32x4*>(Ks + (i / BKV) * Cfg::K_BYTES + (i % BKV) * RSK + CPR * 16) = u32x4{0u, 0u, 0u, 0u};
     }
@@ -136,12 +149,14 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
-        const int col = 16 * s + 8 * hi;
+        const bool tail = PACK && s == KS - 1;                 // packed tail step: BOTH lane halves hold columns 32..39
+        const int col = tail ? 16 * s : 16 * s + 8 * hi;
         if (q_ok && col < D) {
             x0 = *reinterpret_cast<const f32x4*>(Qf + (long long)qrow * p.ldq + col);
             x1 = *reinterpret_cast<const f32x4*>(Qf + (long long)qrow * p.ldq + col + 4);
         }
         sp_split8(x0, x1, qh[s], qm[s], ql[s]);
+        if (tail && hi) ql[s] = qh[s];                         // the third operand of the tail step is [Q_l | Q_h] against the K image [K_h | K_l]
     }
 
     f32x4 rk[NLD][2], rv[NLD][2];
@@ -175,14 +190,16 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
                 u32x4 h, m, l;
                 sp_split8(rk[i][0], rk[i][1], h, m, l);
                 unsigned char* kd = Ks + buf * 3 * Cfg::K_BYTES + row * RSK + c8 * 16;
-                *reinterpret_cast<u32x4*>(kd) = h;
-                *reinterpret_cast<u32x4*>(kd + Cfg::K_BYTES) = m;
-                *reinterpret_cast<u32x4*>(kd + 2 * Cfg::K_BYTES) = l;
-                sp_split8(rv[i][0], rv[i][1], h, m, l);
                 unsigned char* vd = Vs + buf * 3 * Cfg::V_BYTES + row * RSV + c8 * 16;
+                const bool tail = PACK && c8 == CPR - 1;       // columns 32..39: K plane 0 gets [h | m], K plane 1 [h | l]; V plane 0 gets [h | m | l]
+                *reinterpret_cast<u32x4*>(kd) = h;
+                *reinterpret_cast<u32x4*>(tail ? kd + 16 : kd + Cfg::K_BYTES) = m;
+                *reinterpret_cast<u32x4*>(tail ? kd + Cfg::K_BYTES + 16 : kd + 2 * Cfg::K_BYTES) = l;
+                if (tail) *reinterpret_cast<u32x4*>(kd + Cfg::K_BYTES) = h;
+                sp_split8(rv[i][0], rv[i][1], h, m, l);
                 *reinterpret_cast<u32x4*>(vd) = h;
-                *reinterpret_cast<u32x4*>(vd + Cfg::V_BYTES) = m;
-                *reinterpret_cast<u32x4*>(vd + 2 * Cfg::V_BYTES) = l;
+                *reinterpret_cast<u32x4*>(tail ? vd + 16 : vd + Cfg::V_BYTES) = m;
+                *reinterpret_cast<u32x4*>(tail ? vd + 32 : vd + 2 * Cfg::V_BYTES) = l;
             }
         }
     };
@@ -224,6 +241,19 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             u32x4 kf[KT][3];
+            if (PACK && ks == KS - 1) {   // packed tail step: [K_h | K_l] x [Q_l | Q_h], then [K_h | K_m] x Q_m and x Q_h: the same six products in three instructions
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) kf[kt][pl] = *reinterpret_cast<const u32x4*>(Kt + pl * Cfg::K_BYTES + kt * 32 * RSK + ks * 32);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(kf[kt][1]), sp_bf(ql[ks]), s[kt], 0, 0, 0);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(kf[kt][0]), sp_bf(qm[ks]), s[kt], 0, 0, 0);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(kf[kt][0]), sp_bf(qh[ks]), s[kt], 0, 0, 0);
+                continue;
+            }
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -293,12 +323,24 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-                    for (int pn = 0; pn < 3; ++pn) {
+                    for (int pn = 0; pn < ((PACK && dt == NDT - 1) ? 1 : 3); ++pn) {
                         const unsigned char* vb = Vt + pn * Cfg::V_BYTES + st * 16 * RSV + dt * 64;
                         const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_s16x4*>((const lds_s16x4*)vb));
                         const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_s16x4*>((const lds_s16x4*)(vb + 8 * RSV)));
                         vf[dt][pn] = __builtin_bit_cast(u32x4, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
                     }
+                if constexpr (PACK) {   // tile 0: six products; the packed tail tile (rows 0..7 = V_h, 8..15 = V_m, 16..23 = V_l of columns 32..39): all nine products in three
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(vf[0][2]), sp_bf(ph[h2]), o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(vf[1][0]), sp_bf(pl[h2]), o[1], 0, 0, 0);
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(vf[0][0]), sp_bf(pl[h2]), o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(vf[1][0]), sp_bf(pm[h2]), o[1], 0, 0, 0);
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(vf[0][1]), sp_bf(pm[h2]), o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(vf[1][0]), sp_bf(ph[h2]), o[1], 0, 0, 0);
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(vf[0][1]), sp_bf(ph[h2]), o[0], 0, 0, 0);
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(vf[0][0]), sp_bf(pm[h2]), o[0], 0, 0, 0);
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(vf[0][0]), sp_bf(ph[h2]), o[0], 0, 0, 0);
+                    continue;
+                }
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(vf[dt][2]), sp_bf(ph[h2]), o[dt], 0, 0, 0);
 #pragma unroll
@@ -317,6 +359,11 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
 
         if (more) lstore(cur ^ 1);
         __syncthreads();
+    }
+
+    if constexpr (PACK) {   // column 32 + (r & 3) + 4 hi = the V_l, V_m and V_h row groups of the packed tile, smallest first (all in this lane)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[NDT - 1][r] = (o[NDT - 1][r + 8] + o[NDT - 1][r + 4]) + o[NDT - 1][r];
     }
 
     if (n_split > 1) {   // a key slice: unnormalised rows + (maximum in log2 units, row sum) for launch_attention_combine
@@ -351,9 +398,9 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
     }
 }
 
-template <int D, int NW>
+template <int D, int NW, bool PK>
 static hipError_t launch_attn_split_d(const AttnParams& p, hipStream_t stream) {
-    auto k = attn_split_kernel<D, NW>;
+    auto k = attn_split_kernel<D, NW, PK>;
     const size_t lds = AttnSpCfg<D, NW>::LDS_BYTES;
     if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds); e != hipSuccess) return e;
     dim3 grid((p.nq + 32 * NW - 1) / (32 * NW), p.n * p.n_head, p.kv_splits > 1 ? p.kv_splits : 1);
@@ -367,8 +414,14 @@ static hipError_t launch_attn_split_any(const AttnParams& p, hipStream_t stream)
     // the matrix instructions of the other) and splits a K / V tile with half the work per thread -- per unit of work it is 1.5 x the 4-wave form
     // (profiles/r05l: 64 x 64, one sample: 185 us on 256 4-wave workgroups, two samples 142 us on 256 8-wave workgroups)
     const long long bh = (long long)p.n * p.n_head * (p.kv_splits > 1 ? p.kv_splits : 1);
-    if ((long long)((p.nq + 255) / 256) * bh >= 256) return launch_attn_split_d<D, 8>(p, stream);
-    return launch_attn_split_d<D, 4>(p, stream);
+    if constexpr (D == 40) {
+        if (p.pack_tail) {
+            if ((long long)((p.nq + 255) / 256) * bh >= 256) return launch_attn_split_d<D, 8, true>(p, stream);
+            return launch_attn_split_d<D, 4, true>(p, stream);
+        }
+    }
+    if ((long long)((p.nq + 255) / 256) * bh >= 256) return launch_attn_split_d<D, 8, false>(p, stream);
+    return launch_attn_split_d<D, 4, false>(p, stream);
 }
 
 bool attn_split_supported(const AttnParams& p) {

@@ -151,6 +151,7 @@ struct AttnParams {
     int kv_splits;
     float* part_o;                      // [S][n][nq][n_head * d_head]
     float* part_ml;                     // [S][n][n_head][nq][2]
+    int pack_tail;                      // k_attn_split.hip, d = 40: the packed form of the head's last 8 columns (kernel header); 0 = the six-instruction form (A/B, tests)
 };
 bool attn_supported_head_dim(int d);
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);

@@ -420,6 +420,36 @@ def test_qkv_attention_split_is_fp32_accurate(sd_ops, case):
     assert errs[1] < 3.0 * errs[0] + 2e-7
 
 
+@pytest.mark.parametrize("case", [(2, 4096, 4096, 320, 8), (2, 1024, 77, 320, 8), (1, 300, 77, 320, 8), (1, 517, 1000, 320, 8), (1, 64, 2, 40, 1), (2, 1024, 1024, 320, 8)])
+@pytest.mark.parametrize("splits", [0, 3])
+def test_qkv_attention_packed_tail_d40(sd_ops, case, splits):
+    """k_attn_split.hip at d = 40 (round 5): columns 32..39 of q / k ride a PACKED k step ([K_h | K_m], [K_h | K_l] against the query columns in both lane halves) and
+    columns 32..39 of v a packed output tile (V_h, V_m, V_l as row groups, summed per lane after the key loop).  Against the six-instruction form (attn_pack_tail=0) and
+    the fp64 oracle: the same bar, an error no larger than the old form's (it adds three partial products), and every column -- the packed ones separately -- within it;
+    v's columns carry different magnitudes so that a row group landing in the wrong column would show."""
+    n, nq, nk, c, heads = case
+    g = _rng(5000 + nq + nk + splits)
+    q = (g.standard_normal((n, nq, c)) * 1.5).astype(np.float32)
+    k = (g.standard_normal((n, nk, c)) * 1.5).astype(np.float32)
+    v = (g.standard_normal((n, nk, c)) * np.exp2(g.integers(-4, 5, (1, 1, c))) + np.arange(c, dtype=np.float32) % 7).astype(np.float32)
+    ref = O.qkv_attention(_t(q), _t(k), _t(v), None, heads).numpy()
+    errs = {}
+    try:
+        sd_ops.set_option("attn_kv_splits", splits)
+        for mode in (1, 0):
+            sd_ops.set_option("attn_pack_tail", mode)
+            got = sd_ops.qkv_attention(q, k, v, None, heads)
+            _check(got, ref, f"qkv_attention{case} attn_pack_tail={mode} attn_kv_splits={splits}")
+            d = c // heads
+            tail = np.abs(got - ref).reshape(n, nq, heads, d)[..., 32:].max()
+            errs[mode] = (float(np.abs(got - ref).max() / np.abs(ref).max()), float(tail / np.abs(ref).max()))
+    finally:
+        sd_ops.set_option("attn_pack_tail", 1)
+        sd_ops.set_option("attn_kv_splits", 0)
+    print(f"attention {case} S={splits}: max |gpu - fp64| / max|ref| (all columns, columns 32..39): packed {errs[1]}, six-instruction {errs[0]}")
+    assert errs[1][0] < 1.5 * errs[0][0] + 1e-7 and errs[1][1] < 1.5 * errs[0][1] + 1e-7
+
+
 def test_qkv_attention_causal_mask(sd_ops):
     """attn_decoder_mask (attention.rs:47-56) as the additive mask."""
     n, s, c, heads = 1, 77, 320, 8
