@@ -1043,7 +1043,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "cfg_share") opt_cfg_share_ = std::stoi(value);
     else if (key == "attn_kv_splits") opt_attn_kv_splits_ = std::stoi(value);
     else if (key == "attn_kv_prefer8") opt_attn_kv_prefer8_ = std::stoi(value);
-    else if (key == "attn_pack_tail") opt_attn_pack_tail_ = std::stoi(value);
+    else if (key == "attn_pack_tail") opt_attn_pack_tail_ = (value == "default") ? 3 : std::stoi(value);
     else if (key == "gn32_min_wgs") opt_gn32_min_wgs_ = (opt_gn32_min_wgs_ & ~0xFFFF) | (std::stoi(value) & 0xFFFF);
     else if (key == "gn32_stats_chunk_kb") launch_group_norm_tune(std::stoi(value));
     else if (key == "gn32_stats_min_wgs") opt_gn32_min_wgs_ = (opt_gn32_min_wgs_ & 0xFFFF) | ((std::stoi(value) + 1) << 16);   // the statistics pass cut differently from the apply pass (-1: the same)

@@ -367,7 +367,8 @@ private:
                                      // is cut coarser (every apply workgroup merges all chunk partials).  Options gn32_min_wgs / gn32_stats_min_wgs / gn32_stats_chunk_kb;
                                      // measured at batch 1: GroupNorm class 21.3 -> 17.3 ms per image (profiles/r05d, r05f, r05o, r05p)
     GnTune gn_tune_;                 // launch geometry of the bf16 / MXFP8 GroupNorm passes (kernels.hpp; options gn_target_wgs, gn_max_threads, gn_unroll)
-    int opt_attn_pack_tail_ = 1;     // fp32 attention, d = 40: columns 32..39 as a packed k step / packed output tile (k_attn_split.hip; 0 = A/B, tests)
+    int opt_attn_pack_tail_ = 3;     // fp32 attention (k_attn_split.hip): bit 0: d = 40's columns 32..39 as a packed k step / packed output tile; bit 1: scores in log2 units with the
+                                     // reference maximum as accumulator input and the row sum from a ones column (A/B, tests)
     int opt_attn_kv_prefer8_ = 1;    // ... and, for k_attn_split.hip, as many slices as let its 8-wave form fill the chip (A/B switch)
     int opt_attn_kv_splits_ = 0;     // fp32 attention: key slices + merge launch where the query-tile grid leaves CUs idle (Engine::attention): 0 = automatic, 1 = never, S = forced
     int opt_cfg_share_ = 1;          // sample_latent: the part of the UNet in front of the first cross attention is computed once for the two identical halves of a CFG step (unet_run)

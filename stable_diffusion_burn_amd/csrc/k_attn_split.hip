@@ -18,6 +18,11 @@
 // instructions; (ii) the tail tile of V^T stacks planes along its rows: V plane 0 holds [V_h | V_m | V_l | 0] in columns 32..63, so one instruction per probability plane
 // yields the rows V_h P, V_m P, V_l P -- all nine products (three more than before, each < 2^-16 of the product) in three instructions, summed per lane after the key loop.
 // 15 + 9 instead of 18 + 12 instructions per 32 keys (-20 %), 10 + 8 fragment reads instead of 18 + 12.
+// Round 5 -- the softmax of k_attn_bf16.hip (template flag LG, the form that runs): q is multiplied by scale^2 log2(e) before its split (scores in log2 units), the reference
+// maximum enters as the accumulator input of a score tile's first instruction (the pipe returns s - m: one v_exp_f32 per probability, no multiply-add), it is raised only when a
+// tile exceeds it by 2^8 (wave-uniform slow path), and the row sum is a column of ones in V's high plane, accumulated by the P V instructions in a spare row of the last tile.
+// Per pair of probabilities 12 vector instructions instead of 16; with the packed tail: attention class 40.3 -> 34.9 ms per batch-1 image (profiles/r05u_*, r05v_*), the 64 x 64
+// self attention 290 -> 222 us = 193 TFLOP/s, matrix pipe ~ 61 % busy (2 waves x 66 instructions x 32 cycles per 64-key tile against ~ 6 900 cycles measured).
 // Measured (rocprofv3 --pmc, 2 x 8 heads x 4096^2, d = 40; before the packed tail): matrix pipe 56 % busy, 138 TFLOP/s against 95 for k_attn.hip; 8.4 bf16
 // flops are issued per fp32 flop (6 products x 1.4 for padding d = 40 to 48 in K Q^T and to 64 in V^T P^T).  A software-pipelined
 // variant (S(t+1) issued between the exponentials of tile t, staging between the MFMAs of V^T P^T) measured 3 % SLOWER and was
@@ -95,7 +100,7 @@ __device__ __forceinline__ void sp_split8(const f32x4 x0, const f32x4 x1, u32x4&
 }
 __device__ __forceinline__ bf16x8 sp_bf(const u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-template <int D, int NW, bool PK = false>
+template <int D, int NW, bool PK = false, bool LG = false>
 __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p) {
     using Cfg = AttnSpCfg<D, NW>;
     constexpr int NT = Cfg::NT, BKV = Cfg::BKV, KS = Cfg::KS, NDT = Cfg::NDT, RSK = Cfg::RSK, RSV = Cfg::RSV, NLD = Cfg::NLD;
@@ -105,6 +110,12 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
     // d = 40 (round 5): the head's last 8 columns would occupy a 16-deep k step of K Q^T and a 32-row tile of O^T on their own, six matrix instructions each for
     // 8 useful columns.  Both are PACKED instead (kernel header): 3 instructions per tail k step, 3 per tail tile -- 15 + 9 instead of 18 + 12 per 32 keys.
     constexpr bool PACK = PK;
+    // LG (round 5): the softmax of k_attn_bf16.hip.  q is multiplied by scale^2 log2(e) before its split, so the scores leave the matrix pipe in log2 units; the row's
+    // reference maximum enters as the ACCUMULATOR INPUT of each score tile's first instruction (the pipe returns s - m: the probabilities are one v_exp_f32 each);
+    // m is raised only when a tile exceeds it by 2^8 (a wave-uniform slow path rescales O, m and the scores -- the three bf16 planes carry 24 bits of a probability
+    // whatever its magnitude); the row sum is a COLUMN OF ONES appended to V's high plane, accumulated by the P V instructions in a spare row of the last O^T tile.
+    constexpr int SUM_R = PACK ? 12 : 4 * ((D % 32) / 8);   // ... that row: register SUM_R of the lanes with hi = 0 (packed tile: row 24; otherwise row D % 32)
+    constexpr float kDefer = 8.0f;
     static_assert(!PK || D == 40, "the packed tail is the d = 40 form");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sp[];
@@ -136,10 +147,14 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
     const int tps = (n_tiles + n_split - 1) / n_split;
     const int t_begin = min((int)blockIdx.z * tps, n_tiles), t_end = min(t_begin + tps, n_tiles);
 
-    if constexpr (PACK) {         // V plane 0, columns 56..63 (rows 24..31 of the packed tail tile) = 0 in both buffers, once; every other byte that is read is staged per tile
+    if constexpr (PACK) {         // V plane 0, columns 56..63 (rows 24..31 of the packed tail tile) = (1, 0, .., 0) in both buffers, once: row 24 sums the probabilities (LG)
         for (int i = tid; i < 2 * BKV; i += NT)
-            *reinterpret_cast<u32x4*>(Vs + (i / BKV) * 3 * Cfg::V_BYTES + (i % BKV) * RSV + 7 * 16) = u32x4{0u, 0u, 0u, 0u};
-    } else if constexpr (Cfg::DK > D) {  // zero the K columns D..DK-1 of every plane once (the staging never touches them)
+            *reinterpret_cast<u32x4*>(Vs + (i / BKV) * 3 * Cfg::V_BYTES + (i % BKV) * RSV + 7 * 16) = u32x4{LG ? 0x3F80u : 0u, 0u, 0u, 0u};
+    } else if constexpr (LG) {    // V[key][D] = 1 in the high plane, 0 in the other two, both buffers, once (the staging never touches that chunk)
+        for (int i = tid; i < 6 * BKV; i += NT)
+            *reinterpret_cast<u32x4*>(Vs + (i / BKV) * Cfg::V_BYTES + (i % BKV) * RSV + CPR * 16) = u32x4{(i / BKV) % 3 == 0 ? 0x3F80u : 0u, 0u, 0u, 0u};
+    }
+    if constexpr (!PACK && Cfg::DK > D) {  // zero the K columns D..DK-1 of every plane once (the staging never touches them)
         for (int i = tid; i < 6 * BKV; i += NT)
             *reinterpret_cast<u32x4*>(Ks + (i / BKV) * Cfg::K_BYTES + (i % BKV) * RSK + CPR * 16) = u32x4{0u, 0u, 0u, 0u};
     }
@@ -155,6 +170,7 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
             x0 = *reinterpret_cast<const f32x4*>(Qf + (long long)qrow * p.ldq + col);
             x1 = *reinterpret_cast<const f32x4*>(Qf + (long long)qrow * p.ldq + col + 4);
         }
+        if constexpr (LG) { x0 *= cs; x1 *= cs; }
         sp_split8(x0, x1, qh[s], qm[s], ql[s]);
         if (tail && hi) ql[s] = qh[s];                         // the third operand of the tail step is [Q_l | Q_h] against the K image [K_h | K_l]
     }
@@ -211,6 +227,9 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -INFINITY;  // running row max, raw score units
     float l_run = 0.f;        // this lane's share of the row sum
+    f32x16 negm;              // LG: -m in every register (m = the row's reference maximum, log2 units; 0 before the first tile)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
 
     // per-lane LDS offsets: K fragment row c, chunk hi; V transpose-read row 4 hi + (i >> 2), columns 16 (G & 1) + 4 (i & 3)
     const int k_off = c * RSK + hi * 16;
@@ -237,7 +256,7 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[kt][r] = LG ? negm[r] : 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             u32x4 kf[KT][3];
@@ -288,13 +307,31 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kt][r]);
         mt = sp_partner_max(mt);
-        const float m_new = fmaxf(m_run, mt);
-        const float mc = m_new * cs;
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
-        m_run = m_new;
-        if (__any(alpha != 1.0f)) {  // the running max moved somewhere in the wave
+        float mc = 0.f, alpha = 1.0f;
+        if constexpr (LG) {
+            if (tile == t_begin || __any(mt > kDefer)) {   // wave-uniform: the reference maximum moves (always on the first tile, where it is still 0)
+                const float delta = tile == t_begin ? mt : fmaxf(mt, 0.f);
+                if (tile != t_begin) {
+                    alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
+                    for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[r] -= delta;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[kt][r] -= delta;
+            }
+        } else {
+            const float m_new = fmaxf(m_run, mt);
+            mc = m_new * cs;
+            alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
+            m_run = m_new;
+            if (__any(alpha != 1.0f)) {  // the running max moved somewhere in the wave
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
+            }
         }
 
         // ---- per 32-key tile: probabilities (fp32), their three-way split, and O^T += V^T P^T for its two 16-key steps
@@ -304,9 +341,9 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
             unsigned pa[2][4], pb[2][4], pc[2][4];     // [16-key step of this tile][4 dwords = 8 bf16] x (h, m, l)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], cs, -mc));
-                const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r + 1], cs, -mc));
-                psum += e0 + e1;
+                const float e0 = __builtin_amdgcn_exp2f(LG ? s[kt][r] : __builtin_fmaf(s[kt][r], cs, -mc));
+                const float e1 = __builtin_amdgcn_exp2f(LG ? s[kt][r + 1] : __builtin_fmaf(s[kt][r + 1], cs, -mc));
+                if constexpr (!LG) psum += e0 + e1;
                 sp_split2(e0, e1, pa[r >> 3][(r & 7) >> 1], pb[r >> 3][(r & 7) >> 1], pc[r >> 3][(r & 7) >> 1]);
             }
             u32x4 ph[2], pm[2], pl[2];
@@ -355,7 +392,7 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
                 for (int dt = 0; dt < NDT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_bf(vf[dt][0]), sp_bf(ph[h2]), o[dt], 0, 0, 0);
             }
         }
-        l_run = l_run * alpha + psum;
+        if constexpr (!LG) l_run = l_run * alpha + psum;
 
         if (more) lstore(cur ^ 1);
         __syncthreads();
@@ -366,6 +403,8 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
         for (int r = 0; r < 4; ++r) o[NDT - 1][r] = (o[NDT - 1][r + 8] + o[NDT - 1][r + 4]) + o[NDT - 1][r];
     }
 
+    if constexpr (LG) l_run = hi ? 0.f : o[NDT - 1][SUM_R];    // the ones column's row of O^T: the whole row sum, in the lane with hi = 0
+    const float m_log2 = LG ? (t_begin < t_end ? -negm[0] : -INFINITY) : m_run * cs;
     if (n_split > 1) {   // a key slice: unnormalised rows + (maximum in log2 units, row sum) for launch_attention_combine
         const float l_tot = sp_partner_sum(l_run);
         if (q_ok) {
@@ -377,7 +416,7 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
                     const int dcol = 32 * dt + 8 * rq + 4 * hi;
                     if (dcol < D) *reinterpret_cast<f32x4*>(po + dcol) = f32x4{o[dt][4 * rq], o[dt][4 * rq + 1], o[dt][4 * rq + 2], o[dt][4 * rq + 3]};
                 }
-            if (hi == 0) *reinterpret_cast<f32x2*>(p.part_ml + ((((long long)blockIdx.z * p.n + b) * p.n_head + hh) * p.nq + qrow) * 2) = f32x2{m_run * cs, l_tot};
+            if (hi == 0) *reinterpret_cast<f32x2*>(p.part_ml + ((((long long)blockIdx.z * p.n + b) * p.n_head + hh) * p.nq + qrow) * 2) = f32x2{m_log2, l_tot};
         }
         return;
     }
@@ -398,9 +437,9 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
     }
 }
 
-template <int D, int NW, bool PK>
+template <int D, int NW, bool PK, bool LG>
 static hipError_t launch_attn_split_d(const AttnParams& p, hipStream_t stream) {
-    auto k = attn_split_kernel<D, NW, PK>;
+    auto k = attn_split_kernel<D, NW, PK, LG>;
     const size_t lds = AttnSpCfg<D, NW>::LDS_BYTES;
     if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds); e != hipSuccess) return e;
     dim3 grid((p.nq + 32 * NW - 1) / (32 * NW), p.n * p.n_head, p.kv_splits > 1 ? p.kv_splits : 1);
@@ -414,14 +453,15 @@ static hipError_t launch_attn_split_any(const AttnParams& p, hipStream_t stream)
     // the matrix instructions of the other) and splits a K / V tile with half the work per thread -- per unit of work it is 1.5 x the 4-wave form
     // (profiles/r05l: 64 x 64, one sample: 185 us on 256 4-wave workgroups, two samples 142 us on 256 8-wave workgroups)
     const long long bh = (long long)p.n * p.n_head * (p.kv_splits > 1 ? p.kv_splits : 1);
+    const bool w8 = (long long)((p.nq + 255) / 256) * bh >= 256;
     if constexpr (D == 40) {
-        if (p.pack_tail) {
-            if ((long long)((p.nq + 255) / 256) * bh >= 256) return launch_attn_split_d<D, 8, true>(p, stream);
-            return launch_attn_split_d<D, 4, true>(p, stream);
+        if (p.pack_tail & 1) {
+            if (p.pack_tail & 2) return w8 ? launch_attn_split_d<D, 8, true, true>(p, stream) : launch_attn_split_d<D, 4, true, true>(p, stream);
+            return w8 ? launch_attn_split_d<D, 8, true, false>(p, stream) : launch_attn_split_d<D, 4, true, false>(p, stream);
         }
     }
-    if ((long long)((p.nq + 255) / 256) * bh >= 256) return launch_attn_split_d<D, 8, false>(p, stream);
-    return launch_attn_split_d<D, 4, false>(p, stream);
+    if (p.pack_tail & 2) return w8 ? launch_attn_split_d<D, 8, false, true>(p, stream) : launch_attn_split_d<D, 4, false, true>(p, stream);
+    return w8 ? launch_attn_split_d<D, 8, false, false>(p, stream) : launch_attn_split_d<D, 4, false, false>(p, stream);
 }
 
 bool attn_split_supported(const AttnParams& p) {
