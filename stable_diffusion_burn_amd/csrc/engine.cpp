@@ -646,7 +646,7 @@ void Engine::ensure_arena(int group) {
 Engine::TempSplit::TempSplit(Engine* e_, const float* bt_, long long rows, long long K) : e(e_), bt(bt_) {
     if (e->bf16_ || K % 32 || rows <= 0) return;
     planes = e->pool_.alloc((size_t)rows * K * 6);
-    hipError_t err = launch_pack_split3(bt, planes, rows, (int)K, e->stream_);
+    hipError_t err = launch_pack_split3(bt, planes, rows, (int)K, e->stream_, e->b3_grouped(rows));
     if (err != hipSuccess) { e->pool_.free(planes); planes = nullptr; SDMI_HIP(err); }
     e->temp_split_bt_ = bt;
     e->temp_split_planes_ = planes;
@@ -736,7 +736,7 @@ void Engine::stage_commit(WeightEntry& e, size_t offset, int half) {
             const long long rows = e.kind == 0 ? e.dims[0] : e.dims[1];
             const long long K = e.kind == 0 ? (e.dims[1] == 3 ? 4 : e.dims[1]) * e.dims[2] * e.dims[3] : e.dims[0];
             void* planes = const_cast<void*>(split_planes(*e.dst));
-            if (planes && K % 32 == 0) SDMI_HIP(launch_pack_split3(*e.dst, planes, rows, (int)K, stream_));
+            if (planes && K % 32 == 0) SDMI_HIP(launch_pack_split3(*e.dst, planes, rows, (int)K, stream_, b3_grouped(rows)));
         }
     }
     e.set = true;
@@ -1043,6 +1043,11 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "cfg_share") opt_cfg_share_ = std::stoi(value);
     else if (key == "attn_kv_splits") opt_attn_kv_splits_ = std::stoi(value);
     else if (key == "attn_kv_prefer8") opt_attn_kv_prefer8_ = std::stoi(value);
+    else if (key == "b3_grouped") {
+        if (!entries_.empty() && std::any_of(entries_.begin(), entries_.end(), [](const WeightEntry& w) { return w.set; }))
+            throw Error(SDMI_ERR_STATE, "b3_grouped selects the layout the weight planes are packed in: set it before the first weight is loaded");
+        opt_b3_grouped_ = std::stoi(value);
+    }
     else if (key == "attn_pack_tail") opt_attn_pack_tail_ = (value == "default") ? 3 : std::stoi(value);
     else if (key == "gn32_min_wgs") opt_gn32_min_wgs_ = (opt_gn32_min_wgs_ & ~0xFFFF) | (std::stoi(value) & 0xFFFF);
     else if (key == "gn32_stats_chunk_kb") launch_group_norm_tune(std::stoi(value));
@@ -1233,6 +1238,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     auto it = table.find(key);
     const bool x32_ok = !in_dt && p.CS == 32 && p.Cin % 32 == 0 && p.out_mode == 0;   // what k_gemm2x.hip handles
     p.Bt3 = in_dt ? nullptr : split_planes(p.Bt);
+    p.b3_grouped = b3_grouped((long long)p.N * (p.geglu ? 2 : 1)) ? 1 : 0;   // the layout the planes of a weight with that many rows were packed in
     p.variant = in_dt ? opt_gemm_bf16x_variant_ : opt_gemm3x_variant_;
     // k_gemm3x.hip: the same layers, when the weight has its bf16 planes (weights in the arenas; not e.g. the K / V operands of
     // the unfused VAE attention) and the 32-bit piece offsets reach

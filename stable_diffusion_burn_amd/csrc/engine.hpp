@@ -227,6 +227,9 @@ private:
     struct SplitRegion { char* base; size_t bytes; char* planes; };
     std::vector<SplitRegion> split_regions_;
     const void* split_planes(const float* bt) const;
+    // weight planes of a tensor with `rows` rows: 16-row fragment groups (kernels.hpp, ConvGemm::b3_grouped) whenever the rows fill whole groups.  Packer and launches
+    // apply the same rule; sub-views of a packed tensor (q | k | v) start and end on multiples of 16 rows.
+    bool b3_grouped(long long rows) const { return opt_b3_grouped_ != 0 && rows % 16 == 0; }
     // operator-level calls (op_conv2d, op_linear, bench_conv ...) pack their weight into a pool buffer: this gives it planes for
     // the duration of the call, so that those calls run the kernels the model runs
     struct TempSplit {
@@ -367,6 +370,7 @@ private:
                                      // is cut coarser (every apply workgroup merges all chunk partials).  Options gn32_min_wgs / gn32_stats_min_wgs / gn32_stats_chunk_kb;
                                      // measured at batch 1: GroupNorm class 21.3 -> 17.3 ms per image (profiles/r05d, r05f, r05o, r05p)
     GnTune gn_tune_;                 // launch geometry of the bf16 / MXFP8 GroupNorm passes (kernels.hpp; options gn_target_wgs, gn_max_threads, gn_unroll)
+    int opt_b3_grouped_ = 1;         // precision 0: weight planes in 16-row fragment groups (1 KiB DMA pieces, sequential per group); 0 = row-major planes.  Before the weights are loaded.
     int opt_attn_pack_tail_ = 3;     // fp32 attention (k_attn_split.hip): bit 0: d = 40's columns 32..39 as a packed k step / packed output tile; bit 1: scores in log2 units with the
                                      // reference maximum as accumulator input and the row sum from a ones column (A/B, tests)
     int opt_attn_kv_prefer8_ = 1;    // ... and, for k_attn_split.hip, as many slices as let its 8-wave form fill the chip (A/B switch)

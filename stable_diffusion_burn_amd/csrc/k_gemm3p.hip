@@ -55,6 +55,7 @@ struct P3Wave {
     int a_iy0[NAG], a_ix0[NAG];
     unsigned a_off[NAG];        // byte offset of the sample + this lane's chunk (operands are < 4 GiB: launch side checks)
     unsigned w_off[NBW];
+    unsigned w_kstep;           // bytes between a weight piece's k tiles: 192 (row-major planes) or 3072 (16-row groups, ConvGemm::b3_grouped)
     const char *Abase, *Wbase, *zero, *a_src;
     unsigned pix_bytes;
     int Hin, Win, ups, Ws, KH, KW, wave;
@@ -79,7 +80,7 @@ struct P3Wave {
             __builtin_amdgcn_global_load_lds((global_cvoid*)(a_src + pl * 64), (lds_void*)(next_stage + ((wave + NWV * jg) * 3 + pl) * 1024), 16, 0, 0);
         } else {
             constexpr int j = J - NA;
-            const char* src = Wbase + (w_off[j] + (unsigned)kt_next * 192u);
+            const char* src = Wbase + (w_off[j] + (unsigned)kt_next * w_kstep);
             __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(next_stage + A_BYTES + (wave + NWV * j) * 1024), 16, 0, 0);
         }
         if constexpr (J == NP - 1) {
@@ -256,8 +257,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3p_kernel(const Conv
         }
         // rows past N (ragged last tile) and the pieces past PW fetch the last valid row: real memory, never stored
         if (n >= p.N) wrow -= (n - (p.N - 1));
-        w.w_off[j] = (unsigned)wrow * w_row_bytes + pl * 64 + ch * 16;
+        w.w_off[j] = p.b3_grouped ? (unsigned)(wrow >> 4) * (w_row_bytes * 16u) + pl * 1024 + (unsigned)(wrow & 15) * 64 + ch * 16
+                                  : (unsigned)wrow * w_row_bytes + pl * 64 + ch * 16;
     }
+    w.w_kstep = p.b3_grouped ? 3072u : 192u;
 
     w.cs = kt_begin / T;
     const int tap0 = kt_begin - w.cs * T;

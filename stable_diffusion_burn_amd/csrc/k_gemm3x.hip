@@ -65,6 +65,7 @@ struct S3Wave {
     int a_iy0[NA], a_ix0[NA];
     unsigned a_off[NA];               // byte offset of the sample + this lane's chunk (operands are < 4 GiB: launch_gemm checks)
     unsigned w_off[NBW];
+    unsigned w_kstep;           // bytes between a weight piece's k tiles: 192 (row-major planes) or 3072 (16-row groups, ConvGemm::b3_grouped)
     const char *Abase, *Wbase, *zero;
     unsigned pix_bytes;
     int Hin, Win, ups, Ws, KH, KW, wave;
@@ -90,7 +91,7 @@ struct S3Wave {
             __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(next_stage + (wave + 8 * J) * 1024), 16, 0, 0);
         } else {
             constexpr int j = J - NA;
-            const char* src = Wbase + (w_off[j] + (unsigned)kt_next * 192u);
+            const char* src = Wbase + (w_off[j] + (unsigned)kt_next * w_kstep);
             __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(next_stage + A_BYTES + (wave + 8 * j) * 1024), 16, 0, 0);
         }
         if constexpr (J == NP - 1) {
@@ -263,8 +264,10 @@ __global__ __launch_bounds__(512) void conv_gemm3x_kernel(const ConvGemm p) {
         // rows past N (ragged last tile) and the pieces past PW fetch the last valid row instead: real memory, and the
         // accumulator columns they feed are never stored
         if (n >= p.N) wrow -= (n - (p.N - 1));
-        w.w_off[j] = (unsigned)wrow * w_row_bytes + pl * 64 + ch * 16;
+        w.w_off[j] = p.b3_grouped ? (unsigned)(wrow >> 4) * (w_row_bytes * 16u) + pl * 1024 + (unsigned)(wrow & 15) * 64 + ch * 16
+                                  : (unsigned)wrow * w_row_bytes + pl * 64 + ch * 16;
     }
+    w.w_kstep = p.b3_grouped ? 3072u : 192u;
 
     w.cs = kt_begin / T;
     const int tap0 = kt_begin - w.cs * T;
@@ -368,9 +371,38 @@ hipError_t launch_conv_gemm3x(const ConvGemm& p, int cfg, hipStream_t stream) {
 // ---- weight planes ---------------------------------------------------------------------------------------------------
 // bt [rows][K] fp32 in the kernels' k order (K % 32 == 0) -> w3 [rows][K / 32][3][32] bf16: split3_rows_kernel (k_gemm3p.hip), the
 // split every plane producer uses (k_split3.hpp: chunk g of a plane row = k-tile elements 4g..4g+3, 16+4g..16+4g+3).
-hipError_t launch_pack_split3(const float* bt, void* w3, long long rows, int K, hipStream_t s) {
+// grouped (round 5; rows % 16 == 0): [rows / 16][K / 32][3][16][32] -- the 16 rows of a fragment group side by side per (k tile, plane), so that the DMA piece a wave
+// fetches (16 rows x 64 B of one plane) is 1 KiB of consecutive bytes and a group's k tiles are consecutive 3 KiB blocks: the weight stream of a small-M layer (8 x 8 and
+// 16 x 16 levels: 88-176 MB of planes read once per forward) becomes sequential per fragment group instead of 64-byte pieces 6 K bytes apart.
+__global__ void pack_split3_grouped_kernel(const float* __restrict__ x, unsigned short* __restrict__ y3, long long rows, int kt) {
+    const long long total = rows * kt * 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i & 3);
+        const long long rk = i >> 2;
+        const long long row = rk / kt;
+        const int k = (int)(rk - row * kt);
+        const float* src = x + row * ((long long)kt * 32) + k * 32;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(src + 4 * g);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 16 + 4 * g);
+        u32x4 ph, pm, plo;
+        s3_split8(lo, hi, ph, pm, plo);
+        unsigned short* dst = y3 + ((row >> 4) * kt + k) * 1536 + (row & 15) * 32 + g * 8;
+        *reinterpret_cast<u32x4*>(dst) = ph;
+        *reinterpret_cast<u32x4*>(dst + 512) = pm;
+        *reinterpret_cast<u32x4*>(dst + 1024) = plo;
+    }
+}
+
+hipError_t launch_pack_split3(const float* bt, void* w3, long long rows, int K, hipStream_t s, bool grouped) {
     if (K % 32) return hipErrorInvalidValue;
-    return launch_split3_rows(bt, w3, rows, K, K, (long long)(K / 32) * 192, s);
+    if (!grouped) return launch_split3_rows(bt, w3, rows, K, K, (long long)(K / 32) * 192, s);
+    if (rows % 16) return hipErrorInvalidValue;
+    const long long total = rows * (K / 32) * 4;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pack_split3_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, s, bt, reinterpret_cast<unsigned short*>(w3), rows, K / 32);
+    return hipGetLastError();
 }
 
 }  // namespace sdmi

@@ -20,6 +20,8 @@ struct ConvGemm {
     const float* A;       // source activations [NB][Hs][Ws][Cin]
     const float* Bt;      // packed weights [N][K]
     const void* Bt3;      // split kernels (k_gemm3x.hip, k_gemm3p.hip): the same weights as three bf16 planes, [N][K / 32][3][32]
+    int b3_grouped;       // ... 0: that row-major layout; 1 (round 5): 16-row fragment groups, [N / 16][K / 32][3][16][32] -- a DMA piece (one plane of one group's k tile) is
+                          // 1 KiB of consecutive bytes and a group's k tiles follow each other, instead of sixteen 64-byte pieces 6 K bytes apart (launch_pack_split3)
     const void* A3;       // plane kernel (k_gemm3p.hip): the source activations as three bf16 planes, [NB][Hs][Ws][a3_ld / 192 slices][3][32]
     int a3_ld;            // bytes between source pixels in A3 (192 per 32 channels of the -- possibly wider -- buffer)
     float* C;             // output [M][ldc]; may be null when C3 is set
@@ -95,7 +97,7 @@ hipError_t launch_conv_gemm2x(const ConvGemm& p, int tile_cfg, hipStream_t strea
 constexpr int kNumGemmTilesS = 6;
 const GemmTileInfo& gemm_tile_info_s(int cfg);
 hipError_t launch_conv_gemm3x(const ConvGemm& p, int tile_cfg, hipStream_t stream);
-hipError_t launch_pack_split3(const float* bt, void* w3, long long rows, int K, hipStream_t s);
+hipError_t launch_pack_split3(const float* bt, void* w3, long long rows, int K, hipStream_t s, bool grouped = false);   // grouped needs rows % 16 == 0
 // the same arithmetic with the ACTIVATIONS as planes too, written once by their producer (k_gemm3p.hip; tile_cfg 300 + x; needs p.A3)
 constexpr int kNumGemmTilesP = 9;
 const GemmTileInfo& gemm_tile_info_p(int cfg);
