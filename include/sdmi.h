@@ -318,7 +318,12 @@ int sdmi_op_timestep_embedding(sdmi_ctx* ctx, int32_t t, int32_t dim, float* out
  * precision >= 1: "conv3_reuse" (default 1: 3x3 / stride-1 convolutions that chose the 256 x 320 / 256 x 256 bf16 tile run on k_gemm_bf16t.hip, which stages a kernel
  * row's activations once for its three taps; results are bit-identical to "0"); "gemm_bf16x_variant" (default 1: bit 0 = the large-tile bf16 GEMM as a persistent tile
  * loop where a launch has no split-K, no residual and more tiles than CUs; bit-identical to "0"); "gn_target_wgs" / "gn_max_threads" / "gn_unroll" (launch geometry of
- * the bf16 / MXFP8 GroupNorm passes: results equal to fp32 rounding, not bit-identical across settings -- the chunking orders the fp64 merges). */
+ * the bf16 / MXFP8 GroupNorm passes: results equal to fp32 rounding, not bit-identical across settings -- the chunking orders the fp64 merges).
+ * precision = 0, round 5: "b3_grouped" (default 1; ONLY before the first weight is loaded, SDMI_ERR_STATE afterwards): the weights' bf16 planes are stored in 16-row fragment
+ * groups, [N / 16][K / 32][3][16][32] (1 KiB DMA pieces), 0 = row-major planes; same values.  "attn_pack_tail" (default 3; k_attn_split.hip): bit 0 = the last 8 columns
+ * of a d = 40 head as a packed k step / packed output tile, bit 1 = scores in log2 units with the reference maximum as accumulator input and the row sum from a ones
+ * column; 0 = round 4's form; all within the same parity bar (tests/test_ops_gpu.py::test_qkv_attention_packed_tail_d40).  "attn_kv_splits" (0 = automatic): key slices + a
+ * merge launch where the query-tile grid leaves CUs idle.  "cfg_share" (default 1): the UNet layers in front of the first cross attention are computed once per CFG step. */
 int sdmi_set_option(sdmi_ctx* ctx, const char* key, const char* value);
 /* time (ms, HIP events on the context stream) and kernel count of the last
  * hot-path call; flops = algorithmic FLOPs it executed (2*MAC of conv/GEMM/attention). */
