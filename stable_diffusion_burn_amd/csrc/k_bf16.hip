@@ -308,7 +308,7 @@ hipError_t launch_layer_norm_bf16(const void* x, void* y, const float* gamma, co
 }
 
 // ---- elementwise ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_erf_h(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_h(float x) { return gelu_gate_fast(x); }   // the fused epilogue's form (k_common.hpp), so that fused and unfused gates agree
 
 __global__ void geglu_bf16_kernel(const unsigned short* __restrict__ proj, unsigned short* __restrict__ out, long long rows, int hidden8) {
     const long long total = rows * hidden8;

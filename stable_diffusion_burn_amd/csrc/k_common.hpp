@@ -26,6 +26,22 @@ __device__ __forceinline__ GemmWork gemm_work_of_block(const ConvGemm& p, int MT
     return w;
 }
 
+// ---- the GEGLU gate's GELU (unet/mod.rs:587-590: x * 0.5 * (1 + erf(x / sqrt 2))) for the REDUCED-PRECISION kernels (bf16 / MXFP8 results) ---------------------------------
+// erff() is ~ 35 instructions and two divergent branches per element; the fused bf16 GEGLU epilogue evaluates it 64 times per thread per 256 x 256 tile -- ~ 5 us beside a
+// 6 us matrix loop (round 5).  Here: Phi(g) = 0.5 erfc(-g / sqrt 2) with Abramowitz-Stegun 7.1.26 (erfc(x) = t (a1 + t (a2 + ... a5 t)) exp(-x^2), t = 1 / (1 + p x),
+// |error| <= 1.5e-7) on the hardware reciprocal and exp2: 17 instructions, no branch.  |gate - exact| <= 4.7e-7 over |g| <= 12 (tests/test_split_oracle_cpu.py), i.e.
+// far inside the bf16 rounding of the result (1.4 % of the results land on the neighbouring bf16 value, always the adjacent one).  The fp32 kernels keep erff().
+__device__ __forceinline__ float gelu_gate_fast(float g) {
+    const float x = __builtin_fabsf(g) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, x, 1.0f));
+    float pl = __builtin_fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+    pl = __builtin_fmaf(pl, t, 0.5f * 1.421413741f);
+    pl = __builtin_fmaf(pl, t, 0.5f * -0.284496736f);
+    pl = __builtin_fmaf(pl, t, 0.5f * 0.254829592f);
+    const float h = (pl * t) * __builtin_amdgcn_exp2f((g * g) * -0.72134752044448170368f);    // 0.5 erfc(|g| / sqrt 2)
+    return g * (0.5f + __builtin_copysignf(0.5f - h, g));
+}
+
 // ---- GroupNorm statistics (groupnorm/mod.rs:75-82) ---------------------------------------------------------
 // Partial statistics of one (sample, chunk, group) are (mean, M2 = sum (x - mean)^2) over the chunk's rows x (C/G)
 // channels: part[((smp*chunks + chunk)*G + g)*2 + {0, 1}].  Producers: gn_stats_kernel / gn_stats_bf16_kernel and the

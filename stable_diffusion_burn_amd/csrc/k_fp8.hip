@@ -610,7 +610,7 @@ hipError_t launch_layer_norm_fp8(const void* x, void* y8, void* y_scale, const f
 }
 
 // the GEGLU gate (unet/mod.rs:579-591) with MXFP8 output: proj bf16 [rows][2 H] -> out e4m3 [rows][Hp] + scales
-__device__ __forceinline__ float gelu_erf_q(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_q(float x) { return gelu_gate_fast(x); }   // (k_common.hpp)
 __global__ void geglu_fp8_kernel(const unsigned short* __restrict__ proj, unsigned char* __restrict__ y, unsigned char* __restrict__ ys, long long rows,
                                  int H, int Hp) {
     const int hq = H >> 3;

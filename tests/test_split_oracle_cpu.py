@@ -75,3 +75,41 @@ def test_small_integers_need_the_low_planes_and_come_out_exact():
     assert np.array_equal(S.gemm_split(a, w), exact)
     h = S.split3(a)[0]
     assert not np.array_equal(h, a)                   # bf16 alone (the h plane) cannot hold 9-bit integers
+
+
+def test_reduced_precision_geglu_gate_formula():
+    """The GELU of the GEGLU gate in the bf16 / MXFP8 kernels (csrc/k_common.hpp gelu_gate_fast; reference unet/mod.rs:587-590: x * 0.5 * (1 + erf(x / sqrt 2))):
+    Phi(g) = 0.5 erfc(-g / sqrt 2) with Abramowitz-Stegun 7.1.26 on a reciprocal and an exp2, restated here in float32 step by step.  Its distance from the exact gate is
+    below 6e-7 over |g| <= 12 -- three orders of magnitude inside the bf16 rounding of the result -- and a result lands on a different bf16 value than the exact gate's in
+    under 2 % of normally distributed inputs (then on the adjacent one)."""
+    from scipy.special import erf
+    f = np.float32
+
+    def gate(g):
+        g = g.astype(f)
+        x = (np.abs(g) * f(0.70710678118654752440)).astype(f)
+        t = (f(1.0) / (f(0.3275911) * x + f(1.0)).astype(f)).astype(f)
+        a = [f(0.5 * v) for v in (0.254829592, -0.284496736, 1.421413741, -1.453152027, 1.061405429)]
+        p = (t * a[4] + a[3]).astype(f)
+        for k in (2, 1, 0):
+            p = (p * t + a[k]).astype(f)
+        h = ((p * t).astype(f) * np.exp2(((g * g).astype(f) * f(-0.72134752044448170368)).astype(f)).astype(f)).astype(f)
+        return (g * (f(0.5) + np.copysign((f(0.5) - h).astype(f), g)).astype(f)).astype(f)
+
+    def exact(g):
+        g = g.astype(np.float64)
+        return g * 0.5 * (1.0 + erf(g / np.sqrt(2.0)))
+
+    g = np.linspace(-12.0, 12.0, 1200001).astype(f)
+    assert np.abs(gate(g).astype(np.float64) - exact(g)).max() < 6e-7
+    assert gate(np.array([0.0, -0.0], f)).tolist() == [0.0, 0.0] and np.isfinite(gate(np.array([-80.0, 80.0, 1e-30], f))).all()
+    assert gate(np.array([80.0], f))[0] == f(80.0) and abs(float(gate(np.array([-80.0], f))[0])) == 0.0
+
+    def bf16(x):
+        u = x.astype(f).view(np.uint32).astype(np.uint64)
+        return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(f)
+
+    gg = (np.random.default_rng(0).standard_normal(400000) * 2).astype(f)
+    a, b = bf16(gate(gg)), bf16(exact(gg).astype(f))
+    assert np.mean(a != b) < 0.02
+    assert np.abs(a.astype(np.float64) - b.astype(np.float64)).max() <= np.abs(b).max() * 2.0 ** -7
