@@ -67,3 +67,29 @@ def test_large_tile_bf16_epilogue_form(tmp_path):
         loop = body.split("v_mfma_f32_16x16x32_bf16", 1)[1].rsplit("v_mfma_f32_16x16x32_bf16", 1)[0]
         assert "v_readlane_b32" not in loop and "v_writelane_b32" not in loop, name
         assert body.count("s_barrier") >= 2, name                        # the k loop's barrier + the one in front of the next tile's first DMA
+
+
+def test_fp32_attention_d40_packed_tail_instruction_counts(tmp_path):
+    """k_attn_split.hip at d = 40 (round 5): the packed tail is 15 + 9 matrix instructions per 32 keys instead of 18 + 12 (66 instead of 84 per 64-key tile), and the
+    log2-unit softmax has no multiply-add in front of an exponential and no row-sum addition -- properties the measured 13 % of the attention class rest on."""
+    funcs = _functions("k_attn_split", tmp_path)
+    def body(pk, lg):
+        return funcs[f"_ZN4sdmi17attn_split_kernelILi40ELi8ELb{pk}ELb{lg}EEEvNS_10AttnParamsE"]
+    assert body(1, 1).count("v_mfma_f32_32x32x16_bf16") == 66 and body(1, 0).count("v_mfma_f32_32x32x16_bf16") == 66
+    assert body(0, 1).count("v_mfma_f32_32x32x16_bf16") == 84 and body(0, 0).count("v_mfma_f32_32x32x16_bf16") == 84
+    assert body(1, 1).count("ds_read_b64_tr_b16") < body(0, 1).count("ds_read_b64_tr_b16")          # the tail tile reads one plane, not three
+    assert body(1, 1).count("v_fma_f32") + 24 <= body(1, 0).count("v_fma_f32")                      # (32 score scalings per tile gone)
+    assert body(1, 1).count("v_add_f32") + 24 <= body(1, 0).count("v_add_f32")                      # (32 row-sum additions per tile gone)
+
+
+def test_reduced_precision_geglu_epilogue_has_no_erf_branches(tmp_path):
+    """The fused GEGLU epilogue of the bf16 / MXFP8 large-tile kernels evaluates the gate's GELU with gelu_gate_fast (k_common.hpp): one reciprocal and one exp2 per element and
+    no divergent branch -- erff() was ~ 35 instructions and two s_and_saveexec regions per element (round 5, profiles/r05ad_*)."""
+    funcs = _functions("k_gemm_bf16x", tmp_path)
+    geglu = {k: v for k, v in funcs.items() if "conv_gemm_bf16x_kernel" in k and k.endswith("ELi2EEEvNS_8ConvGemmE")}      # PM = 2: the persistent GEGLU form
+    assert len(geglu) == 2, sorted(geglu)
+    for name, body in geglu.items():
+        n_exp, n_rcp = body.count("v_exp_f32"), body.count("v_rcp_f32")
+        assert n_exp >= 32 and n_rcp >= n_exp, name
+        assert "v_rndne_f32" not in body and "v_ldexp_f32" not in body, name            # (the library erff's range reduction)
+        assert body.count("s_and_saveexec_b64") < 80, name                              # (120 with erff(); what remains are the store predicates)
