@@ -45,6 +45,7 @@ sys.path.insert(0, str(ROOT))
 FP8_MFMA_PEAK_TFLOPS = 5000.0   # same table, "Peak FP8 MFMA" (dense; the MX-scaled K = 128 instruction)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA" (dense)
+HBM_ACHIEVABLE_TBPS = 6.29      # same guide: "HBM3E peak BW 8.0 TB/s spec; 6.29 TB/s measured (float4 copy)" -- the rate the two-sided roof prices bytes at
 SPLIT_PRODUCTS = 6              # k_gemm3x.hip: bf16 MFMAs issued per fp32 16x16x32 block (csrc/k_gemm3x.hip header)
 F_UNET = 0.8033e12              # FLOP per UNet forward per sample, T = 77
 F_VAE = 2.5145e12               # FLOP per decoded image
@@ -213,11 +214,22 @@ class Runner:
         """Live HIP-event timing of every launch, in a separate un-timed pass (sdmi_profile_stats)."""
         sd = self.sd
         sd.set_option("profile_reset", 1)
-        sd.set_option("profile", 1)
+        sd.set_option("profile", 2)    # 2: the samples are also accumulated per launch tag (class + shape + tile): the two-sided roof below is per shape
         self.step()
         self.torch.cuda.synchronize()
         sd.set_option("profile", 0)
         prof = sd.profile_stats()
+        tags = []
+        try:
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                sd.set_option("dump_profile_tags", os.path.join(td, "tags.txt"))
+                for line in Path(td, "tags.txt").read_text().splitlines():
+                    nums, tag = line.split("\t", 1)
+                    ms, n, fl, by = nums.split()
+                    tags.append((float(ms), int(n), float(fl), float(by), tag))
+        except Exception:  # noqa: BLE001
+            tags = []
         # precision = 0: the dominant kernel is the split kernel (fp32 operands as three bf16 terms, six bf16 MFMAs per fp32
         # 16x16x32 block) unless it is switched off (--opt gemm_f32s=0), then the fp32-MFMA kernels
         split = (not self.bf16) and prof["conv_gemm_split"]["ms"] > prof["conv_gemm"]["ms"]
@@ -246,7 +258,7 @@ class Runner:
                 c = j.get("configs", {}).get(ckey) or ({"classes": j["classes"], "commit": j.get("commit")} if ckey == "fp32_b1_s20" and "classes" in j else None)
                 t = c["classes"].get(cls, {}).get("hbm_bytes_per_launch") if c else None
                 if t:
-                    from_profiles = {"hbm_bytes_per_launch": t, "collected_on_commit": c.get("commit"), "source": f"profiles/pmc_summary.json configs[{ckey}] classes[{cls}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command"}
+                    from_profiles = {"hbm_bytes_per_launch": t, "collected_on_commit": c.get("commit"), "kernel_source_digest": c.get("kernel_source_digest"), "source": f"profiles/pmc_summary.json configs[{ckey}] classes[{cls}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command"}
             except Exception:  # noqa: BLE001
                 from_profiles = None
         roof = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
@@ -258,6 +270,34 @@ class Runner:
                 "launches_per_image": g["launches"] / self.B, "avg_launch_us": g["ms"] * 1e3 / g["launches"],
                 "flop_per_launch": g["flops"] / g["launches"],
                 "share_of_gpu_time": g["ms"] / max(1e-9, sum(v["ms"] for v in prof.values()))}
+        # The same class against the roof EACH SHAPE can reach (round 6): a launch of 2 M N K flops over its algorithmic bytes is bounded by
+        # max(flops / matrix peak, bytes / achievable HBM rate); the short-K Linear / 1x1 layers (K = 320 .. 1280 at N <= 2 K) are HBM-bound by that rule at
+        # every batch size, so `frac` above (matrix peak only) is not a bound they can reach.  `frac_two_sided` = sum of per-launch roof times / measured time.
+        import re
+        sel = [t for t in tags if (t[4].startswith("gemm_fp8 ") if self.fp8 else (t[4].startswith("gemm ") and (self.bf16 or (int(re.search(r"cfg=(\d+)", t[4]).group(1)) >= 200) == split)))]
+        if sel and sum(t[0] for t in sel) > 0:
+            t_meas = sum(t[0] for t in sel) * 1e-3
+            t_mfma = [t[2] / (peak * 1e12) for t in sel]                        # class totals per tag: launches x per-launch time
+            t_hbm = [t[3] / (HBM_ACHIEVABLE_TBPS * 1e12) for t in sel]
+            t_roof = [max(a, b) for a, b in zip(t_mfma, t_hbm)]
+            hb = [i for i in range(len(sel)) if t_hbm[i] > t_mfma[i]]
+            roof["two_sided"] = {
+                "rule": f"per launch shape: max(2 M N K / {peak:g} TFLOP/s, algorithmic bytes / {HBM_ACHIEVABLE_TBPS} TB/s (measured copy rate, MI355X_MICROARCH.md)); summed over the class",
+                "frac_two_sided": sum(t_roof) / t_meas,
+                "hbm_bound_shapes": {"share_of_class_time": sum(sel[i][0] for i in hb) * 1e-3 / t_meas, "launches_per_image": sum(sel[i][1] for i in hb) / self.B,
+                                     "frac_of_their_hbm_roof": (sum(t_hbm[i] for i in hb) / (sum(sel[i][0] for i in hb) * 1e-3)) if hb else None},
+                "mfma_bound_shapes": {"share_of_class_time": 1.0 - sum(sel[i][0] for i in hb) * 1e-3 / t_meas,
+                                      "frac_of_mfma_peak": (sum(t_mfma[i] for i in range(len(sel)) if i not in hb) / max(1e-12, sum(sel[i][0] for i in range(len(sel)) if i not in hb) * 1e-3))},
+            }
+        if from_profiles is not None:
+            # the PMC passes cannot run inside this process: say whether the tree they were collected on is this one (digest of csrc/ + the tile tables, build.py)
+            try:
+                from stable_diffusion_burn_amd import build as _b
+                here = _b._digest()[:16]
+            except Exception:  # noqa: BLE001
+                here = None
+            from_profiles["kernel_source_digest_here"] = here
+            roof["traffic_stale"] = not (here and from_profiles.get("kernel_source_digest") == here)
         if split:
             o = prof["conv_gemm"]
             roof["peak_note"] = (f"dense bf16 MFMA peak {BF16_MFMA_PEAK_TFLOPS:g} TFLOP/s / {SPLIT_PRODUCTS} matrix instructions per fp32 block; "
@@ -381,6 +421,9 @@ def main():
     bf16 = args.precision in ("bf16", "fp8")
     t_load = run.t_load
     classes = run.class_summary(prof) if prof is not None else {}
+    ao = run.sd.applied_options
+    applied_options = {"set": [f"{k}={v}" for k, v in ao if k != "tune"], "tune_lines": sum(1 for k, _ in ao if k == "tune"),
+                       "from_env_SDMI_OPTS": [f"{k}={v}" for k, v in run.sd.options_from_env]}
     run.close()
 
     # ---- secondary: the reduced-precision configurations BASELINE.json names, witnessed by the same run ----------
@@ -399,8 +442,11 @@ def main():
             entry = {"config": {"workload": workload_name(prec2, b2, s2, args.scale), "global_batch": b2, "ddim_steps": s2,
                                 "cfg_scale": args.scale, "context_len": T_CTX},
                      "dtype": "f32" if prec2 == "fp32" else "bf16" if prec2 == "bf16" else "fp8(e4m3, MX)+bf16", "value": v2, "unit": "images/sec", "steps": k2, "warmup": 2, "ms_per_step": e2 / k2 * 1e3,
-                     "algorithmic_tflop_per_image": fpi / 1e12, "executed_tflop_per_image": r2.sd.last_call_stats()["flops"] / b2 / 1e12, "whole_path_tflops_per_gpu": v2 * fpi / 1e12,
-                     "whole_path_frac_of_bf16_mfma_peak": v2 * fpi / 1e12 / BF16_MFMA_PEAK_TFLOPS, "roofline": roof2,
+                     "algorithmic_tflop_per_image": fpi / 1e12, "executed_tflop_per_image": r2.sd.last_call_stats()["flops"] / b2 / 1e12,
+                     # round 6: from the flops the engine EXECUTED (the shared CFG prefix and the hoisted projections are not counted); the reference's algorithmic count beside it
+                     "whole_path_tflops_per_gpu": v2 * r2.sd.last_call_stats()["flops"] / b2 / 1e12, "whole_path_algorithmic_tflops_per_gpu": v2 * fpi / 1e12,
+                     "whole_path_frac_of_bf16_mfma_peak": v2 * r2.sd.last_call_stats()["flops"] / b2 / 1e12 / BF16_MFMA_PEAK_TFLOPS, "roofline": roof2,
+                     "applied_options": [f"{k}={v}" for k, v in r2.sd.applied_options],
                      "kernels_per_image": r2.sd.last_call_stats()["kernels"] / b2,
                      "weights_load_s": r2.t_load}
             if prec2 == "fp32":
@@ -443,13 +489,17 @@ def main():
             # of the first cross attention is computed once for the two identical halves of a CFG step (option cfg_share) and the text context's K / V
             # projections and the time-embedding MLPs are hoisted out of the step loop
             "executed_tflop_per_image": stats["flops"] / B / 1e12,
-            "whole_path_tflops_per_gpu": value / world * flop_per_image / 1e12,
-            "whole_path_frac_of_applicable_mfma_peak": value / world * flop_per_image / 1e12 / peak,
+            # round 6: priced from the EXECUTED flops (the algorithmic figure, 2.7 % larger, beside it)
+            "whole_path_tflops_per_gpu": value / world * stats["flops"] / B / 1e12,
+            "whole_path_algorithmic_tflops_per_gpu": value / world * flop_per_image / 1e12,
+            "whole_path_frac_of_applicable_mfma_peak": value / world * stats["flops"] / B / 1e12 / peak,
             "applicable_mfma_peak_tflops": peak,
             "applicable_mfma_peak_note": ("dense bf16 MFMA peak" if bf16 else f"dense bf16 MFMA peak / {SPLIT_PRODUCTS} (fp32 operands as three bf16 terms, six partial products)" if split_on
                                           else "fp32 matrix instruction peak"),
             "kernels_per_image": stats["kernels"] / B, "weights_load_s": t_load, "weights_generate_s": t_gen,
             "roofline": roofline, "cpu_baseline": cpu,
+            # every engine option this run set beyond the defaults (--opt, the tile table's "tune" lines are counted, SDMI_OPTS from the environment listed by name)
+            "applied_options": applied_options,
         }
         out["parity_in_run"] = parity
         out.update(classes)

@@ -294,36 +294,11 @@ int sdmi_op_geglu_forward(sdmi_ctx* ctx, const float* x, const float* weight, co
 int sdmi_op_timestep_embedding(sdmi_ctx* ctx, int32_t t, int32_t dim, float* out);
 
 /* ---- tuning / introspection ---------------------------------------------------- */
-/* "key=value" knobs for tests and tuning, e.g. "gemm_tile=auto", "splitk=0", "profile=1" (Engine::set_option).
- * Arithmetic selectors of precision = 0 (both default 1): "gemm_f32s" = conv / linear GEMMs with Cin % 32 == 0 multiply on the bf16
- * matrix pipe with fp32 operands split exactly into three bf16 terms, six partial products, fp32 accumulation (k_gemm3x.hip);
- * "attn_split" = the same for qkv_attention at head dims 40 / 80 (k_attn_split.hip).  0 = the fp32 matrix instruction
- * (v_mfma_f32_16x16x4_f32) everywhere.  Same parity bars either way.
- * "gemm_planes" (default 1): the activations of those GEMMs are written as three bf16 planes by the kernel that produces them
- * (GroupNorm / LayerNorm / GEGLU / attention / GEMM epilogues) and read by k_gemm3p.hip; 0 = staged as fp32 and split inside the
- * GEMM's k loop (k_gemm3x.hip); 2 = test mode, fp32 tensors converted in front of every GEMM.
- *
- * fp32 semantics of precision = 0 with the split kernels (tests/test_planes_gpu.py::test_plane_path_at_the_edges_of_the_fp32_range):
- *   - finite operands up to FLT_MAX: as the fp32 matrix instruction, to about one fp32 rounding per product (a value whose bf16
- *     round-to-nearest would overflow takes a truncated high term instead);
- *   - NaN stays NaN; an INFINITE operand gives a non-finite result, but possibly NaN where fp32 arithmetic gives +-inf (its low-order
- *     partial products contain 0 * inf);
- *   - |x| < 2^-109: the low-order terms of x fall below bf16's normal range and are dropped (absolute error < 2^-118 |w| per term);
- *   - which kernel a layer runs on is a function of its shape and options only, never of the data.
- * Size limit of the plane form: a tensor kept as planes must stay below 4 GiB (6 bytes per element, 32-bit offsets); past it a call fails with
- * SDMI_ERR_UNSUPPORTED naming the limit (64x64x960 concat: CFG batch 2n <= 182, i.e. n <= 91 images per call; "gemm_planes=0" lifts it to the fp32 tensors' 273).
- * A caller that needs IEEE behaviour on infinities sets gemm_f32s = 0 / attn_split = 0.
- * precision = 2 selectors: "fp8_convs" (0: the fp8-capable layers on the bf16 kernels), "fp8_linear" (see sdmi_config.precision),
- * "fp8_min_rows" (GEMMs with fewer output rows stay bf16), "fp8_tile".
- * precision >= 1: "conv3_reuse" (default 1: 3x3 / stride-1 convolutions that chose the 256 x 320 / 256 x 256 bf16 tile run on k_gemm_bf16t.hip, which stages a kernel
- * row's activations once for its three taps; results are bit-identical to "0"); "gemm_bf16x_variant" (default 1: bit 0 = the large-tile bf16 GEMM as a persistent tile
- * loop where a launch has no split-K, no residual and more tiles than CUs; bit-identical to "0"); "gn_target_wgs" / "gn_max_threads" / "gn_unroll" (launch geometry of
- * the bf16 / MXFP8 GroupNorm passes: results equal to fp32 rounding, not bit-identical across settings -- the chunking orders the fp64 merges).
- * precision = 0, round 5: "b3_grouped" (default 1; ONLY before the first weight is loaded, SDMI_ERR_STATE afterwards): the weights' bf16 planes are stored in 16-row fragment
- * groups, [N / 16][K / 32][3][16][32] (1 KiB DMA pieces), 0 = row-major planes; same values.  "attn_pack_tail" (default 3; k_attn_split.hip): bit 0 = the last 8 columns
- * of a d = 40 head as a packed k step / packed output tile, bit 1 = scores in log2 units with the reference maximum as accumulator input and the row sum from a ones
- * column; 0 = round 4's form; all within the same parity bar (tests/test_ops_gpu.py::test_qkv_attention_packed_tail_d40).  "attn_kv_splits" (0 = automatic): key slices + a
- * merge launch where the query-tile grid leaves CUs idle.  "cfg_share" (default 1): the UNet layers in front of the first cross attention are computed once per CFG step. */
+/* "key=value" option of one context (Engine::set_option), e.g. "profile=1", "gemm_tile=auto".  No reference counterpart (the
+ * reference's knobs are Burn backend type parameters, sample/main.rs:59-83).  An unknown key returns SDMI_ERR_INVALID.  The
+ * defaults are the measured configuration; the option table -- arithmetic selectors (gemm_f32s, attn_split, gemm_planes and
+ * the fp32 semantics of the split kernels at the edges of the range), the precision >= 1 / = 2 selectors, launch geometry,
+ * profiling and dump switches -- is DESIGN.md section 11, one line per key. */
 int sdmi_set_option(sdmi_ctx* ctx, const char* key, const char* value);
 /* time (ms, HIP events on the context stream) and kernel count of the last
  * hot-path call; flops = algorithmic FLOPs it executed (2*MAC of conv/GEMM/attention). */

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -108,10 +109,25 @@ Engine::ProfScope::ProfScope(Engine* e_, int cls_, double flops_, double bytes_,
 Engine::ProfScope::~ProfScope() {
     if (!a) return;
     (void)hipEventRecord(b, e->stream_);
-    e->prof_pending_.push_back({cls, a, b, flops, bytes, n_launch});
+    e->prof_pending_.push_back({cls, a, b, flops, bytes, n_launch, tag});
     if (e->prof_pending_.size() >= 2048) {
         try { e->prof_flush(); } catch (...) {}
     }
+}
+
+void Engine::ProfScope::set_tag(const char* fmt, ...) {
+    if (!a || !e->prof_tagging_) return;
+    char buf[192];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    auto it = e->prof_tag_ids_.find(buf);
+    if (it == e->prof_tag_ids_.end()) {
+        it = e->prof_tag_ids_.emplace(buf, (int)e->prof_tag_names_.size()).first;
+        e->prof_tag_names_.push_back(buf);
+    }
+    tag = it->second;
 }
 
 // What an (a, b) event pair reads with NOTHING between its two records: the pair's own cost on the stream, which would otherwise be
@@ -148,6 +164,10 @@ void Engine::prof_flush() {
             prof_[p.cls].launches += p.n_launch;
             prof_[p.cls].flops += p.flops;
             prof_[p.cls].bytes += p.bytes;
+            if (p.tag >= 0) {
+                ProfStat& t = prof_tags_[prof_tag_names_[p.tag]];
+                t.ms += ms; t.launches += p.n_launch; t.flops += p.flops; t.bytes += p.bytes;
+            }
         }
         prof_free_.push_back(p.a);
         prof_free_.push_back(p.b);
@@ -1050,13 +1070,13 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     }
     else if (key == "attn_pack_tail") opt_attn_pack_tail_ = (value == "default") ? 3 : std::stoi(value);
     else if (key == "gn32_min_wgs") opt_gn32_min_wgs_ = (opt_gn32_min_wgs_ & ~0xFFFF) | (std::stoi(value) & 0xFFFF);
-    else if (key == "gn32_stats_chunk_kb") launch_group_norm_tune(std::stoi(value));
     else if (key == "gn32_stats_min_wgs") opt_gn32_min_wgs_ = (opt_gn32_min_wgs_ & 0xFFFF) | ((std::stoi(value) + 1) << 16);   // the statistics pass cut differently from the apply pass (-1: the same)
     else if (key == "gn_target_wgs") gn_tune_.target_wgs = std::stoi(value);
     else if (key == "gn_max_threads") gn_tune_.max_threads = std::stoi(value);
     else if (key == "gn_unroll") gn_tune_.unroll = std::stoi(value);
     else if (key == "fp8_tile") opt_fp8_tile_ = (value == "auto") ? -1 : std::stoi(value);
     else if (key == "attn_bf16") opt_attn_bf16_ = std::stoi(value);
+    else if (key == "attn_bf16_variant") opt_attn_bf16_variant_ = std::stoi(value);
     else if (key == "attn_split") opt_attn_split_ = std::stoi(value);
     else if (key == "gemm_bf16x") opt_gemm_bf16x_ = std::stoi(value);
     else if (key == "gemm_x32") opt_gemm_x32_ = std::stoi(value);
@@ -1079,7 +1099,13 @@ void Engine::set_option(const std::string& key, const std::string& value) {
         if (!f) throw Error(SDMI_ERR_IO, "dump_choices: cannot write " + value);
         for (auto& kv : choice_counts_) f << kv.first << " x" << kv.second << "\n";
     }
-    else if (key == "profile") { prof_flush(); profiling_ = std::stoi(value) != 0; if (profiling_) prof_calibrate(); }
+    else if (key == "profile") { prof_flush(); profiling_ = std::stoi(value) != 0; prof_tagging_ = std::stoi(value) >= 2; if (profiling_) prof_calibrate(); }
+    else if (key == "dump_profile_tags") {   // profile=2: "ms launches flops bytes<TAB>tag" per line
+        prof_flush();
+        std::ofstream f(value);
+        if (!f) throw Error(SDMI_ERR_IO, "dump_profile_tags: cannot write " + value);
+        for (auto& kv : prof_tags_) f << kv.second.ms << " " << kv.second.launches << " " << kv.second.flops << " " << kv.second.bytes << "\t" << kv.first << "\n";
+    }
     else if (key == "profile_reset") prof_reset();
     else if (key == "tune" || key == "tune_bf16") {
         // "M,N,K=cfg,splits" (tune_bf16: cfg 100 + x selects a k_gemm_bf16x.hip tile)
@@ -1346,6 +1372,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     if (splits == 1) {
         p.slab_stride = 0;
         ProfScope ps(this, pc, flops, gemm_bytes);
+        ps.set_tag("gemm %d,%d,%d k%d%s cfg=%d splits=1", p.M, p.N, p.K, p.KH, p.geglu ? " geglu" : "", tc.cfg);
         SDMI_HIP(launch(p));
         count_kernel(flops);
     } else {
@@ -1354,11 +1381,13 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         p.slabs = slab.f();
         {
             ProfScope ps(this, pc, flops, gemm_bytes);
+            ps.set_tag("gemm %d,%d,%d k%d%s cfg=%d splits=%d", p.M, p.N, p.K, p.KH, p.geglu ? " geglu" : "", tc.cfg, splits);
             SDMI_HIP(launch(p));
         }
         count_kernel(flops);
         {
             ProfScope ps(this, PC_SPLITK_REDUCE, 0, (double)(splits + 1) * p.slab_stride * 4.0);
+            ps.set_tag("reduce %d,%d,%d k%d cfg=%d splits=%d", p.M, p.N, p.K, p.KH, tc.cfg, splits);
             if (in_dt) SDMI_HIP(launch_splitk_reduce_bf16(p, stream_));
             else SDMI_HIP(launch_splitk_reduce(p, stream_));
             count_kernel();
@@ -1502,6 +1531,7 @@ void Engine::group_norm(const NormW& w, const Act& x, Act& y, bool silu) {
     if (x.dt != y.dt) throw Error(SDMI_ERR_STATE, "group_norm: in/out storage types disagree");
     Buf part(this, x.dt ? gn_partials_bytes_bf16(x.n, hw, x.c, gn_tune_) : gn_partials_bytes(x.n, hw, x.c, opt_gn32_min_wgs_));
     ProfScope ps(this, PC_GROUP_NORM, 0, 2.0 * (double)x.bytes(), 2);  // algorithmic: one read + one write; two launches (statistics, apply)
+    ps.set_tag("group_norm n%d hw%d c%d%s", x.n, hw, x.c, silu ? " silu" : "");
     if (y.view) throw Error(SDMI_ERR_STATE, "group_norm: output must be dense");
     if (!x.p) throw Error(SDMI_ERR_STATE, "group_norm: the input must exist as fp32");
     if (y.p3 && !y.p) {   // the consumer is a plane GEMM: the normalised tensor is written as three bf16 planes only
@@ -1516,6 +1546,7 @@ void Engine::group_norm(const NormW& w, const Act& x, Act& y, bool silu) {
 void Engine::layer_norm(const NormW& w, const float* x, long long rows, float* y, int dt, void* y3) {
     if (dt < 0) dt = edt();
     ProfScope ps(this, PC_LAYER_NORM, 0, 2.0 * (double)rows * w.c * (dt ? 2.0 : 4.0));
+    ps.set_tag("layer_norm rows%lld c%d", rows, w.c);
     if (y3) {
         if (dt) throw Error(SDMI_ERR_STATE, "layer_norm: planes are an fp32-engine format");
         SDMI_HIP(launch_layer_norm_planes(x, y3, w.gamma, w.beta, (int)rows, w.c, w.eps, stream_));
@@ -1548,6 +1579,7 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
         p.q_log2 = q_log2 ? 1 : 0;
         p.o3 = o3; p.ldo3 = (n_head * d_head / 32) * 192;
         p.pack_tail = opt_attn_pack_tail_;
+        p.variant = opt_attn_bf16_variant_;
         if (dt && mask) throw Error(SDMI_ERR_UNSUPPORTED, "attention: additive mask is fp32-only");
         const double fl = 4.0 * n * n_head * (double)nq * nk * d_head;
         const bool on_split = !dt && opt_attn_split_ && attn_split_supported(p);
@@ -1574,6 +1606,7 @@ void Engine::attention(const float* q, int ldq, long long q_bs, const float* k, 
             p.kv_splits = kv_splits; p.part_o = part_o->f(); p.part_ml = part_ml->f();
         }
         ProfScope ps(this, PC_ATTENTION, fl, 0, kv_splits > 1 ? 2 : 1);
+        ps.set_tag("attention n%d nq%d nk%d h%d d%d slices=%d", n, nq, nk, n_head, d_head, kv_splits);
         if (dt && opt_attn_bf16_ && (d_head == 40 || d_head == 80 || d_head == 160)) SDMI_HIP(launch_attention_bf16(p, stream_));
         else if (on_split) SDMI_HIP(launch_attention_split(p, stream_));
         else SDMI_HIP(launch_attention(p, stream_));
@@ -1772,6 +1805,7 @@ void Engine::launch_fp8(ConvGemm& p, double flops) {
     const double fp8_bytes = ((double)p.NB * p.Hs * p.Ws * p.a_ld + (double)p.N * p.K) * (1.0 + 1.0 / 32.0) + (double)p.M * p.N * 2.0;
     if (splits == 1) {
         ProfScope ps(this, PC_CONV_FP8, flops, fp8_bytes);
+        ps.set_tag("gemm_fp8 %d,%d,%d k%d cfg=%d splits=1", p.M, p.N, p.K, p.KH, cfg);
         SDMI_HIP(launch_conv_gemm_fp8x(p, cfg, stream_));
         count_kernel(flops);
     } else {
@@ -1780,6 +1814,7 @@ void Engine::launch_fp8(ConvGemm& p, double flops) {
         p.slabs = slab.f();
         {
             ProfScope ps(this, PC_CONV_FP8, flops, fp8_bytes);
+            ps.set_tag("gemm_fp8 %d,%d,%d k%d cfg=%d splits=%d", p.M, p.N, p.K, p.KH, cfg, splits);
             SDMI_HIP(launch_conv_gemm_fp8x(p, cfg, stream_));
         }
         count_kernel(flops);

@@ -345,15 +345,22 @@ public:
     void prof_flush();
     void prof_calibrate();
     double prof_overhead_ms_ = 0;    // what an empty event pair reads (subtracted from every sample)
-    void prof_reset() { prof_flush(); for (auto& p : prof_) p = ProfStat{}; }
+    void prof_reset() { prof_flush(); for (auto& p : prof_) p = ProfStat{}; prof_tags_.clear(); }
+    // option "profile=2": the same samples also accumulated per launch TAG (class + shape + tile choice), option dump_profile_tags writes them:
+    // where inside a class the time goes (tools/shape_times.py)
+    std::map<std::string, ProfStat> prof_tags_;
 
 private:
     struct ProfScope {
-        Engine* e; int cls; double flops, bytes; int n_launch; hipEvent_t a = nullptr, b = nullptr;
+        Engine* e; int cls; double flops, bytes; int n_launch; hipEvent_t a = nullptr, b = nullptr; int tag = -1;
         ProfScope(Engine* e_, int cls_, double flops_ = 0, double bytes_ = 0, int n_launch_ = 1);    // n_launch: kernels inside the scope (GroupNorm: statistics + apply)
         ~ProfScope();
+        void set_tag(const char* fmt, ...) __attribute__((format(printf, 2, 3)));   // no-op unless profile=2
     };
-    struct ProfPending { int cls; hipEvent_t a, b; double flops, bytes; int n_launch; };
+    struct ProfPending { int cls; hipEvent_t a, b; double flops, bytes; int n_launch; int tag; };
+    bool prof_tagging_ = false;
+    std::vector<std::string> prof_tag_names_;
+    std::map<std::string, int> prof_tag_ids_;
     hipEvent_t prof_event();
     bool profiling_ = false;
     std::vector<hipEvent_t> prof_free_;
@@ -437,6 +444,7 @@ private:
     int opt_force_tile_ = -1;
     int opt_force_splits_ = 0;
     int opt_attn_bf16_ = 1;
+    int opt_attn_bf16_variant_ = 0;   // k_attn_bf16.hip: bit 0 = 4-wave workgroups, two per CU (AttnParams::variant)
     int opt_geglu_fuse_ = 1;    // GEGLU gate in the projection GEMM's epilogue: 0 never, 1 where there are >= 4 rounds of tiles, 2 / 3 always (256x128 / 256x256 tiles; tests)
     int opt_attn_split_ = 1;    // precision = 0: 1 = d_head 40 / 80 attention on the bf16 matrix pipe with three-way split operands (k_attn_split.hip)
     int opt_gemm_f32s_ = 1;     // precision = 0: 1 = fp32 GEMMs on the bf16 matrix pipe (three-way operand split, k_gemm3x.hip) where faster

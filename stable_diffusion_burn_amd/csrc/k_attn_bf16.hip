@@ -84,8 +84,10 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));  // v_cvt_pk_bf16_f32 (RNE)
 }
 
-template <int D, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) {
+// WPE (round 6): waves per SIMD the register budget is cut for -- 2 with NW = 4 lets TWO 4-wave workgroups share a CU (2 x 77.8 KB of LDS at d = 40), each with its own
+// barrier, so the two waves of a SIMD are in different phases of their tiles (one in its matrix instructions while the other exponentiates / stages / reads fragments)
+template <int D, int NW, int WPE = 1>
+__global__ __launch_bounds__(NW * 64, WPE) void attn_bf16_kernel(const AttnParams p) {
     using Cfg = AttnBfCfg<D, NW>;
     constexpr int NT = Cfg::NT, BKV = Cfg::BKV, KS = Cfg::KS, NDT = Cfg::NDT, RSK = Cfg::RSK, RSV = Cfg::RSV, NLD = Cfg::NLD;
     constexpr int KT = Cfg::KT, ST = Cfg::ST;
@@ -326,9 +328,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_kernel(const AttnParams p) 
     }
 }
 
-template <int D, int NW>
+template <int D, int NW, int WPE = 1>
 static hipError_t launch_attn_bf16_d(const AttnParams& p, hipStream_t stream) {
-    auto k = attn_bf16_kernel<D, NW>;
+    auto k = attn_bf16_kernel<D, NW, WPE>;
     const size_t lds = AttnBfCfg<D, NW>::LDS_BYTES;
     if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds); e != hipSuccess) return e;
     dim3 grid((p.nq + 32 * NW - 1) / (32 * NW), p.n * p.n_head);
@@ -340,6 +342,9 @@ template <int D>
 static hipError_t launch_attn_bf16_any(const AttnParams& p, hipStream_t stream) {
     // widest workgroup that still gives every CU a workgroup (256 CUs)
     const long long bh = (long long)p.n * p.n_head;
+    if constexpr (D == 40 || D == 80) {
+        if ((p.variant & 1) && (long long)((p.nq + 127) / 128) * bh >= 512) return launch_attn_bf16_d<D, 4, 2>(p, stream);
+    }
     if ((long long)((p.nq + 255) / 256) * bh >= 256) return launch_attn_bf16_d<D, 8>(p, stream);
     if ((long long)((p.nq + 127) / 128) * bh >= 256) return launch_attn_bf16_d<D, 4>(p, stream);
     return launch_attn_bf16_d<D, 2>(p, stream);

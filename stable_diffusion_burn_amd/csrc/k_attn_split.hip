@@ -230,6 +230,10 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
     f32x16 negm;              // LG: -m in every register (m = the row's reference maximum, log2 units; 0 before the first tile)
 #pragma unroll
     for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+    // round 6: the 8-wave d = 80 form holds 256 registers; there -m is ONE register, copied into a score tile's accumulator input in front of its first instruction
+    // (32 v_mov per 64-key tile beside ~ 700 vector instructions) instead of sixteen live ones -- the same values, and the two spilled registers are gone
+    constexpr bool NEGM1 = LG && D == 80 && NW == 8;
+    float negm1 = 0.f;
 
     // per-lane LDS offsets: K fragment row c, chunk hi; V transpose-read row 4 hi + (i >> 2), columns 16 (G & 1) + 4 (i & 3)
     const int k_off = c * RSK + hi * 16;
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = LG ? negm[r] : 0.f;
+            for (int r = 0; r < 16; ++r) s[kt][r] = LG ? (NEGM1 ? negm1 : negm[r]) : 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             u32x4 kf[KT][3];
@@ -316,8 +320,11 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
 #pragma unroll
                     for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
                 }
+                if constexpr (NEGM1) negm1 -= delta;
+                else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) negm[r] -= delta;
+                    for (int r = 0; r < 16; ++r) negm[r] -= delta;
+                }
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
     }
 
     if constexpr (LG) l_run = hi ? 0.f : o[NDT - 1][SUM_R];    // the ones column's row of O^T: the whole row sum, in the lane with hi = 0
-    const float m_log2 = LG ? (t_begin < t_end ? -negm[0] : -INFINITY) : m_run * cs;
+    const float m_log2 = LG ? (t_begin < t_end ? -(NEGM1 ? negm1 : negm[0]) : -INFINITY) : m_run * cs;
     if (n_split > 1) {   // a key slice: unnormalised rows + (maximum in log2 units, row sum) for launch_attention_combine
         const float l_tot = sp_partner_sum(l_run);
         if (q_ok) {
@@ -461,7 +468,9 @@ static hipError_t launch_attn_split_any(const AttnParams& p, hipStream_t stream)
         }
     }
     if (p.pack_tail & 2) return w8 ? launch_attn_split_d<D, 8, false, true>(p, stream) : launch_attn_split_d<D, 4, false, true>(p, stream);
-    return w8 ? launch_attn_split_d<D, 8, false, false>(p, stream) : launch_attn_split_d<D, 4, false, false>(p, stream);
+    // round 4's softmax (the A/B form, attn_pack_tail bit 1 = 0): its 8-wave d = 80 instantiation needs 260 registers (it spilled 4); that form runs 4-wave workgroups at d = 80
+    if constexpr (D == 80) return launch_attn_split_d<D, 4, false, false>(p, stream);
+    else return w8 ? launch_attn_split_d<D, 8, false, false>(p, stream) : launch_attn_split_d<D, 4, false, false>(p, stream);
 }
 
 bool attn_split_supported(const AttnParams& p) {

@@ -342,6 +342,7 @@ hipError_t launch_conv_gemm3x(const ConvGemm& p, int cfg, hipStream_t stream) {
     if (cfg < 0 || cfg >= kNumGemmTilesS) return hipErrorInvalidValue;
     if ((p.Cin % 32) || p.CS != 32 || !p.zero_page || !p.Bt3 || p.out_mode != 0) return hipErrorInvalidValue;
     const bool odd_ni = (cfg == 0 || cfg == 1 || cfg == 4);
+    if (p.geglu != 0 && p.geglu != 1) return hipErrorInvalidValue;   // the wave-column form (geglu = 2) exists in k_gemm3p.hip only: this kernel's weight-piece mapping is the interleaved form
     if (p.geglu && (odd_ni || p.splits != 1 || (p.N & 7) || (p.ldc & 7) || p.rowvec || p.resid)) return hipErrorInvalidValue;
     if ((unsigned long long)p.N * (p.geglu ? 2 : 1) * (unsigned long long)p.kt_total * 192ull >= 0xFFFFFF00ull) return hipErrorInvalidValue;   // 32-bit piece offsets
     const int bm = kTilesS[cfg].bm, bn = kTilesS[cfg].bn;

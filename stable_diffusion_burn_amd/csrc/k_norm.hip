@@ -42,10 +42,10 @@ struct GnGeom { int cq, R, threads, chunks, rows_per_chunk; };
 
 // min_wgs > 0 (round 5, option gn32_min_wgs): at least that many workgroups over the n samples, where the tensor has the rows -- a batch-1 tensor cut by size alone
 // (80 chunks x 2 samples) leaves 96 CUs without a workgroup, and the apply pass is bound by the busy CUs' store path
-// bytes per chunk of the STATISTICS pass (option gn32_stats_chunk_kb; a process-wide A/B switch): larger than the apply pass's 64 KB -- every apply workgroup merges all
-// chunk partials of its sample, so fewer partials shorten the latency chain in front of its first store (profiles/r05o, r05p: 64 -> 128 KB, class -1.4 %)
-static int g_gn32_stats_chunk_kb = 128;
-void launch_group_norm_tune(int stats_chunk_kb) { g_gn32_stats_chunk_kb = stats_chunk_kb > 0 ? stats_chunk_kb : 128; }
+// bytes per chunk of the STATISTICS pass: larger than the apply pass's 64 KB -- every apply workgroup merges all chunk partials of its sample, so fewer partials
+// shorten the latency chain in front of its first store (profiles/r05o, r05p: 64 -> 128 KB, class -1.4 %).  A constant since round 6 (round 5's process-wide probe
+// switch could select a cut finer than gn_partials_bytes() sizes the buffer for).
+constexpr int kGn32StatsChunkKb = 128;
 static inline GnGeom gn_geom(int hw, int c, int n = 1, int min_wgs = 0, int chunk_kb = 64) {
     GnGeom g;
     g.cq = c / 4;
@@ -67,7 +67,7 @@ static inline GnGeom gn_geom(int hw, int c, int n = 1, int min_wgs = 0, int chun
 
 size_t gn_partials_bytes(int n, int hw, int c, int min_wgs) {
     const int min_apply = min_wgs & 0xFFFF, min_stats = (min_wgs >> 16) ? (min_wgs >> 16) - 1 : min_apply;
-    return (size_t)n * gn_geom(hw, c, n, min_stats, 16).chunks * 64 * 2 * sizeof(double);   // (room for any statistics cut the probe switch can select)
+    return (size_t)n * gn_geom(hw, c, n, min_stats, kGn32StatsChunkKb).chunks * 64 * 2 * sizeof(double);   // the cut launch_group_norm_any makes
 }
 
 // Partial statistics of one (sample, chunk, group): part[((smp*chunks + chunk)*G + g)*2 + {0: mean, 1: M2}]
@@ -199,7 +199,7 @@ static hipError_t launch_group_norm_any(const float* x, void* y, bool planes, co
     // min_wgs: low 16 bits = the apply pass's minimum workgroup count, bits 16.. = the statistics pass's (0 = the same): the apply pass re-reads every chunk partial of
     // its sample in every workgroup, so the two passes need not be cut alike
     const int min_apply = min_wgs & 0xFFFF, min_stats = (min_wgs >> 16) ? (min_wgs >> 16) - 1 : min_apply;
-    const GnGeom gs = gn_geom(hw, c, n, min_stats, g_gn32_stats_chunk_kb), g = gn_geom(hw, c, n, min_apply);
+    const GnGeom gs = gn_geom(hw, c, n, min_stats, kGn32StatsChunkKb), g = gn_geom(hw, c, n, min_apply);
     double* part = reinterpret_cast<double*>(partials);
     const size_t lds = (size_t)(2 * gs.R + 1) * c * sizeof(float) + (size_t)2 * c * sizeof(double);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(gs.chunks, n), dim3(gs.threads), lds, stream, x, hw, c, ldx, n_group,

@@ -153,6 +153,7 @@ struct AttnParams {
     int kv_splits;
     float* part_o;                      // [S][n][nq][n_head * d_head]
     float* part_ml;                     // [S][n][n_head][nq][2]
+    int variant;                        // k_attn_bf16.hip (option attn_bf16_variant): bit 0 = 4-wave workgroups, TWO per CU (independent barriers: the two waves of a SIMD drift out of phase)
     int pack_tail;                      // k_attn_split.hip, d = 40: the packed form of the head's last 8 columns (kernel header); 0 = the six-instruction form (A/B, tests)
 };
 bool attn_supported_head_dim(int d);
@@ -176,7 +177,6 @@ hipError_t launch_softmax_rows(float* x, int rows, int cols, float scale, hipStr
 // ---- normalisation (HBM-bound class) --------------------------------------------
 // GroupNorm (+SiLU) over NHWC: stats pass (per-chunk partial sums) + apply pass.
 // `partials` needs gn_partials_bytes(n, hw, c) bytes of scratch.
-void launch_group_norm_tune(int stats_chunk_kb);   // probe switch: bytes per statistics chunk (default 64 KB)
 size_t gn_partials_bytes(int n, int hw, int c, int min_wgs = 0);    // min_wgs: k_norm.hip gn_geom (option gn32_min_wgs)
 // ldx: elements between pixels of x (>= c; x may be a channel slice of a wider buffer); y is dense [n][hw][c]
 hipError_t launch_group_norm(const float* x, float* y, const float* gamma, const float* beta,

@@ -108,10 +108,16 @@ class StableDiffusion:
         cfg.clip_ctx = config.clip_ctx
         self._ctx = C.c_void_p()
         check(self._lib.sdmi_create(C.byref(self._ctx), C.byref(cfg)))
-        # SDMI_OPTS="key=value key=value": engine options applied to every context of the process (A/B runs of the test suite under another kernel setting)
+        # every option this context was given, in order (bench.py prints the non-default ones next to its figures: `applied_options`)
+        self.applied_options: list[tuple[str, str]] = []
+        # SDMI_OPTS="key=value key=value": engine options applied to every context of the process (A/B runs of the test suite under another kernel setting).
+        # A malformed entry is an error, not a silent no-op: a stale variable must not change a published figure unnoticed.
         for kv in os.environ.get("SDMI_OPTS", "").split():
-            k, _, v = kv.partition("=")
+            k, eq, v = kv.partition("=")
+            if not k or not eq:
+                raise ValueError(f"SDMI_OPTS: '{kv}' is not key=value")
             self.set_option(k, v)
+        self.options_from_env = list(self.applied_options)
         self.unet = UNet(self)
         self.autoencoder = Autoencoder(self)
         self.clip = CLIP(self)
@@ -310,8 +316,13 @@ class StableDiffusion:
     def synchronize(self):
         check(self._lib.sdmi_synchronize(self._ctx))
 
+    # options that change no kernel choice (measurement / dump switches): not listed as non-default settings
+    _PASSIVE_OPTIONS = ("profile", "profile_reset", "record_shapes", "dump_shapes", "dump_choices", "dump_profile_tags", "roctx")
+
     def set_option(self, key: str, value) -> None:
         check(self._lib.sdmi_set_option(self._ctx, key.encode(), str(value).encode()))
+        if hasattr(self, "applied_options") and key not in self._PASSIVE_OPTIONS:
+            self.applied_options.append((key, str(value)))
 
     def last_call_stats(self) -> dict:
         ms, nk, fl = C.c_double(), C.c_int64(), C.c_double()

@@ -71,7 +71,7 @@ def share_flat_array(make, rank: int, world: int, barrier, tag: str, directory: 
         # names left behind by a crashed earlier run (same tag = same MASTER_PORT) are removed FIRST: behind the barrier a rank maps only what this call wrote --
         # the sidecar `<path>.len` names the byte count, and a mapping of any other size is refused
         for path in paths:
-            for leftover in (path, path + ".len", path + ".tmp"):
+            for leftover in (path, path + ".len", path + ".tmp", path + ".len.tmp"):
                 try:
                     os.unlink(leftover)
                 except OSError:
@@ -86,25 +86,30 @@ def share_flat_array(make, rank: int, world: int, barrier, tag: str, directory: 
                 with os.fdopen(fd, "wb") as f:
                     arr.tofile(f)
                 os.replace(tmp, path)          # the name appears only once the file is complete
-                with open(path + ".len", "w") as f:
+                # the sidecar the same way (own fresh file, no planted link, renamed when complete): a rank that sees `<path>.len` sees a complete data file
+                fd = os.open(path + ".len.tmp", os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+                with os.fdopen(fd, "w") as f:
                     f.write(str(arr.nbytes))
+                os.replace(path + ".len.tmp", path + ".len")
                 written = path
                 break
             except OSError:
-                try:
-                    os.unlink(tmp)
-                except OSError:
-                    pass
+                for name in (tmp, path + ".len.tmp", path + ".len", path):   # nothing of a failed attempt stays behind (the multi-GB data file included)
+                    try:
+                        os.unlink(name)
+                    except OSError:
+                        pass
     barrier()
     if rank != 0:
         for path in paths:
             try:
                 with open(path + ".len") as f:
                     nbytes = int(f.read().strip())
+                have = os.path.getsize(path)
             except (OSError, ValueError):
-                continue
-            if os.path.getsize(path) != nbytes:
-                raise RuntimeError(f"share_flat_array: {path} has {os.path.getsize(path)} bytes, rank 0 wrote {nbytes}")
+                continue                       # no sidecar, or a sidecar without its data file: the next directory, then make()
+            if have != nbytes:
+                raise RuntimeError(f"share_flat_array: {path} has {have} bytes, rank 0 wrote {nbytes}")
             arr = np.memmap(path, dtype=np.float32, mode="r")
             break
         else:

@@ -163,6 +163,14 @@ def test_golden_fixtures_are_consistent():
     assert np.abs(g1["latent32"] - g1["latent64"]).max() < 1e-4
     gu = np.load(GOLD / "sd14_synth_unet.npz")
     assert np.abs(gu["eps32_t999"] - gu["eps64_t999"]).max() < 1e-5
+    # round 6: the full-resolution float image (2^-13 fixed point, tests/golden/gen_golden_rgb_full.py) is the image whose stride-4 samples and truncated u8 form
+    # the older fixture holds -- at every pixel
+    gf = np.load(GOLD / "sd14_synth_cfg2_rgb_full.npz")
+    full = gf["rgb32_q"].astype(np.float64) / float(1 << int(gf["shift"]))
+    assert full.shape == (3, 512, 512)
+    assert np.abs(full[:, ::4, ::4] - g2["rgb32_s4"]).max() <= 2.0 ** -(int(gf["shift"]) + 1) + 1e-7
+    u8f = np.clip((full + 1.0) / 2.0 * 255.0, 0, 255).astype(np.uint8).transpose(1, 2, 0)
+    assert np.abs(u8f.astype(np.int16) - g2["rgb_u8"].astype(np.int16)).max() <= 1
 
 
 @pytest.mark.slow

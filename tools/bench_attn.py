@@ -18,4 +18,12 @@ for s in SHAPES:
         sd.set_option("attn_bf16" if BF16 else "attn_split", variant)   # fp32: 0 = k_attn.hip (fp32 MFMA), 1 = k_attn_split.hip
         ms = sd.bench_attention(*s, iters=10)
         row.append(f"v{variant}: {ms * 1e3:8.1f} us {fl / ms / 1e9:6.1f} TF")
+    if BF16:   # --bf16-variants 1,2,..: k_attn_bf16.hip forms (option attn_bf16_variant), after the default (0)
+        for arg in sys.argv:
+            if arg.startswith("--bf16-variants="):
+                for bv in arg.split("=", 1)[1].split(","):
+                    sd.set_option("attn_bf16_variant", int(bv))
+                    ms = sd.bench_attention(*s, iters=10)
+                    row.append(f"variant {bv}: {ms * 1e3:8.1f} us {fl / ms / 1e9:6.1f} TF")
+                sd.set_option("attn_bf16_variant", 0)
     print(f"{str(s):34s} " + " | ".join(row), flush=True)

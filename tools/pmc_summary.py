@@ -72,7 +72,15 @@ def main():
     doc["source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py [--config N] --steps 1 --warmup 0 "
                      "--no-cpu-baseline --no-roofline --no-secondary ; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md; "
                      "Infinity-Cache hits are counted, so this is an upper bound on DRAM bytes)")
-    doc.setdefault("configs", {})[key] = {"images_in_trace": images, "commit": commit, "classes": classes}
+    # the tree the counters were collected on, as the build sees it (csrc/ sources + headers + tile tables + flags): bench.py compares it with the running tree's and
+    # marks `traffic_stale` when they differ -- the summary must be written in the same gpurun call as the passes
+    try:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from stable_diffusion_burn_amd import build as _b
+        digest = _b._digest()[:16]
+    except Exception:  # noqa: BLE001
+        digest = None
+    doc.setdefault("configs", {})[key] = {"images_in_trace": images, "commit": commit, "kernel_source_digest": digest, "classes": classes}
     if key == "fp32_b1_s20":
         doc.update({"images_in_trace": images, "commit": commit, "classes": classes,
                     "conv_gemm_hbm_bytes_per_launch": classes.get("conv_gemm", {}).get("hbm_bytes_per_launch"),
