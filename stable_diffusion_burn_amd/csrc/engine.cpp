@@ -1075,8 +1075,9 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "gn_max_threads") gn_tune_.max_threads = std::stoi(value);
     else if (key == "gn_unroll") gn_tune_.unroll = std::stoi(value);
     else if (key == "fp8_tile") opt_fp8_tile_ = (value == "auto") ? -1 : std::stoi(value);
+    else if (key == "resid_acc") opt_resid_acc_ = std::stoi(value);
     else if (key == "attn_bf16") opt_attn_bf16_ = std::stoi(value);
-    else if (key == "attn_bf16_variant") opt_attn_bf16_variant_ = std::stoi(value);
+    else if (key == "attn_bf16_variant") opt_attn_bf16_variant_ = (value == "default") ? kAttnBf16VariantDefault : std::stoi(value, nullptr, 0);
     else if (key == "attn_split") opt_attn_split_ = std::stoi(value);
     else if (key == "gemm_bf16x") opt_gemm_bf16x_ = std::stoi(value);
     else if (key == "gemm_x32") opt_gemm_x32_ = std::stoi(value);
@@ -1363,6 +1364,8 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
         return launch_conv_gemm2(q, tc.cfg, stream_);
     };
     p.slabs = nullptr;
+    // round 6: the large-tile bf16 kernels take the residual as the accumulators' initial value (k_gemm_bf16_epi.hpp gemm_acc_init_bf16) where their 8-byte loads apply
+    p.resid_acc = (opt_resid_acc_ && in_dt && tc.cfg >= 100 && p.resid && splits == 1 && !p.geglu && (p.N % 8) == 0 && (p.ldr % 4) == 0 && (p.ldc % 8) == 0) ? 1 : 0;
     const int pc = (!in_dt && tc.cfg >= 200) ? PC_CONV_SPLIT : PC_CONV_GEMM;   // k_gemm3x.hip launches are timed as their own class
     // ALGORITHMIC bytes of the launch in the formats the tensors are stored in: the source activations once, the weights once, the result once (bf16 2 B, fp32 4 B,
     // planes 6 B per element; split-K slabs and im2col / tile re-reads are not algorithmic) -- what the PMC byte counters of profiles/pmc_summary.json are held against
@@ -1796,6 +1799,7 @@ void Engine::launch_fp8(ConvGemm& p, double flops) {
     p.kt_per_split = (p.kt_total + splits - 1) / splits;
     splits = (p.kt_total + p.kt_per_split - 1) / p.kt_per_split;
     p.splits = splits;
+    p.resid_acc = (opt_resid_acc_ && p.resid && splits == 1 && (p.N % 8) == 0 && (p.ldr % 4) == 0 && (p.ldc % 8) == 0) ? 1 : 0;   // (as Engine::launch_gemm)
     if (record_shapes_) {   // option dump_choices: the MXFP8 launches are listed with their own tag, so a test can pin WHICH layers run on fp8 operands
         char ck[128];
         std::snprintf(ck, sizeof ck, "%d,%d,%d k%d s%d u%d W%d fp8 cfg=%d splits=%d", p.M, p.N, p.K, p.KH, p.stride, p.ups, p.Ws, cfg, splits);

@@ -443,8 +443,10 @@ private:
     // options
     int opt_force_tile_ = -1;
     int opt_force_splits_ = 0;
+    int opt_resid_acc_ = 1;     // precision >= 1: 1 = the large-tile kernels load a residual into the accumulators in front of the k loop (ConvGemm::resid_acc); 0 = in the epilogue (round 5)
     int opt_attn_bf16_ = 1;
-    int opt_attn_bf16_variant_ = 0;   // k_attn_bf16.hip: bit 0 = 4-wave workgroups, two per CU (AttnParams::variant)
+    static constexpr int kAttnBf16VariantDefault = 7;
+    int opt_attn_bf16_variant_ = kAttnBf16VariantDefault;   // k_attn_bf16.hip (AttnParams::variant): bit 0 = 4-wave workgroups, two per CU; bit 1 / 2 = 64 query rows per wave (d = 40) on 8- / 4-wave workgroups; 0x100 = whatever the grid (tests)
     int opt_geglu_fuse_ = 1;    // GEGLU gate in the projection GEMM's epilogue: 0 never, 1 where there are >= 4 rounds of tiles, 2 / 3 always (256x128 / 256x256 tiles; tests)
     int opt_attn_split_ = 1;    // precision = 0: 1 = d_head 40 / 80 attention on the bf16 matrix pipe with three-way split operands (k_attn_split.hip)
     int opt_gemm_f32s_ = 1;     // precision = 0: 1 = fp32 GEMMs on the bf16 matrix pipe (three-way operand split, k_gemm3x.hip) where faster

@@ -49,10 +49,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short h16;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-template <int D, int NW>
+template <int D, int NW, int QR = 1>
 struct AttnBfCfg {
     static constexpr int NT = NW * 64;
-    static constexpr int BKV = (D <= 40) ? 128 : 64;          // keys per tile: d = 40 is softmax-bound, fewer / longer iterations
+    static constexpr int BKV = (D <= 40 && QR == 1) ? 128 : 64;   // keys per tile: d = 40 is softmax-bound, fewer / longer iterations (QR = 2: two score blocks per 32 keys, 64 keys fit the registers)
     static constexpr int KT = BKV / 32;                      // 32-key score tiles per K/V tile
     static constexpr int ST = BKV / 16;                      // 16-key steps of P V
     static constexpr int DK = (D + 15) / 16 * 16;            // contraction width of K Q^T (48 / 80 / 160)
@@ -86,9 +86,12 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 
 // WPE (round 6): waves per SIMD the register budget is cut for -- 2 with NW = 4 lets TWO 4-wave workgroups share a CU (2 x 77.8 KB of LDS at d = 40), each with its own
 // barrier, so the two waves of a SIMD are in different phases of their tiles (one in its matrix instructions while the other exponentiates / stages / reads fragments)
-template <int D, int NW, int WPE = 1>
+// QR (round 6): 32-row query blocks per wave.  QR = 2: a wave owns 64 query rows -- every K / V^T fragment it reads from LDS feeds two matrix instructions (half the
+// fragment reads and half the K / V staging per score), and the two blocks' chains (K Q^T -> maximum -> exp -> V^T P^T) are independent, so a wave that waits on one
+// block's exponentials or matrix results has the other block's instructions to issue (profiles/r04z: with one block per wave the parts of a tile ADD).
+template <int D, int NW, int WPE = 1, int QR = 1>
 __global__ __launch_bounds__(NW * 64, WPE) void attn_bf16_kernel(const AttnParams p) {
-    using Cfg = AttnBfCfg<D, NW>;
+    using Cfg = AttnBfCfg<D, NW, QR>;
     constexpr int NT = Cfg::NT, BKV = Cfg::BKV, KS = Cfg::KS, NDT = Cfg::NDT, RSK = Cfg::RSK, RSV = Cfg::RSV, NLD = Cfg::NLD;
     constexpr int KT = Cfg::KT, ST = Cfg::ST;
     constexpr int CPR = D / 8;  // chunks per HBM row
@@ -105,8 +108,13 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_bf16_kernel(const AttnParam
 
     const int b = blockIdx.y / p.n_head;
     const int hh = blockIdx.y - b * p.n_head;
-    const int qrow = blockIdx.x * (32 * NW) + wave * 32 + c;
-    const bool q_ok = qrow < p.nq;
+    int qrow[QR];
+    bool q_ok[QR];
+#pragma unroll
+    for (int g = 0; g < QR; ++g) {
+        qrow[g] = blockIdx.x * (32 * NW * QR) + (wave * QR + g) * 32 + c;
+        q_ok[g] = qrow[g] < p.nq;
+    }
 
     const h16* Qh = reinterpret_cast<const h16*>(p.q) + (long long)b * p.q_bs + hh * D;
     const h16* Kh = reinterpret_cast<const h16*>(p.k) + (long long)b * p.k_bs + hh * D;
@@ -132,14 +140,16 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_bf16_kernel(const AttnParam
     }
 
     // Q^T fragments: B[k = 16 s + 8 hi + j][n = query]
-    bf16x8 qf[KS];
+    bf16x8 qf[QR][KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        const int col = 16 * s + 8 * hi;
-        if (q_ok && col < D) v = *reinterpret_cast<const u32x4*>(Qh + (long long)qrow * p.ldq + col);
-        qf[s] = __builtin_bit_cast(bf16x8, v);
-    }
+    for (int g = 0; g < QR; ++g)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            const int col = 16 * s + 8 * hi;
+            if (q_ok[g] && col < D) v = *reinterpret_cast<const u32x4*>(Qh + (long long)qrow[g] * p.ldq + col);
+            qf[g][s] = __builtin_bit_cast(bf16x8, v);
+        }
 
     u32x4 rk[NLD], rv[NLD];
     auto gload = [&](int tile) {
@@ -172,15 +182,19 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_bf16_kernel(const AttnParam
         }
     };
 
-    f32x16 o[NDT];
+    f32x16 o[QR][NDT];
+    f32x16 negm[QR];          // -m in every register: the accumulator input of K Q^T (m = the row's reference maximum, log2 units; 0 before the first tile)
+    float l_run[QR];          // d = 160 (no spare row): this lane's share of the row sum
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
+    for (int g = 0; g < QR; ++g) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-    f32x16 negm;              // -m in every register: the accumulator input of K Q^T (m = the row's reference maximum, log2 units; 0 before the first tile)
+        for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
-    float l_run = 0.f;        // d = 160 (no spare row): this lane's share of the row sum
+            for (int r = 0; r < 16; ++r) o[g][dt][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[g][r] = 0.f;
+        l_run[g] = 0.f;
+    }
 
     // per-lane LDS offsets: K fragment row c, chunk hi; V transpose-read row 4 hi + (i >> 2), columns 16 (G & 1) + 4 (i & 3)
     const int k_off = c * RSK + hi * 16;
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_bf16_kernel(const AttnParam
         // otherwise reads each fragment right in front of its MFMA and the wave sits out one LDS latency per MFMA).
         // (d = 160: ten fragments per tile -- a second set does not fit the register file; read in place as before)
         constexpr bool PF = KS <= 5;
-        f32x16 s[KT];
+        f32x16 s[QR][KT];
         bf16x8 kf[PF ? 2 : 1][KS];
         if constexpr (PF) {
 #pragma unroll
@@ -222,9 +236,12 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_bf16_kernel(const AttnParam
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) kf[0][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Kt + kt * 32 * RSK + ks * 32));
             }
-            s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PF ? (kt & 1) : 0][0], qf[0], negm, 0, 0, 0);     // s - m
 #pragma unroll
-            for (int ks = 1; ks < KS; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PF ? (kt & 1) : 0][ks], qf[ks], s[kt], 0, 0, 0);
+            for (int g = 0; g < QR; ++g) s[g][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PF ? (kt & 1) : 0][0], qf[g][0], negm[g], 0, 0, 0);     // s - m
+#pragma unroll
+            for (int ks = 1; ks < KS; ++ks)
+#pragma unroll
+                for (int g = 0; g < QR; ++g) s[g][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PF ? (kt & 1) : 0][ks], qf[g][ks], s[g][kt], 0, 0, 0);
             if constexpr (PF) __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -238,45 +255,65 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_bf16_kernel(const AttnParam
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= nk) s[kt][r] = -INFINITY;
+                    if (key >= nk) {
+#pragma unroll
+                        for (int g = 0; g < QR; ++g) s[g][kt][r] = -INFINITY;
+                    }
                 }
         }
 
-        float mt = s[0][0];
+        float mt[QR], alpha[QR];
+        bool moves = tile == 0;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kt][r]);
-        mt = partner_max(mt);         // the tile's maximum relative to m
-        float alpha = 1.0f;
-        if (tile == 0 || __any(mt > kDefer)) {   // wave-uniform: the reference maximum moves (always on the first tile, where it is still 0)
-            const float delta = tile == 0 ? mt : fmaxf(mt, 0.f);
-            if (tile != 0) {
-                alpha = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) negm[r] -= delta;
+        for (int g = 0; g < QR; ++g) {
+            float m1 = s[g][0][0];
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[kt][r] -= delta;
+                for (int r = 0; r < 16; ++r) m1 = fmaxf(m1, s[g][kt][r]);
+            mt[g] = partner_max(m1);         // the tile's maximum relative to m
+            alpha[g] = 1.0f;
+            moves = moves || mt[g] > kDefer;
+        }
+        if (tile == 0 || __any(moves)) {   // wave-uniform: a reference maximum moves (always on the first tile, where it is still 0)
+#pragma unroll
+            for (int g = 0; g < QR; ++g) {
+                const float delta = tile == 0 ? mt[g] : fmaxf(mt[g], 0.f);
+                if (tile != 0) {
+                    alpha[g] = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt) o[g][dt] *= alpha[g];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[g][r] -= delta;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[g][kt][r] -= delta;
+            }
         }
 
-        unsigned pb[ST][4];  // [16-key step][4 dwords = 8 bf16]
-        float psum = 0.f;
+        unsigned pb[QR][ST][4];  // [16-key step][4 dwords = 8 bf16]
+        float psum[QR];
+#pragma unroll
+        for (int g = 0; g < QR; ++g) psum[g] = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float e0 = __builtin_amdgcn_exp2f(s[kt][r]);
-                const float e1 = __builtin_amdgcn_exp2f(s[kt][r + 1]);
-                if constexpr (!SUMCOL) psum += e0 + e1;
-                pb[kt * 2 + (r >> 3)][(r & 7) >> 1] = pack_bf16(e0, e1);
+#pragma unroll
+                for (int g = 0; g < QR; ++g) {     // the blocks' exponentials side by side: independent instructions next to each other
+                    const float e0 = __builtin_amdgcn_exp2f(s[g][kt][r]);
+                    const float e1 = __builtin_amdgcn_exp2f(s[g][kt][r + 1]);
+                    if constexpr (!SUMCOL) psum[g] += e0 + e1;
+                    pb[g][kt * 2 + (r >> 3)][(r & 7) >> 1] = pack_bf16(e0, e1);
+                }
             }
         }
-        if constexpr (!SUMCOL) l_run = l_run * alpha + psum;
+        if constexpr (!SUMCOL) {
+#pragma unroll
+            for (int g = 0; g < QR; ++g) l_run[g] = l_run[g] * alpha[g] + psum[g];
+        }
 
         // O^T += V^T P^T, 16 keys at a time; the V^T fragments of step st + 1 are read before the MFMAs of step st (fenced, as above)
         auto read_vf = [&](bf16x8 (&vf)[NDT], int st) {
@@ -298,10 +335,13 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_bf16_kernel(const AttnParam
             } else {
                 read_vf(vf[0], st);
             }
-            const u32x4 pw = {pb[st][0], pb[st][1], pb[st][2], pb[st][3]};
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PF ? (st & 1) : 0][dt], __builtin_bit_cast(bf16x8, pw), o[dt], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < QR; ++g) {
+                    const u32x4 pw = {pb[g][st][0], pb[g][st][1], pb[g][st][2], pb[g][st][3]};
+                    o[g][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PF ? (st & 1) : 0][dt], __builtin_bit_cast(bf16x8, pw), o[g][dt], 0, 0, 0);
+                }
             if constexpr (PF) __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -309,31 +349,34 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_bf16_kernel(const AttnParam
         __syncthreads();
     }
 
-    float l_own = l_run;
-    if constexpr (SUMCOL) l_own = hi ? 0.f : o[SUM_DT][SUM_R];     // row D of O^T = sum of the probabilities
-    const float inv = 1.0f / partner_sum(l_own);
-    if (q_ok) {
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
+    for (int g = 0; g < QR; ++g) {
+        float l_own = l_run[g];
+        if constexpr (SUMCOL) l_own = hi ? 0.f : o[g][SUM_DT][SUM_R];     // row D of O^T = sum of the probabilities
+        const float inv = 1.0f / partner_sum(l_own);
+        if (q_ok[g]) {
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int dcol = 32 * dt + 8 * rq + 4 * hi;
-                if (dcol < D) {
-                    const u32x2 w = {pack_bf16(o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv),
-                                     pack_bf16(o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv)};
-                    *reinterpret_cast<u32x2*>(Oh + (long long)qrow * p.ldo + dcol) = w;
+            for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int dcol = 32 * dt + 8 * rq + 4 * hi;
+                    if (dcol < D) {
+                        const u32x2 w = {pack_bf16(o[g][dt][4 * rq] * inv, o[g][dt][4 * rq + 1] * inv),
+                                         pack_bf16(o[g][dt][4 * rq + 2] * inv, o[g][dt][4 * rq + 3] * inv)};
+                        *reinterpret_cast<u32x2*>(Oh + (long long)qrow[g] * p.ldo + dcol) = w;
+                    }
                 }
             }
         }
     }
 }
 
-template <int D, int NW, int WPE = 1>
+template <int D, int NW, int WPE = 1, int QR = 1>
 static hipError_t launch_attn_bf16_d(const AttnParams& p, hipStream_t stream) {
-    auto k = attn_bf16_kernel<D, NW, WPE>;
-    const size_t lds = AttnBfCfg<D, NW>::LDS_BYTES;
+    auto k = attn_bf16_kernel<D, NW, WPE, QR>;
+    const size_t lds = AttnBfCfg<D, NW, QR>::LDS_BYTES;
     if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds); e != hipSuccess) return e;
-    dim3 grid((p.nq + 32 * NW - 1) / (32 * NW), p.n * p.n_head);
+    dim3 grid((p.nq + 32 * NW * QR - 1) / (32 * NW * QR), p.n * p.n_head);
     hipLaunchKernelGGL(k, grid, dim3(NW * 64), lds, stream, p);
     return hipGetLastError();
 }
@@ -342,8 +385,18 @@ template <int D>
 static hipError_t launch_attn_bf16_any(const AttnParams& p, hipStream_t stream) {
     // widest workgroup that still gives every CU a workgroup (256 CUs)
     const long long bh = (long long)p.n * p.n_head;
+    // Round 6 forms (AttnParams::variant; 0x100 = tests: the form whatever the grid size).  Measured at CFG batch 16 (profiles/r06d_*, r06e_*):
+    //   bit 1  d = 40, self attention: 64 query rows per wave on 8-wave workgroups -- 64 x 64: 555 -> 476 us (619 -> 721 TFLOP/s);
+    //   bit 2  d = 40, a context of at most two 64-key tiles: the same on 4-wave workgroups, two per CU -- 4096 x 77: 50.5 -> 34.6 us;
+    //   bit 0  d = 80 (and d = 40 without bits 1 / 2): 4-wave workgroups, two per CU -- 1024 x 77: 23.2 -> 19.7 us; no gain on the self attentions, so short contexts only.
+    const bool force = (p.variant & 0x100) != 0;
+    const bool short_ctx = p.nk <= 128;
+    if constexpr (D == 40) {
+        if ((p.variant & 4) && (force ? !(p.variant & 2) : (short_ctx && (long long)((p.nq + 255) / 256) * bh >= 512))) return launch_attn_bf16_d<D, 4, 2, 2>(p, stream);
+        if ((p.variant & 2) && (force || (!short_ctx && (long long)((p.nq + 511) / 512) * bh >= 256))) return launch_attn_bf16_d<D, 8, 2, 2>(p, stream);
+    }
     if constexpr (D == 40 || D == 80) {
-        if ((p.variant & 1) && (long long)((p.nq + 127) / 128) * bh >= 512) return launch_attn_bf16_d<D, 4, 2>(p, stream);
+        if ((p.variant & 1) && (force || (short_ctx && (long long)((p.nq + 127) / 128) * bh >= 512))) return launch_attn_bf16_d<D, 4, 2>(p, stream);
     }
     if ((long long)((p.nq + 255) / 256) * bh >= 256) return launch_attn_bf16_d<D, 8>(p, stream);
     if ((long long)((p.nq + 127) / 128) * bh >= 256) return launch_attn_bf16_d<D, 4>(p, stream);

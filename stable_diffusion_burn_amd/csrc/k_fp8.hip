@@ -262,12 +262,8 @@ __global__ __launch_bounds__(512) void conv_gemm_fp8x_kernel(const ConvGemm p) {
     const int bs_base = SCALE_OFF + BM * 4 + (wn * 16 * NI + c15) * 4 + g4;
 
     f32x4 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     issue(0);
+    gemm_acc_init_bf16<MI, NI, WM, WN>(p, acc, m0, n0, wave, lane);   // zero, or the residual tile (ConvGemm::resid_acc), behind the first k tile's DMA
     for (int t = 0; t < n_t; ++t) {
         const int cur = t & 1;
         __syncthreads();                    // k tile t (operands and scales) is in LDS; every wave is done with stage cur ^ 1

@@ -29,6 +29,37 @@ __device__ __forceinline__ unsigned xpack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bepi_bf16x2));
 }
 
+// The accumulators' initial value: zero, or (ConvGemm::resid_acc, round 6) the residual tile -- C = R + A B with R read in the accumulators' own layout (lane (c, g) of
+// fragment (mi, ni): row c, columns 4 g .. 4 g + 3: one 8-byte load of four bf16) in FRONT of the k loop, where its latency hides behind the first k tile's DMA, instead
+// of in the epilogue, where every fragment group of the residual path waited out its own loads (profiles/r04ae: N = 320, K = 320 at M = 131 072: 48.9 us without a
+// residual, 80 us with one).  The epilogue then takes its no-residual paths (2-byte scratch, persistent tile loop).  Needs N % 4 == 0 and ldr % 4 == 0 (launcher).
+template <int MI, int NI, int WM, int WN, bool MAY_RESID = true>
+__device__ __forceinline__ void gemm_acc_init_bf16(const ConvGemm& p, bepi_f32x4 (&acc)[MI][NI], const int m0, const int n0, const int wave, const int lane) {
+    if (!MAY_RESID || !p.resid_acc) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = bepi_f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
+    const int c15 = lane & 15, g4 = lane >> 4;
+    const unsigned short* Rh = reinterpret_cast<const unsigned short*>(p.resid);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + (wm * MI + mi) * 16 + c15;
+        const unsigned short* row = Rh + (long long)(m < p.M ? m : 0) * p.ldr;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + (wn * NI + ni) * 16 + g4 * 4;
+            // (rows / columns past the tile's extent read the zero page: a pointer select, no predicated load)
+            const bepi_u32x2 rr = *reinterpret_cast<const bepi_u32x2*>((m < p.M && n < p.N) ? reinterpret_cast<const void*>(row + n) : p.zero_page);
+            acc[mi][ni] = bepi_f32x4{xbf16_lo(rr[0]), xbf16_hi(rr[0]), xbf16_lo(rr[1]), xbf16_hi(rr[1])};
+        }
+    }
+}
+
 // pre_synced: the caller has already passed a workgroup barrier behind the last k tile (the persistent kernel, which issues the next tile's first DMA between that
 //             barrier and this epilogue) -- smem_x is then the stage the next tile does NOT land in.
 // MODE: -1 = every decision below is taken at run time from p (the one-tile-per-workgroup kernels); 0 / 2 = bf16 output through the 16-byte paths, known at compile
@@ -56,7 +87,7 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4
     unsigned short* Ch = reinterpret_cast<unsigned short*>(p.C);
     const unsigned short* Rh = reinterpret_cast<const unsigned short*>(p.resid);
     const int ldc = split ? p.N : p.ldc;
-    const bool has_resid = MODE < 0 ? (!split && p.resid) : false;
+    const bool has_resid = MODE < 0 ? (!split && p.resid && !p.resid_acc) : false;   // (resid_acc: already in the accumulators)
     const bool vec_ok = MODE < 0 ? (((p.N & 7) == 0) && ((ldc & 7) == 0) && ((p.ldr & 7) == 0 || !has_resid)) : true;
     constexpr int LDSW = WNC + 4;       // scratch row stride in floats (336 B for NI = 5: 16-byte aligned, rows on distinct banks)
     if (geglu) {   // launch-side guarantees: NI even, no split-K, N % 8 == 0, ldc % 8 == 0, no rowvec / residual
@@ -288,7 +319,7 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4
                     if (!split) {
                         if (p.bias) sv += p.bias[n + r];
                         if (p.rowvec) sv += p.rowvec[(long long)smp * p.rowvec_stride + n + r];
-                        if (p.resid) sv += __uint_as_float((unsigned)Rh[(long long)m * p.ldr + n + r] << 16);
+                        if (p.resid && !p.resid_acc) sv += __uint_as_float((unsigned)Rh[(long long)m * p.ldr + n + r] << 16);
                     }
                     if (out_f32) Cf[(long long)m * ldc + n + r] = sv;
                     else Ch[(long long)m * ldc + n + r] = (unsigned short)xf32_to_bf16_bits(sv);

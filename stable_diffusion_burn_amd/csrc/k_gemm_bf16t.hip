@@ -131,10 +131,6 @@ __global__ __launch_bounds__(512) void conv3_gemm_bf16t_kernel(const ConvGemm p)
     const int fb_off1 = c15 * 128 + (((4 + g4) ^ (c15 & 7)) << 4);
 
     f32x4 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // k tile t of this slice = tap kx = t % 3 of kernel row g = t / 3 = (cs, ky) with cs = kt / 9, ky = (kt % 9) / 3
     int kt = kt_begin;
@@ -144,6 +140,7 @@ __global__ __launch_bounds__(512) void conv3_gemm_bf16t_kernel(const ConvGemm p)
 #pragma unroll
     for (int j = 0; j < NAJ; ++j) issue_a(j, cs, ky, 0);
     issue_b(kt, kt & 1);
+    gemm_acc_init_bf16<MI, NI, WM, WN>(p, acc, m0, n0, wave, lane);   // zero, or the residual tile (ConvGemm::resid_acc), behind the first DMAs
     const int n_t = 3 * n_g;
     for (int t = 0; t < n_t; ++t) {
         __syncthreads();                                     // everything issued so far has landed (k tile kt, this kernel row's activations); the buffers written next are free

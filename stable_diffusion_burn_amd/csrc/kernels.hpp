@@ -51,6 +51,8 @@ struct ConvGemm {
     const void* b_scale;        // fp8 kernel: E8M0 scales of Bt, [N][b_ld / 32] bytes
     int variant;                // k_gemm3x.hip A/B switches (option gemm3x_variant): bit 0 DMA issued in one block per k tile, 1 scalar residual subtractions,
                                 // 2 two LDS stages on the 128-row tiles, 4 s_setprio 1 for waves 4-7; k_gemm_bf16x.hip (option gemm_bf16x_variant): bit 0 persistent tile loop
+    int resid_acc;              // large-tile bf16 / MXFP8 kernels (round 6): the (bf16) residual is loaded INTO THE ACCUMULATORS in front of the k loop (C = R + A B) instead of
+                                // being read by the epilogue one fragment group at a time -- eight exposed load latencies per 256-row tile there; set by Engine::launch_gemm / launch_fp8
     int geglu;                  // large-tile kernels: Bt holds 2 N rows (N value rows, then N gate rows; bias likewise) and the
                                 // epilogue writes value * gelu_erf(gate) -- GEGLU::forward (unet/mod.rs:579-591) without the [M, 2N] tensor
     unsigned long long* probe;  // diagnostic (option gemm_probe; k_gemm3p.hip tiles 300 / 303 / 304 only): when non-null the PROBE instantiation runs and

@@ -266,15 +266,43 @@ def test_qkv_attention_bf16(ops16, case, mfma16):
     _check(got, ref, f"qkv_attention bf16 {case}", 2 ** -7 if heads > 1 else 2 ** -6)
 
 
+@pytest.mark.parametrize("case", [(2, 256, 256, 320, 8), (2, 256, 77, 320, 8), (3, 2048, 512, 320, 8), (4, 2048, 192, 320, 8), (2, 50, 100, 320, 8), (1, 300, 333, 320, 8),
+                                  (2, 64, 2, 320, 8), (1, 700, 130, 320, 8), (2, 1024, 1024, 640, 8), (2, 50, 100, 640, 8)])
+@pytest.mark.parametrize("variant", [1, 2, 4])
+def test_qkv_attention_bf16_variants(ops16, case, variant):
+    """Round 6, option attn_bf16_variant (k_attn_bf16.hip): bit 0 = two 4-wave workgroups per CU, bit 1 = 64 query rows per wave (two score blocks sharing every K / V^T fragment)
+    on 8-wave workgroups, bit 2 = the same on 4-wave workgroups; 0x100 forces the form whatever the grid.  Same products and the same per-row softmax as the default form
+    (the two-block forms walk 64-key tiles instead of 128-key ones, so a row's reference maximum may move at other keys): the operator's 2^-7 bar against the oracle, and
+    agreement with the default form to the same bar.  Ragged query and key counts, one-tile and two-key contexts included; head dims without the form fall back to the default."""
+    n, nq, nk, c, heads = case
+    ops16.set_option("attn_bf16", 1)
+    g = np.random.default_rng(hash(case) % (2 ** 31))
+    q, k, v = (bf16_round(g.standard_normal((n, s, c))) for s in (nq, nk, nk))
+    ref = O.qkv_attention(_t(q), _t(k), _t(v), None, heads).numpy()
+    try:
+        ops16.set_option("attn_bf16_variant", 0)
+        base = ops16.qkv_attention(q, k, v, None, heads)
+        ops16.set_option("attn_bf16_variant", 0x100 | variant)
+        got = ops16.qkv_attention(q, k, v, None, heads)
+    finally:
+        ops16.set_option("attn_bf16_variant", "default")
+    _check(got, ref, f"qkv_attention bf16 variant {variant} {case}", 2 ** -7)
+    assert np.abs(got.astype(np.float64) - base.astype(np.float64)).max() <= 2 ** -7 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("variant", [0, 0x102, 0x104])
 @pytest.mark.parametrize("case", [(2, 512, 1024, 320, 8), (1, 256, 700, 640, 8), (1, 128, 512, 1280, 8)])
 @pytest.mark.parametrize("gain", [4.0, 12.0])
-def test_qkv_attention_bf16_moving_maximum(ops16, case, gain):
+def test_qkv_attention_bf16_moving_maximum(ops16, case, gain, variant):
     """k_attn_bf16.hip raises its reference maximum only when a tile's maximum exceeds it by 2^8: keys ordered so that the row maxima keep
     growing tile after tile (every tile takes the rescale path at gain 12, some at gain 4), scores spread over tens of log2 units.  Rows are
     nearly one-hot here, so the oracle is given exactly the q the kernel multiplies -- bf16(q d^-0.5 log2 e), what the boundary's conversion
     produces (the rounding of that conversion is test_qkv_attention_bf16's subject) -- and the bar is the fused kernels' 2^-8."""
     n, nq, nk, c, heads = case
+    if variant and c // heads != 40:
+        pytest.skip("the two-block forms are d = 40 instantiations")
     ops16.set_option("attn_bf16", 1)
+    ops16.set_option("attn_bf16_variant", variant)
     g = np.random.default_rng(int(gain) + nk)
     q = bf16_round(g.standard_normal((n, nq, c)))
     k = bf16_round(g.standard_normal((n, nk, c)) * np.linspace(0.2, gain, nk)[None, :, None])      # later keys score higher in magnitude
@@ -283,6 +311,7 @@ def test_qkv_attention_bf16_moving_maximum(ops16, case, gain):
     f = np.float32(1.4426950408889634 / math.sqrt(c // heads))       # kernels.hpp attn_bf16_q_scale
     q_seen = bf16_round(q * f).astype(np.float64) / np.float64(f)
     ref = O.qkv_attention(_t(q_seen), _t(k), _t(v), None, heads).numpy()
+    ops16.set_option("attn_bf16_variant", "default")
     assert np.isfinite(got).all()
     _check(got, ref, f"qkv_attention bf16 moving maximum {case} gain={gain}", 2 ** -8)
 
