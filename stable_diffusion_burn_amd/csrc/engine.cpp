@@ -1365,7 +1365,12 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     };
     p.slabs = nullptr;
     // round 6: the large-tile bf16 kernels take the residual as the accumulators' initial value (k_gemm_bf16_epi.hpp gemm_acc_init_bf16) where their 8-byte loads apply
-    p.resid_acc = (opt_resid_acc_ && in_dt && tc.cfg >= 100 && p.resid && splits == 1 && !p.geglu && (p.N % 8) == 0 && (p.ldr % 4) == 0 && (p.ldc % 8) == 0) ? 1 : 0;
+    // (option resid_acc: bit 0 = the residual, bit 1 = bias + time-embedding row; launches without split-K only -- the split-K combine adds them otherwise)
+    p.resid_acc = 0;
+    if (in_dt && tc.cfg >= 100 && splits == 1 && (p.N % 8) == 0 && (p.ldc % 8) == 0) {
+        if ((opt_resid_acc_ & 1) && p.resid && !p.geglu && (p.ldr % 4) == 0) p.resid_acc |= 1;
+        if ((opt_resid_acc_ & 2) && (p.bias || p.rowvec) && (p.rowvec_stride % 4) == 0) p.resid_acc |= 2;
+    }
     const int pc = (!in_dt && tc.cfg >= 200) ? PC_CONV_SPLIT : PC_CONV_GEMM;   // k_gemm3x.hip launches are timed as their own class
     // ALGORITHMIC bytes of the launch in the formats the tensors are stored in: the source activations once, the weights once, the result once (bf16 2 B, fp32 4 B,
     // planes 6 B per element; split-K slabs and im2col / tile re-reads are not algorithmic) -- what the PMC byte counters of profiles/pmc_summary.json are held against
@@ -1799,7 +1804,11 @@ void Engine::launch_fp8(ConvGemm& p, double flops) {
     p.kt_per_split = (p.kt_total + splits - 1) / splits;
     splits = (p.kt_total + p.kt_per_split - 1) / p.kt_per_split;
     p.splits = splits;
-    p.resid_acc = (opt_resid_acc_ && p.resid && splits == 1 && (p.N % 8) == 0 && (p.ldr % 4) == 0 && (p.ldc % 8) == 0) ? 1 : 0;   // (as Engine::launch_gemm)
+    p.resid_acc = 0;   // (as Engine::launch_gemm)
+    if (splits == 1 && (p.N % 8) == 0 && (p.ldc % 8) == 0) {
+        if ((opt_resid_acc_ & 1) && p.resid && (p.ldr % 4) == 0) p.resid_acc |= 1;
+        if ((opt_resid_acc_ & 2) && (p.bias || p.rowvec) && (p.rowvec_stride % 4) == 0) p.resid_acc |= 2;
+    }
     if (record_shapes_) {   // option dump_choices: the MXFP8 launches are listed with their own tag, so a test can pin WHICH layers run on fp8 operands
         char ck[128];
         std::snprintf(ck, sizeof ck, "%d,%d,%d k%d s%d u%d W%d fp8 cfg=%d splits=%d", p.M, p.N, p.K, p.KH, p.stride, p.ups, p.Ws, cfg, splits);

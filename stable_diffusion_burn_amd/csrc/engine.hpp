@@ -443,7 +443,8 @@ private:
     // options
     int opt_force_tile_ = -1;
     int opt_force_splits_ = 0;
-    int opt_resid_acc_ = 1;     // precision >= 1: 1 = the large-tile kernels load a residual into the accumulators in front of the k loop (ConvGemm::resid_acc); 0 = in the epilogue (round 5)
+    int opt_resid_acc_ = 3;     // precision >= 1, large-tile kernels without split-K (ConvGemm::resid_acc): bit 0 = the residual, bit 1 = bias + time-embedding row are the accumulators'
+                                // initial value, loaded in front of the k loop; 0 = added by the epilogue (round 5)
     int opt_attn_bf16_ = 1;
     static constexpr int kAttnBf16VariantDefault = 7;
     int opt_attn_bf16_variant_ = kAttnBf16VariantDefault;   // k_attn_bf16.hip (AttnParams::variant): bit 0 = 4-wave workgroups, two per CU; bit 1 / 2 = 64 query rows per wave (d = 40) on 8- / 4-wave workgroups; 0x100 = whatever the grid (tests)

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(512) void conv_gemm_fp8x_kernel(const ConvGemm p) {
 
     f32x4 acc[MI][NI];
     issue(0);
-    gemm_acc_init_bf16<MI, NI, WM, WN>(p, acc, m0, n0, wave, lane);   // zero, or the residual tile (ConvGemm::resid_acc), behind the first k tile's DMA
+    gemm_acc_init_bf16<MI, NI, WM, WN, 0>(p, acc, m0, n0, wave, lane, HoWo);   // zero, or the residual tile (ConvGemm::resid_acc), behind the first k tile's DMA
     for (int t = 0; t < n_t; ++t) {
         const int cur = t & 1;
         __syncthreads();                    // k tile t (operands and scales) is in LDS; every wave is done with stage cur ^ 1

@@ -305,6 +305,43 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const ConvGemm 
     unsigned short* Ch = reinterpret_cast<unsigned short*>(p.C);
     const unsigned short* Rh = reinterpret_cast<const unsigned short*>(p.resid);
     const long long total = (long long)p.M * p.N;
+    // round 6: four outputs per thread (16-byte slab loads, two slices in flight), the bias / time-embedding row / residual requested in front of the slab loads;
+    // the same sums in the same order as the scalar form below (which stays for odd strides): bit-identical
+    if (((p.N | p.ldc | p.rowvec_stride) & 3) == 0 && (!p.resid || (p.ldr & 3) == 0)) {
+        typedef float rf32x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned int ru32x2 __attribute__((ext_vector_type(2)));
+        const int n4 = p.N >> 2;
+        const long long total4 = (long long)p.M * n4;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+            const int m = (int)(i / n4);
+            const int n = (int)(i - (long long)m * n4) * 4;
+            const long long off = (long long)m * p.N + n;
+            rf32x4 eb = {0.f, 0.f, 0.f, 0.f}, ev = eb, er = eb;
+            if (p.bias) eb = *reinterpret_cast<const rf32x4*>(p.bias + n);
+            if (p.rowvec) ev = *reinterpret_cast<const rf32x4*>(p.rowvec + (long long)(m / HoWo) * p.rowvec_stride + n);
+            if (p.resid) {
+                const ru32x2 rr = *reinterpret_cast<const ru32x2*>(Rh + (long long)m * p.ldr + n);
+                er = rf32x4{__uint_as_float(rr[0] << 16), __uint_as_float(rr[0] & 0xFFFF0000u), __uint_as_float(rr[1] << 16), __uint_as_float(rr[1] & 0xFFFF0000u)};
+            }
+            rf32x4 v = *reinterpret_cast<const rf32x4*>(slabs + off);
+            int sl = 1;
+            for (; sl + 1 < p.splits; sl += 2) {
+                const rf32x4 a0 = *reinterpret_cast<const rf32x4*>(slabs + (long long)sl * p.slab_stride + off);
+                const rf32x4 a1 = *reinterpret_cast<const rf32x4*>(slabs + (long long)(sl + 1) * p.slab_stride + off);
+                v += a0; v += a1;
+            }
+            if (sl < p.splits) v += *reinterpret_cast<const rf32x4*>(slabs + (long long)sl * p.slab_stride + off);
+            if (p.bias) v += eb;
+            if (p.rowvec) v += ev;
+            if (p.resid) v += er;
+            if (out_f32) *reinterpret_cast<rf32x4*>(Cf + (long long)m * p.ldc + n) = v;
+            else {
+                const ru32x2 o = {f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16), f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16)};
+                *reinterpret_cast<ru32x2*>(Ch + (long long)m * p.ldc + n) = o;
+            }
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int m = (int)(i / p.N);
         const int n = (int)(i - (long long)m * p.N);
@@ -383,7 +420,8 @@ hipError_t launch_conv_gemm_bf16(const ConvGemm& p, int cfg, hipStream_t stream)
 }
 
 hipError_t launch_splitk_reduce_bf16(const ConvGemm& p, hipStream_t stream) {
-    const long long work = (long long)p.M * p.N;
+    const bool vec = ((p.N | p.ldc | p.rowvec_stride) & 3) == 0 && (!p.resid || (p.ldr & 3) == 0);    // the kernel's 16-byte path: four outputs per thread
+    const long long work = (long long)p.M * p.N / (vec ? 4 : 1);
     int blocks = (int)((work + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;

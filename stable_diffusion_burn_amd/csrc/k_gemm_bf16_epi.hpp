@@ -29,13 +29,21 @@ __device__ __forceinline__ unsigned xpack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bepi_bf16x2));
 }
 
-// The accumulators' initial value: zero, or (ConvGemm::resid_acc, round 6) the residual tile -- C = R + A B with R read in the accumulators' own layout (lane (c, g) of
-// fragment (mi, ni): row c, columns 4 g .. 4 g + 3: one 8-byte load of four bf16) in FRONT of the k loop, where its latency hides behind the first k tile's DMA, instead
-// of in the epilogue, where every fragment group of the residual path waited out its own loads (profiles/r04ae: N = 320, K = 320 at M = 131 072: 48.9 us without a
-// residual, 80 us with one).  The epilogue then takes its no-residual paths (2-byte scratch, persistent tile loop).  Needs N % 4 == 0 and ldr % 4 == 0 (launcher).
-template <int MI, int NI, int WM, int WN, bool MAY_RESID = true>
-__device__ __forceinline__ void gemm_acc_init_bf16(const ConvGemm& p, bepi_f32x4 (&acc)[MI][NI], const int m0, const int n0, const int wave, const int lane) {
-    if (!MAY_RESID || !p.resid_acc) {
+// The accumulators' initial value (round 6): zero, or -- ConvGemm::resid_acc, set by the engine for launches without split-K -- what the epilogue used to ADD from
+// global memory: bit 0 = the (bf16) residual tile, bit 1 = bias + time-embedding row.  C = (bias + rowvec + R) + A B, read in the accumulators' own layout (lane (c, g) of
+// fragment (mi, ni): row c, columns 4 g .. 4 g + 3: one 8-byte load of four bf16 / one 16-byte load of four floats) in FRONT of the k loop, where the latency hides
+// behind the first k tile's DMA, instead of in the epilogue, where every 16-row fragment group waited out its own loads (profiles/r04ae: N = 320, K = 320 at
+// M = 131 072: 48.9 us without a residual, 80 us with one; profiles/r06g: +2.6 % per bf16 image).  The epilogue then issues no global load at all and takes its
+// no-residual paths (2-byte scratch, persistent tile loop).  Needs N % 4 == 0, ldr % 4 == 0, rowvec_stride % 4 == 0 (engine).
+// GEGLU_T: -1 = p.geglu at run time, 0 / 1 = known at compile time (fragment ni even = value columns, odd = their gate columns; bias rows N apart).
+template <int MI, int NI, int WM, int WN, int GEGLU_T = -1>
+__device__ __forceinline__ void gemm_acc_init_bf16(const ConvGemm& p, bepi_f32x4 (&acc)[MI][NI], const int m0, const int n0, const int wave, const int lane,
+                                                   const int HoWo) {
+    const bool geglu = GEGLU_T < 0 ? p.geglu != 0 : GEGLU_T == 1;
+    const bool with_r = GEGLU_T != 1 && (p.resid_acc & 1);
+    const bool with_b = (p.resid_acc & 2) && p.bias;
+    const bool with_v = GEGLU_T != 1 && (p.resid_acc & 2) && p.rowvec;
+    if (!with_r && !with_b && !with_v) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -46,16 +54,33 @@ __device__ __forceinline__ void gemm_acc_init_bf16(const ConvGemm& p, bepi_f32x4
     const int wn = wave - wm * WN;
     const int c15 = lane & 15, g4 = lane >> 4;
     const unsigned short* Rh = reinterpret_cast<const unsigned short*>(p.resid);
+    // per-column terms first (the same for every fragment row): NI 16-byte loads
+    bepi_f32x4 colv[NI];
+    int ncol[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int n = geglu ? n0 + wn * (8 * NI) + (ni >> 1) * 16 + g4 * 4 : n0 + (wn * NI + ni) * 16 + g4 * 4;
+        ncol[ni] = n;
+        colv[ni] = bepi_f32x4{0.f, 0.f, 0.f, 0.f};
+        if (with_b) colv[ni] = *reinterpret_cast<const bepi_f32x4*>(n < p.N ? reinterpret_cast<const void*>(p.bias + n + ((geglu && (ni & 1)) ? p.N : 0)) : p.zero_page);
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + (wm * MI + mi) * 16 + c15;
-        const unsigned short* row = Rh + (long long)(m < p.M ? m : 0) * p.ldr;
+        const int mm = m < p.M ? m : 0;
+        const unsigned short* row = Rh + (long long)mm * p.ldr;
+        const float* rv = with_v ? p.rowvec + (long long)(mm / HoWo) * p.rowvec_stride : nullptr;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const int n = n0 + (wn * NI + ni) * 16 + g4 * 4;
+            const int n = ncol[ni];
+            bepi_f32x4 v = colv[ni];
             // (rows / columns past the tile's extent read the zero page: a pointer select, no predicated load)
-            const bepi_u32x2 rr = *reinterpret_cast<const bepi_u32x2*>((m < p.M && n < p.N) ? reinterpret_cast<const void*>(row + n) : p.zero_page);
-            acc[mi][ni] = bepi_f32x4{xbf16_lo(rr[0]), xbf16_hi(rr[0]), xbf16_lo(rr[1]), xbf16_hi(rr[1])};
+            if (with_v) v += *reinterpret_cast<const bepi_f32x4*>(n < p.N ? reinterpret_cast<const void*>(rv + n) : p.zero_page);
+            if (with_r) {
+                const bepi_u32x2 rr = *reinterpret_cast<const bepi_u32x2*>((m < p.M && n < p.N) ? reinterpret_cast<const void*>(row + n) : p.zero_page);
+                v += bepi_f32x4{xbf16_lo(rr[0]), xbf16_hi(rr[0]), xbf16_lo(rr[1]), xbf16_hi(rr[1])};
+            }
+            acc[mi][ni] = v;
         }
     }
 }
@@ -87,7 +112,7 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4
     unsigned short* Ch = reinterpret_cast<unsigned short*>(p.C);
     const unsigned short* Rh = reinterpret_cast<const unsigned short*>(p.resid);
     const int ldc = split ? p.N : p.ldc;
-    const bool has_resid = MODE < 0 ? (!split && p.resid && !p.resid_acc) : false;   // (resid_acc: already in the accumulators)
+    const bool has_resid = MODE < 0 ? (!split && p.resid && !(p.resid_acc & 1)) : false;   // (resid_acc bit 0: already in the accumulators)
     const bool vec_ok = MODE < 0 ? (((p.N & 7) == 0) && ((ldc & 7) == 0) && ((p.ldr & 7) == 0 || !has_resid)) : true;
     constexpr int LDSW = WNC + 4;       // scratch row stride in floats (336 B for NI = 5: 16-byte aligned, rows on distinct banks)
     if (geglu) {   // launch-side guarantees: NI even, no split-K, N % 8 == 0, ldc % 8 == 0, no rowvec / residual
@@ -100,7 +125,7 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4
             auto gate = [&](int mi, int j) {
                 const int n = nw0 + j * 16 + g4 * 4;
                 f32x4 v = acc[mi][2 * j], g = acc[mi][2 * j + 1];
-                if (p.bias && n < p.N) {
+                if (p.bias && !(p.resid_acc & 2) && n < p.N) {     // (resid_acc bit 1: already in the accumulators)
                     v += *reinterpret_cast<const f32x4*>(p.bias + n);
                     g += *reinterpret_cast<const f32x4*>(p.bias + p.N + n);
                 }
@@ -183,7 +208,7 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4
             for (int ni = 0; ni < NI; ++ni) {
                 const int n = nw0 + ni * 16 + g4 * 4;
                 f32x4 v = acc[mi][ni];
-                if (!split && n < p.N) {
+                if (!split && !(p.resid_acc & 2) && n < p.N) {
                     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
                     if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)smp * p.rowvec_stride + n);
                 }
@@ -206,7 +231,7 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4
                 for (int ni = 0; ni < NI; ++ni) {
                     const int n = nw0 + ni * 16 + g4 * 4;
                     f32x4 v = acc[mi][ni];
-                    if (n < p.N) {
+                    if (!(p.resid_acc & 2) && n < p.N) {
                         if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
                         if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)smp * p.rowvec_stride + n);
                     }
@@ -317,9 +342,9 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4
                 if (n + r < p.N) {
                     float sv = v[r];
                     if (!split) {
-                        if (p.bias) sv += p.bias[n + r];
-                        if (p.rowvec) sv += p.rowvec[(long long)smp * p.rowvec_stride + n + r];
-                        if (p.resid && !p.resid_acc) sv += __uint_as_float((unsigned)Rh[(long long)m * p.ldr + n + r] << 16);
+                        if (p.bias && !(p.resid_acc & 2)) sv += p.bias[n + r];
+                        if (p.rowvec && !(p.resid_acc & 2)) sv += p.rowvec[(long long)smp * p.rowvec_stride + n + r];
+                        if (p.resid && !(p.resid_acc & 1)) sv += __uint_as_float((unsigned)Rh[(long long)m * p.ldr + n + r] << 16);
                     }
                     if (out_f32) Cf[(long long)m * ldc + n + r] = sv;
                     else Ch[(long long)m * ldc + n + r] = (unsigned short)xf32_to_bf16_bits(sv);

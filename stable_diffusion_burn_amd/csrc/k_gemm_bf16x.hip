@@ -225,7 +225,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     int s0 = 0;      // LDS stage of the tile's first k tile
     issue(0);
     for (;;) {
-    gemm_acc_init_bf16<MI, NI, WM, WN, PM != 2>(p, acc, m0, n0, wave, PERSIST ? opaque_lane() : lane);   // zero, or the residual tile (ConvGemm::resid_acc)
+    gemm_acc_init_bf16<MI, NI, WM, WN, (PM < 0 ? -1 : PM == 2 ? 1 : 0)>(p, acc, m0, n0, wave, PERSIST ? opaque_lane() : lane, HoWo);   // zero, or the residual tile (ConvGemm::resid_acc)
 
     for (int t = 0; t < n_t; ++t) {
         const int cur = (s0 + t) & 1;
@@ -331,7 +331,7 @@ static int persistent_workgroups() {
 // epilogue spills inside the tile loop) and the conditions under which gemm_epilogue_bf16 takes its 16-byte bf16 paths (checked here, compiled in there)
 int conv_gemm_bf16x_persistent_mode(const ConvGemm& p, int cfg) {
     if (!(p.variant & 1) || p.splits != 1 || cfg < 0 || cfg >= kNumGemmTilesX || p.out_mode == 1) return -1;
-    if ((p.N & 7) || (p.ldc & 7) || (p.resid && !p.resid_acc)) return -1;
+    if ((p.N & 7) || (p.ldc & 7) || (p.resid && !(p.resid_acc & 1))) return -1;
     const int bm = kTilesX[cfg].bm, bn = kTilesX[cfg].bn;
     const int bno = p.geglu ? bn / 2 : bn;
     const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bno - 1) / bno);

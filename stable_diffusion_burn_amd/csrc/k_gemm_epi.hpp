@@ -124,6 +124,35 @@ __device__ __forceinline__ void gemm_epilogue_f32(const ConvGemm& p, epi_f32x4 (
         __syncthreads();                // every wave is done with the last k tile
         float* scr = reinterpret_cast<float*>(smem_x32 + wave * (16 * LDSW * 4));
         const int nw0 = n0 + wn * WNC;
+        constexpr int CH = WNC / 4;   // 16-byte chunks per row
+        constexpr int NQ = (16 * CH + 63) / 64;     // row-coalesced 16-byte pieces per lane per fragment group
+        // Round 6 (ConvGemm::variant bit 5 = off): every global LOAD of the epilogue is issued before its first fragment group is transposed -- the bias of the wave's
+        // columns once (it was re-read for each of the MI groups: a store that may alias sits between two groups) and, on the tiles whose groups fit the registers
+        // (MI NQ <= 8 pieces), the residual of ALL groups -- so the groups' load latencies overlap each other and the first LDS round trip instead of adding up.
+        const bool early = !(p.variant & 32);
+        constexpr bool PRE_R = MI * NQ <= 8;
+        f32x4 bias_v[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = nw0 + ni * 16 + g4 * 4;
+            bias_v[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (early && !split && p.bias && n < p.N) bias_v[ni] = *reinterpret_cast<const f32x4*>(p.bias + n);
+        }
+        f32x4 res_v[PRE_R ? MI : 1][PRE_R ? NQ : 1];
+        if constexpr (PRE_R) {
+            if (early && has_resid) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int r = 0; r < NQ; ++r) {
+                        const int q = r * 64 + lane;
+                        const int row = q / CH, c4 = q - row * CH;
+                        const int m = m0 + (wm * MI + mi) * 16 + row, n = nw0 + c4 * 4;
+                        res_v[mi][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (q < 16 * CH && m < p.M && n < p.N) res_v[mi][r] = *reinterpret_cast<const f32x4*>(p.resid + (long long)m * p.ldr + n);
+                    }
+            }
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int mrow0 = m0 + (wm * MI + mi) * 16;
@@ -135,22 +164,25 @@ __device__ __forceinline__ void gemm_epilogue_f32(const ConvGemm& p, epi_f32x4 (
                     const int n = nw0 + ni * 16 + g4 * 4;
                     f32x4 v = acc[mi][ni];
                     if (!split && n < p.N) {
-                        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                        if (early) v += bias_v[ni];
+                        else if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
                         if (p.rowvec) v += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)smp * p.rowvec_stride + n);
                     }
                     *reinterpret_cast<f32x4*>(scr + c15 * LDSW + ni * 16 + g4 * 4) = v;
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            constexpr int CH = WNC / 4;   // 16-byte chunks per row
 #pragma unroll
-            for (int q0 = 0; q0 < 16 * CH; q0 += 64) {
-                const int q = q0 + lane;
+            for (int r = 0; r < NQ; ++r) {
+                const int q = r * 64 + lane;
                 const int row = q / CH, c4 = q - row * CH;
                 const int m = mrow0 + row, n = nw0 + c4 * 4;
                 if (q < 16 * CH && m < p.M && n < p.N) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(scr + row * LDSW + c4 * 4);
-                    if (has_resid) v += *reinterpret_cast<const f32x4*>(p.resid + (long long)m * p.ldr + n);
+                    if (has_resid) {
+                        if (PRE_R && early) v += res_v[PRE_R ? mi : 0][PRE_R ? r : 0];
+                        else v += *reinterpret_cast<const f32x4*>(p.resid + (long long)m * p.ldr + n);
+                    }
                     if (split) *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;     // (Cf = this k slice's slab)
                     else {
                         if (Cf) *reinterpret_cast<f32x4*>(Cf + (long long)m * ldc + n) = v;

@@ -150,9 +150,10 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__
         h0 = *reinterpret_cast<const f32x4*>(x + xbase + (long long)row * ldx);
         h1 = *reinterpret_cast<const f32x4*>(x + xbase + (long long)(row + R) * ldx);
     }
-    gn_finalize(part, smp, G, cpg, hw, stat_chunks, stat_rows, eps, s_red, s_mean_hi, s_mean_lo, s_rstd);
+    // (round 6: gamma / beta too -- behind gn_finalize's barriers they were one more exposed round trip of a 7 - 9 us launch)
     const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c4 * 4);
     const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c4 * 4);
+    gn_finalize(part, smp, G, cpg, hw, stat_chunks, stat_rows, eps, s_red, s_mean_hi, s_mean_lo, s_rstd);
     f32x4 mean_hi, mean_lo, rstd;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -257,6 +258,16 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
             sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
+    // round 6: gamma / beta are requested here, behind the row's loads and in front of the two reductions, not behind them -- the launch (6 - 8 us, 960 per
+    // batch-1 image) is one memory round trip deep instead of two.  Exact-width instantiations only (40 registers); same operations: bit-identical.
+    f32x4 gmv[NV > 0 ? NV : 1], btv[NV > 0 ? NV : 1];
+    if constexpr (NV > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            gmv[i] = *reinterpret_cast<const f32x4*>(gamma + (l + i * L) * 4);
+            btv[i] = *reinterpret_cast<const f32x4*>(beta + (l + i * L) * 4);
+        }
+    }
 #pragma unroll
     for (int off = L / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
     const float mean = sum / (float)C;
@@ -279,8 +290,8 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
     for (int i = 0; i < NVEC; ++i) {
         const int f = l + i * L;
         if (NV > 0 || f < cq) {
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + f * 4);
-            const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + f * 4);
+            const f32x4 gm = NV > 0 ? gmv[NV > 0 ? i : 0] : *reinterpret_cast<const f32x4*>(gamma + f * 4);
+            const f32x4 bt = NV > 0 ? btv[NV > 0 ? i : 0] : *reinterpret_cast<const f32x4*>(beta + f * 4);
             const f32x4 o = (v[i] - mean) * rstd * gm + bt;
             if constexpr (P3) s3_store4(yr3, f * 4, o);
             else *reinterpret_cast<f32x4*>(yr + f * 4) = o;
