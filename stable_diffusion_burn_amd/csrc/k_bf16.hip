@@ -161,13 +161,18 @@ __global__ void gn_apply_bf16_kernel(const unsigned short* __restrict__ x, unsig
 #pragma unroll
         for (int u = 0; u < U; ++u) w0[u] = *reinterpret_cast<const u32x4*>(x + xbase + (long long)(row + u * R) * ldx);
     }
-    gn_finalize(part, smp, G, cpg, hw, stat_chunks, stat_rows, eps, s_red, s_mean_hi, s_mean_lo, s_rstd);
+    // (round 6: gamma / beta too, as two 16-byte loads each -- behind gn_finalize's barriers they were one more exposed round trip per workgroup)
     float gr[8], bt[8], mean_hi[8], mean_lo[8];
+    {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c8 * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + c8 * 8 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c8 * 8), b1 = *reinterpret_cast<const f32x4*>(beta + c8 * 8 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { gr[i] = g0[i]; gr[4 + i] = g1[i]; bt[i] = b0[i]; bt[4 + i] = b1[i]; }
+    }
+    gn_finalize(part, smp, G, cpg, hw, stat_chunks, stat_rows, eps, s_red, s_mean_hi, s_mean_lo, s_rstd);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int ch = c8 * 8 + i;
-        gr[i] = gamma[ch];
-        bt[i] = beta[ch];
         mean_hi[i] = s_mean_hi[ch / cpg];
         mean_lo[i] = s_mean_lo[ch / cpg];
     }

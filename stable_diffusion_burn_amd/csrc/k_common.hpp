@@ -6,6 +6,14 @@
 
 namespace sdmi {
 
+// Round 6.  A workgroup barrier that PUBLISHES LDS-DMA data (global_load_lds) is only correct if every wave waits for ITS OWN outstanding pieces before it enters the
+// barrier -- vmcnt is per wave, and the pieces a wave reads behind the barrier were issued by other waves.  __syncthreads() alone does not promise that wait: on gfx950
+// a workgroup-scope fence needs no vmcnt(0), and hipcc places the wait it derives for the LDS-DMA -> ds_read dependence wherever its pass decides -- in front of the
+// barrier in every kernel of rounds 1-5, BEHIND it in the persistent GEGLU instantiation of k_gemm_bf16x.hip once its loop head changed (profiles/r06i: batch-32
+// forwards differing by 3e-2 from run to run).  Every k-loop barrier of the LDS-DMA kernels therefore spells the wait out; tests/test_code_objects_cpu.py checks the ISA.
+__device__ __forceinline__ void sdmi_dma_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+
 // ---- which (M tile, N tile, split-K slice) a GEMM block works on ------------------------------------------------------
 // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed; a speed assumption only, never a correctness one:
 // every work item is covered exactly once whatever the placement): an XCD works on a contiguous band of tiles, blockIdx.z is the slice.

@@ -266,6 +266,7 @@ __global__ __launch_bounds__(512) void conv_gemm_fp8x_kernel(const ConvGemm p) {
     gemm_acc_init_bf16<MI, NI, WM, WN, 0>(p, acc, m0, n0, wave, lane, HoWo);   // zero, or the residual tile (ConvGemm::resid_acc), behind the first k tile's DMA
     for (int t = 0; t < n_t; ++t) {
         const int cur = t & 1;
+        sdmi_dma_landed();        // (k_common.hpp: this wave's LDS-DMA pieces have landed BEFORE it enters the barrier)
         __syncthreads();                    // k tile t (operands and scales) is in LDS; every wave is done with stage cur ^ 1
         if (t + 1 < n_t) issue(cur ^ 1);
         const unsigned char* stage = smem_q + cur * STAGE;
@@ -381,13 +382,16 @@ __global__ void gn_apply_fp8_kernel(const unsigned short* __restrict__ x, unsign
     const int row_first = blockIdx.x * rows_per_chunk + r0;
     u32x4 w_first = {0u, 0u, 0u, 0u};
     if (row_first < min(blockIdx.x * rows_per_chunk + rows_per_chunk, hw)) w_first = *reinterpret_cast<const u32x4*>(x + (long long)smp * hw * ldx + c8 * 8 + (long long)row_first * ldx);
-    gn_finalize(part, smp, G, cpg, hw, stat_chunks, stat_rows, eps, s_red, s_mean_hi, s_mean_lo, s_rstd);
     float gm[8], bt[8], mean_hi[8], mean_lo[8], rstd[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {     // (round 6: gamma / beta requested in front of gn_finalize's barriers, not behind them)
+        gm[i] = gamma[c8 * 8 + i];
+        bt[i] = beta[c8 * 8 + i];
+    }
+    gn_finalize(part, smp, G, cpg, hw, stat_chunks, stat_rows, eps, s_red, s_mean_hi, s_mean_lo, s_rstd);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int ch = c8 * 8 + i;
-        gm[i] = gamma[ch];
-        bt[i] = beta[ch];
         mean_hi[i] = s_mean_hi[ch / cpg];
         mean_lo[i] = s_mean_lo[ch / cpg];
         rstd[i] = s_rstd[ch / cpg];

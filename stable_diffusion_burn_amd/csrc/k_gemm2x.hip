@@ -152,6 +152,7 @@ __global__ __launch_bounds__(512) void conv_gemm2x_kernel(const ConvGemm p) {
     issue(0);
     for (int t = 0; t < n_t; ++t) {
         const int cur = t & 1;
+        sdmi_dma_landed();        // (k_common.hpp: this wave's LDS-DMA pieces have landed BEFORE it enters the barrier)
         __syncthreads();                    // k tile t is in LDS; every wave is done with stage cur ^ 1
         if (t + 1 < n_t) issue(cur ^ 1);
         const unsigned char* stage = smem_x32 + cur * STAGE;

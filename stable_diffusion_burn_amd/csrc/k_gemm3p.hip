@@ -294,6 +294,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3p_kernel(const Conv
             const int cur = t & 1;
             unsigned long long pa = 0;
             if constexpr (PROBE) pa = __builtin_amdgcn_s_memtime();
+            sdmi_dma_landed();        // (k_common.hpp: this wave's LDS-DMA pieces have landed BEFORE it enters the barrier)
             __syncthreads();                    // k tile t is in LDS; every wave is done with stage cur ^ 1
             if constexpr (PROBE) pwait += __builtin_amdgcn_s_memtime() - pa;
             w.next_stage = smem_p3 + (cur ^ 1) * STAGE;

@@ -295,6 +295,7 @@ __global__ __launch_bounds__(512) void conv_gemm3x_kernel(const ConvGemm p) {
     if constexpr (NSTG == 2) {
         for (int t = 0; t < n_t; ++t) {
             const int cur = t & 1;
+            sdmi_dma_landed();        // (k_common.hpp: this wave's LDS-DMA pieces have landed BEFORE it enters the barrier)
             __syncthreads();                    // k tile t is in LDS; every wave is done with stage cur ^ 1
             w.next_stage = smem_x32 + (cur ^ 1) * STAGE;
             w.a_tile = smem_x32 + cur * STAGE + a_base;

@@ -143,6 +143,7 @@ __global__ __launch_bounds__(512) void conv3_gemm_bf16t_kernel(const ConvGemm p)
     gemm_acc_init_bf16<MI, NI, WM, WN, 0>(p, acc, m0, n0, wave, lane, HoWo);   // zero, or the residual tile (ConvGemm::resid_acc), behind the first DMAs
     const int n_t = 3 * n_g;
     for (int t = 0; t < n_t; ++t) {
+        sdmi_dma_landed();        // (k_common.hpp: this wave's LDS-DMA pieces have landed BEFORE it enters the barrier)
         __syncthreads();                                     // everything issued so far has landed (k tile kt, this kernel row's activations); the buffers written next are free
         const int abuf = g & 1;
         const bool more_g = g + 1 < n_g;

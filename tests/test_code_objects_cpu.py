@@ -92,3 +92,55 @@ def test_reduced_precision_geglu_epilogue_has_no_erf_branches(tmp_path):
         assert n_exp >= 32 and n_rcp >= n_exp, name
         assert "v_rndne_f32" not in body and "v_ldexp_f32" not in body, name            # (the library erff's range reduction)
         assert body.count("s_and_saveexec_b64") < 80, name                              # (120 with erff(); what remains are the store predicates)
+
+
+DMA_UNITS = ["k_gemm_bf16x", "k_gemm_bf16t", "k_fp8", "k_gemm2x", "k_gemm3p", "k_gemm3x"]
+
+
+@pytest.mark.parametrize("unit", DMA_UNITS)
+def test_lds_dma_barriers_wait_for_the_waves_own_pieces(unit, tmp_path):
+    """Round 6 (profiles/r06i_*): a barrier that publishes LDS-DMA data is correct only if every wave waits for ITS OWN pieces (vmcnt is per wave) BEFORE it enters the
+    barrier.  hipcc derives that wait from the DMA -> ds_read dependence and once placed it BEHIND the barrier (persistent GEGLU instantiation of k_gemm_bf16x.hip:
+    nondeterministic results at batch 32).  The kernels now spell the wait out (sdmi_dma_landed / the counted waits of the three-stage tiles); here the ISA is checked:
+    in every kernel that issues global_load_lds, each s_barrier that has matrix instructions between it and the NEXT barrier (a k-loop barrier: what follows reads
+    DMA'd tiles) is preceded by an s_waitcnt with a vmcnt term, with no LDS-DMA issue between that wait and the barrier."""
+    funcs = _functions(unit, tmp_path)
+    checked = 0
+    for name, body in funcs.items():
+        if "global_load_lds" not in body or "kernel" not in name:
+            continue
+        ins, addr = [], []
+        for ln in body.splitlines():
+            m = re.match(r"\s*(\S.*?)\s*//\s*([0-9A-Fa-f]+):", ln)
+            if m:
+                ins.append(m.group(1)); addr.append(int(m.group(2), 16))
+        # loops = backward branches (simm16 in dwords relative to the next instruction)
+        loops = []
+        for i, x in enumerate(ins):
+            m = re.match(r"s_(?:cbranch_\w+|branch)\s+(\d+)$", x)
+            if m and i + 1 < len(ins):
+                off = int(m.group(1))
+                off = off - 65536 if off >= 32768 else off
+                tgt = addr[i + 1] + 4 * off
+                if tgt <= addr[i]:
+                    loops.append((next(k for k, a in enumerate(addr) if a >= tgt), i))
+        for b, x in enumerate(ins):
+            if not x.startswith("s_barrier"):
+                continue
+            inside = [(lo, hi) for lo, hi in loops if lo <= b <= hi and any("v_mfma" in y for y in ins[lo:hi + 1]) and any("global_load_lds" in y for y in ins[lo:hi + 1])]
+            if not inside:
+                continue                      # not a k-loop barrier (prologue / epilogue)
+            lo, hi = min(inside, key=lambda t: t[1] - t[0])
+            j, steps = b - 1, 0
+            while True:                       # walk backwards through the loop body, cyclically
+                if j < lo:
+                    j = hi
+                y = ins[j]
+                if y.startswith("s_waitcnt") and "vmcnt" in y:
+                    break
+                assert "global_load_lds" not in y, f"{unit}: {name}: an LDS-DMA issue reaches a k-loop barrier without a vmcnt wait in between"
+                steps += 1
+                assert steps < hi - lo + 1, f"{unit}: {name}: k loop without any vmcnt wait"
+                j -= 1
+            checked += 1
+    assert checked > 0, unit
