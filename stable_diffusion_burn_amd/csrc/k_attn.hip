@@ -134,21 +134,6 @@ __global__ __launch_bounds__(NW * 64) void attn2_kernel(const AttnParams p) {
     const int tps = (n_tiles + n_split - 1) / n_split;
     const int t_begin = min((int)blockIdx.z * tps, n_tiles), t_end = min(t_begin + tps, n_tiles);
 
-    const float qscale = p.scale * p.scale * kLog2e;  // (q*s)(k*s) = q k s^2, in log2 units
-    f32x2 qf[DC];
-#pragma unroll
-    for (int cc = 0; cc < DC; ++cc) {
-        f32x2 v = {0.f, 0.f};
-        if (q_ok) {
-            if constexpr (H16) {
-                const unsigned w = *reinterpret_cast<const unsigned*>(Qh + (long long)qrow * p.ldq + cc * 8 + g * 2);
-                v = f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u)};
-            } else {
-                v = *reinterpret_cast<const f32x2*>(Qb + (long long)qrow * p.ldq + cc * 8 + g * 2);
-            }
-        }
-        qf[cc] = v * qscale;
-    }
 
     f32x4 rk[NLD], rv[NLD];
     auto gload = [&](int tile) {
@@ -209,10 +194,24 @@ __global__ __launch_bounds__(NW * 64) void attn2_kernel(const AttnParams p) {
     float m_run = -INFINITY;
     float l_run = 0.f;
 
-    if (t_begin < t_end) {
-        gload(t_begin);
-        lstore(0);
+    // (round 6: the first K / V tile is requested before the query row, k_attn_split.hip)
+    if (t_begin < t_end) gload(t_begin);
+    const float qscale = p.scale * p.scale * kLog2e;  // (q*s)(k*s) = q k s^2, in log2 units
+    f32x2 qf[DC];
+#pragma unroll
+    for (int cc = 0; cc < DC; ++cc) {
+        f32x2 v = {0.f, 0.f};
+        if (q_ok) {
+            if constexpr (H16) {
+                const unsigned w = *reinterpret_cast<const unsigned*>(Qh + (long long)qrow * p.ldq + cc * 8 + g * 2);
+                v = f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u)};
+            } else {
+                v = *reinterpret_cast<const f32x2*>(Qb + (long long)qrow * p.ldq + cc * 8 + g * 2);
+            }
+        }
+        qf[cc] = v * qscale;
     }
+    if (t_begin < t_end) lstore(0);
     __syncthreads();
 
     for (int tile = t_begin; tile < t_end; ++tile) {
@@ -396,16 +395,43 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnParams p) {
         const int hh = (int)((i / d4) % p.n_head);
         const long long bq = i / ((long long)d4 * p.n_head);
         const int q = (int)(bq % p.nq), b = (int)(bq / p.nq);
-        float m = -INFINITY;
-        for (int s = 0; s < p.kv_splits; ++s) m = fmaxf(m, p.part_ml[((((long long)s * p.n + b) * p.n_head + hh) * p.nq + q) * 2]);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         float l = 0.f;
-        for (int s = 0; s < p.kv_splits; ++s) {
-            const f32x2 ml = *reinterpret_cast<const f32x2*>(p.part_ml + ((((long long)s * p.n + b) * p.n_head + hh) * p.nq + q) * 2);
-            if (ml[0] == -INFINITY) continue;
-            const float w = __builtin_amdgcn_exp2f(ml[0] - m);
-            acc += *reinterpret_cast<const f32x4*>(p.part_o + (((long long)s * p.n + b) * p.nq + q) * row_elems + hh * D + c4 * 4) * w;
-            l += ml[1] * w;
+        if (p.kv_splits <= 8) {
+            // round 6: every slice's (m, l) and output piece requested at once (<= 8 slices: 40 registers) -- the loops below are two to three DEPENDENT round trips per slice
+            // (660 launches of ~ 8 us per batch-1 image were that chain).  Same operations in slice order: bit-identical.
+            f32x2 ml[8];
+            f32x4 po[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                ml[s] = f32x2{-INFINITY, 0.f};
+                po[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (s < p.kv_splits) {
+                    ml[s] = *reinterpret_cast<const f32x2*>(p.part_ml + ((((long long)s * p.n + b) * p.n_head + hh) * p.nq + q) * 2);
+                    po[s] = *reinterpret_cast<const f32x4*>(p.part_o + (((long long)s * p.n + b) * p.nq + q) * row_elems + hh * D + c4 * 4);
+                }
+            }
+            float m = -INFINITY;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) m = fmaxf(m, ml[s][0]);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s < p.kv_splits && ml[s][0] != -INFINITY) {
+                    const float w = __builtin_amdgcn_exp2f(ml[s][0] - m);
+                    acc += po[s] * w;
+                    l += ml[s][1] * w;
+                }
+            }
+        } else {
+            float m = -INFINITY;
+            for (int s = 0; s < p.kv_splits; ++s) m = fmaxf(m, p.part_ml[((((long long)s * p.n + b) * p.n_head + hh) * p.nq + q) * 2]);
+            for (int s = 0; s < p.kv_splits; ++s) {
+                const f32x2 ml = *reinterpret_cast<const f32x2*>(p.part_ml + ((((long long)s * p.n + b) * p.n_head + hh) * p.nq + q) * 2);
+                if (ml[0] == -INFINITY) continue;
+                const float w = __builtin_amdgcn_exp2f(ml[0] - m);
+                acc += *reinterpret_cast<const f32x4*>(p.part_o + (((long long)s * p.n + b) * p.nq + q) * row_elems + hh * D + c4 * 4) * w;
+                l += ml[1] * w;
+            }
         }
         const f32x4 r = acc * (1.0f / l);
         if (p.o3) s3_store4(reinterpret_cast<unsigned char*>(p.o3) + ((long long)b * p.nq + q) * p.ldo3, hh * D + c4 * 4, r);

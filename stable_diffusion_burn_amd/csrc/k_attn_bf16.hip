@@ -139,18 +139,6 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_bf16_kernel(const AttnParam
             *reinterpret_cast<u32x4*>(Ks + (i / BKV) * Cfg::K_BYTES + (i % BKV) * RSK + CPR * 16) = u32x4{0u, 0u, 0u, 0u};
     }
 
-    // Q^T fragments: B[k = 16 s + 8 hi + j][n = query]
-    bf16x8 qf[QR][KS];
-#pragma unroll
-    for (int g = 0; g < QR; ++g)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            const int col = 16 * s + 8 * hi;
-            if (q_ok[g] && col < D) v = *reinterpret_cast<const u32x4*>(Qh + (long long)qrow[g] * p.ldq + col);
-            qf[g][s] = __builtin_bit_cast(bf16x8, v);
-        }
-
     u32x4 rk[NLD], rv[NLD];
     auto gload = [&](int tile) {
         const int kv0 = tile * BKV;
@@ -201,7 +189,19 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_bf16_kernel(const AttnParam
     const int i16 = lane & 15;
     const int v_off = (4 * hi + (i16 >> 2)) * RSV + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
 
-    gload(0);
+    gload(0);     // (round 6: the first K / V tile is requested before the query rows, k_attn_split.hip)
+    // Q^T fragments: B[k = 16 s + 8 hi + j][n = query]
+    bf16x8 qf[QR][KS];
+#pragma unroll
+    for (int g = 0; g < QR; ++g)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            const int col = 16 * s + 8 * hi;
+            if (q_ok[g] && col < D) v = *reinterpret_cast<const u32x4*>(Qh + (long long)qrow[g] * p.ldq + col);
+            qf[g][s] = __builtin_bit_cast(bf16x8, v);
+        }
+
     lstore(0);
     __syncthreads();
 
@@ -245,7 +245,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_bf16_kernel(const AttnParam
             if constexpr (PF) __builtin_amdgcn_sched_barrier(0);
         }
 
-        // the next tile's global loads go out here, not at the top of the iteration: hipcc puts a vmcnt(0) in front of the first
+        // (round 6, measured and not kept -- profiles/r06k_*: requesting tile t + 2's rows during tile t through a second staging register set changes nothing, 490.7 vs 488.6 us:
+    // the staging loads are not what a tile waits for)
+    // the next tile's global loads go out here, not at the top of the iteration: hipcc puts a vmcnt(0) in front of the first
         // MFMA of the loop body, which made every tile wait for the loads it had just issued; they are consumed by lstore() below
         if (more) gload(tile + 1);
 

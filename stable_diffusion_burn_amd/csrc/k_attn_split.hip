@@ -159,22 +159,6 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
             *reinterpret_cast<u32x4*>(Ks + (i / BKV) * Cfg::K_BYTES + (i % BKV) * RSK + CPR * 16) = u32x4{0u, 0u, 0u, 0u};
     }
 
-    // Q^T fragments, split: B[k = 16 s + 8 hi + j][n = query]
-    u32x4 qh[KS], qm[KS], ql[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
-        const bool tail = PACK && s == KS - 1;                 // packed tail step: BOTH lane halves hold columns 32..39
-        const int col = tail ? 16 * s : 16 * s + 8 * hi;
-        if (q_ok && col < D) {
-            x0 = *reinterpret_cast<const f32x4*>(Qf + (long long)qrow * p.ldq + col);
-            x1 = *reinterpret_cast<const f32x4*>(Qf + (long long)qrow * p.ldq + col + 4);
-        }
-        if constexpr (LG) { x0 *= cs; x1 *= cs; }
-        sp_split8(x0, x1, qh[s], qm[s], ql[s]);
-        if (tail && hi) ql[s] = qh[s];                         // the third operand of the tail step is [Q_l | Q_h] against the K image [K_h | K_l]
-    }
-
     f32x4 rk[NLD][2], rv[NLD][2];
     auto gload = [&](int tile) {
         const int kv0 = tile * BKV;
@@ -240,10 +224,26 @@ __global__ __launch_bounds__(NW * 64) void attn_split_kernel(const AttnParams p)
     const int i16 = lane & 15;
     const int v_off = (4 * hi + (i16 >> 2)) * RSV + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
 
-    if (t_begin < t_end) {
-        gload(t_begin);
-        lstore(0);
+    // round 6: the first K / V tile is requested BEFORE the query rows (whose split then runs while it is in flight): one memory round trip in front of the key loop
+    // instead of two -- 860 attention launches per batch-1 image, the short ones 12 - 23 us
+    if (t_begin < t_end) gload(t_begin);
+    // Q^T fragments, split: B[k = 16 s + 8 hi + j][n = query]
+    u32x4 qh[KS], qm[KS], ql[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+        const bool tail = PACK && s == KS - 1;                 // packed tail step: BOTH lane halves hold columns 32..39
+        const int col = tail ? 16 * s : 16 * s + 8 * hi;
+        if (q_ok && col < D) {
+            x0 = *reinterpret_cast<const f32x4*>(Qf + (long long)qrow * p.ldq + col);
+            x1 = *reinterpret_cast<const f32x4*>(Qf + (long long)qrow * p.ldq + col + 4);
+        }
+        if constexpr (LG) { x0 *= cs; x1 *= cs; }
+        sp_split8(x0, x1, qh[s], qm[s], ql[s]);
+        if (tail && hi) ql[s] = qh[s];                         // the third operand of the tail step is [Q_l | Q_h] against the K image [K_h | K_l]
     }
+
+    if (t_begin < t_end) lstore(0);
     __syncthreads();
 
     for (int tile = t_begin; tile < t_end; ++tile) {

@@ -50,6 +50,13 @@ __device__ __forceinline__ void gemm_epilogue_f32(const ConvGemm& p, epi_f32x4 (
             const float* scr_g = reinterpret_cast<const float*>(smem_x32 + (vg ? wave : pw) * (16 * LDSW * 4));
             const int nw0 = n0 + col * WNC;
             const float* bias = p.bias ? p.bias + (vg ? p.N : 0) : nullptr;
+            f32x4 bias_g[NI];     // (round 6: the wave's bias columns once, in front of the fragment groups -- they were re-read behind each group's stores)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int n = nw0 + ni * 16 + g4 * 4;
+                bias_g[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (bias && n < p.N) bias_g[ni] = *reinterpret_cast<const f32x4*>(bias + n);
+            }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const int mrow0 = m0 + (wm * MI + mi) * 16;
@@ -57,7 +64,7 @@ __device__ __forceinline__ void gemm_epilogue_f32(const ConvGemm& p, epi_f32x4 (
                 for (int ni = 0; ni < NI; ++ni) {
                     const int n = nw0 + ni * 16 + g4 * 4;
                     f32x4 v = acc[mi][ni];
-                    if (bias && n < p.N) v += *reinterpret_cast<const f32x4*>(bias + n);
+                    if (bias && n < p.N) v += bias_g[ni];
                     *reinterpret_cast<f32x4*>(scr + c15 * LDSW + ni * 16 + g4 * 4) = v;
                 }
                 __syncthreads();
