@@ -258,7 +258,9 @@ class Runner:
                 c = j.get("configs", {}).get(ckey) or ({"classes": j["classes"], "commit": j.get("commit")} if ckey == "fp32_b1_s20" and "classes" in j else None)
                 t = c["classes"].get(cls, {}).get("hbm_bytes_per_launch") if c else None
                 if t:
-                    from_profiles = {"hbm_bytes_per_launch": t, "collected_on_commit": c.get("commit"), "kernel_source_digest": c.get("kernel_source_digest"), "source": f"profiles/pmc_summary.json configs[{ckey}] classes[{cls}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command"}
+                    from_profiles = {"hbm_bytes_per_launch": t, "collected_on_commit": c.get("commit"), "kernel_source_digest": c.get("kernel_source_digest"),
+                                     # round 6: the matrix pipe's busy share from the same evidence pass (SQ_VALU_MFMA_BUSY_CYCLES), time-weighted over the GEMM / attention kernels
+                                     "mfma_busy_pmc": c.get("mfma_busy"), "source": f"profiles/pmc_summary.json configs[{ckey}] classes[{cls}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command"}
             except Exception:  # noqa: BLE001
                 from_profiles = None
         roof = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

@@ -1776,14 +1776,15 @@ void Engine::launch_fp8(ConvGemm& p, double flops) {
     if ((unsigned long long)p.NB * p.Hs * p.Ws * (unsigned long long)p.a_ld >= 0xFFFFFFE0ull || (unsigned long long)p.N * p.K >= 0xFFFFFFE0ull) throw Error(SDMI_ERR_UNSUPPORTED, "fp8 GEMM: operand larger than 4 GiB");
     // tile + split-K: rounds of workgroups on 256 CUs x the time of one tile at the rate each tile shape sustains when the
     // chip is full (tools/bench_gemm_fp8.py on MI355X: 256x320 2.4, 256x256 2.1, 256x128 1.7 PFLOP/s); K is split only when
-    // the tiles would leave more than half of the chip idle
+    // the tiles would leave half of the chip or more idle
     static const double kRate[kNumGemmTilesQ] = {2400.0, 2100.0, 1700.0};
     int cfg = opt_fp8_tile_, splits = 1;
     auto plan = [&](int c, int* sp) {
         const int bm = gemm_tile_info_q(c).bm, bn = gemm_tile_info_q(c).bn;
         const long long tiles = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
         int s_ = 1;
-        if (tiles < 128) s_ = (int)std::max<long long>(1, std::min<long long>(p.kt_total / 4, (256 + tiles - 1) / tiles));
+        // (round 6: <= 128 -- half a round of tiles is split too: M = 8192, N = 1280 on 256 x 320 tiles is 128 workgroups; K = 11520: 167.5 -> 143.0 us, K = 23040: 314 -> 240, profiles/r06q_fp8_shapes.txt)
+        if (tiles <= 128) s_ = (int)std::max<long long>(1, std::min<long long>(p.kt_total / 4, (256 + tiles - 1) / tiles));
         *sp = s_;
         const double rounds = (double)((tiles * s_ + 255) / 256);
         return rounds * (double)bm * bn / kRate[c] / s_ + (s_ > 1 ? 0.15 * (double)bm * bn / kRate[c] : 0.0);

@@ -50,6 +50,25 @@ __device__ __forceinline__ float gelu_gate_fast(float g) {
     return g * (0.5f + __builtin_copysignf(0.5f - h, g));
 }
 
+// Two gates at once (round 6): the same operations on <2 x float>, which gfx950 issues as v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 -- one issue slot per PAIR for 13 of
+// the 17 operations (the reciprocals and exponentials stay scalar).  Each half is computed exactly as gelu_gate_fast computes it: bit-identical results.
+typedef float kc_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ kc_f32x2 gelu_gate_fast2(const kc_f32x2 g) {
+    const kc_f32x2 ag = kc_f32x2{__builtin_fabsf(g[0]), __builtin_fabsf(g[1])};
+    const kc_f32x2 x = ag * 0.70710678118654752440f;
+    const kc_f32x2 den = __builtin_elementwise_fma(kc_f32x2{0.3275911f, 0.3275911f}, x, kc_f32x2{1.0f, 1.0f});
+    const kc_f32x2 t = kc_f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    kc_f32x2 pl = __builtin_elementwise_fma(t, kc_f32x2{0.5f * 1.061405429f, 0.5f * 1.061405429f}, kc_f32x2{0.5f * -1.453152027f, 0.5f * -1.453152027f});
+    pl = __builtin_elementwise_fma(pl, t, kc_f32x2{0.5f * 1.421413741f, 0.5f * 1.421413741f});
+    pl = __builtin_elementwise_fma(pl, t, kc_f32x2{0.5f * -0.284496736f, 0.5f * -0.284496736f});
+    pl = __builtin_elementwise_fma(pl, t, kc_f32x2{0.5f * 0.254829592f, 0.5f * 0.254829592f});
+    const kc_f32x2 ex = (g * g) * -0.72134752044448170368f;
+    const kc_f32x2 h = (pl * t) * kc_f32x2{__builtin_amdgcn_exp2f(ex[0]), __builtin_amdgcn_exp2f(ex[1])};    // 0.5 erfc(|g| / sqrt 2)
+    const kc_f32x2 d = 0.5f - h;
+    const kc_f32x2 sd = kc_f32x2{__builtin_copysignf(d[0], g[0]), __builtin_copysignf(d[1], g[1])};
+    return g * (0.5f + sd);
+}
+
 // ---- GroupNorm statistics (groupnorm/mod.rs:75-82) ---------------------------------------------------------
 // Partial statistics of one (sample, chunk, group) are (mean, M2 = sum (x - mean)^2) over the chunk's rows x (C/G)
 // channels: part[((smp*chunks + chunk)*G + g)*2 + {0, 1}].  Producers: gn_stats_kernel / gn_stats_bf16_kernel and the

@@ -129,10 +129,10 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4
                     v += *reinterpret_cast<const f32x4*>(p.bias + n);
                     g += *reinterpret_cast<const f32x4*>(p.bias + p.N + n);
                 }
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = v[e] * gelu_gate_fast(g[e]);   // (k_common.hpp: erff() costs 5 us per 256 x 256 tile here; profiles/r05ad_*)
-                return o;
+                // (k_common.hpp: erff() cost 5 us per 256 x 256 tile here, profiles/r05ad_*; round 6: two gates per instruction where the operation has a packed form)
+                const kc_f32x2 g01 = gelu_gate_fast2(kc_f32x2{g[0], g[1]}), g23 = gelu_gate_fast2(kc_f32x2{g[2], g[3]});
+                const kc_f32x2 o01 = kc_f32x2{v[0], v[1]} * g01, o23 = kc_f32x2{v[2], v[3]} * g23;
+                return f32x4{o01[0], o01[1], o23[0], o23[1]};
             };
             constexpr int CH = WNO / 8;
             if (MODE >= 0 || p.out_mode != 1) {

@@ -19,7 +19,7 @@ for cfg in 1 2 3 4; do
   (cd $R && python tools/pmc_summary.py $out/pmc_fetch_$cfg $out/pmc_write_$cfg $imgs $out/pmc_summary.json $key $COMMIT) > $R/$out/r06n_pmc_summary_$key.txt 2>&1; echo "pmc summary cfg $cfg rc=$?"
   rm -rf $R/$out/pmc_fetch_$cfg $R/$out/pmc_write_$cfg
   timeout 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/$out/pmc_mfma_$cfg -- python $R/bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-secondary --no-parity $(python -c "print({1:'--pmc-ddim-steps 4',2:'--pmc-ddim-steps 2',3:'--pmc-ddim-steps 2',4:'--pmc-ddim-steps 2'}[$cfg])") > $R/$out/pmc_mfma_$cfg.log 2>&1; echo "pmc mfma cfg $cfg rc=$?"
-  (cd $R && python tools/pmc_kernels.py $out/pmc_mfma_$cfg conv_gemm attn) > $R/$out/r06n_mfma_busy_$key.txt 2>&1
+  (cd $R && python tools/pmc_kernels.py $out/pmc_mfma_$cfg conv_gemm conv3_gemm attn --json=$out/pmc_summary.json:$key) > $R/$out/r06n_mfma_busy_$key.txt 2>&1
   rm -rf $R/$out/pmc_mfma_$cfg
 done
 cd $R; cat $out/r06n_pmc_summary_*.txt | head -60; head -12 $out/r06n_mfma_busy_*.txt
