@@ -17,6 +17,9 @@
 //   * two LDS stages, one __syncthreads() per k tile: [barrier: tile t landed, stage t^1 free] -> issue the
 //     DMA of tile t+1 -> 2 x (fragment reads + MFMAs) on tile t.  The DMA is in flight during the whole MFMA
 //     phase; the barrier's vmcnt(0) retires it.
+// Round 6, measured and removed (tools/probes/r06w_k_gemm_bf16r_probe.hip.txt, profiles/r06w_ring_vs_two_stage.txt): a FOUR-stage ring of 32-deep k steps on the 256 x 256 /
+// 256 x 128 tiles (DMA three steps ahead, counted vmcnt) -- bit-identical (72 operator cases incl. split-K) and 10 - 12 % SLOWER on every shape, hot and cold: the
+// 30 % of wave cycles these kernels spend at the barrier (SQ_WAIT_ANY, profiles/r06v_*) is not the DMA round trip, and twice the barriers cost more than the lead time buys.
 // k order, weight packing, swapped MFMA operands (a lane holds 4 consecutive output channels), XCD-aware tile
 // map, deterministic split-K and the fused epilogue are those of k_gemm_bf16.hip.
 #include "kernels.hpp"

@@ -379,7 +379,7 @@ def test_linear_bf16_persistent_and_direct_epilogue(ops16, tile, rows, cin, cout
 
 
 @pytest.mark.parametrize("case", [(8, 64, 97, 97, 320, 3, 1, 0), (8, 64, 49, 48, 200, 3, 1, 1), (8, 128, 96, 96, 64, 1, 1, 0), (8, 64, 96, 96, 64, 3, 1, 0)])
-@pytest.mark.parametrize("tile", [100, 102])
+@pytest.mark.parametrize("tile", [100, 101, 102])
 def test_conv2d_bf16_persistent_and_direct_epilogue(ops16, tile, case):
     n, cin, h, w, cout, k, stride, ups = case
     g = np.random.default_rng(5100 + tile + cin + cout + h)
