@@ -461,8 +461,8 @@ private:
     unsigned long long* probe_buf_ = nullptr;
     int opt_bench_cold_ = 0;    // bench_conv: 1 = evict the weights from the Infinity Cache between timed launches (what a layer sees inside the model)
     int opt_gemm_x32_ = 1;      // precision = 0: 1 = large-tile LDS-DMA fp32 GEMM (k_gemm2x.hip) where measured / modelled faster
-    static constexpr int kGemmBf16xVariantDefault = 1;
-    int opt_gemm_bf16x_variant_ = kGemmBf16xVariantDefault; // precision >= 1, k_gemm_bf16x.hip: bit 0 = persistent tile loop (launches without split-K or residual and with more tiles than CUs;
+    static constexpr int kGemmBf16xVariantDefault = 5;
+    int opt_gemm_bf16x_variant_ = kGemmBf16xVariantDefault; // precision >= 1, k_gemm_bf16x.hip / k_gemm_bf16t.hip: bit 2 (round 6) = waves 4 - 7 issue their DMA pieces between a tile's two k steps (one-tile forms and the kernel-row convolution); bit 0 = persistent tile loop (launches without split-K or residual and with more tiles than CUs;
                                      // bit-identical results, +0.4 ... 0.7 % per image: profiles/r05a_*)
     int opt_gemm_bf16x_ = 1;    // precision = 1: 1 = large-tile LDS-DMA GEMM where the cost model prefers it; 0 = never
     void* zero_page_ = nullptr;

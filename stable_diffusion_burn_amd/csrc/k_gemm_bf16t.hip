@@ -147,20 +147,28 @@ __global__ __launch_bounds__(512) void conv3_gemm_bf16t_kernel(const ConvGemm p)
         __syncthreads();                                     // everything issued so far has landed (k tile kt, this kernel row's activations); the buffers written next are free
         const int abuf = g & 1;
         const bool more_g = g + 1 < n_g;
-        if (t + 1 < n_t) issue_b(kt + 1, (kt + 1) & 1);
-        if (more_g) {                                        // the next kernel row's activations, spread over this row's three taps
-            int cs1 = cs, ky1 = ky + 1;
-            if (ky1 == 3) { ky1 = 0; ++cs1; }
-            if (kx == 0) { issue_a(0, cs1, ky1, abuf ^ 1); issue_a(1, cs1, ky1, abuf ^ 1); }
-            else if (kx == 1) { issue_a(2, cs1, ky1, abuf ^ 1); issue_a(3, cs1, ky1, abuf ^ 1); }
-            else if (NAJ > 4) issue_a(4, cs1, ky1, abuf ^ 1);
-        }
+        auto issue_next = [&]() {
+            if (t + 1 < n_t) issue_b(kt + 1, (kt + 1) & 1);
+            if (more_g) {                                        // the next kernel row's activations, spread over this row's three taps
+                int cs1 = cs, ky1 = ky + 1;
+                if (ky1 == 3) { ky1 = 0; ++cs1; }
+                if (kx == 0) { issue_a(0, cs1, ky1, abuf ^ 1); issue_a(1, cs1, ky1, abuf ^ 1); }
+                else if (kx == 1) { issue_a(2, cs1, ky1, abuf ^ 1); issue_a(3, cs1, ky1, abuf ^ 1); }
+                else if (NAJ > 4) issue_a(4, cs1, ky1, abuf ^ 1);
+            }
+        };
+        // Round 6 (ConvGemm::variant bit 2): the second wave of every SIMD (waves 4 - 7) issues its DMA pieces BETWEEN the tile's two k steps, not in front of them: behind the
+        // barrier half of the waves read fragments and start the matrix pipe while the other half issue DMA -- every wave used to do both in the same order at the same
+        // time (a 72 KB LDS read burst under an idle matrix pipe at the top of every k tile).  Same products in the same order: bit-identical.
+        const bool late_dma = (p.variant & 4) && wave >= 4;
+        if (!late_dma) issue_next();
         const unsigned char* sa = As + abuf * A_BYTES;
         const unsigned char* sb = Bs + (kt & 1) * B_BYTES;
         const int ck = c15 + kx;                             // fragment row c of tap kx: padded column (multiple of 16) + c + kx
         constexpr int GM = 4, NG = MI / GM;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 1 && late_dma) issue_next();
             const int fo = ck * 128 + ((((kk ? 4 : 0) + g4) ^ (ck & 7)) << 4);
             const int fbo = kk ? fb_off1 : fb_off0;
             u32x4 fb[NI];

@@ -234,7 +234,12 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
         const int cur = (s0 + t) & 1;
         sdmi_dma_landed();        // (k_common.hpp: this wave's LDS-DMA pieces have landed BEFORE it enters the barrier)
         __syncthreads();                    // k tile t is in LDS; every wave is done with stage cur ^ 1
-        if (t + 1 < n_t) issue(cur ^ 1);
+        // variant bit 2 (round 6, default): the second wave of every SIMD (waves 4 - 7) issues its DMA pieces BETWEEN the tile's two k steps instead of in front of them, so that
+        // behind the barrier half of the waves read fragments and start the matrix pipe while the other half issue DMA (every wave used to do both in the same order at
+        // the same time: an LDS read burst of 72 KB with an idle matrix pipe at the top of every k tile).  One-tile forms only: the tile loop has no registers for the
+        // second issue point.  Same products in the same order: bit-identical.  Per shape -5 ... -10 % (profiles/r06x_*, r06y_*).
+        const bool late_dma = !PERSIST && (p.variant & 4) && wave >= 4;     // (the one-tile 256 x 256 / 256 x 128 forms: the 256 x 320 tile and the tile loop have no registers for the second issue point)
+        if (t + 1 < n_t && !late_dma) issue(cur ^ 1);
         const unsigned char* stage = smem_x + cur * STAGE;
         // Fragment reads run one group of rows ahead of the MFMAs that use them: the reads of rows [g+1] are issued
         // before the MFMAs of rows [g], so the compiler's counted lgkmcnt waits find the data already there
@@ -243,6 +248,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
         constexpr int NG = MI / GM;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 1 && t + 1 < n_t && late_dma) issue(cur ^ 1);
             const int fo = kk ? fr_off1 : fr_off0;
             u32x4 fb[NI];
             u32x4 fa[2][GM];
@@ -335,6 +341,7 @@ static int persistent_workgroups() {
 // epilogue spills inside the tile loop) and the conditions under which gemm_epilogue_bf16 takes its 16-byte bf16 paths (checked here, compiled in there)
 int conv_gemm_bf16x_persistent_mode(const ConvGemm& p, int cfg) {
     if (!(p.variant & 1) || p.splits != 1 || cfg < 0 || cfg >= kNumGemmTilesX || p.out_mode == 1) return -1;
+    // (round 6, measured and not kept -- profiles/r06z_*: sending launches of >= 8 k tiles to the staggered one-tile form instead of the tile loop: GEMM class 30.94 -> 31.10 ms)
     if ((p.N & 7) || (p.ldc & 7) || (p.resid && !(p.resid_acc & 1))) return -1;
     const int bm = kTilesX[cfg].bm, bn = kTilesX[cfg].bn;
     const int bno = p.geglu ? bn / 2 : bn;
