@@ -237,7 +237,8 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
         // variant bit 2 (round 6, default): the second wave of every SIMD (waves 4 - 7) issues its DMA pieces BETWEEN the tile's two k steps instead of in front of them, so that
         // behind the barrier half of the waves read fragments and start the matrix pipe while the other half issue DMA (every wave used to do both in the same order at
         // the same time: an LDS read burst of 72 KB with an idle matrix pipe at the top of every k tile).  One-tile forms only: the tile loop has no registers for the
-        // second issue point.  Same products in the same order: bit-identical.  Per shape -5 ... -10 % (profiles/r06x_*, r06y_*).
+        // second issue point (tried: 19 - 27 SGPRs spilled to lanes, 31 VGPRs on the 256 x 320 tile; on the 256 x 256 / 256 x 128 tile loops no gain per image, profiles/r06za_*).
+        // Same products in the same order: bit-identical.  Per shape -5 ... -10 % (profiles/r06x_*, r06y_*).
         const bool late_dma = !PERSIST && (p.variant & 4) && wave >= 4;     // (the one-tile 256 x 256 / 256 x 128 forms: the 256 x 320 tile and the tile loop have no registers for the second issue point)
         if (t + 1 < n_t && !late_dma) issue(cur ^ 1);
         const unsigned char* stage = smem_x + cur * STAGE;
