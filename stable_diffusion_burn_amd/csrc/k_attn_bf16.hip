@@ -245,7 +245,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_bf16_kernel(const AttnParam
             if constexpr (PF) __builtin_amdgcn_sched_barrier(0);
         }
 
-        // (round 6, measured and not kept -- profiles/r06s_*: 128-key LDS tiles walked as two 64-key compute chunks by the two-block form, one barrier and two staging rounds per
+        // (round 6, measured and not kept -- profiles/r06zb_*: the second wave of every SIMD one phase late (its V^T P^T of tile t - 1 at the top of iteration t, a third V buffer, the
+    // packed probabilities carried across the barrier; bit-identical, 74 operator cases): 481 -> 522 us, attention class 7.32 -> 7.80 ms per bf16 image -- what pays in the GEMMs'
+    // k loops (staggered DMA issue) does not pay here; profiles/r06s_*: 128-key LDS tiles walked as two 64-key compute chunks by the two-block form, one barrier and two staging rounds per
     // 128 keys: attention class 6.80 -> 7.09 ms per bf16 image; profiles/r06k_*: requesting tile t + 2's rows during tile t through a second staging register set changes nothing, 490.7 vs 488.6 us:
     // the staging loads are not what a tile waits for)
     // the next tile's global loads go out here, not at the top of the iteration: hipcc puts a vmcnt(0) in front of the first
