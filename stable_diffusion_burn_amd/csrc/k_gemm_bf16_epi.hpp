@@ -36,9 +36,75 @@ __device__ __forceinline__ unsigned xpack_bf16x2(float a, float b) {
 // M = 131 072: 48.9 us without a residual, 80 us with one; profiles/r06g: +2.6 % per bf16 image).  The epilogue then issues no global load at all and takes its
 // no-residual paths (2-byte scratch, persistent tile loop).  Needs N % 4 == 0, ldr % 4 == 0, rowvec_stride % 4 == 0 (engine).
 // GEGLU_T: -1 = p.geglu at run time, 0 / 1 = known at compile time (fragment ni even = value columns, odd = their gate columns; bias rows N apart).
+// The per-column part of that initial value (the bias; zeros without one): NI 16-byte loads.  The tile loop of k_gemm_bf16x.hip requests the NEXT tile's in front of the
+// epilogue's stores -- vmcnt retires in order, so a load issued behind 16 stores waits for all of them (profiles/r06zh_*: 2.1 us per tile in front of the k loop).
+template <int NI, int WN, int GEGLU_T = -1>
+__device__ __forceinline__ void gemm_acc_cols_bf16(const ConvGemm& p, bepi_f32x4 (&colv)[NI], const int n0, const int wave, const int lane) {
+    const bool geglu = GEGLU_T < 0 ? p.geglu != 0 : GEGLU_T == 1;
+    const bool with_b = (p.resid_acc & 2) && p.bias;
+    const int wn = wave % WN;
+    const int g4 = lane >> 4;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int n = geglu ? n0 + wn * (8 * NI) + (ni >> 1) * 16 + g4 * 4 : n0 + (wn * NI + ni) * 16 + g4 * 4;
+        colv[ni] = bepi_f32x4{0.f, 0.f, 0.f, 0.f};
+        if (with_b) colv[ni] = *reinterpret_cast<const bepi_f32x4*>(n < p.N ? reinterpret_cast<const void*>(p.bias + n + ((geglu && (ni & 1)) ? p.N : 0)) : p.zero_page);
+    }
+}
+
 template <int MI, int NI, int WM, int WN, int GEGLU_T = -1>
+__device__ __forceinline__ void gemm_acc_init_bf16(const ConvGemm& p, bepi_f32x4 (&acc)[MI][NI], const bepi_f32x4 (&colv)[NI], const int m0, const int n0, const int wave,
+                                                   const int lane, const int HoWo) {
+    const bool geglu = GEGLU_T < 0 ? p.geglu != 0 : GEGLU_T == 1;
+    const bool with_r = GEGLU_T != 1 && (p.resid_acc & 1);
+    const bool with_v = GEGLU_T != 1 && (p.resid_acc & 2) && p.rowvec;
+    if (!with_r && !with_v) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = colv[ni];
+        return;
+    }
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
+    const int c15 = lane & 15, g4 = lane >> 4;
+    const unsigned short* Rh = reinterpret_cast<const unsigned short*>(p.resid);
+    int ncol[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) ncol[ni] = geglu ? n0 + wn * (8 * NI) + (ni >> 1) * 16 + g4 * 4 : n0 + (wn * NI + ni) * 16 + g4 * 4;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + (wm * MI + mi) * 16 + c15;
+        const int mm = m < p.M ? m : 0;
+        const unsigned short* row = Rh + (long long)mm * p.ldr;
+        const float* rv = with_v ? p.rowvec + (long long)(mm / HoWo) * p.rowvec_stride : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = ncol[ni];
+            bepi_f32x4 v = colv[ni];
+            // (rows / columns past the tile's extent read the zero page: a pointer select, no predicated load)
+            if (with_v) v += *reinterpret_cast<const bepi_f32x4*>(n < p.N ? reinterpret_cast<const void*>(rv + n) : p.zero_page);
+            if (with_r) {
+                const bepi_u32x2 rr = *reinterpret_cast<const bepi_u32x2*>((m < p.M && n < p.N) ? reinterpret_cast<const void*>(row + n) : p.zero_page);
+                v += bepi_f32x4{xbf16_lo(rr[0]), xbf16_hi(rr[0]), xbf16_lo(rr[1]), xbf16_hi(rr[1])};
+            }
+            acc[mi][ni] = v;
+        }
+    }
+}
+
+// The one-call forms.  ONE_PASS = false: the two calls above (hipcc then feeds the bias registers to the first matrix instructions instead of copying them into 128 - 160
+// accumulators behind a wait: profiles/r06zi_* against r06zl_*, Linear shapes on the 256 x 320 tile -9 % more, MXFP8 image +0.9 %); ONE_PASS = true: round 6's first form in one
+// body, which the kernel-row convolution's NI = 5 instantiations need (the two-call form spills 21 - 25 registers there).
+template <int MI, int NI, int WM, int WN, int GEGLU_T = -1, bool ONE_PASS = false>
 __device__ __forceinline__ void gemm_acc_init_bf16(const ConvGemm& p, bepi_f32x4 (&acc)[MI][NI], const int m0, const int n0, const int wave, const int lane,
                                                    const int HoWo) {
+    if constexpr (!ONE_PASS) {
+        bepi_f32x4 colv2[NI];
+        gemm_acc_cols_bf16<NI, WN, GEGLU_T>(p, colv2, n0, wave, lane);
+        gemm_acc_init_bf16<MI, NI, WM, WN, GEGLU_T>(p, acc, colv2, m0, n0, wave, lane, HoWo);
+        return;
+    }
     const bool geglu = GEGLU_T < 0 ? p.geglu != 0 : GEGLU_T == 1;
     const bool with_r = GEGLU_T != 1 && (p.resid_acc & 1);
     const bool with_b = (p.resid_acc & 2) && p.bias;
@@ -115,6 +181,100 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const ConvGemm& p, bepi_f32x4
     const bool has_resid = MODE < 0 ? (!split && p.resid && !(p.resid_acc & 1)) : false;   // (resid_acc bit 0: already in the accumulators)
     const bool vec_ok = MODE < 0 ? (((p.N & 7) == 0) && ((ldc & 7) == 0) && ((p.ldr & 7) == 0 || !has_resid)) : true;
     constexpr int LDSW = WNC + 4;       // scratch row stride in floats (336 B for NI = 5: 16-byte aligned, rows on distinct banks)
+    // ---- the lean form (round 6; ConvGemm::variant bit 3 switches it off): an INTERIOR tile with bf16 output whose bias / time-embedding row / residual are already in the
+    // accumulators (resid_acc) needs no bounds check, no global load and no per-row address arithmetic.  The general form below spends ~110 executed instructions per 16-row
+    // fragment group on them (an integer division for the sample index of a time-embedding row it does not add, 64-bit row address products, exec-mask branches around
+    // loads that are not taken, register copies behind predicated LDS reads that put an lgkmcnt(0) right behind every read) -- profiles/r06zg_*: 4.1 us of a 256 x 256 tile's
+    // 20.6 us at K = 320 sat in the epilogue, of which the stores were 1 - 2 us (r06zf_*).  Here every lane-derived address is computed ONCE per tile: one LDS write
+    // address, NR LDS read addresses, NR 32-bit store offsets against a wave-uniform row pointer that advances by 16 rows per group.  Same values, same single rounding.
+    constexpr int BMT = 16 * MI * WM, BNT = 16 * NI * WN;
+    if (!(p.variant & 8) && m0 + BMT <= p.M) {
+        const int wu = __builtin_amdgcn_readfirstlane(wave);
+        const int wmu = wu / WN, wnu = wu - wmu * WN;
+        if (geglu) {
+            if constexpr (NI % 2 == 0) {
+                if (n0 + BNT / 2 <= p.N && (MODE >= 0 || p.out_mode != 1) && (!p.bias || (p.resid_acc & 2))) {
+                    constexpr int WNO = WNC / 2, RSB = WNO * 2 + 16, CH = WNO / 8, NR = (16 * CH + 63) / 64, REM = 16 * CH - (NR - 1) * 64;
+                    static_assert(((RSB / 16) & 1) == 1 && ((NR * 64 - 1) / CH) * RSB + CH * 16 <= 16 * (WNO + 4) * 4, "scratch rows on distinct 16-byte bank slots, reads inside the wave's scratch");
+                    if (!pre_synced) __syncthreads();
+                    unsigned char* sb = smem_x + wu * (16 * (WNO + 4) * 4);
+                    unsigned char* wr = sb + c15 * RSB + g4 * 8;
+                    const unsigned char* rd[NR];
+                    unsigned goff[NR];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const int q = r * 64 + lane, row = q / CH, c8 = q - row * CH;
+                        rd[r] = sb + row * RSB + c8 * 16;
+                        goff[r] = (unsigned)(row * p.ldc + c8 * 8) * 2u;
+                    }
+                    unsigned char* gbase = reinterpret_cast<unsigned char*>(p.C) + ((long long)(m0 + wmu * MI * 16) * p.ldc + n0 + wnu * WNO) * 2;
+                    const long long gstep = (long long)p.ldc * 32;
+                    auto stage_g = [&](int mi) {
+#pragma unroll
+                        for (int j = 0; j < NI / 2; ++j) {
+                            const f32x4 v = acc[mi][2 * j], g = acc[mi][2 * j + 1];
+                            const kc_f32x2 g01 = gelu_gate_fast2(kc_f32x2{g[0], g[1]}), g23 = gelu_gate_fast2(kc_f32x2{g[2], g[3]});
+                            const kc_f32x2 o01 = kc_f32x2{v[0], v[1]} * g01, o23 = kc_f32x2{v[2], v[3]} * g23;
+                            *reinterpret_cast<u32x2*>(wr + j * 32) = u32x2{xpack_bf16x2(o01[0], o01[1]), xpack_bf16x2(o23[0], o23[1])};
+                        }
+                    };
+                    stage_g(0);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        u32x4 o[NR];
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) o[r] = *reinterpret_cast<const u32x4*>(rd[r]);
+                        __builtin_amdgcn_wave_barrier();
+                        if (mi + 1 < MI) stage_g(mi + 1);
+#pragma unroll
+                        for (int r = 0; r < NR; ++r)
+                            if (r + 1 < NR || REM == 64 || lane < REM) *reinterpret_cast<u32x4*>(gbase + goff[r]) = o[r];
+                        gbase += gstep;
+                    }
+                    return;
+                }
+            }
+        } else if (n0 + BNT <= p.N && !out_f32 && !has_resid && vec_ok && (!(p.bias || p.rowvec) || (p.resid_acc & 2))) {
+            constexpr int RSB = WNC * 2 + 16, CH = WNC / 8, NR = (16 * CH + 63) / 64, REM = 16 * CH - (NR - 1) * 64;
+            static_assert(((RSB / 16) & 1) == 1 && ((NR * 64 - 1) / CH) * RSB + CH * 16 <= 16 * LDSW * 4, "scratch rows on distinct 16-byte bank slots, reads inside the wave's scratch");
+            if (!pre_synced) __syncthreads();
+            unsigned char* sb = smem_x + wu * (16 * LDSW * 4);
+            unsigned char* wr = sb + c15 * RSB + g4 * 8;
+            const unsigned char* rd[NR];
+            unsigned goff[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int q = r * 64 + lane, row = q / CH, c8 = q - row * CH;
+                rd[r] = sb + row * RSB + c8 * 16;
+                goff[r] = (unsigned)(row * ldc + c8 * 8) * 2u;
+            }
+            unsigned char* gbase = reinterpret_cast<unsigned char*>(Ch) + ((long long)(m0 + wmu * MI * 16) * ldc + n0 + wnu * WNC) * 2;
+            const long long gstep = (long long)ldc * 32;
+            auto stage_l = [&](int mi) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const f32x4 v = acc[mi][ni];
+                    *reinterpret_cast<u32x2*>(wr + ni * 32) = u32x2{xpack_bf16x2(v[0], v[1]), xpack_bf16x2(v[2], v[3])};
+                }
+            };
+            stage_l(0);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                u32x4 o[NR];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < NR; ++r) o[r] = *reinterpret_cast<const u32x4*>(rd[r]);      // (a last partial round reads past row 15, inside this wave's scratch; only its store is predicated)
+                __builtin_amdgcn_wave_barrier();
+                if (mi + 1 < MI) stage_l(mi + 1);    // (in-order LDS: lands behind the reads above)
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    if (r + 1 < NR || REM == 64 || lane < REM) *reinterpret_cast<u32x4*>(gbase + goff[r]) = o[r];
+                gbase += gstep;
+            }
+            return;
+        }
+    }
     if (geglu) {   // launch-side guarantees: NI even, no split-K, N % 8 == 0, ldc % 8 == 0, no rowvec / residual
         if constexpr (NI % 2 == 0) {
             constexpr int WNO = WNC / 2;     // output columns of a wave tile

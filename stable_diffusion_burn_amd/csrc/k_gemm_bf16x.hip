@@ -48,7 +48,7 @@ const GemmTileInfo& gemm_tile_info_x(int cfg) { return kTilesX[cfg]; }
 // PM: -1 = one tile per workgroup; 0 / 2 = persistent, with the epilogue's mode fixed at compile time (k_gemm_bf16_epi.hpp: plain / GEGLU gate; bf16 out, no residual).
 // In the tile loop hipcc hoists every lane-derived invariant of the per-tile code (piece rows, scratch offsets, ...) in front of the loop, where it lives through the k
 // loop beside 160 accumulators and 52 fragment registers -- 30 to 200 spilled registers; the per-tile code therefore derives them from an opaque copy of the lane index.
-template <int MI, int NI, int WM, int WN, int PM>
+template <int MI, int NI, int WM, int WN, int PM, bool LIN = false>
 __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) {
     constexpr bool PERSIST = PM >= 0;
     constexpr int BM = 16 * MI * WM;
@@ -97,6 +97,14 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
 
     const int T = p.KH * p.KW;
     const int HoWo = p.Ho * p.Wo;
+    // Linear layers and 1x1 convolutions (round 6): output row m IS input pixel m -- no sample / row / column split of m (two integer divisions per DMA piece, in setup()
+    // and again in the tile loop's issue_first(): profiles/r06zg_*, 1.9 us of a 256 x 256 tile's 20.6 us at K = 320)
+    // The tile loop takes the case as a template parameter (LIN, chosen by the launcher): as a run-time flag both address forms sit in its per-tile code and the
+    // 256 x 320 tile spills.
+    auto is_lin = [&]() {
+        if constexpr (PERSIST) return LIN;
+        return T == 1 && p.stride == 1 && p.pad == 0 && p.ups == 0 && p.Ho == p.Hs && p.Wo == p.Ws;
+    };
     f32x4 acc[MI][NI];
     const int c15 = lane & 15, g4 = lane >> 4;
     const int Hin = p.Hs << p.ups;
@@ -121,11 +129,18 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
         const int lane_o = opaque_lane();
         const int sub = lane_o >> 3;
         const int chunk = (lane_o & 7) ^ sub;
+        const bool lin = is_lin();
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int m = m0 + (wave + 8 * j) * 8 + sub;
             const bool ok = m < p.M;
             const int mm = ok ? m : 0;
+            if (lin) {
+                a_nboff[j] = (long long)mm * pix_bytes + chunk * 16;
+                a_iy0[j] = ok ? 0 : -(1 << 28);
+                a_ix0[j] = 0;
+                continue;
+            }
             const int nb = mm / HoWo;
             const int rem = mm - nb * HoWo;
             const int oy = rem / p.Wo;
@@ -189,10 +204,16 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
         const int lane_o = opaque_lane();
         const int sub = lane_o >> 3;
         const int chunk = (lane_o & 7) ^ sub;
+        const bool lin = is_lin();
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int m = m0n + (wave + 8 * j) * 8 + sub;
             const int mm = m < p.M ? m : 0;
+            if (lin) {
+                const char* src = m < p.M ? Abase + (long long)mm * pix_bytes + chunk * 16 : zero;
+                __builtin_amdgcn_global_load_lds((global_cvoid*)src, (lds_void*)(stage + (wave + 8 * j) * 1024), 16, 0, 0);
+                continue;
+            }
             const int nb = mm / HoWo;
             const int rem = mm - nb * HoWo;
             const int oy = rem / p.Wo;
@@ -227,9 +248,17 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     setup();
     int s0 = 0;      // LDS stage of the tile's first k tile
     issue(0);
+    constexpr int GT = PM < 0 ? -1 : PM == 2 ? 1 : 0;
+    // the per-column part of the accumulators' initial value (k_gemm_bf16_epi.hpp): the tile loop requests the NEXT tile's in front of the epilogue's stores (vmcnt retires in
+    // order: behind them the loads waited out every store of the tile, 2.1 us per tile -- profiles/r06zh_*).  The 256 x 320 tile has no registers for the 20 values beside
+    // its epilogue (68 spilled) and loads them where it always did.
+    constexpr bool COLS_AHEAD = PERSIST && MI * NI <= 32;
+    bepi_f32x4 colv[NI];
+    if constexpr (COLS_AHEAD) gemm_acc_cols_bf16<NI, WN, GT>(p, colv, n0, wave, opaque_lane());
     for (;;) {
-    gemm_acc_init_bf16<MI, NI, WM, WN, (PM < 0 ? -1 : PM == 2 ? 1 : 0)>(p, acc, m0, n0, wave, PERSIST ? opaque_lane() : lane, HoWo);   // zero, or the residual tile (ConvGemm::resid_acc)
-
+    // the bias, or zero; + the residual tile (ConvGemm::resid_acc)
+    if constexpr (COLS_AHEAD) gemm_acc_init_bf16<MI, NI, WM, WN, GT>(p, acc, colv, m0, n0, wave, opaque_lane(), HoWo);
+    else gemm_acc_init_bf16<MI, NI, WM, WN, GT>(p, acc, m0, n0, wave, PERSIST ? opaque_lane() : lane, HoWo);
     for (int t = 0; t < n_t; ++t) {
         const int cur = (s0 + t) & 1;
         sdmi_dma_landed();        // (k_common.hpp: this wave's LDS-DMA pieces have landed BEFORE it enters the barrier)
@@ -298,6 +327,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
             m0 = tm * BM;
             n0 = tn * BNO;
             issue_first(L, m0, n0);
+            if constexpr (COLS_AHEAD) gemm_acc_cols_bf16<NI, WN, GT>(p, colv, n0, wave, opaque_lane());
         }
         // (the lane index is made opaque per tile: the epilogue's lane-derived offsets are then recomputed here instead of being hoisted out of the tile loop, where
         // they would live through the k loop beside the accumulators)
@@ -310,9 +340,9 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     }
 }
 
-template <int MI, int NI, int WM, int WN, int PM>
+template <int MI, int NI, int WM, int WN, int PM, bool LIN = false>
 static hipError_t launch_cfg_bf16x(const ConvGemm& p, dim3 grid, hipStream_t stream) {
-    auto k = conv_gemm_bf16x_kernel<MI, NI, WM, WN, PM>;
+    auto k = conv_gemm_bf16x_kernel<MI, NI, WM, WN, PM, LIN>;
     constexpr size_t lds = 2 * (size_t)(16 * MI * WM + 16 * NI * WN) * 128;
     if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(k), (int)lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, dim3(512), lds, stream, p);
@@ -320,8 +350,11 @@ static hipError_t launch_cfg_bf16x(const ConvGemm& p, dim3 grid, hipStream_t str
 }
 template <int MI, int NI, int WM, int WN>
 static hipError_t launch_persist_bf16x(const ConvGemm& p, int mode, dim3 grid, hipStream_t stream) {
-    if (mode == 0) return launch_cfg_bf16x<MI, NI, WM, WN, 0>(p, grid, stream);
-    if constexpr (NI % 2 == 0) { if (mode == 2) return launch_cfg_bf16x<MI, NI, WM, WN, 2>(p, grid, stream); }
+    const bool lin = p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0 && p.ups == 0 && p.Ho == p.Hs && p.Wo == p.Ws;   // (kernel: LIN)
+    if (mode == 0) return lin ? launch_cfg_bf16x<MI, NI, WM, WN, 0, true>(p, grid, stream) : launch_cfg_bf16x<MI, NI, WM, WN, 0>(p, grid, stream);
+    if constexpr (NI % 2 == 0) {
+        if (mode == 2) return lin ? launch_cfg_bf16x<MI, NI, WM, WN, 2, true>(p, grid, stream) : launch_cfg_bf16x<MI, NI, WM, WN, 2>(p, grid, stream);
+    }
     return hipErrorInvalidValue;
 }
 

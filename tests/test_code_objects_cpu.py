@@ -56,9 +56,17 @@ def test_kernel_row_conv_issues_one_tap_per_loop_body(tmp_path):
 def test_large_tile_bf16_epilogue_form(tmp_path):
     funcs = _functions("k_gemm_bf16x", tmp_path)
     inst = {k: v for k, v in funcs.items() if "conv_gemm_bf16x_kernel" in k}
-    one_tile = {k: v for k, v in inst.items() if k.endswith("ELin1EEEvNS_8ConvGemmE")}      # PM = -1: one tile per workgroup, every epilogue decision at run time
+    one_tile = {k: v for k, v in inst.items() if k.endswith("ELin1ELb0EEEvNS_8ConvGemmE")}  # PM = -1: one tile per workgroup, every epilogue decision at run time
     persistent = {k: v for k, v in inst.items() if k not in one_tile}                         # PM = 0 / 2: the tile loop with its epilogue mode compiled in (round 5)
-    assert len(one_tile) == 4 and len(persistent) == 6, sorted(inst)                          # 4 tiles plain + the two even-NI tiles' GEGLU form
+    assert len(one_tile) == 4 and len(persistent) == 12, sorted(inst)                         # (4 tiles plain + the two even-NI tiles' GEGLU form) x (general / Linear addressing, round 6)
+    # round 6, the lean epilogue of interior tiles: 16-byte stores against a wave-uniform row pointer (scalar base + one 32-bit lane offset computed once per tile), no
+    # per-row 64-bit address product, and in the Linear-addressing tile loops no integer division at all between two tiles (v_rcp_iflag_f32 is hipcc's division sequence)
+    for name, body in inst.items():
+        assert len(re.findall(r"global_store_dwordx4 v\d+, v\[\d+:\d+\], s\[\d+:\d+\]", body)) >= 4, name
+    for name, body in persistent.items():
+        if name.endswith("ELb1EEEvNS_8ConvGemmE"):      # the Linear-addressing twin carries neither address form's sample / row / column split: v_mul_hi_u32 is the division by a hoisted reciprocal
+            twin = persistent[name.replace("ELb1EEEvNS_8ConvGemmE", "ELb0EEEvNS_8ConvGemmE")]
+            assert body.count("v_mul_hi_u32") + 8 <= twin.count("v_mul_hi_u32"), name
     for name, body in inst.items():
         tail = body.rsplit("v_mfma_f32_16x16x32_bf16", 1)[1]               # everything behind the last matrix instruction: the epilogue
         assert "v_cvt_pk_bf16_f32" in tail and "ds_write_b64" in tail and "ds_read_b128" in tail, name
@@ -87,8 +95,8 @@ def test_reduced_precision_geglu_epilogue_has_no_erf_branches(tmp_path):
     """The fused GEGLU epilogue of the bf16 / MXFP8 large-tile kernels evaluates the gate's GELU with gelu_gate_fast (k_common.hpp): one reciprocal and one exp2 per element and
     no divergent branch -- erff() was ~ 35 instructions and two s_and_saveexec regions per element (round 5, profiles/r05ad_*)."""
     funcs = _functions("k_gemm_bf16x", tmp_path)
-    geglu = {k: v for k, v in funcs.items() if "conv_gemm_bf16x_kernel" in k and k.endswith("ELi2EEEvNS_8ConvGemmE")}      # PM = 2: the persistent GEGLU form
-    assert len(geglu) == 2, sorted(geglu)
+    geglu = {k: v for k, v in funcs.items() if "conv_gemm_bf16x_kernel" in k and re.search(r"ELi2ELb[01]EEEvNS_8ConvGemmE$", k)}      # PM = 2: the persistent GEGLU form (x general / Linear addressing)
+    assert len(geglu) == 4, sorted(geglu)
     for name, body in geglu.items():
         n_exp, n_rcp = body.count("v_exp_f32"), body.count("v_rcp_f32")
         assert n_exp >= 32 and n_rcp >= n_exp, name

@@ -1,0 +1,23 @@
+#!/bin/bash
+# round 6, call zm: the lean epilogue + Linear addressing + bias ahead of the stores, third build (two-call accumulator init everywhere but the kernel-row NI = 5 instantiations): operator
+# tests, per shape and per image against the build of PREV_COMMIT.txt (alternating processes, same box)
+out=gpurun_out
+new=stable_diffusion_burn_amd/lib/libsdmi.so
+cp $new /tmp/libsdmi_new.so
+python -m pytest tests/test_bf16_gpu.py tests/test_fp8_gpu.py -x -q > $out/r06zm_pytest_ops.txt 2>&1; tail -n 2 $out/r06zm_pytest_ops.txt
+rm -f $out/r06zm_shapes_*.txt
+for which in prev new; do
+  if [ $which = prev ]; then cp tools/probes/libs/libsdmi_prev.so $new; else cp /tmp/libsdmi_new.so $new; fi
+  python tools/probes/r06zj_shapes.py 1 >> $out/r06zm_shapes_$which.txt 2>&1
+done
+paste -d'|' $out/r06zm_shapes_prev.txt $out/r06zm_shapes_new.txt | cut -c1-200
+for rep in 1 2; do
+  for which in prev new; do
+    if [ $which = prev ]; then cp tools/probes/libs/libsdmi_prev.so $new; else cp /tmp/libsdmi_new.so $new; fi
+    python tools/ab_variants.py --precision bf16 --batch 16 --arms cfg_share=1 --rounds 3 --out $out/r06zm_bf16_b16_${which}_$rep.jsonl > $out/r06zm_a$which$rep.log 2>&1
+    python tools/ab_variants.py --precision fp8 --batch 16 --arms cfg_share=1 --rounds 3 --out $out/r06zm_fp8_b16_${which}_$rep.jsonl > $out/r06zm_b$which$rep.log 2>&1
+    python tools/ab_variants.py --precision bf16 --batch 1 --arms cfg_share=1 --rounds 3 --out $out/r06zm_bf16_b1_${which}_$rep.jsonl > $out/r06zm_c$which$rep.log 2>&1
+  done
+done
+cp /tmp/libsdmi_new.so $new
+for f in $out/r06zm_*_b*_*.jsonl; do echo $f; cut -c1-330 $f; done
