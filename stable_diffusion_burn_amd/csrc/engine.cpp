@@ -1380,7 +1380,7 @@ void Engine::launch_gemm(ConvGemm& p, int in_dt, int force_cfg, int force_splits
     if (splits == 1) {
         p.slab_stride = 0;
         ProfScope ps(this, pc, flops, gemm_bytes);
-        ps.set_tag("gemm %d,%d,%d k%d%s cfg=%d splits=1", p.M, p.N, p.K, p.KH, p.geglu ? " geglu" : "", tc.cfg);
+        ps.set_tag("gemm %d,%d,%d k%d%s%s%s cfg=%d splits=1", p.M, p.N, p.K, p.KH, p.geglu ? " geglu" : "", p.resid ? " resid" : "", p.rowvec ? " rowvec" : "", tc.cfg);
         SDMI_HIP(launch(p));
         count_kernel(flops);
     } else {
@@ -1819,7 +1819,7 @@ void Engine::launch_fp8(ConvGemm& p, double flops) {
     const double fp8_bytes = ((double)p.NB * p.Hs * p.Ws * p.a_ld + (double)p.N * p.K) * (1.0 + 1.0 / 32.0) + (double)p.M * p.N * 2.0;
     if (splits == 1) {
         ProfScope ps(this, PC_CONV_FP8, flops, fp8_bytes);
-        ps.set_tag("gemm_fp8 %d,%d,%d k%d cfg=%d splits=1", p.M, p.N, p.K, p.KH, cfg);
+        ps.set_tag("gemm_fp8 %d,%d,%d k%d%s%s cfg=%d splits=1", p.M, p.N, p.K, p.KH, p.resid ? " resid" : "", p.rowvec ? " rowvec" : "", cfg);
         SDMI_HIP(launch_conv_gemm_fp8x(p, cfg, stream_));
         count_kernel(flops);
     } else {

@@ -36,42 +36,52 @@ __device__ __forceinline__ unsigned xpack_bf16x2(float a, float b) {
 // M = 131 072: 48.9 us without a residual, 80 us with one; profiles/r06g: +2.6 % per bf16 image).  The epilogue then issues no global load at all and takes its
 // no-residual paths (2-byte scratch, persistent tile loop).  Needs N % 4 == 0, ldr % 4 == 0, rowvec_stride % 4 == 0 (engine).
 // GEGLU_T: -1 = p.geglu at run time, 0 / 1 = known at compile time (fragment ni even = value columns, odd = their gate columns; bias rows N apart).
-// The per-column part of that initial value (the bias; zeros without one): NI 16-byte loads.  The tile loop of k_gemm_bf16x.hip requests the NEXT tile's in front of the
-// epilogue's stores -- vmcnt retires in order, so a load issued behind 16 stores waits for all of them (profiles/r06zh_*: 2.1 us per tile in front of the k loop).
-template <int NI, int WN, int GEGLU_T = -1>
-__device__ __forceinline__ void gemm_acc_cols_bf16(const ConvGemm& p, bepi_f32x4 (&colv)[NI], const int n0, const int wave, const int lane) {
-    const bool geglu = GEGLU_T < 0 ? p.geglu != 0 : GEGLU_T == 1;
-    const bool with_b = (p.resid_acc & 2) && p.bias;
-    const int wn = wave % WN;
-    const int g4 = lane >> 4;
+// The residual tile of an INTERIOR tile on top of the per-column terms colv, its loads issued in straight-line batches (RBM fragment rows x NI 8-byte loads in flight: what
+// the caller's registers allow) and consumed afterwards.  The general form below -- `if (with_v) load; if (with_r) load;` per fragment -- is compiled to one block per
+// load with an s_waitcnt vmcnt(0) at its end: 40 serialized round trips per 256 x 320 tile (profiles/r06zp_*: M = 131 072, N = K = 320 took 79 us with a residual,
+// 41 us without; 13 us is what the residual's bytes cost).  Batching THAT form (predicates and pointer selects for 40 loads up front) spilled 30 - 180 registers in the
+// 8-wave kernels, so it stays as it is for edge tiles and time-embedding rows, and the batched form has no predicate at all: one address per fragment row.
+template <int MI, int NI, int WM, int WN, int RBM>
+__device__ __forceinline__ void gemm_acc_resid_bf16(const ConvGemm& p, bepi_f32x4 (&acc)[MI][NI], const bepi_f32x4 (&colv)[NI], const int ncol0, const int m0,
+                                                    const int wave, const int lane) {
+    constexpr int RB = MI > RBM ? RBM : MI;
+    static_assert(RB > 0 && MI % RB == 0, "whole batches");
+    const int wm = wave / WN;
+    const int c15 = lane & 15;
+    const unsigned short* Rh = reinterpret_cast<const unsigned short*>(p.resid);
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int n = geglu ? n0 + wn * (8 * NI) + (ni >> 1) * 16 + g4 * 4 : n0 + (wn * NI + ni) * 16 + g4 * 4;
-        colv[ni] = bepi_f32x4{0.f, 0.f, 0.f, 0.f};
-        if (with_b) colv[ni] = *reinterpret_cast<const bepi_f32x4*>(n < p.N ? reinterpret_cast<const void*>(p.bias + n + ((geglu && (ni & 1)) ? p.N : 0)) : p.zero_page);
+    for (int mb = 0; mb < MI / RB; ++mb) {
+        bepi_u32x2 raw[RB * NI];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const unsigned short* row = Rh + (long long)(m0 + (wm * MI + mb * RB + i) * 16 + c15) * p.ldr + ncol0;     // one address per fragment row, the fragments at + 32 B
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) raw[i * NI + ni] = *reinterpret_cast<const bepi_u32x2*>(row + ni * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const bepi_u32x2 rr = raw[i * NI + ni];
+                acc[mb * RB + i][ni] = colv[ni] + bepi_f32x4{xbf16_lo(rr[0]), xbf16_hi(rr[0]), xbf16_lo(rr[1]), xbf16_hi(rr[1])};
+            }
+        __builtin_amdgcn_sched_barrier(0);      // (one batch's loads at a time)
     }
 }
 
-template <int MI, int NI, int WM, int WN, int GEGLU_T = -1>
-__device__ __forceinline__ void gemm_acc_init_bf16(const ConvGemm& p, bepi_f32x4 (&acc)[MI][NI], const bepi_f32x4 (&colv)[NI], const int m0, const int n0, const int wave,
-                                                   const int lane, const int HoWo) {
-    const bool geglu = GEGLU_T < 0 ? p.geglu != 0 : GEGLU_T == 1;
-    const bool with_r = GEGLU_T != 1 && (p.resid_acc & 1);
-    const bool with_v = GEGLU_T != 1 && (p.resid_acc & 2) && p.rowvec;
-    if (!with_r && !with_v) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = colv[ni];
-        return;
+// interior: the whole tile lies inside M x N (uniform)
+template <int MI, int NI, int WM, int WN, int RBM>
+__device__ __forceinline__ void gemm_acc_rows_bf16(const ConvGemm& p, bepi_f32x4 (&acc)[MI][NI], const bepi_f32x4 (&colv)[NI], const int (&ncol)[NI], const bool with_r,
+                                                   const bool with_v, const bool interior, const int m0, const int wave, const int lane, const int HoWo) {
+    if constexpr (RBM > 0) {     // (RBM = 0: the kernel-row convolution's NI = 5 instantiations, 248 registers in their k loop, spill 21 with the batched form beside the general one)
+        if (with_r && !with_v && interior) {     // the common case (attention / feed-forward output projections, the ResBlocks' second convolution): batched, no predicates
+            gemm_acc_resid_bf16<MI, NI, WM, WN, RBM>(p, acc, colv, ncol[0], m0, wave, lane);
+            return;
+        }
     }
     const int wm = wave / WN;
-    const int wn = wave - wm * WN;
-    const int c15 = lane & 15, g4 = lane >> 4;
+    const int c15 = lane & 15;
     const unsigned short* Rh = reinterpret_cast<const unsigned short*>(p.resid);
-    int ncol[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) ncol[ni] = geglu ? n0 + wn * (8 * NI) + (ni >> 1) * 16 + g4 * 4 : n0 + (wn * NI + ni) * 16 + g4 * 4;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + (wm * MI + mi) * 16 + c15;
@@ -93,16 +103,53 @@ __device__ __forceinline__ void gemm_acc_init_bf16(const ConvGemm& p, bepi_f32x4
     }
 }
 
+// The per-column part of that initial value (the bias; zeros without one): NI 16-byte loads.  The tile loop of k_gemm_bf16x.hip requests the NEXT tile's in front of the
+// epilogue's stores -- vmcnt retires in order, so a load issued behind 16 stores waits for all of them (profiles/r06zh_*: 2.1 us per tile in front of the k loop).
+template <int NI, int WN, int GEGLU_T = -1>
+__device__ __forceinline__ void gemm_acc_cols_bf16(const ConvGemm& p, bepi_f32x4 (&colv)[NI], const int n0, const int wave, const int lane) {
+    const bool geglu = GEGLU_T < 0 ? p.geglu != 0 : GEGLU_T == 1;
+    const bool with_b = (p.resid_acc & 2) && p.bias;
+    const int wn = wave % WN;
+    const int g4 = lane >> 4;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int n = geglu ? n0 + wn * (8 * NI) + (ni >> 1) * 16 + g4 * 4 : n0 + (wn * NI + ni) * 16 + g4 * 4;
+        colv[ni] = bepi_f32x4{0.f, 0.f, 0.f, 0.f};
+        if (with_b) colv[ni] = *reinterpret_cast<const bepi_f32x4*>(n < p.N ? reinterpret_cast<const void*>(p.bias + n + ((geglu && (ni & 1)) ? p.N : 0)) : p.zero_page);
+    }
+}
+
+template <int MI, int NI, int WM, int WN, int GEGLU_T = -1, int RBM = (NI > 4 ? 2 : 4)>
+__device__ __forceinline__ void gemm_acc_init_bf16(const ConvGemm& p, bepi_f32x4 (&acc)[MI][NI], const bepi_f32x4 (&colv)[NI], const int m0, const int n0, const int wave,
+                                                   const int lane, const int HoWo) {
+    const bool geglu = GEGLU_T < 0 ? p.geglu != 0 : GEGLU_T == 1;
+    const bool with_r = GEGLU_T != 1 && (p.resid_acc & 1);
+    const bool with_v = GEGLU_T != 1 && (p.resid_acc & 2) && p.rowvec;
+    if (!with_r && !with_v) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = colv[ni];
+        return;
+    }
+    const int wn = wave % WN;
+    const int g4 = lane >> 4;
+    int ncol[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) ncol[ni] = geglu ? n0 + wn * (8 * NI) + (ni >> 1) * 16 + g4 * 4 : n0 + (wn * NI + ni) * 16 + g4 * 4;
+    gemm_acc_rows_bf16<MI, NI, WM, WN, RBM>(p, acc, colv, ncol, with_r, with_v, m0 + 16 * MI * WM <= p.M && n0 + 16 * NI * WN <= p.N, m0, wave, lane, HoWo);
+}
+
 // The one-call forms.  ONE_PASS = false: the two calls above (hipcc then feeds the bias registers to the first matrix instructions instead of copying them into 128 - 160
 // accumulators behind a wait: profiles/r06zi_* against r06zl_*, Linear shapes on the 256 x 320 tile -9 % more, MXFP8 image +0.9 %); ONE_PASS = true: round 6's first form in one
 // body, which the kernel-row convolution's NI = 5 instantiations need (the two-call form spills 21 - 25 registers there).
-template <int MI, int NI, int WM, int WN, int GEGLU_T = -1, bool ONE_PASS = false>
+template <int MI, int NI, int WM, int WN, int GEGLU_T = -1, bool ONE_PASS = false, int RBM = (NI > 4 ? 2 : 4)>
 __device__ __forceinline__ void gemm_acc_init_bf16(const ConvGemm& p, bepi_f32x4 (&acc)[MI][NI], const int m0, const int n0, const int wave, const int lane,
                                                    const int HoWo) {
     if constexpr (!ONE_PASS) {
         bepi_f32x4 colv2[NI];
         gemm_acc_cols_bf16<NI, WN, GEGLU_T>(p, colv2, n0, wave, lane);
-        gemm_acc_init_bf16<MI, NI, WM, WN, GEGLU_T>(p, acc, colv2, m0, n0, wave, lane, HoWo);
+        gemm_acc_init_bf16<MI, NI, WM, WN, GEGLU_T, RBM>(p, acc, colv2, m0, n0, wave, lane, HoWo);
         return;
     }
     const bool geglu = GEGLU_T < 0 ? p.geglu != 0 : GEGLU_T == 1;

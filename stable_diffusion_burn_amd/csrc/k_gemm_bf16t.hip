@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512) void conv3_gemm_bf16t_kernel(const ConvGemm p)
 #pragma unroll
     for (int j = 0; j < NAJ; ++j) issue_a(j, cs, ky, 0);
     issue_b(kt, kt & 1);
-    gemm_acc_init_bf16<MI, NI, WM, WN, 0, (NI == 5)>(p, acc, m0, n0, wave, lane, HoWo);   // zero, or the residual tile (ConvGemm::resid_acc), behind the first DMAs
+    gemm_acc_init_bf16<MI, NI, WM, WN, 0, (NI == 5), (NI == 5 ? 0 : 4)>(p, acc, m0, n0, wave, lane, HoWo);   // zero, or the residual tile (ConvGemm::resid_acc), behind the first DMAs
     const int n_t = 3 * n_g;
     for (int t = 0; t < n_t; ++t) {
         sdmi_dma_landed();        // (k_common.hpp: this wave's LDS-DMA pieces have landed BEFORE it enters the barrier)

@@ -257,8 +257,9 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16x_kernel(const ConvGemm p) 
     if constexpr (COLS_AHEAD) gemm_acc_cols_bf16<NI, WN, GT>(p, colv, n0, wave, opaque_lane());
     for (;;) {
     // the bias, or zero; + the residual tile (ConvGemm::resid_acc)
-    if constexpr (COLS_AHEAD) gemm_acc_init_bf16<MI, NI, WM, WN, GT>(p, acc, colv, m0, n0, wave, opaque_lane(), HoWo);
-    else gemm_acc_init_bf16<MI, NI, WM, WN, GT>(p, acc, m0, n0, wave, PERSIST ? opaque_lane() : lane, HoWo);
+    constexpr int RBM = PERSIST ? 2 : NI > 4 ? 2 : 4;      // fragment rows of residual loads in flight: what the registers beside the tile loop allow
+    if constexpr (COLS_AHEAD) gemm_acc_init_bf16<MI, NI, WM, WN, GT, RBM>(p, acc, colv, m0, n0, wave, opaque_lane(), HoWo);
+    else gemm_acc_init_bf16<MI, NI, WM, WN, GT, false, RBM>(p, acc, m0, n0, wave, PERSIST ? opaque_lane() : lane, HoWo);
     for (int t = 0; t < n_t; ++t) {
         const int cur = (s0 + t) & 1;
         sdmi_dma_landed();        // (k_common.hpp: this wave's LDS-DMA pieces have landed BEFORE it enters the barrier)
