@@ -127,6 +127,98 @@ __device__ __forceinline__ void gemm_epilogue_f32(const ConvGemm& p, epi_f32x4 (
         }
         return;
     }
+    // ---- the lean form (round 6; ConvGemm::variant bit 6 switches it off), k_gemm_bf16_epi.hpp's for fp32 output: an INTERIOR tile whose rows belong to one sample (the
+    // time-embedding row is then a per-column term like the bias) needs no bounds check, no sample-index division per fragment group and no 64-bit address product per
+    // store.  Every lane-derived address is computed once per tile -- one LDS write address, NI LDS read addresses, NI 32-bit offsets each for the output, the residual and
+    // the planes -- against wave-uniform row pointers that advance by 16 rows per group; the residual of group mi + 1 is requested before group mi is stored.  The general
+    // form below executed ~3x the instructions per group and waited out every time-embedding load where it was issued.  Same values in the same order.
+    if (!(p.variant & 64) && vec_ok && m0 + BM <= p.M && n0 + BN <= p.N) {
+        int smp0 = 0;
+        bool one_smp = true;
+        if (!split && p.rowvec) {
+            smp0 = m0 / HoWo;
+            one_smp = (m0 + BM - 1) / HoWo == smp0;
+        }
+        if (one_smp) {
+            typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+            const int wu = __builtin_amdgcn_readfirstlane(wave);
+            const int wmu = wu / WN, wnu = wu - wmu * WN;
+            constexpr int CH = WNC / 4;   // 16-byte chunks per row; 16 rows x CH chunks = NI x 64 lanes exactly
+            __syncthreads();                // every wave is done with the last k tile
+            float* scr = reinterpret_cast<float*>(smem_x32 + wu * (16 * LDSW * 4));
+            const int nw0 = n0 + wnu * WNC;
+            const bool has_c3 = !split && p.C3;
+            f32x4 bias_v[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int n = nw0 + ni * 16 + g4 * 4;
+                bias_v[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!split && p.bias) bias_v[ni] = *reinterpret_cast<const f32x4*>(p.bias + n);
+                if (!split && p.rowvec) bias_v[ni] += *reinterpret_cast<const f32x4*>(p.rowvec + (long long)smp0 * p.rowvec_stride + n);
+            }
+            float* wr = scr + c15 * LDSW + g4 * 4;
+            const float* rd[NI];
+            unsigned goff[NI], roff[NI], poff[NI];
+#pragma unroll
+            for (int r = 0; r < NI; ++r) {
+                const int q = r * 64 + lane, row = q / CH, c4 = q - row * CH;
+                rd[r] = scr + row * LDSW + c4 * 4;
+                goff[r] = (unsigned)(row * ldc + c4 * 4) * 4u;
+                roff[r] = has_resid ? (unsigned)(row * p.ldr + c4 * 4) * 4u : 0u;
+                poff[r] = has_c3 ? (unsigned)(row * p.ldc3) + (unsigned)s3_plane_byte(nw0 + c4 * 4, 0) : 0u;
+            }
+            const long long mw0 = m0 + wmu * MI * 16;
+            unsigned char* gbase = reinterpret_cast<unsigned char*>(Cf) + (mw0 * ldc + nw0) * 4;
+            const unsigned char* rbase = reinterpret_cast<const unsigned char*>(p.resid) + (has_resid ? (mw0 * p.ldr + nw0) * 4 : 0);
+            unsigned char* pbase = reinterpret_cast<unsigned char*>(p.C3) + (has_c3 ? mw0 * p.ldc3 : 0);
+            f32x4 res[NI];
+            if (has_resid) {
+#pragma unroll
+                for (int r = 0; r < NI; ++r) res[r] = *reinterpret_cast<const f32x4*>(rbase + roff[r]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    f32x4 v = acc[mi][ni];
+                    if (!split) v += bias_v[ni];
+                    *reinterpret_cast<f32x4*>(wr + ni * 16) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                f32x4 o[NI];
+#pragma unroll
+                for (int r = 0; r < NI; ++r) o[r] = *reinterpret_cast<const f32x4*>(rd[r]);
+                __builtin_amdgcn_wave_barrier();
+                if (has_resid) {
+#pragma unroll
+                    for (int r = 0; r < NI; ++r) o[r] += res[r];
+                    if (mi + 1 < MI) {
+                        rbase += (long long)p.ldr * 64;
+#pragma unroll
+                        for (int r = 0; r < NI; ++r) res[r] = *reinterpret_cast<const f32x4*>(rbase + roff[r]);
+                    }
+                }
+                if (Cf) {
+#pragma unroll
+                    for (int r = 0; r < NI; ++r) *reinterpret_cast<f32x4*>(gbase + goff[r]) = o[r];
+                    gbase += (long long)ldc * 64;
+                }
+                if (has_c3) {
+#pragma unroll
+                    for (int r = 0; r < NI; ++r) {
+                        unsigned h[2], m[2], l[2];
+                        s3_split4(o[r], h, m, l);
+                        unsigned char* d = pbase + poff[r];
+                        *reinterpret_cast<u2*>(d) = u2{h[0], h[1]};
+                        *reinterpret_cast<u2*>(d + 64) = u2{m[0], m[1]};
+                        *reinterpret_cast<u2*>(d + 128) = u2{l[0], l[1]};
+                    }
+                    pbase += (long long)p.ldc3 * 16;
+                }
+            }
+            return;
+        }
+    }
     if (vec_ok) {
         __syncthreads();                // every wave is done with the last k tile
         float* scr = reinterpret_cast<float*>(smem_x32 + wave * (16 * LDSW * 4));
