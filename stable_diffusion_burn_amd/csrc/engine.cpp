@@ -1086,7 +1086,7 @@ void Engine::set_option(const std::string& key, const std::string& value) {
     else if (key == "gemm_probe") opt_gemm_probe_ = std::stoi(value);
     else if (key == "conv3_reuse") opt_conv3_reuse_ = std::stoi(value);
     else if (key == "gemm_planes") opt_gemm_planes_ = (value == "default") ? kGemmPlanesDefault : std::stoi(value);
-    else if (key == "gemm3x_variant") opt_gemm3x_variant_ = std::stoi(value);
+    else if (key == "gemm3x_variant") opt_gemm3x_variant_ = (value == "default") ? kGemm3xVariantDefault : std::stoi(value);
     else if (key == "gemm_bf16x_variant") opt_gemm_bf16x_variant_ = (value == "default") ? kGemmBf16xVariantDefault : std::stoi(value);
     else if (key == "geglu_fuse") opt_geglu_fuse_ = std::stoi(value);
     else if (key == "record_shapes") { record_shapes_ = std::stoi(value) != 0; if (record_shapes_) { shape_counts_.clear(); choice_counts_.clear(); } }

@@ -451,7 +451,8 @@ private:
     int opt_geglu_fuse_ = 1;    // GEGLU gate in the projection GEMM's epilogue: 0 never, 1 where there are >= 4 rounds of tiles, 2 / 3 always (256x128 / 256x256 tiles; tests)
     int opt_attn_split_ = 1;    // precision = 0: 1 = d_head 40 / 80 attention on the bf16 matrix pipe with three-way split operands (k_attn_split.hip)
     int opt_gemm_f32s_ = 1;     // precision = 0: 1 = fp32 GEMMs on the bf16 matrix pipe (three-way operand split, k_gemm3x.hip) where faster
-    int opt_gemm3x_variant_ = 2;     // k_gemm3x.hip: bit 0: DMA in one block per k tile; bit 1: scalar residual subtractions (+0.7 %); bit 2: two LDS stages on the 128-row tiles
+    static constexpr int kGemm3xVariantDefault = 2;
+    int opt_gemm3x_variant_ = kGemm3xVariantDefault;     // k_gemm3x.hip: bit 0: DMA in one block per k tile; bit 1: scalar residual subtractions (+0.7 %); bit 2: two LDS stages on the 128-row tiles
                                      // (default three: +5..10 % on long K); bit 4: s_setprio 1 for waves 4-7 (measured: no gain)
     static constexpr int kGemmPlanesDefault = 1;
     int opt_gemm_planes_ = kGemmPlanesDefault;   // precision = 0: k_gemm3p.hip (activations as bf16 planes too, no split in the k loop): 0 never, 1 every launch that would take a k_gemm3x.hip tile,

@@ -124,7 +124,7 @@ __device__ __forceinline__ void gemm_acc_init_bf16(const ConvGemm& p, bepi_f32x4
                                                    const int lane, const int HoWo) {
     const bool geglu = GEGLU_T < 0 ? p.geglu != 0 : GEGLU_T == 1;
     const bool with_r = GEGLU_T != 1 && (p.resid_acc & 1);
-    const bool with_v = GEGLU_T != 1 && (p.resid_acc & 2) && p.rowvec;
+    bool with_v = GEGLU_T != 1 && (p.resid_acc & 2) && p.rowvec;
     if (!with_r && !with_v) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -137,7 +137,30 @@ __device__ __forceinline__ void gemm_acc_init_bf16(const ConvGemm& p, bepi_f32x4
     int ncol[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) ncol[ni] = geglu ? n0 + wn * (8 * NI) + (ni >> 1) * 16 + g4 * 4 : n0 + (wn * NI + ni) * 16 + g4 * 4;
-    gemm_acc_rows_bf16<MI, NI, WM, WN, RBM>(p, acc, colv, ncol, with_r, with_v, m0 + 16 * MI * WM <= p.M && n0 + 16 * NI * WN <= p.N, m0, wave, lane, HoWo);
+    // a tile whose rows belong to ONE sample (every level but the 8 x 8 one): the time-embedding row is a per-column term like the bias -- NI loads in one batch instead of
+    // MI x NI loads, each waited for where it is issued, behind a sample-index division per fragment row (the same sum in the same order: bias + row, then the residual)
+    bepi_f32x4 cv[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) cv[ni] = colv[ni];
+    constexpr bool FOLD = !(GEGLU_T < 0 && MI * NI >= 40);     // (the one-tile 256 x 320 bf16 form, every epilogue decision at run time, spills 4 registers with one more path)
+    if (FOLD && with_v) {
+        const int mlast = (m0 + 16 * MI * WM <= p.M ? m0 + 16 * MI * WM : p.M) - 1;
+        const int s0 = m0 / HoWo;
+        if (mlast / HoWo == s0) {
+            const float* rv = p.rowvec + (long long)s0 * p.rowvec_stride;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) cv[ni] += *reinterpret_cast<const bepi_f32x4*>(ncol[ni] < p.N ? reinterpret_cast<const void*>(rv + ncol[ni]) : p.zero_page);
+            with_v = false;
+            if (!with_r) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = cv[ni];
+                return;
+            }
+        }
+    }
+    gemm_acc_rows_bf16<MI, NI, WM, WN, RBM>(p, acc, cv, ncol, with_r, with_v, m0 + 16 * MI * WM <= p.M && n0 + 16 * NI * WN <= p.N, m0, wave, lane, HoWo);
 }
 
 // The one-call forms.  ONE_PASS = false: the two calls above (hipcc then feeds the bias registers to the first matrix instructions instead of copying them into 128 - 160
@@ -155,7 +178,7 @@ __device__ __forceinline__ void gemm_acc_init_bf16(const ConvGemm& p, bepi_f32x4
     const bool geglu = GEGLU_T < 0 ? p.geglu != 0 : GEGLU_T == 1;
     const bool with_r = GEGLU_T != 1 && (p.resid_acc & 1);
     const bool with_b = (p.resid_acc & 2) && p.bias;
-    const bool with_v = GEGLU_T != 1 && (p.resid_acc & 2) && p.rowvec;
+    bool with_v = GEGLU_T != 1 && (p.resid_acc & 2) && p.rowvec;
     if (!with_r && !with_b && !with_v) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -176,6 +199,16 @@ __device__ __forceinline__ void gemm_acc_init_bf16(const ConvGemm& p, bepi_f32x4
         ncol[ni] = n;
         colv[ni] = bepi_f32x4{0.f, 0.f, 0.f, 0.f};
         if (with_b) colv[ni] = *reinterpret_cast<const bepi_f32x4*>(n < p.N ? reinterpret_cast<const void*>(p.bias + n + ((geglu && (ni & 1)) ? p.N : 0)) : p.zero_page);
+    }
+    if (with_v) {     // a tile inside one sample: the time-embedding row joins the per-column terms (see the two-call form)
+        const int mlast = (m0 + 16 * MI * WM <= p.M ? m0 + 16 * MI * WM : p.M) - 1;
+        const int s0 = m0 / HoWo;
+        if (mlast / HoWo == s0) {
+            const float* rv0 = p.rowvec + (long long)s0 * p.rowvec_stride;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) colv[ni] += *reinterpret_cast<const bepi_f32x4*>(ncol[ni] < p.N ? reinterpret_cast<const void*>(rv0 + ncol[ni]) : p.zero_page);
+            with_v = false;
+        }
     }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {

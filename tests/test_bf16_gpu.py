@@ -339,7 +339,7 @@ def test_geglu_forward_bf16(ops16, rows, cin, hidden, fuse):
 # the oracle.  The shapes have more tiles than the chip has CUs (the persistent form's condition), ragged M, N tails, one to twenty k tiles, padding taps in a tile's
 # FIRST k tile (issue_first); with a residual the launch stays on the one-tile form (checked to be a no-op here).  (Round 5 also measured an epilogue without the LDS
 # transpose -- v_permlane16_swap pairs, 64-byte row pieces -- bit-identical and 4 ... 7 % slower per launch: removed, profiles/r05a_*.)
-def _variants(ops16, fn, what, variants=(1, 4, 5)):     # bit 0: persistent tile loop (round 5); bit 2: staggered DMA issue of the two wave groups (round 6); 5 = the default
+def _variants(ops16, fn, what, variants=(1, 4, 5, 8, 13)):     # bit 0: persistent tile loop (round 5); bit 2: staggered DMA issue of the two wave groups (round 6); 5 = the default; bit 3: the GENERAL epilogue on interior tiles too (round 6: variant 0 and the default take the lean one)
     try:
         ops16.set_option("gemm_bf16x_variant", 0)
         base = fn()

@@ -86,6 +86,31 @@ def test_conv2d_plane_tiles_short_k(sd_ops, tile, case):
     _check(got, ref.numpy(), f"conv planes short K tile={tile} {case}")
 
 
+@pytest.mark.parametrize("tile", PTILES)
+@pytest.mark.parametrize("splitk", [1, 3])
+def test_lean_fp32_epilogue_equals_the_general_one_bit_for_bit(sd_ops, tile, splitk):
+    """Round 6 (k_gemm_epi.hpp): interior single-sample tiles take an epilogue with every address computed once per tile; gemm3x_variant bit 6 sends them through the general form.
+    Same values in the same order: the two must agree bit for bit -- on shapes with interior AND edge tiles, one sample per tile and several (8 x 8 images: the lean form must
+    step aside), 1x1 and 3x3, with split-K slabs."""
+    for case in [(2, 64, 32, 32, 320, 1), (2, 64, 32, 32, 320, 3), (5, 96, 8, 8, 160, 3), (1, 128, 40, 36, 200, 1), (3, 32, 16, 16, 128, 3)]:
+        n, cin, h, w, cout, k = case
+        g = np.random.default_rng(9700 + tile + 7 * splitk + cin + cout)
+        x = g.standard_normal((n, cin, h, w)).astype(np.float32)
+        wt = (g.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k)).astype(np.float32)
+        b = g.standard_normal(cout).astype(np.float32)
+        outs = {}
+        try:
+            with _Forced(sd_ops, tile, splitk):
+                for variant in (2, 66):
+                    sd_ops.set_option("gemm3x_variant", variant)
+                    outs[variant] = sd_ops.op_conv2d(x, wt, b)
+        finally:
+            sd_ops.set_option("gemm3x_variant", "default")
+        assert np.array_equal(outs[2], outs[66]), f"tile {tile} splitk {splitk} {case}: lean and general epilogue differ"
+        ref = O.conv2d(_t(x), (_t(wt), _t(b)), padding=1 if k == 3 else 0)
+        _check(outs[2], ref.numpy(), f"conv planes lean epilogue tile={tile} splitk={splitk} {case}")
+
+
 def test_plane_kernel_is_fp32_accurate_and_exact_on_small_integers(sd_ops):
     """The K = 11520, ten-binades-per-channel convolution of test_conv2d_split_bf16_is_fp32_accurate: the plane kernel's error against fp64 is
     of the size of the fp32 matrix instruction's own; integers whose products and sums stay below 2^24 come out bit-exact (they need the
