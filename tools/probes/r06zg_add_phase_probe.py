@@ -18,7 +18,7 @@ s = rep(s, """    setup();
 """, """    unsigned acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned tprev = 0;
     unsigned long long rt0 = 0;
-    const bool probing = PERSIST && p.probe != nullptr;
+    const bool probing = p.probe != nullptr;
 #define STAMP(i) do { if (probing) { __builtin_amdgcn_sched_barrier(0); const unsigned tn_ = (unsigned)__builtin_readcyclecounter(); acc_t[i] += tn_ - tprev; tprev = tn_; __builtin_amdgcn_sched_barrier(0); } } while (0)
     if (probing) { rt0 = __builtin_amdgcn_s_memrealtime(); tprev = (unsigned)__builtin_readcyclecounter(); }
     setup();
@@ -41,9 +41,18 @@ s = rep(s, """        __syncthreads();                    // k tile t is in LDS;
 """, """        __syncthreads();                    // k tile t is in LDS; every wave is done with stage cur ^ 1
         if (t == 0) STAMP(1);
 """)
-s = rep(s, """        const int L = (s0 + n_t - 1) & 1;     // stage of the last k tile
-""", """        STAMP(2);
-        const int L = (s0 + n_t - 1) & 1;     // stage of the last k tile
+s = rep(s, """    if constexpr (!PERSIST) {
+        gemm_epilogue_bf16<MI, NI, WM, WN>(p, acc, smem_x, m0, n0, z, wave, lane, HoWo);
+        break;
+    } else {
+""", """    STAMP(2);
+    if constexpr (!PERSIST) {
+        gemm_epilogue_bf16<MI, NI, WM, WN>(p, acc, smem_x, m0, n0, z, wave, lane, HoWo);
+        STAMP(5);
+        if (probing) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        STAMP(6);      // (one-tile form: the drain of its own stores)
+        break;
+    } else {
 """)
 s = rep(s, """        __syncthreads();                      // every wave is done with stage L (and, since the top of the last k iteration, with stage L ^ 1)
         if (more) {""", """        __syncthreads();                      // every wave is done with stage L (and, since the top of the last k iteration, with stage L ^ 1)
@@ -63,7 +72,7 @@ s = rep(s, """        advance_k();      // (k tile 0 is on its way)
     }
     }
     if (probing && wave == 0 && lane == 0) {
-        unsigned long long* d = p.probe + 24ull * blockIdx.x;
+        unsigned long long* d = p.probe + 24ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.z);
         for (int i = 0; i < 8; ++i) d[i] = acc_t[i];
         d[8] = __builtin_amdgcn_s_memrealtime() - rt0;
         d[9] = 1;
